@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REAL reference.
+
+Runs only in the build container (needs /root/reference, read-only).  It
+imports the reference package, feeds it seeded inputs and stores inputs +
+outputs as small .npz fixtures.  Nothing of the reference's source travels: the
+fixtures are data.  Re-run:  python tests/golden/make_golden.py
+
+Versions the numbers were produced with are recorded in golden_meta.json.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(REF, "examples"))
+
+import networkx as nx  # noqa: E402
+import scipy  # noqa: E402
+
+from mac.solvers.mac import MAC  # noqa: E402
+from mac.solvers.baseline import NaiveGreedy  # noqa: E402
+from mac.utils.conversions import nx_to_mac  # noqa: E402
+from mac.utils.fiedler import find_fiedler_pair  # noqa: E402
+from mac.utils.graphs import (Edge, weight_graph_lap_from_edge_list,  # noqa: E402
+                              weight_graph_lap_from_edges)
+from mac.utils.rounding import round_madow, round_nearest  # noqa: E402
+import mac.optimization.frankwolfe as fw  # noqa: E402
+import mac.optimization.constraints as constraints  # noqa: E402
+
+
+def edges_to_arrays(edges):
+    return (np.array([e.i for e in edges], dtype=np.int64),
+            np.array([e.j for e in edges], dtype=np.int64),
+            np.array([e.weight for e in edges], dtype=np.float64))
+
+
+def save(name, **kw):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **kw)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+def run_solve(fixed, cand, n, k, x_init, max_iters, **kw):
+    """MAC.solve with the per-iteration (f, grad) sequence recorded."""
+    mac = MAC(fixed, cand, n)
+    fs, gs, xs = [], [], []
+    orig = mac.problem
+
+    def rec(x, cache=None):
+        f, g = orig(x, cache=cache)
+        fs.append(f); gs.append(g.copy()); xs.append(np.array(x, copy=True))
+        return f, g
+    mac.problem = rec
+    rounded, w, u = mac.solve(k, x_init, max_iters=max_iters, **kw)
+    return mac, rounded, w, u, np.array(fs), np.array(gs), np.array(xs)
+
+
+def fiedler_case(name, fixed, cand, n, x):
+    mac = MAC(fixed, cand, n)
+    L = mac.laplacian(x)
+    lam, v, X = find_fiedler_pair(L)
+    f, g = mac.problem(x)
+    fi, fj, fwt = edges_to_arrays(fixed)
+    ci, cj, cw = edges_to_arrays(cand)
+    Lc = L.tocsr(); Lc.sort_indices()
+    save(name, n=n, fi=fi, fj=fj, fw=fwt, ci=ci, cj=cj, cw=cw, x=x, lam=lam,
+         v=np.array(v), X=np.array(X), grad=g, f=f,
+         L_indptr=Lc.indptr, L_indices=Lc.indices, L_data=Lc.data)
+
+
+def main():
+    meta = {"numpy": np.__version__, "scipy": scipy.__version__,
+            "networkx": nx.__version__, "python": sys.version.split()[0]}
+
+    # ---- G1: K5 (tests/utils/test_fiedler.py:26-33) and G2: paths ----------
+    for nm, G in [("k5", nx.complete_graph(5)), ("p2", nx.path_graph(2)),
+                  ("p3", nx.path_graph(3)), ("p50", nx.path_graph(50)),
+                  ("c12", nx.cycle_graph(12)), ("star9", nx.star_graph(8))]:
+        el = nx_to_mac(G)
+        n = G.number_of_nodes()
+        L = weight_graph_lap_from_edge_list(el, n)
+        lam, v, X = find_fiedler_pair(L)
+        i, j, w = edges_to_arrays(el)
+        save("fiedler_" + nm, n=n, ei=i, ej=j, ew=w, lam=lam, v=np.array(v), X=np.array(X))
+
+    # ---- Laplacian builders vs networkx (tests/utils/test_graphs.py:27-50) --
+    G = nx.petersen_graph()
+    rs = np.random.RandomState(7)
+    for (u, v) in G.edges():
+        G[u][v]["weight"] = float(rs.rand()) + 0.1
+    el = nx_to_mac(G)
+    L1 = weight_graph_lap_from_edge_list(el, 10)
+    i, j, w = edges_to_arrays(el)
+    L2 = weight_graph_lap_from_edges(np.stack([i, j], 1), w, 10)
+    Lnx = nx.laplacian_matrix(G).toarray()
+    assert np.allclose(L1.toarray(), Lnx) and np.allclose(L2.toarray(), Lnx)
+    save("laplacian_petersen_weighted", n=10, ei=i, ej=j, ew=w, L_dense=L1.toarray())
+
+    # ---- G3: Petersen / MST fixed, k=3 -------------------------------------
+    G = nx.petersen_graph()
+    tree = nx.minimum_spanning_tree(G)
+    loop = nx.difference(G, tree)
+    fixed, cand = nx_to_mac(tree), nx_to_mac(loop)
+    x0 = np.array([1., 1., 1., 0., 0., 0.])
+    fiedler_case("petersen_x0", fixed, cand, 10, x0)
+    mac, rounded, w, u, fs, gs, xs = run_solve(fixed, cand, 10, 3, x0, 5)
+    fi, fj, fwt = edges_to_arrays(fixed); ci, cj, cw = edges_to_arrays(cand)
+    save("petersen_solve_k3", n=10, fi=fi, fj=fj, fw=fwt, ci=ci, cj=cj, cw=cw, k=3,
+         x_init=x0, max_iters=5, rounded=rounded, unrounded=w, upper=u, f_traj=fs,
+         g_traj=gs, x_traj=xs, lam_tree=MAC(fixed, cand, 10).evaluate_objective(np.zeros(6)),
+         lam_all=MAC(fixed, cand, 10).evaluate_objective(np.ones(6)))
+
+    # ---- G4: the sweep of tests/solvers/test_mac.py:35-60 ------------------
+    rows = []
+    for pct in [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9]:
+        k = int(pct * len(cand))
+        xi = np.zeros(len(cand)); xi[:k] = 1.0
+        m = MAC(fixed, cand, 10)
+        r, un, up = m.solve(k, xi, max_iters=100)
+        rows.append([pct, k, m.evaluate_objective(xi), m.evaluate_objective(un),
+                     m.evaluate_objective(r), up])
+    save("petersen_sweep", rows=np.array(rows))
+
+    # ---- small seeded ER graphs with random weights ------------------------
+    for nm, n, p, seed, frac, iters in [("er300", 300, 0.05, 1, 0.2, 8),
+                                        ("er2000", 2000, 0.006, 2, 0.1, 6)]:
+        G = nx.fast_gnp_random_graph(n, p, seed=seed)
+        rs = np.random.RandomState(seed)
+        fixed = [Edge(a, a + 1, float(0.5 + rs.rand())) for a in range(n - 1)]
+        cand = []
+        for (a, b) in G.edges():
+            if abs(a - b) != 1:
+                cand.append(Edge(min(a, b), max(a, b), float(0.5 + rs.rand())))
+        m_ = len(cand); k = int(frac * m_)
+        x0 = np.zeros(m_); x0[rs.choice(m_, k, replace=False)] = 1.0
+        xr = rs.rand(m_) * (rs.rand(m_) < 0.5)   # fractional x with zeros
+        fiedler_case(nm + "_x0", fixed, cand, n, x0)
+        fiedler_case(nm + "_xfrac", fixed, cand, n, xr)
+        mac, rounded, w, u, fs, gs, xs = run_solve(fixed, cand, n, k, x0, iters)
+        fi, fj, fwt = edges_to_arrays(fixed); ci, cj, cw = edges_to_arrays(cand)
+        save(nm + "_solve", n=n, fi=fi, fj=fj, fw=fwt, ci=ci, cj=cj, cw=cw, k=k,
+             x_init=x0, max_iters=iters, rounded=rounded, unrounded=w, upper=u,
+             f_traj=fs, x_traj_last=xs[-1], g_traj_last=gs[-1],
+             supp=np.array([(x > 1e-10).sum() for x in xs]))
+
+    # ---- G5-G7: pose graphs through the reference's own g2o reader ----------
+    for mod in ["evo", "evo.core", "evo.core.trajectory", "evo.core.sync",
+                "evo.core.metrics"]:
+        sys.modules.setdefault(mod, types.ModuleType(mod))
+    sys.modules["evo.core.trajectory"].PoseTrajectory3D = object
+    sys.modules["evo.core"].sync = sys.modules["evo.core.sync"]
+    sys.modules["evo.core"].metrics = sys.modules["evo.core.metrics"]
+    sys.modules["evo.core.metrics"].PoseRelation = object
+    sys.modules["evo.core.metrics"].Unit = object
+    import matplotlib
+    matplotlib.use("Agg")
+    from pose_graph_utils import read_g2o_file, split_edges, rpm_to_mac
+
+    for nm, iters in [("intel", 20), ("sphere2500", 20), ("city10000", 20)]:
+        meas, n = read_g2o_file(os.path.join(REF, "data", nm + ".g2o"))
+        odom, lc = split_edges(meas)
+        fixed, cand = rpm_to_mac(odom), rpm_to_mac(lc)
+        k = int(0.2 * len(cand))
+        import io, contextlib
+        with contextlib.redirect_stdout(io.StringIO()):
+            x0 = NaiveGreedy(cand).subset(k)
+        mac, rounded, w, u, fs, gs, xs = run_solve(fixed, cand, n, k, x0, iters,
+                                                   rounding="nearest", use_cache=True)
+        madow = round_madow(w, k, seed=np.random.RandomState(42))
+        u42 = np.random.RandomState(42).rand()
+        m0 = MAC(fixed, cand, n)
+        lam_all = m0.evaluate_objective(np.ones(len(cand)))
+        lam0, v0, X0 = find_fiedler_pair(m0.laplacian(x0))
+        fi, fj, fwt = edges_to_arrays(fixed); ci, cj, cw = edges_to_arrays(cand)
+        save("g2o_" + nm, n=n, fi=fi, fj=fj, fw=fwt, ci=ci, cj=cj, cw=cw, k=k,
+             x_init=x0, max_iters=iters, rounded=rounded, unrounded=w, upper=u,
+             f_traj=fs, supp=np.array([(x > 1e-10).sum() for x in xs]),
+             lam_init=lam0, v_init=np.array(v0), grad_init=gs[0], lam_all=lam_all,
+             lam_rounded=m0.evaluate_objective(rounded), madow=madow, madow_u=u42)
+        meta["g2o_" + nm] = {"n": int(n), "fixed": len(fixed), "cand": len(cand), "k": k}
+
+    # ---- G8: ER N=10k (BASELINE.json configs[1]) one Fiedler solve ---------
+    n = 10000
+    G = nx.fast_gnp_random_graph(n, 0.01, seed=0)
+    fixed = [Edge(a, a + 1, 1.0) for a in range(n - 1)]
+    cand = [Edge(min(a, b), max(a, b), 1.0) for (a, b) in G.edges() if abs(a - b) != 1]
+    m_ = len(cand); k = m_ // 10
+    x0 = np.zeros(m_); x0[np.random.default_rng(0).choice(m_, k, replace=False)] = 1.0
+    mac = MAC(fixed, cand, n)
+    f, g = mac.problem(x0)
+    lam, v, _ = find_fiedler_pair(mac.laplacian(x0))
+    ci, cj, cw = edges_to_arrays(cand)
+    save("er10k_x0", n=n, m=m_, k=k, lam=lam, v=np.array(v), grad_sum=g.sum(),
+         grad_head=g[:512], grad_stride=g[::997], ci_head=ci[:512], cj_head=cj[:512],
+         x0_idx=np.nonzero(x0)[0].astype(np.int64))
+    meta["er10k"] = {"n": n, "m": m_, "k": k, "lam": float(lam)}
+
+    # ---- Frank-Wolfe toy problems (tests/optimization/test_frankwolfe.py) --
+    def prob(x):
+        return -float(x @ x), -2.0 * x
+    x, u = fw.frank_wolfe(np.ones(3) * 0.7, prob, constraints.solve_box_lp, maxiter=200)
+    x2, u2 = fw.frank_wolfe(np.array([1.0, 0.0]), lambda z: (-float((z - 0.5) @ (z - 0.5)), -2.0 * (z - 0.5)),
+                            lambda g: constraints.solve_subset_box_lp(g, 1), maxiter=300)
+    save("fw_toy", x_box=x, u_box=u, x_subset=x2, u_subset=u2)
+
+    # ---- rounding with tie-breaks -------------------------------------------
+    rs = np.random.RandomState(3)
+    w = np.round(rs.rand(40), 1); wt = rs.rand(40)
+    save("rounding", w=w, weights=wt, k=np.int64(9),
+         nearest_tb=round_nearest(w, 9, weights=wt, break_ties_decimal_tol=10),
+         nearest=round_nearest(rs.rand(40), 9),
+         madow_w=(wm := rs.dirichlet(np.ones(40)) * 9).clip(0, 1),
+         madow=round_madow(wm.clip(0, 1) * (9 / wm.clip(0, 1).sum()), 9, seed=np.random.RandomState(5)),
+         madow_in=wm.clip(0, 1) * (9 / wm.clip(0, 1).sum()), madow_u=np.random.RandomState(5).rand())
+
+    with open(os.path.join(OUT, "golden_meta.json"), "w") as fh:
+        json.dump(meta, fh, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
