@@ -1,0 +1,150 @@
+/*
+ * machip.h -- C ABI of libmachip.so, the MI355X (gfx950) implementation of the
+ * Frank-Wolfe / Fiedler hot path of MarineRoboticsGroup/mac.
+ *
+ * Plain C, no torch / numpy types: pointers + sizes only.  Host pointers are
+ * borrowed for the duration of a call; all device memory is owned by the
+ * handle.  Every function returns a machip_status (0 = OK) and never throws;
+ * machip_last_error() gives the text of the last failure on this thread.
+ * A handle is not thread-safe; distinct handles are independent (one HIP
+ * stream each).
+ *
+ * Each entry point names the reference interface it replaces (paths relative
+ * to the reference repository; "nx:" = networkx 3.4.2
+ * networkx/linalg/algebraicconnectivity.py, the third-party module the
+ * reference delegates the eigen-solve to).  The reference-side binding is
+ * shown in INTEGRATION.md.
+ */
+#ifndef MACHIP_H
+#define MACHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MACHIP_ABI_VERSION 1
+
+typedef enum machip_status {
+    MACHIP_OK = 0,
+    MACHIP_NOT_CONVERGED = 1, /* iteration cap hit (the reference would spin, nx:236)     */
+    MACHIP_DISCONNECTED = 2,  /* lambda_2 ~ 0: graph not connected (reference: SuperLU
+                                 "Factor is exactly singular" RuntimeError)               */
+    MACHIP_BAD_ARG = 3,       /* reference: AssertionError (mac.py:47,52,183; fiedler.py:35) */
+    MACHIP_HIP_ERROR = 4,
+    MACHIP_RCCL_ERROR = 5,
+    MACHIP_NO_DEVICE = 6
+} machip_status;
+
+typedef struct machip_problem machip_problem; /* one MAC instance (mac/solvers/mac.py:16)  */
+
+/* Statistics of the last eigen-solve (n_mv, n_vec counters). */
+typedef struct machip_solve_stats {
+    int64_t lanczos_steps; /* = SpMV count of the Krylov phase                             */
+    int64_t spmv_total;    /* + SpMVs of the explicit residual checks                      */
+    int64_t vec_passes;    /* length-n vector reads+writes outside the SpMV                */
+    int64_t restarts;
+    int64_t nnz;           /* nnz of the assembled L(x) (diagonal included)                */
+    int64_t support;       /* |{k : x_k > min_selection_weight_tol}|                       */
+    double residual;       /* ||L v - lambda v||_1 / ||L||_inf  (the reference's stop rule,
+                              nx:232,246)                                                  */
+    double lnorm;          /* ||L||_inf                                                    */
+    double gpu_ms;         /* device time of the solve (hipEvents on the handle's stream)  */
+} machip_solve_stats;
+
+int machip_version(void);
+int machip_device_count(void);            /* 0 when no GPU is visible                      */
+const char* machip_last_error(void);
+
+/* MAC.__init__ (mac/solvers/mac.py:22-72): fixed + candidate edge lists (SoA,
+ * int32 node ids in [0,n)), n nodes.  Builds the union sparsity pattern once and
+ * keeps weights / edge lists resident in HBM.  Duplicate pairs are summed exactly
+ * as coo->csr does (mac/utils/graphs.py:48,98). */
+int machip_create(int device, int64_t n,
+                  int64_t n_fixed, const int32_t* fi, const int32_t* fj, const double* fw,
+                  int64_t m, const int32_t* ci, const int32_t* cj, const double* cw,
+                  double min_selection_weight_tol, machip_problem** out);
+void machip_destroy(machip_problem* p);
+
+/* x <- host vector (m doubles); x -> host.  (The reference passes x by value
+ * into MAC.laplacian / problem / evaluate_objective, mac.py:74,91,104.) */
+int machip_set_x(machip_problem* p, const double* x);
+int machip_get_x(machip_problem* p, double* x);
+
+/* MAC.laplacian(x) (mac.py:74-89): assemble L(x) = L_fixed + sum_{x_k>tol} x_k w_k L_k
+ * on the device as CSR.  nnz_out may be NULL. */
+int machip_assemble(machip_problem* p, int64_t* nnz_out);
+/* Copy the assembled CSR to the host (indptr n+1, indices nnz, data nnz; the
+ * diagonal is the first entry of each row, the rest sorted by column). */
+int machip_get_laplacian(machip_problem* p, int32_t* indptr, int32_t* indices, double* data);
+
+/* find_fiedler_pair on the assembled L(x) (mac/utils/fiedler.py:9-44 ->
+ * nx:151-256).  Stop rule identical to the reference: ||L v - lambda v||_1 /
+ * ||L||_inf < tol.  x0: optional start vector (n doubles, host) -- the drop-in
+ * passes column 0 of the reference's RandomState(7) block; NULL + warm_start!=0
+ * reuses the previous Fiedler vector resident on the device (the working form of
+ * MAC.Cache, mac.py:17-20); NULL + warm_start==0 uses a fixed device-side
+ * pseudo-random vector.  v_out (n) and X_out (n*q, column-major) may be NULL;
+ * q in [1,4] Ritz vectors are produced when X_out != NULL. */
+int machip_fiedler(machip_problem* p, double tol, int max_steps, const double* x0, int warm_start,
+                   double* lambda2, double* v_out, double* X_out, int q,
+                   machip_solve_stats* stats);
+
+/* Store the cold-start vector (n doubles) used by every later machip_fiedler /
+ * machip_fw_step call that passes x0 = NULL and warm_start = 0: the drop-in sends the
+ * first column of the reference's RandomState(7) block (fiedler.py:27-32) once. */
+int machip_set_start(machip_problem* p, const double* x0);
+
+/* Supergradient g_k = (w_k (v_i - v_j)) (v_i - v_j) for all m candidates from the
+ * device-resident Fiedler vector (mac.py:117-124).  g_out (m) may be NULL. */
+int machip_gradient(machip_problem* p, double* g_out);
+
+/* solve_subset_box_lp(g, k) (mac/optimization/constraints.py:12-22 ->
+ * mac/utils/rounding.py:21-28): s = indicator of the k largest g.  Ties at the
+ * k-th value go to the lowest indices (the reference's argpartition leaves them
+ * unspecified).  s_out (m doubles) may be NULL. */
+int machip_lp_topk(machip_problem* p, int64_t k, double* s_out);
+
+/* One Frank-Wolfe iteration, device-resident (mac/optimization/frankwolfe.py:53-76
+ * with problem = MAC.problem, solve_lp = solve_subset_box_lp):
+ *   assemble L(x); (f, v) = Fiedler pair; g = supergradient; s = top-k(g);
+ *   dual = f + g.(s - x); gnorm = ||g||_2; x_next = x + 2/(iter+2) (s - x).
+ * x_next is staged; machip_fw_commit() makes it current (the caller applies the
+ * reference's stop tests first: on a stop the reference returns the pre-update
+ * x, frankwolfe.py:65-74).  Only scalars cross PCIe. */
+int machip_fw_step(machip_problem* p, int64_t k, int iter, double tol, int max_steps, int warm_start,
+                   double* f, double* dual, double* gnorm, machip_solve_stats* stats);
+int machip_fw_commit(machip_problem* p);
+
+/* find_fiedler_pair(L) for an arbitrary scipy CSR Laplacian
+ * (mac/utils/fiedler.py:9, called that way by tests/utils/test_fiedler.py:32). */
+int machip_fiedler_csr(int device, int64_t n, const int32_t* indptr, const int32_t* indices,
+                       const double* data, double tol, int max_steps, const double* x0,
+                       double* lambda2, double* v_out, double* X_out, int q,
+                       machip_solve_stats* stats);
+
+/* y = L(x) v on the device CSR (host vectors, n doubles): parity probe for the
+ * SpMV kernel. variant: 0 = auto, 1 = LDS row-tile ("stream"), 2 = sub-wave vector. */
+int machip_spmv(machip_problem* p, const double* v, double* y, int variant);
+
+/* Average duration (microseconds, hipEvents on the handle's stream) of `reps`
+ * back-to-back launches of the fused Lanczos SpMV kernel on the assembled L(x),
+ * and its algorithmic bytes per launch (SURVEY section 8(d) B_spmv + the fused vector
+ * traffic).  Used by bench.py for the roofline object. */
+int machip_profile_spmv(machip_problem* p, int reps, double* avg_us, double* bytes_per_launch);
+
+/* Multi-GPU: candidates are sharded in contiguous ranges over
+ * nranks processes (one GPU each); each rank evaluates the supergradient of its
+ * range and one RCCL all-gather over xGMI rebuilds the full m-vector on every
+ * rank.  unique_id: the 128-byte ncclUniqueId from machip_comm_unique_id() on
+ * rank 0, distributed by the caller. */
+int machip_comm_unique_id(void* id128);
+int machip_comm_init(machip_problem* p, int rank, int nranks, const void* id128);
+
+int machip_synchronize(machip_problem* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MACHIP_H */

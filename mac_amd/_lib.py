@@ -1,0 +1,271 @@
+"""ctypes binding of libmachip.so (C ABI: include/machip.h).  No torch, no fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmachip.so")
+
+OK, NOT_CONVERGED, DISCONNECTED, BAD_ARG, HIP_ERROR, RCCL_ERROR, NO_DEVICE = range(7)
+STATUS_NAMES = ["OK", "NOT_CONVERGED", "DISCONNECTED", "BAD_ARG", "HIP_ERROR", "RCCL_ERROR", "NO_DEVICE"]
+
+
+class MachipError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"libmachip: {STATUS_NAMES[status] if 0 <= status < 7 else status}: {msg}")
+        self.status = status
+
+
+class NotConverged(MachipError):
+    pass
+
+
+class Disconnected(MachipError):
+    """lambda_2 ~ 0 (the reference fails with SuperLU 'Factor is exactly singular')."""
+
+
+class SolveStats(C.Structure):
+    _fields_ = [("lanczos_steps", C.c_int64), ("spmv_total", C.c_int64), ("vec_passes", C.c_int64),
+                ("restarts", C.c_int64), ("nnz", C.c_int64), ("support", C.c_int64),
+                ("residual", C.c_double), ("lnorm", C.c_double), ("gpu_ms", C.c_double)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_i32p = C.POINTER(C.c_int32)
+_f64p = C.POINTER(C.c_double)
+_lib = None
+
+# name -> (restype, argtypes); every symbol declared in include/machip.h
+SIGNATURES = {
+    "machip_version": (C.c_int, []),
+    "machip_device_count": (C.c_int, []),
+    "machip_last_error": (C.c_char_p, []),
+    "machip_create": (C.c_int, [C.c_int, C.c_int64, C.c_int64, _i32p, _i32p, _f64p, C.c_int64, _i32p, _i32p,
+                                _f64p, C.c_double, C.POINTER(C.c_void_p)]),
+    "machip_destroy": (None, [C.c_void_p]),
+    "machip_set_x": (C.c_int, [C.c_void_p, _f64p]),
+    "machip_get_x": (C.c_int, [C.c_void_p, _f64p]),
+    "machip_assemble": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "machip_get_laplacian": (C.c_int, [C.c_void_p, _i32p, _i32p, _f64p]),
+    "machip_fiedler": (C.c_int, [C.c_void_p, C.c_double, C.c_int, _f64p, C.c_int, _f64p, _f64p, _f64p, C.c_int,
+                                 C.POINTER(SolveStats)]),
+    "machip_set_start": (C.c_int, [C.c_void_p, _f64p]),
+    "machip_gradient": (C.c_int, [C.c_void_p, _f64p]),
+    "machip_lp_topk": (C.c_int, [C.c_void_p, C.c_int64, _f64p]),
+    "machip_fw_step": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_int, C.c_int, _f64p, _f64p,
+                                 _f64p, C.POINTER(SolveStats)]),
+    "machip_fw_commit": (C.c_int, [C.c_void_p]),
+    "machip_fiedler_csr": (C.c_int, [C.c_int, C.c_int64, _i32p, _i32p, _f64p, C.c_double, C.c_int, _f64p, _f64p,
+                                     _f64p, _f64p, C.c_int, C.POINTER(SolveStats)]),
+    "machip_spmv": (C.c_int, [C.c_void_p, _f64p, _f64p, C.c_int]),
+    "machip_profile_spmv": (C.c_int, [C.c_void_p, C.c_int, _f64p, _f64p]),
+    "machip_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "machip_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "machip_synchronize": (C.c_int, [C.c_void_p]),
+}
+_EXTRA = {"machip_host_tridiag_smallest": (C.c_int, [_f64p, _f64p, C.c_int, _f64p, _f64p])}
+
+
+def load():
+    """Load libmachip.so (built by __graft_entry__.build() / mac_amd/csrc/build.sh)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
+                          "(hipcc --offload-arch=gfx950); mac_amd has no CPU fallback")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in {**SIGNATURES, **_EXTRA}.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def device_count():
+    return int(load().machip_device_count())
+
+
+def require_device():
+    n = device_count()
+    if n <= 0:
+        raise MachipError(NO_DEVICE, "no MI355X / HIP device visible; mac_amd has no CPU fallback")
+    return n
+
+
+def last_error():
+    return (load().machip_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(status, allow=()):
+    if status == OK or status in allow:
+        return status
+    msg = last_error()
+    if status == NOT_CONVERGED:
+        raise NotConverged(status, msg)
+    if status == DISCONNECTED:
+        raise Disconnected(status, msg)
+    if status == BAD_ARG:
+        raise AssertionError(f"libmachip: BAD_ARG: {msg}")     # the reference asserts (mac.py:47,52,183)
+    raise MachipError(status, msg)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def p_f64(a):
+    return None if a is None else a.ctypes.data_as(_f64p)
+
+
+def p_i32(a):
+    return None if a is None else a.ctypes.data_as(_i32p)
+
+
+class Problem:
+    """Owns one ``machip_problem`` handle (one MAC instance resident on one GPU)."""
+
+    def __init__(self, n, fi, fj, fw, ci, cj, cw, min_selection_weight_tol=1e-10, device=0):
+        lib = load()
+        require_device()
+        self.n = int(n)
+        fi, fj, fw = i32(fi), i32(fj), f64(fw)
+        ci, cj, cw = i32(ci), i32(cj), f64(cw)
+        self.m = int(len(cw))
+        h = C.c_void_p()
+        check(lib.machip_create(int(device), self.n, len(fw), p_i32(fi), p_i32(fj), p_f64(fw), self.m,
+                                p_i32(ci), p_i32(cj), p_f64(cw), float(min_selection_weight_tol), C.byref(h)))
+        self._h = h
+        self._lib = lib
+        self.stats = SolveStats()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.machip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- x ----
+    def set_x(self, x):
+        x = f64(x)
+        assert x.shape == (self.m,)
+        check(self._lib.machip_set_x(self._h, p_f64(x)))
+
+    def get_x(self):
+        x = np.empty(self.m)
+        check(self._lib.machip_get_x(self._h, p_f64(x)))
+        return x
+
+    # ---- Laplacian ----
+    def assemble(self):
+        nnz = C.c_int64()
+        check(self._lib.machip_assemble(self._h, C.byref(nnz)))
+        return int(nnz.value)
+
+    def laplacian_csr(self):
+        nnz = self.assemble()
+        indptr = np.empty(self.n + 1, dtype=np.int32)
+        indices = np.empty(nnz, dtype=np.int32)
+        data = np.empty(nnz)
+        check(self._lib.machip_get_laplacian(self._h, p_i32(indptr), p_i32(indices), p_f64(data)))
+        return indptr, indices, data
+
+    def spmv(self, v, variant=0):
+        v = f64(v)
+        y = np.empty(self.n)
+        check(self._lib.machip_spmv(self._h, p_f64(v), p_f64(y), int(variant)))
+        return y
+
+    # ---- eigen-solve / gradient / LP ----
+    def fiedler(self, tol=1e-8, max_steps=0, x0=None, warm_start=False, want_vec=True, q=0):
+        lam = C.c_double()
+        v = np.empty(self.n) if want_vec else None
+        X = np.empty((q, self.n)) if q else None      # row q = column q of the n x q block
+        x0a = f64(x0) if x0 is not None else None
+        st = self._lib.machip_fiedler(self._h, float(tol), int(max_steps), p_f64(x0a), int(bool(warm_start)),
+                                      C.byref(lam), p_f64(v), p_f64(X), int(q), C.byref(self.stats))
+        check(st)
+        return lam.value, v, (X.T if X is not None else None)
+
+    def set_start(self, x0):
+        x0 = f64(x0)
+        assert x0.shape == (self.n,)
+        check(self._lib.machip_set_start(self._h, p_f64(x0)))
+
+    def gradient(self, want=True):
+        g = np.empty(self.m) if want else None
+        check(self._lib.machip_gradient(self._h, p_f64(g)))
+        return g
+
+    def lp_topk(self, k, want=True):
+        s = np.empty(self.m) if want else None
+        check(self._lib.machip_lp_topk(self._h, int(k), p_f64(s)))
+        return s
+
+    def fw_step(self, k, it, tol=1e-8, max_steps=0, warm_start=False):
+        f, d, gn = C.c_double(), C.c_double(), C.c_double()
+        check(self._lib.machip_fw_step(self._h, int(k), int(it), float(tol), int(max_steps),
+                                       int(bool(warm_start)), C.byref(f), C.byref(d), C.byref(gn),
+                                       C.byref(self.stats)))
+        return f.value, d.value, gn.value
+
+    def fw_commit(self):
+        check(self._lib.machip_fw_commit(self._h))
+
+    def profile_spmv(self, reps=200):
+        us, by = C.c_double(), C.c_double()
+        check(self._lib.machip_profile_spmv(self._h, int(reps), C.byref(us), C.byref(by)))
+        return us.value, by.value
+
+    def comm_init(self, rank, nranks, unique_id: bytes):
+        buf = C.create_string_buffer(unique_id, 128)
+        check(self._lib.machip_comm_init(self._h, int(rank), int(nranks), buf))
+
+    def synchronize(self):
+        check(self._lib.machip_synchronize(self._h))
+
+
+def comm_unique_id() -> bytes:
+    buf = C.create_string_buffer(128)
+    check(load().machip_comm_unique_id(buf))
+    return buf.raw
+
+
+def fiedler_csr(indptr, indices, data, n, tol=1e-8, max_steps=0, x0=None, q=0, device=0):
+    lib = load()
+    require_device()
+    indptr, indices, data = i32(indptr), i32(indices), f64(data)
+    lam = C.c_double()
+    v = np.empty(n)
+    X = np.empty((q, n)) if q else None
+    x0a = f64(x0) if x0 is not None else None
+    stats = SolveStats()
+    check(lib.machip_fiedler_csr(int(device), int(n), p_i32(indptr), p_i32(indices), p_f64(data), float(tol),
+                                 int(max_steps), p_f64(x0a), C.byref(lam), p_f64(v), p_f64(X), int(q),
+                                 C.byref(stats)))
+    return lam.value, v, (X.T if X is not None else None), stats
+
+
+def host_tridiag_smallest(a, b):
+    lib = load()
+    a, b = f64(a), f64(b)
+    J = len(a)
+    th = C.c_double()
+    s = np.empty(J)
+    check(lib.machip_host_tridiag_smallest(p_f64(a), p_f64(b), J, C.byref(th), p_f64(s)))
+    return th.value, s

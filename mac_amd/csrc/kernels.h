@@ -1,0 +1,626 @@
+// kernels.h -- hand-written gfx950 kernels of the Frank-Wolfe / Fiedler hot path.
+//
+// All of this is HBM/L2-bound integer + fp64 streaming work: no MFMA (there is no dense
+// contraction on the path).  Conventions: 256-thread workgroups (4 wave64), grids capped at
+// kMaxGrid workgroups with grid-stride loops, reductions = wave butterfly -> 4-entry LDS ->
+// one partial per workgroup, re-reduced in fixed order by the consumer kernel (bit-
+// reproducible; no floating-point atomics anywhere).
+#pragma once
+#include "common.h"
+
+namespace machip {
+
+// ------------------------------------------------------------------------------------------
+// Views (passed by value as kernel arguments)
+// ------------------------------------------------------------------------------------------
+struct CsrView {
+    int n;
+    const int* rowptr;   // n+1
+    const int* col;      // nnz
+    const double* val;   // nnz
+};
+
+// Union sparsity pattern of fixed + candidate edges (built once, machip_create):
+// row r owns slots [prow[r], prow[r+1]); slot p is the off-diagonal (r, pcol[p]) fed by
+// candidate pk[p] (weight pw[p] = w_k) or, when pk[p] < 0, by fixed edges (pw[p] = summed
+// fixed weight).  Slots are sorted by column inside a row.
+struct PatternView {
+    int n;
+    const int* prow;
+    const int* pcol;
+    const int* pk;
+    const double* pw;
+};
+
+struct LanState {   // device-resident step counters: kernels take no per-step arguments,
+    int jA;         // so a chunk of steps can be replayed from a hipGraph.
+    int jB;         // jA is read by k_lan_spmv*, jB by k_lan_update (see those kernels).
+    int pad0, pad1;
+};
+
+struct LanView {
+    int n;
+    LanState* st;
+    double* u;        // un-normalised next Lanczos vector (n)
+    double* w;        // L v_j (n)
+    double* V;        // Lanczos basis, column-major n x cap
+    double* alpha;    // cap
+    double* beta;     // cap+1; beta[j] = ||u_j|| couples v_{j-1}, v_j
+    double* l1;       // cap+1; ||v_j||_1
+    double* part_u;   // 3 x kMaxGrid partials of (sum u, sum u^2, sum |u|)
+    int P_u;          // number of valid partials per row of part_u
+    double* part_a;   // kMaxGrid partials of alpha
+    int P_a;
+};
+
+// ------------------------------------------------------------------------------------------
+// Laplacian assembly  (reference: MAC.laplacian, mac/solvers/mac.py:74-89, and
+// weight_graph_lap_from_edges, mac/utils/graphs.py:58-98)
+// ------------------------------------------------------------------------------------------
+// Pass 1: active entries per row (+1 for the diagonal) and one total per workgroup.
+template <int G>
+__global__ __launch_bounds__(kBlock) void k_asm_count(PatternView P, const double* __restrict__ x,
+                                                      double tol, int rows_per_block,
+                                                      int* __restrict__ cnt, int* __restrict__ blk_sum,
+                                                      int* __restrict__ blk_supp) {
+    __shared__ int sm[4];
+    constexpr int GPB = kBlock / G;
+    const int lane = threadIdx.x % G, g = threadIdx.x / G;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(P.n, r0 + rows_per_block);
+    int local = 0, supp = 0;
+    for (int r = r0 + g; r < r1; r += GPB) {
+        const int b = P.prow[r], e = P.prow[r + 1];
+        int c = 0, sc = 0;
+        for (int p = b + lane; p < e; p += G) {
+            const int k = P.pk[p];
+            const bool cand = k >= 0;
+            const bool act = !cand || (x[k] > tol);
+            c += act;
+            sc += (cand && act && P.pcol[p] > r);   // each candidate counted once (upper slot)
+        }
+        c = group_sum_i<G>(c);
+        sc = group_sum_i<G>(sc);
+        if (lane == 0) {
+            cnt[r] = c + 1;
+            local += c + 1;
+            supp += sc;
+        }
+    }
+    const int tot = block_sum_i(local, sm);
+    const int stot = block_sum_i(supp, sm);
+    if (threadIdx.x == 0) {
+        blk_sum[blockIdx.x] = tot;
+        blk_supp[blockIdx.x] = stot;
+    }
+}
+
+// Pass 2: workgroup base = sum of the preceding workgroup totals; exclusive scan of the row
+// counts in LDS; each G-lane group compacts the active slots of its rows (ballot + popcount,
+// order preserved => columns stay sorted) behind the diagonal entry.
+template <int G>
+__global__ __launch_bounds__(kBlock) void k_asm_fill(PatternView P, const double* __restrict__ x,
+                                                     double tol, int rows_per_block,
+                                                     const int* __restrict__ cnt,
+                                                     const int* __restrict__ blk_sum,
+                                                     int* __restrict__ rowptr, int* __restrict__ col,
+                                                     double* __restrict__ val,
+                                                     double* __restrict__ blk_lnorm) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    int* s_off = reinterpret_cast<int*>(smem_raw);                    // rows_per_block + 1
+    __shared__ int sm_i[4];
+    __shared__ double sm_d[4];
+    __shared__ int s_chunk[kBlock];
+    constexpr int GPB = kBlock / G;
+    const int tid = threadIdx.x;
+    const int lane = tid % G, g = tid / G;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(P.n, r0 + rows_per_block);
+    const int nr = max(0, r1 - r0);
+
+    int acc = 0;
+    for (int b = tid; b < (int)blockIdx.x; b += kBlock) acc += blk_sum[b];
+    const int base = block_sum_i(acc, sm_i);
+
+    // exclusive scan of cnt[r0..r1) -> s_off[0..nr]
+    const int per = (nr + kBlock - 1) / kBlock;
+    int csum = 0;
+    for (int i = 0; i < per; ++i) {
+        const int idx = tid * per + i;
+        if (idx < nr) csum += cnt[r0 + idx];
+    }
+    s_chunk[tid] = csum;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int t = 0; t < kBlock; ++t) { const int c = s_chunk[t]; s_chunk[t] = run; run += c; }
+        s_off[nr] = run;
+    }
+    __syncthreads();
+    {
+        int run = s_chunk[tid];
+        for (int i = 0; i < per; ++i) {
+            const int idx = tid * per + i;
+            if (idx < nr) { s_off[idx] = run; run += cnt[r0 + idx]; }
+        }
+    }
+    __syncthreads();
+
+    double lmax = 0.0;
+    for (int r = r0 + g; r < r1; r += GPB) {
+        const int b = P.prow[r], e = P.prow[r + 1];
+        const int out = base + s_off[r - r0];
+        int pos = out + 1;
+        double dsum = 0.0, asum = 0.0;
+        for (int p0 = b; p0 < e; p0 += G) {
+            const int p = p0 + lane;
+            const bool in = p < e;
+            const int k = in ? P.pk[p] : -1;
+            const double wgt = in ? P.pw[p] : 0.0;
+            double v = 0.0;
+            bool act = false;
+            if (in) {
+                if (k < 0) { act = true; v = wgt; }
+                else { const double xk = x[k]; if (xk > tol) { act = true; v = xk * wgt; } }
+            }
+            const unsigned long long bal = __ballot(act);
+            unsigned long long gm;
+            if (G == 64) gm = bal;
+            else gm = (bal >> (((tid & 63) / G) * G)) & ((1ull << (G & 63)) - 1ull);
+            const int before = __popcll(gm & ((1ull << lane) - 1ull));
+            if (act) { col[pos + before] = P.pcol[p]; val[pos + before] = -v; }
+            pos += __popcll(gm);
+            dsum += v;
+            asum += fabs(v);
+        }
+        dsum = group_sum<G>(dsum);
+        asum = group_sum<G>(asum);
+        if (lane == 0) {
+            rowptr[r] = out;
+            col[out] = r;
+            val[out] = dsum;
+            lmax = fmax(lmax, fabs(dsum) + asum);
+        }
+    }
+    lmax = block_max(lmax, sm_d);
+    if (tid == 0) {
+        blk_lnorm[blockIdx.x] = lmax;
+        if (blockIdx.x == gridDim.x - 1) rowptr[P.n] = base + s_off[nr];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// CSR SpMV bodies.  Two row-to-lane mappings share one "Op" epilogue:
+//   * vec<G>:   a G-lane sub-wave group per row, direct coalesced loads of (col,val) along
+//               the row, butterfly reduce.  Right for long rows.
+//   * stream<TPR>: the workgroup stages the products val*x[col] of a contiguous nnz tile in
+//               LDS with perfectly coalesced loads, then TPR lanes per row reduce the row's
+//               LDS segment ("CSR-stream" row tiles).  Right for short rows.
+// Op interface: begin(sm) once per workgroup; row(r, acc) by one lane per row; end(sm).
+// ------------------------------------------------------------------------------------------
+template <int G, class Op>
+__device__ __forceinline__ void spmv_rows_vec(const CsrView& A, const double* __restrict__ x, Op& op) {
+    constexpr int GPB = kBlock / G;
+    const int lane = threadIdx.x % G, g = threadIdx.x / G;
+    for (int r = blockIdx.x * GPB + g; r < A.n; r += gridDim.x * GPB) {
+        const int b = A.rowptr[r], e = A.rowptr[r + 1];
+        double acc = 0.0;
+        for (int p = b + lane; p < e; p += G) acc += A.val[p] * x[A.col[p]];
+        acc = group_sum<G>(acc);
+        if (lane == 0) op.row(r, acc);
+    }
+}
+
+constexpr int kStreamTile = 2048;   // staged products per LDS tile (16 KB)
+
+template <int TPR, class Op>
+__device__ __forceinline__ void spmv_rows_stream(const CsrView& A, const double* __restrict__ x, Op& op,
+                                                 double* prod, int* sptr) {
+    constexpr int R = kBlock / TPR;
+    const int tid = threadIdx.x;
+    const int row = tid / TPR, sub = tid % TPR;
+    for (int tile = blockIdx.x; tile * R < A.n; tile += gridDim.x) {
+        const int r0 = tile * R;
+        const int nr = min(R, A.n - r0);
+        if (tid <= nr) sptr[tid] = A.rowptr[r0 + tid];
+        __syncthreads();
+        const int p0 = sptr[0], p1 = sptr[nr];
+        double acc = 0.0;
+        for (int base = p0; base < p1; base += kStreamTile) {
+            const int cnt = min(kStreamTile, p1 - base);
+            for (int i = tid; i < cnt; i += kBlock) prod[i] = A.val[base + i] * x[A.col[base + i]];
+            __syncthreads();
+            if (row < nr) {
+                const int lo = max(sptr[row], base), hi = min(sptr[row + 1], base + cnt);
+                for (int q = lo + sub; q < hi; q += TPR) acc += prod[q - base];
+            }
+            __syncthreads();
+        }
+        acc = group_sum<TPR>(acc);
+        if (row < nr && sub == 0) op.row(r0 + row, acc);
+        __syncthreads();
+    }
+}
+
+// ---- plain y = A x ---------------------------------------------------------------------------
+struct OpPlain {
+    double* y;
+    __device__ __forceinline__ void begin(double*) {}
+    __device__ __forceinline__ void row(int r, double acc) { y[r] = acc; }
+    __device__ __forceinline__ void end(double*) {}
+};
+
+// ---- fused Lanczos step, part 1 ---------------------------------------------------------------
+// v_j = (u - mean(u)) / beta_j  (deflates the constant null vector exactly like nx:209-213's
+// project(); L 1 = 0 so the SpMV can gather the raw u and scale afterwards),
+// w = L v_j, alpha partial = v_j . (w - beta_j v_{j-1})   (Paige's ordering).
+struct OpLanczos {
+    LanView L;
+    int j;
+    double mu, beta, inv, ap;
+    const double* vprev;
+    double* vj;
+    __device__ __forceinline__ void begin(double* sm) {
+        j = L.st->jA;
+        const double s1 = reduce_partials(L.part_u, L.P_u, sm);
+        const double s2 = reduce_partials(L.part_u + kMaxGrid, L.P_u, sm);
+        const double s3 = reduce_partials(L.part_u + 2 * kMaxGrid, L.P_u, sm);
+        mu = s1 / (double)L.n;
+        const double nrm2 = s2 - (double)L.n * mu * mu;
+        beta = nrm2 > 0.0 ? sqrt(nrm2) : 0.0;
+        inv = beta > 1e-290 ? 1.0 / beta : 0.0;
+        ap = 0.0;
+        vj = L.V + (size_t)j * (size_t)L.n;
+        vprev = j > 0 ? vj - L.n : nullptr;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            L.beta[j] = beta;
+            L.l1[j] = s3 * inv;
+            L.st->jB = j;
+        }
+    }
+    __device__ __forceinline__ void row(int r, double acc) {
+        const double wr = acc * inv;
+        const double v = (L.u[r] - mu) * inv;
+        vj[r] = v;
+        L.w[r] = wr;
+        const double t = vprev ? wr - beta * vprev[r] : wr;
+        ap += v * t;
+    }
+    __device__ __forceinline__ void end(double* sm) {
+        const double tot = block_sum(ap, sm);
+        if (threadIdx.x == 0) L.part_a[blockIdx.x] = tot;
+    }
+};
+
+template <int G, class Op>
+__global__ __launch_bounds__(kBlock) void k_spmv_vec(CsrView A, const double* __restrict__ x, Op op) {
+    __shared__ double sm[4];
+    op.begin(sm);
+    spmv_rows_vec<G>(A, x, op);
+    op.end(sm);
+}
+
+template <int TPR, class Op>
+__global__ __launch_bounds__(kBlock) void k_spmv_stream(CsrView A, const double* __restrict__ x, Op op) {
+    __shared__ double sm[4];
+    __shared__ double prod[kStreamTile];
+    __shared__ int sptr[kBlock / TPR + 1];
+    op.begin(sm);
+    spmv_rows_stream<TPR>(A, x, op, prod, sptr);
+    op.end(sm);
+}
+
+// ---- fused Lanczos step, part 2 ----------------------------------------------------------------
+// alpha_j = sum of partials; u <- (w - alpha_j v_j) - beta_j v_{j-1}; partial sums of u for the
+// next normalisation.  Advances the step counter read by part 1.
+__global__ __launch_bounds__(kBlock) void k_lan_update(LanView L) {
+    __shared__ double sm[4];
+    const int j = L.st->jB;
+    const double alpha = reduce_partials(L.part_a, L.P_a, sm);
+    const double beta = L.beta[j];
+    const double* vj = L.V + (size_t)j * (size_t)L.n;
+    const double* vp = j > 0 ? vj - L.n : nullptr;
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int r = blockIdx.x * kBlock + threadIdx.x; r < L.n; r += gridDim.x * kBlock) {
+        double t = L.w[r] - alpha * vj[r];
+        if (vp) t -= beta * vp[r];
+        L.u[r] = t;
+        s1 += t;
+        s2 += t * t;
+        s3 += fabs(t);
+    }
+    s1 = block_sum(s1, sm);
+    s2 = block_sum(s2, sm);
+    s3 = block_sum(s3, sm);
+    if (threadIdx.x == 0) {
+        L.part_u[blockIdx.x] = s1;
+        L.part_u[kMaxGrid + blockIdx.x] = s2;
+        L.part_u[2 * kMaxGrid + blockIdx.x] = s3;
+        if (blockIdx.x == 0) {
+            L.alpha[j] = alpha;
+            L.st->jA = j + 1;
+        }
+    }
+}
+
+// One workgroup: finish the pending (beta, ||v||_1) of the vector produced by the last update so
+// the host can read the residual factor without running another SpMV.
+__global__ __launch_bounds__(kBlock) void k_lan_tail(LanView L) {
+    __shared__ double sm[4];
+    const int j = L.st->jA;
+    const double s1 = reduce_partials(L.part_u, L.P_u, sm);
+    const double s2 = reduce_partials(L.part_u + kMaxGrid, L.P_u, sm);
+    const double s3 = reduce_partials(L.part_u + 2 * kMaxGrid, L.P_u, sm);
+    if (threadIdx.x == 0) {
+        const double mu = s1 / (double)L.n;
+        const double nrm2 = s2 - (double)L.n * mu * mu;
+        const double beta = nrm2 > 0.0 ? sqrt(nrm2) : 0.0;
+        L.beta[j] = beta;
+        L.l1[j] = beta > 1e-290 ? s3 / beta : 0.0;
+    }
+}
+
+// Partial sums (sum, sum of squares, sum of abs) of a vector -> part_u layout.
+__global__ __launch_bounds__(kBlock) void k_vec_sums(const double* __restrict__ u, int n,
+                                                     double* __restrict__ part) {
+    __shared__ double sm[4];
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
+        const double t = u[r];
+        s1 += t; s2 += t * t; s3 += fabs(t);
+    }
+    s1 = block_sum(s1, sm); s2 = block_sum(s2, sm); s3 = block_sum(s3, sm);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = s1;
+        part[kMaxGrid + blockIdx.x] = s2;
+        part[2 * kMaxGrid + blockIdx.x] = s3;
+    }
+}
+
+__global__ void k_set_state(LanState* st, int j) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { st->jA = j; st->jB = j; }
+}
+
+// Deterministic pseudo-random start vector in (-1,1) (splitmix64 of the index).
+__global__ __launch_bounds__(kBlock) void k_fill_start(double* __restrict__ u, int n, unsigned long long seed) {
+    for (int r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
+        unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(r + 1);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z = z ^ (z >> 31);
+        u[r] = (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+    }
+}
+
+// Ritz vector y = V[:, 0:J) s, split over the Krylov dimension: grid (row tiles, KS); slice ks
+// accumulates columns ks, ks+KS, ... into ypart[ks*n + r].
+__global__ __launch_bounds__(kBlock) void k_ritz_partial(const double* __restrict__ V, int n, int J,
+                                                         const double* __restrict__ s,
+                                                         double* __restrict__ ypart) {
+    const int KS = gridDim.y, ks = blockIdx.y;
+    for (int r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
+        double a0 = 0.0, a1 = 0.0;
+        int k = ks;
+        for (; k + KS < J; k += 2 * KS) {
+            a0 += V[(size_t)k * n + r] * s[k];
+            a1 += V[(size_t)(k + KS) * n + r] * s[k + KS];
+        }
+        if (k < J) a0 += V[(size_t)k * n + r] * s[k];
+        ypart[(size_t)ks * n + r] = a0 + a1;
+    }
+}
+// y = sum over the KS slices, plus the (sum, sum^2, sum|.|) partials of y.
+__global__ __launch_bounds__(kBlock) void k_ritz_combine(const double* __restrict__ ypart, int n, int KS,
+                                                         double* __restrict__ y, double* __restrict__ part) {
+    __shared__ double sm[4];
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
+        double t = 0.0;
+        for (int ks = 0; ks < KS; ++ks) t += ypart[(size_t)ks * n + r];
+        y[r] = t;
+        s1 += t; s2 += t * t; s3 += fabs(t);
+    }
+    s1 = block_sum(s1, sm); s2 = block_sum(s2, sm); s3 = block_sum(s3, sm);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = s1;
+        part[kMaxGrid + blockIdx.x] = s2;
+        part[2 * kMaxGrid + blockIdx.x] = s3;
+    }
+}
+
+// ||w - rq * v||_1 partials, rq = sum of the alpha partials (the Rayleigh quotient v.Lv of the
+// unit vector v): the reference's convergence test numerator (nx:246).
+__global__ __launch_bounds__(kBlock) void k_resid_l1(const double* __restrict__ w, const double* __restrict__ v,
+                                                     int n, const double* __restrict__ part_a, int P_a,
+                                                     double* __restrict__ part_out, double* __restrict__ rq_out) {
+    __shared__ double sm[4];
+    const double rq = reduce_partials(part_a, P_a, sm);
+    double s = 0.0;
+    for (int r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock)
+        s += fabs(w[r] - rq * v[r]);
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) {
+        part_out[blockIdx.x] = s;
+        if (blockIdx.x == 0) *rq_out = rq;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Supergradient  g_k = (w_k (v_i - v_j)) (v_i - v_j)   (mac/solvers/mac.py:117-124; same
+// operation order, no fused multiply-add, so it is bit-exact with the reference given v)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_grad(const int* __restrict__ ci, const int* __restrict__ cj,
+                                                 const double* __restrict__ cw, const double* __restrict__ v,
+                                                 long lo, long hi, double* __restrict__ g) {
+    for (long k = lo + (long)blockIdx.x * kBlock + threadIdx.x; k < hi; k += (long)gridDim.x * kBlock) {
+        const double d = v[ci[k]] - v[cj[k]];
+        g[k] = __dmul_rn(__dmul_rn(cw[k], d), d);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Top-k LP oracle (solve_subset_box_lp, mac/optimization/constraints.py:12-22): radix select
+// of the k-th largest g on order-preserving 64-bit keys, 6 digit passes (11,11,11,11,11,9 bits),
+// LDS histograms flushed with integer atomics; the last workgroup to finish a pass scans the
+// 2048 bins and publishes (prefix, remaining rank) for the next pass.
+// ------------------------------------------------------------------------------------------
+struct SelState {
+    unsigned long long prefix;   // selected high bits so far (right-aligned)
+    long long kk;                // rank still to find inside the selected bucket (1-based, from the top)
+    long long cnt_eq;            // after the last pass: number of keys == T
+    unsigned long long T;        // after the last pass: the k-th largest key
+    long long tie_limit;         // ties with index <= tie_limit are selected
+    unsigned int ticket[8];
+    long long k;                 // requested k
+};
+
+__device__ __forceinline__ unsigned long long f64_key(double d) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(d);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+constexpr int kBins = 2048;
+
+__device__ __forceinline__ int sel_shift(int pass) { return pass < 5 ? 53 - 11 * pass : 0; }
+__device__ __forceinline__ int sel_bits(int pass) { return pass < 5 ? 11 : 9; }
+
+__global__ __launch_bounds__(kBlock) void k_sel_pass(const double* __restrict__ g, long m, int pass,
+                                                     unsigned int* __restrict__ hist /*[6][kBins]*/,
+                                                     SelState* st) {
+    __shared__ unsigned int lh[kBins];
+    __shared__ unsigned int s_last;
+    __shared__ unsigned int s_scan[kBlock];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < kBins; i += kBlock) lh[i] = 0;
+    __syncthreads();
+    const int sh = sel_shift(pass), nb = sel_bits(pass);
+    const unsigned long long prefix = pass ? st->prefix : 0ull;
+    const unsigned int mask = (1u << nb) - 1u;
+    for (long i = (long)blockIdx.x * kBlock + tid; i < m; i += (long)gridDim.x * kBlock) {
+        const unsigned long long key = f64_key(g[i]);
+        const bool match = pass == 0 || (key >> (sh + nb)) == prefix;
+        if (match) atomicAdd(&lh[(unsigned int)(key >> sh) & mask], 1u);
+    }
+    __syncthreads();
+    unsigned int* gh = hist + pass * kBins;
+    for (int i = tid; i < kBins; i += kBlock)
+        if (lh[i]) atomicAdd(&gh[i], lh[i]);
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = (atomicAdd(&st->ticket[pass], 1u) == gridDim.x - 1);
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    // last workgroup: walk the bins from the top until the cumulative count reaches kk
+    const long long kk = pass ? st->kk : st->k;
+    const int nbins = 1 << nb;
+    const int per = kBins / kBlock;   // 8 bins per thread, thread 0 owns the TOP bins
+    unsigned int c[kBins / kBlock];
+    unsigned int tsum = 0;
+    for (int q = 0; q < per; ++q) {
+        const int bin = nbins - 1 - (tid * per + q);
+        c[q] = bin >= 0 ? __hip_atomic_load(&gh[bin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        tsum += c[q];
+    }
+    s_scan[tid] = tsum;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long run = 0;
+        int t = 0;
+        for (; t < kBlock; ++t) {
+            if ((long long)(run + s_scan[t]) >= kk) break;
+            run += s_scan[t];
+        }
+        s_scan[0] = (unsigned int)t;            // owning thread
+        st->kk = kk - (long long)run;           // provisional: rank inside thread t's bins
+    }
+    __syncthreads();
+    const int owner = (int)s_scan[0];
+    if (tid == owner) {
+        long long rem = st->kk;
+        int q = 0;
+        for (; q < per; ++q) {
+            if ((long long)c[q] >= rem) break;
+            rem -= c[q];
+        }
+        const int bin = nbins - 1 - (tid * per + q);
+        st->kk = rem;
+        st->prefix = (prefix << nb) | (unsigned long long)bin;
+        if (pass == 5) {
+            st->T = (prefix << nb) | (unsigned long long)bin;
+            st->cnt_eq = (long long)c[q];
+        }
+    }
+}
+
+// Ties at the k-th value: select the lowest indices.  One workgroup; exits at once in the
+// common case (every key equal to T is needed).
+__global__ __launch_bounds__(1024) void k_sel_ties(const double* __restrict__ g, long m, SelState* st) {
+    __shared__ int s_cnt[16];
+    __shared__ long long s_found;
+    const long long need = st->kk;        // ties to take (>= 1 when k >= 1)
+    const long long eq = st->cnt_eq;
+    if (st->k <= 0) { if (threadIdx.x == 0) st->tie_limit = -1; return; }
+    if (need >= eq) { if (threadIdx.x == 0) st->tie_limit = 0x7fffffffffffffffll; return; }
+    const unsigned long long T = st->T;
+    const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+    if (tid == 0) s_found = -1;
+    long long run = 0;
+    for (long base = 0; base < m; base += 1024) {
+        const long i = base + tid;
+        const bool is = i < m && f64_key(g[i]) == T;
+        const unsigned long long bal = __ballot(is);
+        __syncthreads();
+        if (ln == 0) s_cnt[wv] = __popcll(bal);
+        __syncthreads();
+        int before = 0, tot = 0;
+        for (int q = 0; q < 16; ++q) { if (q < wv) before += s_cnt[q]; tot += s_cnt[q]; }
+        if (run + tot >= need) {
+            const int rank = before + __popcll(bal & ((1ull << ln) - 1ull));   // 0-based among ties here
+            if (is && run + rank + 1 == need) s_found = i;
+            __syncthreads();
+            if (tid == 0) st->tie_limit = s_found;
+            return;
+        }
+        run += tot;
+    }
+    if (tid == 0) st->tie_limit = 0x7fffffffffffffffll;
+}
+
+// Final fused Frank-Wolfe pass (mac/optimization/frankwolfe.py:59-76): s from the threshold,
+// partials of g.(s - x) and g.g, x_next = x + gamma (s - x) (same rounding as NumPy: no fma).
+__global__ __launch_bounds__(kBlock) void k_fw_final(const double* __restrict__ g, const double* __restrict__ x,
+                                                     long m, const SelState* __restrict__ st, double gamma,
+                                                     double* __restrict__ x_next, double* __restrict__ s_out,
+                                                     double* __restrict__ part /*[2][kMaxGrid]*/) {
+    __shared__ double sm[4];
+    const unsigned long long T = st->T;
+    const long long lim = st->tie_limit;
+    const bool none = st->k <= 0;
+    double d = 0.0, q = 0.0;
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < m; i += (long)gridDim.x * kBlock) {
+        const double gi = g[i];
+        const unsigned long long key = f64_key(gi);
+        const double s = (!none && (key > T || (key == T && (long long)i <= lim))) ? 1.0 : 0.0;
+        if (s_out) s_out[i] = s;
+        if (x) {
+            const double xi = x[i];
+            const double diff = s - xi;
+            d += gi * diff;
+            q += gi * gi;
+            if (x_next) x_next[i] = __dadd_rn(xi, __dmul_rn(gamma, diff));
+        }
+    }
+    d = block_sum(d, sm);
+    q = block_sum(q, sm);
+    if (threadIdx.x == 0) { part[blockIdx.x] = d; part[kMaxGrid + blockIdx.x] = q; }
+}
+
+__global__ void k_sel_init(SelState* st, long long k) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        st->prefix = 0; st->kk = k; st->cnt_eq = 0; st->T = 0; st->tie_limit = -1; st->k = k;
+        for (int i = 0; i < 8; ++i) st->ticket[i] = 0;
+    }
+}
+
+}  // namespace machip

@@ -1,0 +1,550 @@
+// machip.hip -- C ABI of libmachip.so (see include/machip.h).  gfx950 only.
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+#include "solver.h"
+
+namespace machip {
+thread_local std::string g_err;
+}
+using namespace machip;
+
+#define NCCL_TRY(expr)                                                                       \
+    do {                                                                                     \
+        ncclResult_t r__ = (expr);                                                           \
+        if (r__ != ncclSuccess)                                                              \
+            return fail(MACHIP_RCCL_ERROR, std::string(#expr) + ": " + ncclGetErrorString(r__)); \
+    } while (0)
+
+struct machip_problem {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int n = 0;
+    long m = 0, m_pad = 0;
+    double tol_sel = 1e-10;
+    // pattern (device)
+    int *prow = nullptr, *pcol = nullptr, *pk = nullptr;
+    double* pw = nullptr;
+    long P = 0;
+    int asm_G = 16, asm_rpb = 1, asm_grid = 1;
+    // candidates (device)
+    int *ci = nullptr, *cj = nullptr;
+    double* cw = nullptr;
+    double *x = nullptr, *x_next = nullptr, *g = nullptr, *s = nullptr;
+    // assembled CSR (device)
+    int *cnt = nullptr, *blk_sum = nullptr, *blk_supp = nullptr, *rowptr = nullptr, *col = nullptr;
+    double *val = nullptr, *blk_lnorm = nullptr;
+    long nnz = 0, support = 0;
+    double lnorm = 0.0;
+    bool assembled = false, have_vec = false, csr_only = false;
+    // select / FW scalars
+    unsigned int* hist = nullptr;
+    SelState* sel = nullptr;
+    double* part_fw = nullptr;
+    // pinned host
+    int* h_int = nullptr;
+    double* h_dbl = nullptr;
+    Solver sol;
+    // multi-GPU
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+
+    CsrView csr() const { return CsrView{n, rowptr, col, val}; }
+    PatternView pattern() const { return PatternView{n, prow, pcol, pk, pw}; }
+};
+
+namespace {
+
+struct Slot {
+    int col;
+    int k;
+    double w;
+};
+
+int build_pattern(machip_problem* p, int64_t nf, const int32_t* fi, const int32_t* fj, const double* fw,
+                  int64_t m, const int32_t* ci, const int32_t* cj, const double* cw) {
+    const int n = p->n;
+    std::vector<long> deg((size_t)n + 1, 0);
+    auto chk = [&](int a, int b) { return a >= 0 && a < n && b >= 0 && b < n; };
+    for (int64_t e = 0; e < nf; ++e) {
+        if (!chk(fi[e], fj[e])) return fail(MACHIP_BAD_ARG, "fixed edge endpoint out of range");
+        if (fi[e] != fj[e]) { deg[(size_t)fi[e]]++; deg[(size_t)fj[e]]++; }
+    }
+    for (int64_t e = 0; e < m; ++e) {
+        if (!chk(ci[e], cj[e])) return fail(MACHIP_BAD_ARG, "candidate edge endpoint out of range");
+        if (ci[e] != cj[e]) { deg[(size_t)ci[e]]++; deg[(size_t)cj[e]]++; }
+    }
+    std::vector<long> off((size_t)n + 1, 0);
+    for (int r = 0; r < n; ++r) off[(size_t)r + 1] = off[(size_t)r] + deg[(size_t)r];
+    std::vector<Slot> slots((size_t)off[(size_t)n]);
+    std::vector<long> cur(off.begin(), off.end() - 1);
+    for (int64_t e = 0; e < nf; ++e) {
+        const int a = fi[e], b = fj[e];
+        if (a == b) continue;   // a self-loop contributes +w -w = 0 (graphs.py:27-46)
+        slots[(size_t)cur[(size_t)a]++] = Slot{b, -1, fw[e]};
+        slots[(size_t)cur[(size_t)b]++] = Slot{a, -1, fw[e]};
+    }
+    for (int64_t e = 0; e < m; ++e) {
+        const int a = ci[e], b = cj[e];
+        if (a == b) continue;
+        slots[(size_t)cur[(size_t)a]++] = Slot{b, (int)e, cw[e]};
+        slots[(size_t)cur[(size_t)b]++] = Slot{a, (int)e, cw[e]};
+    }
+    // sort each row by (col, fixed first, k); merge duplicate fixed slots (coo->csr sums them)
+    std::vector<int> prow((size_t)n + 1, 0);
+    std::vector<int> pcol, pk;
+    std::vector<double> pw;
+    pcol.reserve(slots.size()); pk.reserve(slots.size()); pw.reserve(slots.size());
+    for (int r = 0; r < n; ++r) {
+        Slot* b = slots.data() + off[(size_t)r];
+        Slot* e = slots.data() + off[(size_t)r + 1];
+        std::sort(b, e, [](const Slot& x, const Slot& y) {
+            if (x.col != y.col) return x.col < y.col;
+            return x.k < y.k;
+        });
+        for (Slot* q = b; q < e; ++q) {
+            if (q->k < 0 && !pcol.empty() && (long)pcol.size() > prow[(size_t)r] && pcol.back() == q->col &&
+                pk.back() < 0) {
+                pw.back() += q->w;
+            } else {
+                pcol.push_back(q->col); pk.push_back(q->k); pw.push_back(q->w);
+            }
+        }
+        if (pcol.size() > 2000000000ull) return fail(MACHIP_BAD_ARG, "pattern exceeds int32 indexing");
+        prow[(size_t)r + 1] = (int)pcol.size();
+    }
+    p->P = (long)pcol.size();
+    ST_TRY(dev_alloc(&p->prow, (size_t)n + 1));
+    ST_TRY(dev_alloc(&p->pcol, (size_t)p->P)); ST_TRY(dev_alloc(&p->pk, (size_t)p->P)); ST_TRY(dev_alloc(&p->pw, (size_t)p->P));
+    HIP_TRY(hipMemcpy(p->prow, prow.data(), sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice));
+    if (p->P) {
+        HIP_TRY(hipMemcpy(p->pcol, pcol.data(), sizeof(int) * (size_t)p->P, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(p->pk, pk.data(), sizeof(int) * (size_t)p->P, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(p->pw, pw.data(), sizeof(double) * (size_t)p->P, hipMemcpyHostToDevice));
+    }
+    // assembly launch shape: G lanes per row ~ half the mean pattern degree
+    const double mean = n ? (double)p->P / n : 1.0;
+    int G = 4;
+    while (G < 64 && G < mean * 0.75) G <<= 1;
+    p->asm_G = env_int("MACHIP_ASM_G", G);
+    const int gpb = kBlock / p->asm_G;
+    long nblk = std::min<long>(kMaxGrid, ((long)n + gpb - 1) / gpb);
+    if (nblk < 1) nblk = 1;
+    long rpb = ((long)n + nblk - 1) / nblk;
+    rpb = (rpb + gpb - 1) / gpb * gpb;
+    p->asm_rpb = (int)rpb;
+    p->asm_grid = (int)(((long)n + rpb - 1) / rpb);
+    if (p->asm_grid < 1) p->asm_grid = 1;
+    return MACHIP_OK;
+}
+
+template <int G>
+void launch_asm(machip_problem* p) {
+    const PatternView P = p->pattern();
+    k_asm_count<G><<<p->asm_grid, kBlock, 0, p->stream>>>(P, p->x, p->tol_sel, p->asm_rpb, p->cnt, p->blk_sum,
+                                                          p->blk_supp);
+    const size_t lds = sizeof(int) * ((size_t)p->asm_rpb + 1);
+    k_asm_fill<G><<<p->asm_grid, kBlock, lds, p->stream>>>(P, p->x, p->tol_sel, p->asm_rpb, p->cnt, p->blk_sum,
+                                                           p->rowptr, p->col, p->val, p->blk_lnorm);
+}
+
+int assemble(machip_problem* p) {
+    if (p->csr_only) return fail(MACHIP_BAD_ARG, "handle wraps a caller CSR; nothing to assemble");
+    switch (p->asm_G) {
+        case 4: launch_asm<4>(p); break;
+        case 8: launch_asm<8>(p); break;
+        case 16: launch_asm<16>(p); break;
+        case 32: launch_asm<32>(p); break;
+        default: launch_asm<64>(p); break;
+    }
+    const int gb = p->asm_grid;
+    HIP_TRY(hipMemcpyAsync(p->h_int, p->blk_sum, sizeof(int) * (size_t)gb, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->h_int + kMaxGrid, p->blk_supp, sizeof(int) * (size_t)gb, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->h_dbl, p->blk_lnorm, sizeof(double) * (size_t)gb, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    long nnz = 0, supp = 0;
+    double ln = 0.0;
+    for (int b = 0; b < gb; ++b) { nnz += p->h_int[b]; supp += p->h_int[kMaxGrid + b]; ln = std::max(ln, p->h_dbl[b]); }
+    p->nnz = nnz; p->support = supp; p->lnorm = ln;
+    p->assembled = true;
+    return MACHIP_OK;
+}
+
+int alloc_common(machip_problem* p) {
+    ST_TRY(p->sol.init(p->n, p->stream));
+    HIP_TRY(hipHostMalloc((void**)&p->h_int, sizeof(int) * 2 * kMaxGrid, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&p->h_dbl, sizeof(double) * 4 * kMaxGrid, hipHostMallocDefault));
+    return MACHIP_OK;
+}
+
+int select_topk(machip_problem* p, long k) {
+    const long m = p->m;
+    if (k < 0) k = 0;
+    if (k > m) k = m;
+    HIP_TRY(hipMemsetAsync(p->hist, 0, sizeof(unsigned int) * 6 * kBins, p->stream));
+    k_sel_init<<<1, 64, 0, p->stream>>>(p->sel, (long long)k);
+    if (k > 0) {
+        const int grid = (int)std::min<long>(kMaxGrid, (m + kBlock * 4 - 1) / (kBlock * 4));
+        for (int pass = 0; pass < 6; ++pass)
+            k_sel_pass<<<std::max(grid, 1), kBlock, 0, p->stream>>>(p->g, m, pass, p->hist, p->sel);
+        k_sel_ties<<<1, 1024, 0, p->stream>>>(p->g, m, p->sel);
+    }
+    return MACHIP_OK;
+}
+
+int compute_gradient(machip_problem* p) {
+    if (!p->have_vec) return fail(MACHIP_BAD_ARG, "no Fiedler vector on the device: call machip_fiedler first");
+    const long m = p->m;
+    long lo = 0, hi = m;
+    if (p->nranks > 1) {
+        const long shard = p->m_pad / p->nranks;
+        lo = std::min(m, shard * p->rank);
+        hi = std::min(m, lo + shard);
+    }
+    if (hi > lo) {
+        const int grid = (int)std::min<long>(kMaxGrid * 4, (hi - lo + kBlock - 1) / kBlock);
+        k_grad<<<grid, kBlock, 0, p->stream>>>(p->ci, p->cj, p->cw, p->sol.yvec, lo, hi, p->g);
+    }
+    if (p->nranks > 1) {
+        const long shard = p->m_pad / p->nranks;
+        NCCL_TRY(ncclAllGather(p->g + shard * p->rank, p->g, (size_t)shard, ncclDouble, p->comm, p->stream));
+    }
+    return MACHIP_OK;
+}
+
+int run_fiedler(machip_problem* p, double tol, int max_steps, const double* x0, int warm_start,
+                double* lambda2, machip_solve_stats* stats) {
+    if (!p->assembled) ST_TRY(assemble(p));
+    if (x0) {
+        HIP_TRY(hipMemcpyAsync(p->sol.start, x0, sizeof(double) * (size_t)p->n, hipMemcpyHostToDevice, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        p->sol.have_start = true;
+    }
+    machip_solve_stats local;
+    memset(&local, 0, sizeof(local));
+    const int st = p->sol.solve(p->csr(), p->nnz, p->lnorm, tol, max_steps, (x0 == nullptr && warm_start) ? 1 : 0,
+                                kAuto, lambda2, &local);
+    local.support = p->support;
+    if (stats) *stats = local;
+    p->have_vec = (st == MACHIP_OK || st == MACHIP_NOT_CONVERGED || st == MACHIP_DISCONNECTED);
+    return st;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+int machip_version(void) { return MACHIP_ABI_VERSION; }
+
+int machip_device_count(void) {
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+    return c;
+}
+
+const char* machip_last_error(void) { return g_err.c_str(); }
+
+int machip_create(int device, int64_t n, int64_t n_fixed, const int32_t* fi, const int32_t* fj, const double* fw,
+                  int64_t m, const int32_t* ci, const int32_t* cj, const double* cw, double min_sel_tol,
+                  machip_problem** out) {
+    if (!out) return fail(MACHIP_BAD_ARG, "out is NULL");
+    *out = nullptr;
+    if (n < 2 || n > 2000000000ll) return fail(MACHIP_BAD_ARG, "num_nodes must be in [2, 2e9]");
+    if (n_fixed < 0 || m < 0 || m > 2000000000ll) return fail(MACHIP_BAD_ARG, "bad edge counts");
+    if ((n_fixed && (!fi || !fj || !fw)) || (m && (!ci || !cj || !cw))) return fail(MACHIP_BAD_ARG, "NULL edge array");
+    // mac/solvers/mac.py:46-52
+    if (n_fixed + m < n - 1) return fail(MACHIP_BAD_ARG, "fewer than n-1 edges: no spanning tree possible");
+    if ((double)(n_fixed + m) > 0.5 * (double)n * (double)(n - 1)) return fail(MACHIP_BAD_ARG, "more edges than the complete graph");
+    if (machip_device_count() <= 0) return fail(MACHIP_NO_DEVICE, "no HIP device visible");
+    HIP_TRY(hipSetDevice(device));
+    machip_problem* p = new machip_problem();
+    p->device = device;
+    p->n = (int)n;
+    p->m = (long)m;
+    p->m_pad = (long)m;
+    p->tol_sel = min_sel_tol;
+    int st = MACHIP_OK;
+    auto body = [&]() -> int {
+        HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+        ST_TRY(build_pattern(p, n_fixed, fi, fj, fw, m, ci, cj, cw));
+        const size_t mp = (size_t)m + 64 * 8;   // slack so a later all-gather padding fits
+        ST_TRY(dev_alloc(&p->ci, mp)); ST_TRY(dev_alloc(&p->cj, mp)); ST_TRY(dev_alloc(&p->cw, mp));
+        ST_TRY(dev_alloc(&p->x, mp)); ST_TRY(dev_alloc(&p->x_next, mp)); ST_TRY(dev_alloc(&p->g, mp)); ST_TRY(dev_alloc(&p->s, mp));
+        if (m) {
+            HIP_TRY(hipMemcpy(p->ci, ci, sizeof(int) * (size_t)m, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(p->cj, cj, sizeof(int) * (size_t)m, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(p->cw, cw, sizeof(double) * (size_t)m, hipMemcpyHostToDevice));
+        }
+        HIP_TRY(hipMemset(p->x, 0, sizeof(double) * mp));
+        HIP_TRY(hipMemset(p->g, 0, sizeof(double) * mp));
+        const size_t cap = (size_t)p->P + (size_t)n + 8;
+        ST_TRY(dev_alloc(&p->cnt, (size_t)n + 1)); ST_TRY(dev_alloc(&p->blk_sum, kMaxGrid)); ST_TRY(dev_alloc(&p->blk_supp, kMaxGrid));
+        ST_TRY(dev_alloc(&p->rowptr, (size_t)n + 1)); ST_TRY(dev_alloc(&p->col, cap)); ST_TRY(dev_alloc(&p->val, cap));
+        ST_TRY(dev_alloc(&p->blk_lnorm, kMaxGrid));
+        ST_TRY(dev_alloc(&p->hist, 6 * kBins)); ST_TRY(dev_alloc(&p->sel, 1)); ST_TRY(dev_alloc(&p->part_fw, 2 * kMaxGrid));
+        ST_TRY(alloc_common(p));
+        return MACHIP_OK;
+    };
+    st = body();
+    if (st != MACHIP_OK) { machip_destroy(p); return st; }
+    *out = p;
+    return MACHIP_OK;
+}
+
+void machip_destroy(machip_problem* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    if (p->comm) (void)ncclCommDestroy(p->comm);
+    p->sol.destroy();
+    void* ptrs[] = {p->prow, p->pcol, p->pk, p->pw, p->ci, p->cj, p->cw, p->x, p->x_next, p->g, p->s, p->cnt,
+                    p->blk_sum, p->blk_supp, p->rowptr, p->col, p->val, p->blk_lnorm, p->hist, p->sel, p->part_fw};
+    for (void* q : ptrs) if (q) (void)hipFree(q);
+    if (p->h_int) (void)hipHostFree(p->h_int);
+    if (p->h_dbl) (void)hipHostFree(p->h_dbl);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+}
+
+int machip_set_x(machip_problem* p, const double* x) {
+    if (!p || !x || p->csr_only) return fail(MACHIP_BAD_ARG, "machip_set_x: bad handle or NULL x");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipMemcpyAsync(p->x, x, sizeof(double) * (size_t)p->m, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    p->assembled = false;
+    return MACHIP_OK;
+}
+
+int machip_get_x(machip_problem* p, double* x) {
+    if (!p || !x || p->csr_only) return fail(MACHIP_BAD_ARG, "machip_get_x: bad handle or NULL x");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipMemcpyAsync(x, p->x, sizeof(double) * (size_t)p->m, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return MACHIP_OK;
+}
+
+int machip_assemble(machip_problem* p, int64_t* nnz_out) {
+    if (!p) return fail(MACHIP_BAD_ARG, "NULL handle");
+    HIP_TRY(hipSetDevice(p->device));
+    ST_TRY(assemble(p));
+    if (nnz_out) *nnz_out = p->nnz;
+    return MACHIP_OK;
+}
+
+int machip_get_laplacian(machip_problem* p, int32_t* indptr, int32_t* indices, double* data) {
+    if (!p || !indptr || !indices || !data) return fail(MACHIP_BAD_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(p->device));
+    if (!p->assembled) ST_TRY(assemble(p));
+    HIP_TRY(hipMemcpyAsync(indptr, p->rowptr, sizeof(int) * ((size_t)p->n + 1), hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpyAsync(indices, p->col, sizeof(int) * (size_t)p->nnz, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpyAsync(data, p->val, sizeof(double) * (size_t)p->nnz, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return MACHIP_OK;
+}
+
+int machip_fiedler(machip_problem* p, double tol, int max_steps, const double* x0, int warm_start,
+                   double* lambda2, double* v_out, double* X_out, int q, machip_solve_stats* stats) {
+    if (!p || !lambda2) return fail(MACHIP_BAD_ARG, "NULL argument");
+    if (X_out && (q < 1 || q > 4)) return fail(MACHIP_BAD_ARG, "q must be in [1,4]");
+    HIP_TRY(hipSetDevice(p->device));
+    const int st = run_fiedler(p, tol, max_steps, x0, warm_start, lambda2, stats);
+    if (st != MACHIP_OK && st != MACHIP_NOT_CONVERGED && st != MACHIP_DISCONNECTED) return st;
+    const std::string keep = g_err;
+    if (v_out) {
+        HIP_TRY(hipMemcpyAsync(v_out, p->sol.yvec, sizeof(double) * (size_t)p->n, hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+    }
+    if (X_out) ST_TRY(p->sol.ritz_block(q, X_out));
+    g_err = keep;
+    return st;
+}
+
+int machip_set_start(machip_problem* p, const double* x0) {
+    if (!p || !x0) return fail(MACHIP_BAD_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipMemcpyAsync(p->sol.start, x0, sizeof(double) * (size_t)p->n, hipMemcpyHostToDevice, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    p->sol.have_start = true;
+    return MACHIP_OK;
+}
+
+int machip_gradient(machip_problem* p, double* g_out) {
+    if (!p || p->csr_only) return fail(MACHIP_BAD_ARG, "bad handle");
+    HIP_TRY(hipSetDevice(p->device));
+    ST_TRY(compute_gradient(p));
+    if (g_out) HIP_TRY(hipMemcpyAsync(g_out, p->g, sizeof(double) * (size_t)p->m, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return MACHIP_OK;
+}
+
+int machip_lp_topk(machip_problem* p, int64_t k, double* s_out) {
+    if (!p || p->csr_only) return fail(MACHIP_BAD_ARG, "bad handle");
+    HIP_TRY(hipSetDevice(p->device));
+    ST_TRY(select_topk(p, (long)k));
+    const int grid = (int)std::min<long>(kMaxGrid, (p->m + kBlock - 1) / kBlock);
+    k_fw_final<<<std::max(grid, 1), kBlock, 0, p->stream>>>(p->g, nullptr, p->m, p->sel, 0.0, nullptr, p->s, p->part_fw);
+    if (s_out) HIP_TRY(hipMemcpyAsync(s_out, p->s, sizeof(double) * (size_t)p->m, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return MACHIP_OK;
+}
+
+int machip_fw_step(machip_problem* p, int64_t k, int iter, double tol, int max_steps, int warm_start,
+                   double* f, double* dual, double* gnorm, machip_solve_stats* stats) {
+    if (!p || p->csr_only || !f || !dual || !gnorm) return fail(MACHIP_BAD_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(p->device));
+    ST_TRY(assemble(p));
+    double lam = 0.0;
+    ST_TRY(run_fiedler(p, tol, max_steps, nullptr, warm_start, &lam, stats));
+    ST_TRY(compute_gradient(p));
+    ST_TRY(select_topk(p, (long)k));
+    const int grid = std::max(1, (int)std::min<long>(kMaxGrid, (p->m + kBlock - 1) / kBlock));
+    const double gamma = 2.0 / ((double)iter + 2.0);   // frankwolfe.py:7-8
+    k_fw_final<<<grid, kBlock, 0, p->stream>>>(p->g, p->x, p->m, p->sel, gamma, p->x_next, nullptr, p->part_fw);
+    HIP_TRY(hipMemcpyAsync(p->h_dbl, p->part_fw, sizeof(double) * 2 * kMaxGrid, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    double d = 0.0, q2 = 0.0;
+    for (int b = 0; b < grid; ++b) { d += p->h_dbl[b]; q2 += p->h_dbl[kMaxGrid + b]; }
+    *f = lam;
+    *dual = lam + d;
+    *gnorm = std::sqrt(q2);
+    return MACHIP_OK;
+}
+
+int machip_fw_commit(machip_problem* p) {
+    if (!p || p->csr_only) return fail(MACHIP_BAD_ARG, "bad handle");
+    std::swap(p->x, p->x_next);
+    p->assembled = false;
+    return MACHIP_OK;
+}
+
+int machip_fiedler_csr(int device, int64_t n, const int32_t* indptr, const int32_t* indices, const double* data,
+                       double tol, int max_steps, const double* x0, double* lambda2, double* v_out, double* X_out,
+                       int q, machip_solve_stats* stats) {
+    if (!indptr || !indices || !data || !lambda2) return fail(MACHIP_BAD_ARG, "NULL argument");
+    if (n < 2 || n > 2000000000ll) return fail(MACHIP_BAD_ARG, "n must be in [2, 2e9]");
+    if (X_out && (q < 1 || q > 4)) return fail(MACHIP_BAD_ARG, "q must be in [1,4]");
+    if (machip_device_count() <= 0) return fail(MACHIP_NO_DEVICE, "no HIP device visible");
+    HIP_TRY(hipSetDevice(device));
+    const long nnz = indptr[n];
+    if (indptr[0] != 0 || nnz < 0) return fail(MACHIP_BAD_ARG, "bad indptr");
+    double lnorm = 0.0;
+    for (int64_t r = 0; r < n; ++r) {
+        if (indptr[r + 1] < indptr[r]) return fail(MACHIP_BAD_ARG, "indptr not monotone");
+        double s = 0.0;
+        for (int pp = indptr[r]; pp < indptr[r + 1]; ++pp) {
+            if (indices[pp] < 0 || indices[pp] >= n) return fail(MACHIP_BAD_ARG, "column index out of range");
+            s += std::fabs(data[pp]);
+        }
+        lnorm = std::max(lnorm, s);   // nx:232
+    }
+    machip_problem* p = new machip_problem();
+    p->device = device; p->n = (int)n; p->csr_only = true;
+    auto body = [&]() -> int {
+        HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+        ST_TRY(dev_alloc(&p->rowptr, (size_t)n + 1)); ST_TRY(dev_alloc(&p->col, (size_t)nnz)); ST_TRY(dev_alloc(&p->val, (size_t)nnz));
+        HIP_TRY(hipMemcpy(p->rowptr, indptr, sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice));
+        if (nnz) {
+            HIP_TRY(hipMemcpy(p->col, indices, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(p->val, data, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
+        }
+        ST_TRY(alloc_common(p));
+        p->nnz = nnz; p->lnorm = lnorm; p->assembled = true;
+        return MACHIP_OK;
+    };
+    int st = body();
+    if (st == MACHIP_OK) st = machip_fiedler(p, tol, max_steps, x0, 0, lambda2, v_out, X_out, q, stats);
+    const std::string keep = g_err;
+    machip_destroy(p);
+    g_err = keep;
+    return st;
+}
+
+int machip_spmv(machip_problem* p, const double* v, double* y, int variant) {
+    if (!p || !v || !y) return fail(MACHIP_BAD_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(p->device));
+    if (!p->assembled) ST_TRY(assemble(p));
+    HIP_TRY(hipMemcpyAsync(p->sol.y_raw, v, sizeof(double) * (size_t)p->n, hipMemcpyHostToDevice, p->stream));
+    const SpmvPlan pl = plan_spmv(p->n, p->nnz, variant);
+    OpPlain op{p->sol.w2};
+    launch_spmv(pl, p->stream, p->csr(), p->sol.y_raw, op);
+    HIP_TRY(hipMemcpyAsync(y, p->sol.w2, sizeof(double) * (size_t)p->n, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return MACHIP_OK;
+}
+
+int machip_profile_spmv(machip_problem* p, int reps, double* avg_us, double* bytes_per_launch) {
+    if (!p || !avg_us || reps < 1) return fail(MACHIP_BAD_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(p->device));
+    if (!p->assembled) ST_TRY(assemble(p));
+    Solver& S = p->sol;
+    const SpmvPlan pl = plan_spmv(p->n, p->nnz, kAuto);
+    // a self-contained Lanczos "column 1" step on scratch state, repeated: same kernel, same
+    // traffic as in the solve (matrix + gathers + v_{j-1} read + w, v_j writes).
+    k_fill_start<<<S.vgrid(), kBlock, 0, p->stream>>>(S.u, p->n, 77ull);
+    k_vec_sums<<<S.vgrid(), kBlock, 0, p->stream>>>(S.u, p->n, S.part_u);
+    k_set_state<<<1, 64, 0, p->stream>>>(S.st, 1);
+    OpLanczos op;
+    op.L = S.view(pl);
+    for (int i = 0; i < 3; ++i) launch_spmv(pl, p->stream, p->csr(), S.u, op);
+    HIP_TRY(hipEventRecord(S.ev0, p->stream));
+    for (int i = 0; i < reps; ++i) launch_spmv(pl, p->stream, p->csr(), S.u, op);
+    HIP_TRY(hipEventRecord(S.ev1, p->stream));
+    HIP_TRY(hipEventSynchronize(S.ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, S.ev0, S.ev1));
+    *avg_us = 1e3 * (double)ms / reps;
+    if (bytes_per_launch) {
+        // B_spmv = nnz*(8+4) + (n+1)*4 + n*8 [x] + n*8 [y]; fused extras: u own-row
+        // read, v_{j-1} read, v_j write = 3*n*8.
+        *bytes_per_launch = (double)p->nnz * 12.0 + ((double)p->n + 1.0) * 4.0 + (double)p->n * 8.0 * 5.0;
+    }
+    p->have_vec = false;
+    return MACHIP_OK;
+}
+
+int machip_comm_unique_id(void* id128) {
+    if (!id128) return fail(MACHIP_BAD_ARG, "NULL id buffer");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+    ncclUniqueId id;
+    NCCL_TRY(ncclGetUniqueId(&id));
+    memcpy(id128, &id, sizeof(id));
+    return MACHIP_OK;
+}
+
+int machip_comm_init(machip_problem* p, int rank, int nranks, const void* id128) {
+    if (!p || p->csr_only || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(MACHIP_BAD_ARG, "bad argument");
+    if (nranks > 64) return fail(MACHIP_BAD_ARG, "at most 64 ranks");
+    HIP_TRY(hipSetDevice(p->device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    NCCL_TRY(ncclCommInitRank(&p->comm, nranks, id, rank));
+    p->rank = rank; p->nranks = nranks;
+    const long shard = (p->m + nranks - 1) / nranks;
+    p->m_pad = shard * nranks;   // <= m + 63 < allocation slack
+    return MACHIP_OK;
+}
+
+int machip_synchronize(machip_problem* p) {
+    if (!p) return fail(MACHIP_BAD_ARG, "NULL handle");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return MACHIP_OK;
+}
+
+// Host-only helper exported for CPU tests of the tridiagonal analysis (not part of the
+// reference surface): smallest eigenpair of the J x J symmetric tridiagonal (a, b[1..J)).
+int machip_host_tridiag_smallest(const double* a, const double* b, int J, double* theta, double* s) {
+    if (!a || !b || J < 1 || !theta || !s) return fail(MACHIP_BAD_ARG, "bad argument");
+    tri::Smallest sm;
+    std::vector<double> wk;
+    tri::smallest_eigpair(a, b, J, nullptr, 0, 0.0, sm, wk);
+    *theta = sm.theta;
+    for (int i = 0; i < J; ++i) s[i] = sm.s[(size_t)i];
+    return MACHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,137 @@
+"""MAC: maximise algebraic connectivity by Frank-Wolfe, same public surface as the
+reference class (mac/solvers/mac.py:16-225), hot path on the MI355X.
+
+Resident on the GPU for the lifetime of the object: the union sparsity pattern of
+fixed + candidate edges, candidate endpoints/weights, x, the gradient, the Fiedler
+vector and the Lanczos basis.  Per Frank-Wolfe iteration only three scalars
+(f, dual bound, ||g||) cross PCIe.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from timeit import default_timer as timer
+from typing import Optional
+
+import numpy as np
+from scipy.sparse import csr_matrix
+
+from mac_amd import _lib
+from mac_amd.utils import fiedler as _fiedler
+from mac_amd.utils.graphs import edges_to_arrays, weight_graph_lap_from_edge_list
+from mac_amd.utils.rounding import round_madow, round_nearest
+
+
+class MAC:
+    @dataclass
+    class Cache:
+        """Warm-start slot (mac/solvers/mac.py:17-20).  In the reference the cache is
+        written back with the old block (mac.py:126-127) and never takes effect; here
+        ``use_cache=True`` warm-starts each eigen-solve from the previous Fiedler vector,
+        which stays on the device.  ``Q`` mirrors the last Ritz block when requested."""
+        Q: Optional[np.ndarray] = None
+
+    def __init__(self, fixed_edges, candidate_edges, num_nodes, fiedler_method="hip",
+                 fiedler_tol=1e-8, min_selection_weight_tol=1e-10, device=0, max_lanczos_steps=0):
+        _fiedler.check_method(fiedler_method)
+        num_edges = len(fixed_edges) + len(candidate_edges)
+        assert (num_nodes - 1) <= num_edges                        # mac.py:47
+        assert num_edges <= 0.5 * num_nodes * (num_nodes - 1)      # mac.py:52
+
+        self.L_fixed = weight_graph_lap_from_edge_list(fixed_edges, num_nodes)   # mac.py:55
+        self.num_nodes = num_nodes
+        fi, fj, fw = edges_to_arrays(fixed_edges)
+        ci, cj, cw = edges_to_arrays(candidate_edges)
+        self.weights = cw                                            # mac.py:58-65
+        self.edge_list = np.stack([ci.astype(np.int64), cj.astype(np.int64)], axis=1) if len(cw) else \
+            np.zeros((0, 2), dtype=np.int64)
+        self.fiedler_method = fiedler_method
+        self.fiedler_tol = fiedler_tol
+        self.min_selection_weight_tol = min_selection_weight_tol
+        self.max_lanczos_steps = max_lanczos_steps
+        self._dev = _lib.Problem(num_nodes, fi, fj, fw, ci, cj, cw,
+                                 min_selection_weight_tol=min_selection_weight_tol, device=device)
+        # every cold eigen-solve starts from column 0 of the reference's block (fiedler.py:27-32)
+        self._dev.set_start(_fiedler.reference_start_block(num_nodes)[:, 0].copy())
+        self.last_stats = None
+
+    # -------------------------------------------------------------------------------
+    def laplacian(self, x):
+        """L(x) as scipy CSR, assembled on the device (mac.py:74-89)."""
+        self._dev.set_x(np.asarray(x, dtype=np.float64))
+        indptr, indices, data = self._dev.laplacian_csr()
+        L = csr_matrix((data, indices, indptr), shape=(self.num_nodes, self.num_nodes))
+        L.sum_duplicates()
+        L.sort_indices()
+        return L
+
+    def evaluate_objective(self, x):
+        """lambda_2(L(x)) with the configured tolerance (mac.py:91-102)."""
+        self._dev.set_x(np.asarray(x, dtype=np.float64))
+        lam, _, _ = self._dev.fiedler(tol=self.fiedler_tol, max_steps=self.max_lanczos_steps,
+                                      want_vec=False)
+        self.last_stats = self._dev.stats.asdict()
+        return lam
+
+    def problem(self, x, cache=None):
+        """(lambda_2(L(x)), supergradient) (mac.py:104-128).  The reference always solves
+        with tol 1e-8 here (mac.py:115); so does this."""
+        self._dev.set_x(np.asarray(x, dtype=np.float64))
+        warm = cache is not None and cache.Q is not None
+        f, _, _ = self._dev.fiedler(tol=1e-8, max_steps=self.max_lanczos_steps,
+                                    warm_start=warm, want_vec=False)
+        self.last_stats = self._dev.stats.asdict()
+        gradf = self._dev.gradient()
+        if cache is not None:
+            cache.Q = True      # marker: the warm-start vector lives on the device
+        return f, gradf
+
+    def solve(self, k, x_init=None, rounding="nearest", fallback=False, max_iters=5,
+              relative_duality_gap_tol=1e-4, grad_norm_tol=1e-8, random_rounding_max_iters=1,
+              verbose=False, return_rounding_time=False, use_cache=False):
+        """Frank-Wolfe on the relaxation, then rounding (mac.py:130-225); returns
+        ``(rounded, unrounded, upper_bound[, rounding_time])``."""
+        m = len(self.weights)
+        if k >= m:                                                   # mac.py:173-180
+            result = np.ones(m)
+            val = self.evaluate_objective(result)
+            if return_rounding_time:
+                return result, result, val, 0.0
+            return result, result, val
+
+        assert len(x_init) == m                                       # mac.py:183
+        dev = self._dev
+        dev.set_x(np.asarray(x_init, dtype=np.float64))
+        u = float("inf")
+        self.trace = []
+        for i in range(max_iters):                                    # frankwolfe.py:53-76
+            f, dual, gnorm = dev.fw_step(k, i, tol=1e-8, max_steps=self.max_lanczos_steps,
+                                         warm_start=bool(use_cache and i > 0))
+            u = min(u, dual)
+            st = dev.stats
+            self.trace.append((f, u, gnorm, int(st.support), int(st.lanczos_steps)))
+            if verbose:
+                print(f"[mac_amd] it {i}: f={f:.12g} u={u:.12g} |g|={gnorm:.3g} "
+                      f"supp={st.support} lanczos={st.lanczos_steps}")
+            if gnorm < grad_norm_tol:
+                break
+            if (u - f) < relative_duality_gap_tol * abs(f):
+                break
+            dev.fw_commit()
+        w = dev.get_x()
+
+        start = timer()
+        if rounding == "madow":
+            rounded = round_madow(w, k, value_fn=self.evaluate_objective, max_iters=random_rounding_max_iters)
+        else:
+            rounded = round_nearest(w, k, weights=self.weights, break_ties_decimal_tol=10)
+        rounding_time = timer() - start
+
+        if fallback:
+            # The reference references an undefined name here (mac.py:218, NameError); the
+            # evident intent -- keep the initial point if rounding made it worse -- is implemented.
+            if self.evaluate_objective(rounded) < self.evaluate_objective(x_init):
+                rounded = np.asarray(x_init, dtype=np.float64)
+
+        if return_rounding_time:
+            return rounded, w, u, rounding_time
+        return rounded, w, u

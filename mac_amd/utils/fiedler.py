@@ -1,0 +1,59 @@
+"""find_fiedler_pair with the reference's signature (mac/utils/fiedler.py:9-44), computed
+on the MI355X by libmachip (Lanczos on L restricted to 1-perp, stop rule = the
+reference's ||Lv - lambda v||_1 / ||L||_inf < tol)."""
+from __future__ import annotations
+
+import numpy as np
+from scipy.sparse import csr_matrix
+
+from mac_amd import _lib
+
+HIP_METHODS = ("hip", "hip_lanczos")
+# method strings of the reference (fiedler.py:38-42 / nx:215-229): accepted so existing call
+# sites run unchanged; the eigen-solve is still the HIP one.
+REFERENCE_METHODS = ("tracemin_lu", "tracemin_cholesky", "tracemin_pcg")
+
+try:  # the reference raises networkx.NetworkXError for unknown methods (nx:229)
+    from networkx import NetworkXError as _BaseErr
+except Exception:  # pragma: no cover
+    _BaseErr = ValueError
+
+
+class UnknownFiedlerMethod(_BaseErr):
+    pass
+
+
+def check_method(method):
+    if method not in HIP_METHODS and method not in REFERENCE_METHODS:
+        raise UnknownFiedlerMethod(f"Unknown linear system solver: {method}")
+
+
+def reference_start_block(n, seed=None):
+    """The reference's start block: RandomState(7).normal(size=(q, n)).T, q = min(4, n-1)
+    (fiedler.py:27-32)."""
+    if seed is None:
+        seed = np.random.RandomState(7)
+    q = min(4, n - 1)
+    return np.asarray(seed.normal(size=(q, n))).T
+
+
+def find_fiedler_pair(L, X=None, method="hip", tol=1e-8, seed=None):
+    """Second-smallest eigenpair of the graph Laplacian ``L`` (any scipy sparse matrix).
+
+    Returns ``(lambda_2, v_2, X)`` like the reference: X is n x q (q = min(4, n-1)), its
+    column 0 is v_2 (unit norm, orthogonal to 1) and the other columns are the next Ritz
+    vectors of the Krylov space.  ``X`` (if given) supplies the start vector in column 0.
+    """
+    check_method(method)
+    L = csr_matrix(L, dtype=np.float64)
+    n = L.shape[0]
+    q = min(4, n - 1)
+    if X is None:
+        X = reference_start_block(n, seed)
+    assert X.shape[0] == L.shape[0]      # fiedler.py:35-36
+    assert X.shape[1] == q
+    L.sum_duplicates()
+    lam, v, Xo, _ = _lib.fiedler_csr(L.indptr, L.indices, L.data, n, tol=tol,
+                                      x0=np.ascontiguousarray(X[:, 0]), q=q)
+    Xo = np.asfortranarray(Xo)
+    return lam, Xo[:, 0], Xo

@@ -1,0 +1,368 @@
+"""GPU parity tests: every call goes through the C ABI of libmachip.so (ctypes) and is compared
+with the CPU oracle on the same inputs, with the committed golden vectors of the reference, and
+-- at BASELINE.json's full sizes -- through size-independent identities.
+
+Tolerances (BASELINE.json north_star: fp64, lambda_2 within 1e-8 relative):
+  lambda_2: 1e-8 relative;  Fiedler vector: max |v - v_ref| <= 2e-6 after sign alignment (both
+  sides stop at residual 1e-8);  supergradient: 1e-5 relative to max|g| across solvers and
+  BIT-EXACT given the same vector;  assembly: structure exact, values exact off-diagonal,
+  diagonal to 1e-14 relative;  top-k / x update: bit-exact.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import oracle
+from conftest import load_golden, sign_align
+from mac_amd import _lib
+from mac_amd.solvers import MAC, NaiveGreedy
+from mac_amd.utils.fiedler import find_fiedler_pair, reference_start_block
+from mac_amd.utils.graphs import Edge, weight_graph_lap_from_edge_list
+
+pytestmark = pytest.mark.gpu
+
+LAM_RTOL = 1e-8
+
+
+def edges_of(g, pre):
+    return [Edge(int(a), int(b), float(w)) for a, b, w in zip(g[pre + "i"], g[pre + "j"], g[pre + "w"])]
+
+
+def problem_of(g):
+    return _lib.Problem(int(g["n"]), g["fi"], g["fj"], g["fw"], g["ci"], g["cj"], g["cw"])
+
+
+def oracle_of(g):
+    return oracle.MacOracle(g["fi"], g["fj"], g["fw"], g["ci"], g["cj"], g["cw"], int(g["n"]))
+
+
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nm", ["petersen_x0", "er300_x0", "er300_xfrac", "er2000_x0", "er2000_xfrac"])
+def test_assembly_matches_reference(nm):
+    g = load_golden(nm)
+    P = problem_of(g)
+    P.set_x(g["x"])
+    indptr, indices, data = P.laplacian_csr()
+    n = int(g["n"])
+    # diagonal first, then sorted columns
+    for r in [0, n // 2, n - 1]:
+        assert indices[indptr[r]] == r
+        assert np.all(np.diff(indices[indptr[r] + 1:indptr[r + 1]]) > 0)
+    L = sp.csr_matrix((data, indices, indptr), shape=(n, n))
+    L.sort_indices()
+    assert np.array_equal(L.indptr, g["L_indptr"]) and np.array_equal(L.indices, g["L_indices"])
+    off = L.indices != np.repeat(np.arange(n), np.diff(L.indptr))
+    assert np.array_equal(L.data[off], g["L_data"][off])             # x_k*w_k: bit-exact
+    assert np.allclose(L.data[~off], g["L_data"][~off], rtol=1e-14, atol=0)
+    assert P.stats is not None
+    P.close()
+
+
+@pytest.mark.parametrize("nm", ["er300_xfrac", "er2000_x0", "er2000_xfrac"])
+@pytest.mark.parametrize("variant", [1, 2])
+def test_spmv_matches_scipy(nm, variant):
+    g = load_golden(nm)
+    P = problem_of(g)
+    P.set_x(g["x"])
+    L = oracle_of(g).laplacian(g["x"])
+    rng = np.random.default_rng(0)
+    v = rng.normal(size=int(g["n"]))
+    y = P.spmv(v, variant=variant)
+    ref = L @ v
+    assert np.abs(y - ref).max() <= 1e-13 * np.abs(ref).max()
+    P.close()
+
+
+def test_spmv_long_rows_all_candidates():
+    g = load_golden("er300_x0")
+    P = problem_of(g)
+    x = np.ones(len(g["cw"]))
+    P.set_x(x)
+    L = oracle_of(g).laplacian(x)
+    v = np.random.default_rng(1).normal(size=int(g["n"]))
+    for variant in (0, 1, 2):
+        y = P.spmv(v, variant=variant)
+        assert np.abs(y - L @ v).max() <= 1e-13 * np.abs(L @ v).max()
+    P.close()
+
+
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nm,exact", [("k5", 5.0), ("p2", 2.0), ("p3", 1.0),
+                                      ("p50", 2 - 2 * np.cos(np.pi / 50)),
+                                      ("c12", 2 - 2 * np.cos(2 * np.pi / 12)), ("star9", 1.0)])
+def test_find_fiedler_pair_closed_forms(nm, exact):
+    g = load_golden("fiedler_" + nm)
+    n = int(g["n"])
+    L = weight_graph_lap_from_edge_list([Edge(int(a), int(b), float(w)) for a, b, w in zip(g["ei"], g["ej"], g["ew"])], n)
+    lam, v, X = find_fiedler_pair(L)                     # reference tests/utils/test_fiedler.py:32
+    assert np.isclose(lam, exact)                        # the reference's own assertion (K5 -> 5)
+    assert abs(lam - exact) <= LAM_RTOL * exact
+    assert abs(lam - g["lam"]) <= LAM_RTOL * exact
+    q = min(4, n - 1)
+    assert X.shape == (n, q) and v.shape == (n,)
+    assert abs(np.linalg.norm(v) - 1) < 1e-12 and abs(v.sum()) < 1e-10
+    assert np.abs(L @ v - lam * v).sum() / abs(L).sum(axis=1).max() < 1e-8      # nx:246 rule
+    assert np.array_equal(X[:, 0], v)
+
+
+@pytest.mark.parametrize("nm", ["petersen_x0", "er300_x0", "er300_xfrac", "er2000_x0", "er2000_xfrac"])
+def test_fiedler_pair_and_gradient_vs_reference(nm):
+    g = load_golden(nm)
+    P = problem_of(g)
+    P.set_x(g["x"])
+    lam, v, X = P.fiedler(tol=1e-8, x0=reference_start_block(int(g["n"]))[:, 0].copy(), q=min(4, int(g["n"]) - 1))
+    assert abs(lam - g["lam"]) <= LAM_RTOL * abs(g["lam"])
+    assert P.stats.residual < 1e-8
+    va = sign_align(v, g["v"])
+    assert np.abs(va - g["v"]).max() <= 2e-6
+    grad = P.gradient()
+    assert np.array_equal(grad, oracle.supergradient(v, g["ci"], g["cj"], g["cw"]))      # bit-exact
+    assert np.abs(grad - g["grad"]).max() <= 1e-5 * np.abs(g["grad"]).max()
+    # Ritz block: orthonormal, column 0 the Fiedler vector
+    assert np.abs(X.T @ X - np.eye(X.shape[1])).max() < 1e-6
+    # identity: sum_k x_k g_k + v^T L_fixed v = lambda_2
+    Lf = oracle.laplacian_from_edges(g["fi"], g["fj"], g["fw"], int(g["n"]))
+    xs = np.where(g["x"] > 1e-10, g["x"], 0.0)
+    assert abs(xs @ grad + v @ (Lf @ v) - lam) <= 1e-9 * max(1.0, abs(lam))
+    P.close()
+
+
+@pytest.mark.parametrize("nm", ["intel", "sphere2500", "city10000"])
+def test_pose_graph_fiedler(nm):
+    g = load_golden("g2o_" + nm)
+    mac = MAC(edges_of(g, "f"), edges_of(g, "c"), int(g["n"]))
+    lam = mac.evaluate_objective(g["x_init"])
+    assert abs(lam - g["lam_init"]) <= LAM_RTOL * g["lam_init"]
+    f, grad = mac.problem(g["x_init"])
+    assert abs(f - g["lam_init"]) <= LAM_RTOL * g["lam_init"]
+    assert np.abs(grad - g["grad_init"]).max() <= 2e-4 * np.abs(g["grad_init"]).max()
+    lam_all = mac.evaluate_objective(np.ones(len(g["cw"])))
+    assert abs(lam_all - g["lam_all"]) <= LAM_RTOL * g["lam_all"]
+
+
+# --------------------------------------------------------------------------------------------
+def test_topk_matches_oracle_and_handles_ties():
+    g = load_golden("er2000_x0")
+    P = problem_of(g)
+    P.set_x(g["x"])
+    P.fiedler(want_vec=False)
+    grad = P.gradient()
+    m = len(grad)
+    for k in [1, 7, m // 10, m // 2, m - 1, m]:
+        s = P.lp_topk(k)
+        assert s.sum() == k
+        kth = np.sort(grad)[-k]
+        assert np.all(s[grad > kth] == 1) and np.all(s[grad < kth] == 0)
+        if np.sum(grad == kth) == 1:
+            assert np.array_equal(s, oracle.solve_subset_box_lp(grad, k))
+    assert P.lp_topk(0).sum() == 0
+    P.close()
+
+
+def test_topk_tie_break_lowest_index():
+    # duplicated candidate pairs give exactly equal gradient entries
+    n = 12
+    fixed = [Edge(i, i + 1, 1.0 + 0.1 * i) for i in range(n - 1)]
+    pairs = [(0, 5)] * 4 + [(2, 9)] * 3 + [(1, 3)] * 2 + [(4, 11), (0, 5), (6, 8)]
+    cand = [Edge(a, b, 1.0) for a, b in pairs]
+    mac = MAC(fixed, cand, n)
+    m = len(cand)
+    P = mac._dev
+    P.set_x(np.zeros(m))
+    P.fiedler(want_vec=False)
+    grad = P.gradient()
+    assert grad[0] == grad[1] == grad[2] == grad[3] == grad[10]
+    for k in range(0, m + 1):
+        s = P.lp_topk(k)
+        assert s.sum() == k
+        if k == 0:
+            continue
+        kth = np.sort(grad)[-k]
+        assert np.all(s[grad > kth] == 1) and np.all(s[grad < kth] == 0)
+        ties = np.nonzero(grad == kth)[0]
+        need = int(k - np.sum(grad > kth))
+        assert np.array_equal(np.nonzero(s[ties])[0], np.arange(need))     # lowest indices win
+
+
+# --------------------------------------------------------------------------------------------
+def test_petersen_solve_matches_reference():
+    g = load_golden("petersen_solve_k3")
+    mac = MAC(edges_of(g, "f"), edges_of(g, "c"), 10)
+    rounded, w, u = mac.solve(3, g["x_init"], max_iters=5)
+    assert np.allclose([t[0] for t in mac.trace], g["f_traj"], rtol=1e-8)
+    assert np.allclose(w, g["unrounded"], atol=1e-12)
+    assert np.array_equal(rounded, g["rounded"])
+    assert abs(u - g["upper"]) <= 1e-7 * abs(g["upper"])
+    assert abs(mac.evaluate_objective(np.zeros(6)) - g["lam_tree"]) <= LAM_RTOL * g["lam_tree"]
+    assert abs(mac.evaluate_objective(np.ones(6)) - 2.0) <= 2 * LAM_RTOL
+
+
+def test_petersen_sweep_like_reference_test_mac():
+    """reference tests/solvers/test_mac.py:35-60 (its own assertion) + golden values."""
+    rows = load_golden("petersen_sweep")["rows"]
+    g = load_golden("petersen_solve_k3")
+    fixed, cand = edges_of(g, "f"), edges_of(g, "c")
+    for pct, k, l_init, l_un, l_r, up in rows:
+        k = int(k)
+        x_init = np.zeros(len(cand))
+        x_init[:k] = 1.0
+        mac = MAC(fixed, cand, 10)
+        result, unrounded, upper = mac.solve(k, x_init, max_iters=100)
+        init_l2 = mac.evaluate_objective(x_init)
+        un_l2 = mac.evaluate_objective(unrounded)
+        assert un_l2 >= init_l2 - 1e-12
+        assert abs(init_l2 - l_init) <= LAM_RTOL * l_init
+        assert abs(un_l2 - l_un) <= 1e-5 * l_un
+        assert abs(upper - up) <= 1e-5 * up
+
+
+@pytest.mark.parametrize("nm", ["er300_solve", "er2000_solve"])
+def test_er_solve_trajectory(nm):
+    g = load_golden(nm)
+    mac = MAC(edges_of(g, "f"), edges_of(g, "c"), int(g["n"]))
+    rounded, w, u = mac.solve(int(g["k"]), g["x_init"], max_iters=int(g["max_iters"]))
+    assert np.allclose([t[0] for t in mac.trace], g["f_traj"], rtol=LAM_RTOL)
+    assert np.array_equal([t[3] for t in mac.trace], g["supp"])
+    assert np.allclose(w, g["unrounded"], atol=1e-12)
+    assert np.array_equal(rounded, g["rounded"])
+    assert abs(u - g["upper"]) <= 1e-6 * abs(g["upper"])
+
+
+@pytest.mark.parametrize("nm", ["intel", "sphere2500"])
+def test_pose_graph_solve_trajectory(nm):
+    g = load_golden("g2o_" + nm)
+    mac = MAC(edges_of(g, "f"), edges_of(g, "c"), int(g["n"]))
+    rounded, w, u = mac.solve(int(g["k"]), g["x_init"], max_iters=20, use_cache=False)
+    ft = np.array([t[0] for t in mac.trace])
+    assert np.allclose(ft, g["f_traj"][:len(ft)], rtol=1e-6)
+    assert np.array_equal([t[3] for t in mac.trace], g["supp"][:len(ft)])
+    assert abs(u - g["upper"]) <= 1e-5 * abs(g["upper"])
+    assert abs(mac.evaluate_objective(rounded) - g["lam_rounded"]) <= 1e-6 * g["lam_rounded"] or \
+        np.array_equal(rounded, g["rounded"])
+    # warm start (the working form of MAC.Cache) reaches the same optimum
+    mac2 = MAC(edges_of(g, "f"), edges_of(g, "c"), int(g["n"]))
+    r2, w2, u2 = mac2.solve(int(g["k"]), g["x_init"], max_iters=20, use_cache=True)
+    assert np.allclose([t[0] for t in mac2.trace], ft, rtol=1e-6)
+
+
+# --------------------------------------------------------------------------------------------
+def test_edge_cases_duplicates_selfloops_reversed():
+    rng = np.random.default_rng(5)
+    n = 40
+    fi = np.arange(n - 1); fj = fi + 1; fw = rng.random(n - 1) + 0.5
+    # duplicate fixed edge, reversed orientation, self loop
+    fi = np.concatenate([fi, [3, 10, 7]]); fj = np.concatenate([fj, [4, 9, 7]]); fw = np.concatenate([fw, [0.25, 0.5, 9.0]])
+    ci = rng.integers(0, n, 120); cj = rng.integers(0, n, 120); cw = rng.random(120) + 0.1
+    ci[0], cj[0] = 3, 4          # candidate on a fixed pair
+    ci[1], cj[1] = 20, 30; ci[2], cj[2] = 30, 20   # duplicate candidate pair, reversed
+    ci[3] = cj[3] = 11           # candidate self loop
+    x = rng.random(120) * (rng.random(120) < 0.6)
+    P = _lib.Problem(n, fi, fj, fw, ci, cj, cw)
+    P.set_x(x)
+    indptr, indices, data = P.laplacian_csr()
+    L = sp.csr_matrix((data, indices, indptr), shape=(n, n)); L.sum_duplicates(); L.sort_indices()
+    mo = oracle.MacOracle(fi, fj, fw, ci, cj, cw, n)
+    Lr = mo.laplacian(x).tocsr(); Lr.sum_duplicates(); Lr.eliminate_zeros(); Lr.sort_indices()
+    L.eliminate_zeros()
+    assert np.abs((L - Lr)).max() <= 1e-14 * abs(Lr).max()
+    lam, v, _ = P.fiedler(x0=reference_start_block(n)[:, 0].copy())
+    f, gr = mo.problem(x)
+    assert abs(lam - f) <= LAM_RTOL * f
+    grad = P.gradient()
+    assert np.array_equal(grad, oracle.supergradient(v, ci, cj, cw))
+    assert grad[3] == 0.0
+    P.close()
+
+
+def test_errors_like_reference():
+    g = load_golden("petersen_solve_k3")
+    fixed, cand = edges_of(g, "f"), edges_of(g, "c")
+    with pytest.raises(AssertionError):
+        MAC(fixed[:3], cand[:2], 10)                       # fewer than n-1 edges (mac.py:47)
+    mac = MAC(fixed, cand, 10)
+    with pytest.raises(AssertionError):
+        mac.solve(2, np.zeros(3))                          # len(x_init) != m (mac.py:183)
+    with pytest.raises((AssertionError, TypeError)):
+        mac.solve(2, None)                                 # x_init=None unsupported (mac.py:182)
+    with pytest.raises(AssertionError):
+        _lib.Problem(4, [0, 1, 2], [1, 2, 9], [1., 1., 1.], [0], [3], [1.0])   # node id out of range
+    # disconnected K3 u K3: the reference raises (SuperLU singular); here a typed error
+    e = [(0, 1), (0, 2), (1, 2), (3, 4), (3, 5), (4, 5)]
+    L = weight_graph_lap_from_edge_list([Edge(a, b, 1.0) for a, b in e], 6)
+    with pytest.raises(_lib.Disconnected):
+        find_fiedler_pair(L)
+    with pytest.raises(AssertionError):
+        find_fiedler_pair(weight_graph_lap_from_edge_list(fixed + cand, 10), X=np.zeros((10, 2)))
+
+
+def test_k_ge_m_shortcut_and_k0():
+    g = load_golden("petersen_solve_k3")
+    mac = MAC(edges_of(g, "f"), edges_of(g, "c"), 10)
+    r, w, val = mac.solve(6, np.zeros(6))
+    assert np.all(r == 1) and abs(val - 2.0) < 1e-7
+    r0, w0, u0 = mac.solve(0, np.zeros(6), max_iters=3)
+    assert r0.sum() == 0 and np.all(w0 == 0)
+
+
+def test_naive_greedy_init_and_laplacian_accessor():
+    g = load_golden("g2o_intel")
+    cand = edges_of(g, "c")
+    x0 = NaiveGreedy(cand).subset(int(g["k"]))
+    assert x0.sum() == int(g["k"])
+    mac = MAC(edges_of(g, "f"), cand, int(g["n"]))
+    L = mac.laplacian(x0)
+    Lr = oracle_of(g).laplacian(x0)
+    assert abs(L - Lr).max() <= 1e-12 * abs(Lr).max()
+    assert mac.weights.shape == (len(cand),) and mac.edge_list.shape == (len(cand), 2)
+    assert abs(mac.L_fixed - oracle.laplacian_from_edges(g["fi"], g["fj"], g["fw"], int(g["n"]))).max() == 0
+
+
+# --------------------------------------------------------------------------------------------
+def make_er(n, p, seed):
+    import networkx as nx
+    G = nx.fast_gnp_random_graph(n, p, seed=seed)
+    e = np.array([(min(a, b), max(a, b)) for a, b in G.edges() if abs(a - b) != 1], dtype=np.int32)
+    return e[:, 0].copy(), e[:, 1].copy()
+
+
+def test_full_size_config2_properties():
+    """BASELINE.json configs[1]: ER N=10k p=0.01, chain fixed, K=10%.  lambda_2 against the
+    reference value captured in tests/golden/er10k_x0.npz; size-independent identities."""
+    g = load_golden("er10k_x0")
+    n = 10000
+    ci, cj = make_er(n, 0.01, 0)
+    m = len(ci)
+    assert m == int(g["m"]) and np.array_equal(ci[:512], g["ci_head"]) and np.array_equal(cj[:512], g["cj_head"])
+    fi = np.arange(n - 1, dtype=np.int32); fj = fi + 1
+    P = _lib.Problem(n, fi, fj, np.ones(n - 1), ci, cj, np.ones(m))
+    x0 = np.zeros(m); x0[g["x0_idx"]] = 1.0
+    P.set_x(x0)
+    lam, v, _ = P.fiedler(tol=1e-8, x0=reference_start_block(n)[:, 0].copy())
+    assert abs(lam - float(g["lam"])) <= LAM_RTOL * float(g["lam"])
+    assert np.abs(sign_align(v, g["v"]) - g["v"]).max() <= 2e-6
+    grad = P.gradient()
+    assert abs(grad.sum() - float(g["grad_sum"])) <= 1e-5 * float(g["grad_sum"])
+    assert np.abs(grad[:512] - g["grad_head"]).max() <= 1e-5 * np.abs(g["grad_head"]).max()
+    # identity lambda_2 = x.g + v^T L_fixed v ; residual rule on an independent SpMV
+    Lf = oracle.laplacian_from_edges(fi, fj, np.ones(n - 1), n)
+    assert abs(x0 @ grad + v @ (Lf @ v) - lam) <= 1e-9 * lam
+    L = oracle.mac_laplacian(Lf, ci.astype(np.int64), cj.astype(np.int64), np.ones(m), x0, n)
+    assert np.abs(L @ v - lam * v).sum() / abs(L).sum(axis=1).max() < 1e-8
+    # FW iterations: dual bound >= f, x stays feasible, support grows by <= K, bit-exact update
+    k = m // 10
+    u = np.inf
+    x_prev = x0
+    for it in range(4):
+        f, dual, gn = P.fw_step(k, it)
+        u = min(u, dual)
+        assert u >= f - 1e-9 * abs(f)
+        grad = P.gradient()
+        s = P.lp_topk(k)
+        assert s.sum() == k
+        P.fw_commit()
+        x = P.get_x()
+        assert np.array_equal(x, x_prev + (2.0 / (it + 2.0)) * (s - x_prev))
+        assert x.min() >= 0 and x.max() <= 1 and x.sum() <= k * (1 + 1e-12)
+        assert abs(dual - (f + grad @ (s - x_prev))) <= 1e-9 * abs(dual)
+        x_prev = x
+    P.close()
