@@ -452,6 +452,7 @@ __global__ __launch_bounds__(kBlock) void k_resid_l1(const double* __restrict__ 
 __global__ __launch_bounds__(kBlock) void k_grad(const int* __restrict__ ci, const int* __restrict__ cj,
                                                  const double* __restrict__ cw, const double* __restrict__ v,
                                                  long lo, long hi, double* __restrict__ g) {
+#pragma clang fp contract(off)   // HIP's __dmul_rn is a plain '*': keep the compiler from fusing
     for (long k = lo + (long)blockIdx.x * kBlock + threadIdx.x; k < hi; k += (long)gridDim.x * kBlock) {
         const double d = v[ci[k]] - v[cj[k]];
         g[k] = __dmul_rn(__dmul_rn(cw[k], d), d);
@@ -593,6 +594,7 @@ __global__ __launch_bounds__(kBlock) void k_fw_final(const double* __restrict__ 
                                                      long m, const SelState* __restrict__ st, double gamma,
                                                      double* __restrict__ x_next, double* __restrict__ s_out,
                                                      double* __restrict__ part /*[2][kMaxGrid]*/) {
+#pragma clang fp contract(off)   // x + gamma*(s - x) must round twice, like NumPy (no fma)
     __shared__ double sm[4];
     const unsigned long long T = st->T;
     const long long lim = st->tie_limit;

@@ -111,6 +111,7 @@ struct Solver {
     std::vector<double> ha, hb, hl1;
     std::vector<double> wk, guess;
     tri::Smallest sm;
+    int J_last = 0;             // dimension of the Krylov space behind the current yvec
 
     int init(int n_, hipStream_t s) {
         n = n_;
@@ -287,6 +288,7 @@ struct Solver {
                 if ((trig && est < 0.5 * last_check_est) || broke || at_cap) {
                     double rq = 0.0, r1 = 0.0;
                     ST_TRY(explicit_check(A, pl, Jeff, sm.s.data(), &rq, &r1));
+                    J_last = Jeff;
                     spmv_total += 1;
                     last_check_est = std::max(est, 1e-300);
                     lam = rq;
@@ -329,28 +331,19 @@ struct Solver {
     }
 
     // q Ritz vectors (column-major n x q) of the last Krylov sequence -> host buffer.  Column 0 is
-    // replaced by the converged Fiedler vector in yvec.
+    // the converged Fiedler vector in yvec; the others are the next Ritz vectors, orthonormalised
+    // on the host; copies produced by Lanczos "ghost" Ritz values are skipped.
     int ritz_block(int q, double* X_host) {
-        const int J = (int)ha.size();
+        const int Jeff = std::max(1, std::min(J_last, (int)ha.size()));
+        const int ncand = std::min(Jeff, q + 6);
         std::vector<double> th, S;
-        int Jeff = J;
-        for (int j = 1; j <= J && j < (int)hb.size(); ++j)
-            if (!(hb[(size_t)j] > 0.0)) { Jeff = j; break; }
-        tri::smallest_block(ha.data(), hb.data(), Jeff, q, th, S, wk);
-        const int qq = (int)th.size();
+        tri::smallest_block(ha.data(), hb.data(), Jeff, ncand, th, S, wk);
         const int g2 = vgrid();
+        HIP_TRY(hipMemcpyAsync(X_host, yvec, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        int acc = 1;
         std::vector<double> col((size_t)n);
-        for (int c = 0; c < q; ++c) {
-            double* dst = X_host + (size_t)c * n;
-            if (c == 0) {
-                HIP_TRY(hipMemcpyAsync(dst, yvec, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, stream));
-                HIP_TRY(hipStreamSynchronize(stream));
-                continue;
-            }
-            if (c >= qq) {   // Krylov space smaller than q: pad with zeros
-                for (int i = 0; i < n; ++i) dst[i] = 0.0;
-                continue;
-            }
+        for (int c = 1; c < (int)th.size() && acc < q; ++c) {
             memcpy(h_pin, S.data() + (size_t)c * Jeff, sizeof(double) * (size_t)Jeff);
             HIP_TRY(hipMemcpyAsync(sdev, h_pin, sizeof(double) * (size_t)Jeff, hipMemcpyHostToDevice, stream));
             const int KS = std::max(1, std::min(ks_max, Jeff / 8));
@@ -358,13 +351,58 @@ struct Solver {
             k_ritz_combine<<<g2, kBlock, 0, stream>>>(ypart, n, KS, y_raw, part_c);
             HIP_TRY(hipMemcpyAsync(col.data(), y_raw, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
-            double mean = 0.0;
+            double mean = 0.0, n0 = 0.0;
             for (int i = 0; i < n; ++i) mean += col[(size_t)i];
             mean /= n;
+            for (int i = 0; i < n; ++i) { col[(size_t)i] -= mean; n0 += col[(size_t)i] * col[(size_t)i]; }
+            for (int pass = 0; pass < 2; ++pass)
+                for (int p = 0; p < acc; ++p) {
+                    const double* xp = X_host + (size_t)p * n;
+                    double dot = 0.0;
+                    for (int i = 0; i < n; ++i) dot += xp[i] * col[(size_t)i];
+                    for (int i = 0; i < n; ++i) col[(size_t)i] -= dot * xp[i];
+                }
             double n2 = 0.0;
-            for (int i = 0; i < n; ++i) { col[(size_t)i] -= mean; n2 += col[(size_t)i] * col[(size_t)i]; }
-            const double inv = n2 > 0 ? 1.0 / std::sqrt(n2) : 0.0;
+            for (int i = 0; i < n; ++i) n2 += col[(size_t)i] * col[(size_t)i];
+            if (!(n2 > 1e-6 * std::max(n0, 1e-300))) continue;   // ghost copy of an accepted vector
+            const double inv = 1.0 / std::sqrt(n2);
+            double* dst = X_host + (size_t)acc * n;
             for (int i = 0; i < n; ++i) dst[i] = col[(size_t)i] * inv;
+            ++acc;
+        }
+        // Krylov space exhausted (tiny or highly symmetric graph): complete the block with
+        // deterministic vectors orthogonal to 1 and to the accepted columns, so X is always an
+        // orthonormal n x q block like the reference's (nx:238).
+        for (unsigned long long seed = 1; acc < q && seed < 64; ++seed) {
+            double mean = 0.0;
+            for (int i = 0; i < n; ++i) {
+                unsigned long long z = seed * 0xD1B54A32D192ED03ull + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
+                z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+                z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+                z = z ^ (z >> 31);
+                col[(size_t)i] = (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+                mean += col[(size_t)i];
+            }
+            mean /= n;
+            for (int i = 0; i < n; ++i) col[(size_t)i] -= mean;
+            for (int pass = 0; pass < 2; ++pass)
+                for (int p = 0; p < acc; ++p) {
+                    const double* xp = X_host + (size_t)p * n;
+                    double dot = 0.0;
+                    for (int i = 0; i < n; ++i) dot += xp[i] * col[(size_t)i];
+                    for (int i = 0; i < n; ++i) col[(size_t)i] -= dot * xp[i];
+                }
+            double n2 = 0.0;
+            for (int i = 0; i < n; ++i) n2 += col[(size_t)i] * col[(size_t)i];
+            if (!(n2 > 1e-12)) continue;
+            const double inv = 1.0 / std::sqrt(n2);
+            double* dst = X_host + (size_t)acc * n;
+            for (int i = 0; i < n; ++i) dst[i] = col[(size_t)i] * inv;
+            ++acc;
+        }
+        for (; acc < q; ++acc) {
+            double* dst = X_host + (size_t)acc * n;
+            for (int i = 0; i < n; ++i) dst[i] = 0.0;
         }
         return MACHIP_OK;
     }

@@ -124,3 +124,22 @@ def test_unknown_method_raises_like_reference():
     import scipy.sparse as sp
     with pytest.raises(UnknownFiedlerMethod):
         find_fiedler_pair(sp.identity(4, format="csr"), method="bogus")
+
+
+@pytest.mark.parametrize("nm", ["intel", "sphere2500", "city10000"])
+def test_g2o_reader_matches_reference_golden(nm):
+    """Edge arrays produced by the reference's own reader (examples/pose_graph_utils.py) were
+    captured in tests/golden/g2o_*.npz; the product parser must reproduce them."""
+    from mac_amd.utils import g2o
+    g = load_golden("g2o_" + nm)
+    i, j, kap, n = g2o.read_g2o_edges(os.path.join(ROOT, "tests", "golden", "data", nm + ".g2o"))
+    fixed = g2o.split_chain(i, j)
+    assert n == int(g["n"])
+    assert np.array_equal(i[fixed], g["fi"]) and np.array_equal(j[fixed], g["fj"])
+    assert np.array_equal(i[~fixed], g["ci"]) and np.array_equal(j[~fixed], g["cj"])
+    assert np.allclose(kap[fixed], g["fw"], rtol=1e-13, atol=0)
+    assert np.allclose(kap[~fixed], g["cw"], rtol=1e-13, atol=0)
+    if nm == "intel":
+        edges, n2 = g2o.read_g2o_file(os.path.join(ROOT, "tests", "golden", "data", nm + ".g2o"))
+        chain, loops = g2o.split_edges(edges)
+        assert n2 == n and len(chain) == 1727 and len(loops) == 785
