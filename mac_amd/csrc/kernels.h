@@ -205,7 +205,7 @@ __device__ __forceinline__ void spmv_rows_vec(const CsrView& A, const double* __
     for (int r = blockIdx.x * GPB + g; r < A.n; r += gridDim.x * GPB) {
         const int b = A.rowptr[r], e = A.rowptr[r + 1];
         double acc = 0.0;
-        for (int p = b + lane; p < e; p += G) acc += A.val[p] * x[A.col[p]];
+        for (int p = b + lane; p < e; p += G) acc += A.val[p] * op.gather(x, A.col[p]);
         acc = group_sum<G>(acc);
         if (lane == 0) op.row(r, acc);
     }
@@ -228,7 +228,7 @@ __device__ __forceinline__ void spmv_rows_stream(const CsrView& A, const double*
         double acc = 0.0;
         for (int base = p0; base < p1; base += kStreamTile) {
             const int cnt = min(kStreamTile, p1 - base);
-            for (int i = tid; i < cnt; i += kBlock) prod[i] = A.val[base + i] * x[A.col[base + i]];
+            for (int i = tid; i < cnt; i += kBlock) prod[i] = A.val[base + i] * op.gather(x, A.col[base + i]);
             __syncthreads();
             if (row < nr) {
                 const int lo = max(sptr[row], base), hi = min(sptr[row + 1], base + cnt);
@@ -246,6 +246,7 @@ __device__ __forceinline__ void spmv_rows_stream(const CsrView& A, const double*
 struct OpPlain {
     double* y;
     __device__ __forceinline__ void begin(double*) {}
+    __device__ __forceinline__ double gather(const double* __restrict__ x, int c) const { return x[c]; }
     __device__ __forceinline__ void row(int r, double acc) { y[r] = acc; }
     __device__ __forceinline__ void end(double*) {}
 };
@@ -278,6 +279,7 @@ struct OpLanczos {
             L.st->jB = j;
         }
     }
+    __device__ __forceinline__ double gather(const double* __restrict__ x, int c) const { return x[c]; }
     __device__ __forceinline__ void row(int r, double acc) {
         const double wr = acc * inv;
         const double v = (L.u[r] - mu) * inv;
@@ -360,6 +362,277 @@ __global__ __launch_bounds__(kBlock) void k_lan_tail(LanView L) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// One-kernel Lanczos step ("pipelined" form).  A kernel boundary costs ~2 us on this chip, every
+// kernel here starts with a cold L2 (the per-XCD L2s are written back / invalidated at launch
+// boundaries) and is latency-bound, so a Lanczos step is ONE launch whose dependent-load chain
+// is as short as CSR allows:
+//   * step j finishes the reductions of step j-1 (alpha_{j-1}, beta_j, mean) from per-workgroup
+//     partials itself, and uses v_j without materialising it:
+//         v_j[c] = ( w_{j-1}[c] - alpha_{j-1} v_{j-1}[c] - beta_{j-1} v_{j-2}[c] - mu ) / beta_j
+//     The three sources sit interleaved in one 24-byte record Z[c] (same cache line a plain x[c]
+//     gather would touch).  By linearity the SpMV accumulates the three raw sums
+//     (L w_{j-1}, L v_{j-1}, L v_{j-2})[r] and combines them afterwards, so the matrix/gather
+//     phase does not depend on the reduction at all and the two overlap (L 1 = 0 removes mu).
+//   * beta_j = ||u_j|| comes from the exact quadratic form in the six inner products of
+//     (w, v1, v2) -- no orthogonality assumed -- which each step accumulates for the next one.
+//   * no per-step host arguments: j = jA (chunk base, device memory) + jrel (baked into the graph
+//     node); chunks have an even number of steps so the Z ping-pong parity is jrel & 1.
+// ------------------------------------------------------------------------------------------
+struct Z3 { double w, v1, v2; };
+constexpr int kNP = 10;   // partial sums per workgroup: ww wv1 wv2 v1v1 v1v2 v2v2 sw s1 s2 |v1|_1
+constexpr int kMaxChunk = 64;
+constexpr int kMaxWaves = 16;
+
+struct PipeView {
+    int n;
+    LanState* st;
+    Z3* Z0;
+    Z3* Z1;
+    double* V;
+    double* tri;      // interleaved (alpha_j, beta_j, ||v_j||_1) records: one D2H copy per chunk
+    double* cb;       // kMaxChunk+1 slots: cb[s] = beta_{j-1} for the launch with jrel = s
+    double* part;     // 2 x kNP x kMaxGrid, ping-ponged like Z: a step reads half (jrel & 1) and
+                      // writes the other, so a late-starting workgroup never sees partials that a
+                      // fast workgroup of the SAME launch has already replaced
+    int P;            // valid partials per quantity (= grid of the step kernel, <= 256)
+};
+
+struct PipeCoef { double alpha, betap, mu, beta, inv, l1prev; };
+
+// ---- wave64 sum on the VALU (DPP row shifts + row broadcasts), ~5x faster than the
+// ds_bpermute butterfly; the total lands in lane 63 and is broadcast through an SGPR. ----------
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_add(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xf, false);
+    return v + __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ double wave_total(double v) {
+    v = dpp_add<0x111, 0xf>(v);   // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);   // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);   // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of each row holds the row sum
+    v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1,3
+    v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2,3 -> lane 63 holds the wave sum
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+// Finish step j-1's reductions from the summed partials.  Identical on every workgroup.
+// All six inner products and three sums are MEASURED, nothing is assumed orthonormal: the
+// quadratic form is then exact for the vectors actually stored, so a rounding error in beta_j
+// only rescales v_j and is accounted for one step later.  (Dropping the "tiny" terms v1.v2,
+// sum(v) or assuming |v2| = 1 turns that into an error-feedback loop that blows up in ~20 steps.)
+__device__ __forceinline__ PipeCoef pipe_coefs(const double (&a)[kNP], double betap, int n) {
+    PipeCoef c;
+    const double ww = a[0], wv1 = a[1], wv2 = a[2], v1v1 = a[3], v1v2 = a[4], v2v2 = a[5];
+    c.betap = betap;                          // couples v_{j-2}, v_{j-1}
+    c.alpha = wv1 - betap * v1v2;             // Paige: v1.(w - beta v2); 0 at j = 0 (v1 = 0)
+    const double al = c.alpha, bp = c.betap;
+    const double uu = ww + al * al * v1v1 + bp * bp * v2v2 - 2.0 * al * wv1 - 2.0 * bp * wv2 + 2.0 * al * bp * v1v2;
+    const double su = a[6] - al * a[7] - bp * a[8];
+    c.mu = su / (double)n;
+    const double nrm2 = uu - (double)n * c.mu * c.mu;
+    // ||u||^2 is a difference of O(||w||^2) terms: below ~1e-10 of their size it is rounding
+    // noise, i.e. the Krylov space is (numerically) invariant -> report an exact breakdown.
+    const double scale = ww + al * al * v1v1 + bp * bp * v2v2;
+    c.beta = (nrm2 > 1e-10 * scale) ? sqrt(nrm2) : 0.0;
+    c.inv = c.beta > 1e-290 ? 1.0 / c.beta : 0.0;
+    c.l1prev = a[9];
+    return c;
+}
+
+// Prologue, run by wave 0 only: sum the P (<= 256) partials of each quantity, derive the
+// coefficients, publish them to the workgroup through LDS (scoef) and -- workgroup 0 -- to the
+// host-visible tridiagonal record.  The other waves go straight to their CSR loads.
+__device__ __forceinline__ void pipe_prologue_wave0(const PipeView& L, int jrel, int adv_jA, double* scoef) {
+    const int lane = threadIdx.x;   // caller guarantees threadIdx.x < 64
+    const int jA = L.st->jA;
+    const double betap = L.cb[jrel];
+    const double* __restrict__ pin = L.part + (size_t)(jrel & 1) * (kNP * kMaxGrid);
+    double a[kNP];
+#pragma unroll
+    for (int q = 0; q < kNP; ++q) a[q] = 0.0;
+    for (int i = lane; i < L.P; i += 64) {
+#pragma unroll
+        for (int q = 0; q < kNP; ++q) a[q] += pin[q * kMaxGrid + i];
+    }
+#pragma unroll
+    for (int q = 0; q < kNP; ++q) a[q] = wave_total(a[q]);
+    const PipeCoef c = pipe_coefs(a, betap, L.n);
+    const int j = jA + jrel;
+    if (lane == 0) {
+        scoef[0] = c.alpha; scoef[1] = c.betap; scoef[2] = c.mu; scoef[3] = c.inv; scoef[4] = (double)j;
+        if (blockIdx.x == 0) {
+            if (j > 0) { L.tri[3 * (j - 1)] = c.alpha; L.tri[3 * (j - 1) + 2] = c.l1prev; }
+            L.tri[3 * j + 1] = c.beta;
+            if (adv_jA >= 0) { L.st->jA = j; L.cb[0] = betap; }   // tail kernel: new chunk base
+            else L.cb[jrel + 1] = c.beta;
+        }
+    }
+}
+
+struct PipeRow {   // per-thread accumulation of the next step's partial sums
+    double acc[kNP];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int q = 0; q < kNP; ++q) acc[q] = 0.0;
+    }
+    // raw sums (L w)[r], (L v1)[r], (L v2)[r] -> w_j[r]; v_j[r] from Z[r]; store V, next Z.
+    __device__ __forceinline__ void finish(double alpha, double betap, double mu, double inv, const Z3& z,
+                                           double sw, double s1, double s2, double* vj, Z3* Zn, int r) {
+        const double v = (((z.w - alpha * z.v1) - betap * z.v2) - mu) * inv;
+        const double w = ((sw - alpha * s1) - betap * s2) * inv;
+        vj[r] = v;
+        Z3 o; o.w = w; o.v1 = v; o.v2 = z.v1;
+        Zn[r] = o;
+        acc[0] += w * w; acc[1] += w * v; acc[2] += w * z.v1;
+        acc[3] += v * v; acc[4] += v * z.v1; acc[5] += z.v1 * z.v1;
+        acc[6] += w; acc[7] += v; acc[8] += z.v1; acc[9] += fabs(v);
+    }
+    // one partial per quantity per workgroup; smw: kMaxWaves*kNP doubles
+    template <int BLOCK>
+    __device__ __forceinline__ void store(const PipeView& L, int jrel, double* smw) {
+        constexpr int NW = BLOCK / 64;
+#pragma unroll
+        for (int q = 0; q < kNP; ++q) acc[q] = wave_total(acc[q]);
+        const int wv = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int q = 0; q < kNP; ++q) smw[wv * kNP + q] = acc[q];
+        }
+        __syncthreads();
+        if (threadIdx.x < kNP) {
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += smw[w * kNP + threadIdx.x];
+            L.part[(size_t)((jrel + 1) & 1) * (kNP * kMaxGrid) + threadIdx.x * kMaxGrid + blockIdx.x] = s;
+        }
+    }
+};
+
+// ---- sub-wave vector form: G lanes per row, BLOCK threads per workgroup -------------------------
+template <int BLOCK, int G>
+__global__ __launch_bounds__(BLOCK) void k_pipe_vec(CsrView A, PipeView L, int jrel) {
+    __shared__ double smw[kMaxWaves * kNP];
+    __shared__ double scoef[8];
+    constexpr int GPB = BLOCK / G;
+    const int lane = threadIdx.x % G, g = threadIdx.x / G;
+    if (threadIdx.x < 64) pipe_prologue_wave0(L, jrel, -1, scoef);
+    const Z3* __restrict__ Zc = (jrel & 1) ? L.Z1 : L.Z0;
+    Z3* __restrict__ Zn = (jrel & 1) ? L.Z0 : L.Z1;
+    PipeRow pr;
+    pr.clear();
+    bool have = false;
+    double alpha = 0.0, betap = 0.0, mu = 0.0, inv = 0.0;
+    double* vj = nullptr;
+    for (int r0 = blockIdx.x * GPB; r0 < A.n; r0 += gridDim.x * GPB) {   // workgroup-uniform trip count
+        const int r = r0 + g;
+        double sw = 0.0, s1 = 0.0, s2 = 0.0;
+        Z3 zr; zr.w = 0.0; zr.v1 = 0.0; zr.v2 = 0.0;
+        if (r < A.n) {
+            const int b = A.rowptr[r], e = A.rowptr[r + 1];
+            if (lane == 0) zr = Zc[r];
+            for (int p = b + lane; p < e; p += G) {
+                const double vv = A.val[p];
+                const Z3 z = Zc[A.col[p]];
+                sw += vv * z.w; s1 += vv * z.v1; s2 += vv * z.v2;
+            }
+            sw = group_sum<G>(sw); s1 = group_sum<G>(s1); s2 = group_sum<G>(s2);
+        }
+        if (!have) {   // first tile: the prologue of wave 0 overlapped with the loads above
+            __syncthreads();
+            alpha = scoef[0]; betap = scoef[1]; mu = scoef[2]; inv = scoef[3];
+            vj = L.V + (size_t)scoef[4] * (size_t)L.n;
+            have = true;
+        }
+        if (r < A.n && lane == 0) pr.finish(alpha, betap, mu, inv, zr, sw, s1, s2, vj, Zn, r);
+    }
+    pr.template store<BLOCK>(L, jrel, smw);
+}
+
+// ---- LDS row-tile ("CSR-stream") form ------------------------------------------------------------
+constexpr int kPipeTile = 1024;   // staged products per LDS tile, x3 arrays (24 KB)
+
+template <int TPR>
+__global__ __launch_bounds__(kBlock) void k_pipe_stream(CsrView A, PipeView L, int jrel) {
+    __shared__ double smw[kMaxWaves * kNP];
+    __shared__ double scoef[8];
+    __shared__ double pw[kPipeTile], p1[kPipeTile], p2[kPipeTile];
+    __shared__ int sptr[kBlock / TPR + 1];
+    constexpr int R = kBlock / TPR;
+    const int tid = threadIdx.x;
+    const int row = tid / TPR, sub = tid % TPR;
+    if (tid < 64) pipe_prologue_wave0(L, jrel, -1, scoef);
+    const Z3* __restrict__ Zc = (jrel & 1) ? L.Z1 : L.Z0;
+    Z3* __restrict__ Zn = (jrel & 1) ? L.Z0 : L.Z1;
+    PipeRow pr;
+    pr.clear();
+    double alpha = 0.0, betap = 0.0, mu = 0.0, inv = 0.0;
+    double* vj = nullptr;
+    for (int tile = blockIdx.x; tile * R < A.n; tile += gridDim.x) {
+        const int r0 = tile * R;
+        const int nr = min(R, A.n - r0);
+        if (tid <= nr) sptr[tid] = A.rowptr[r0 + tid];
+        Z3 zr; zr.w = 0.0; zr.v1 = 0.0; zr.v2 = 0.0;
+        if (row < nr && sub == 0) zr = Zc[r0 + row];
+        __syncthreads();
+        if (!vj) {   // coefficients from wave 0 (published before the barrier above)
+            alpha = scoef[0]; betap = scoef[1]; mu = scoef[2]; inv = scoef[3];
+            vj = L.V + (size_t)scoef[4] * (size_t)L.n;
+        }
+        const int q0 = sptr[0], q1 = sptr[nr];
+        double sw = 0.0, s1 = 0.0, s2 = 0.0;
+        for (int base = q0; base < q1; base += kPipeTile) {
+            const int cnt = min(kPipeTile, q1 - base);
+            for (int i = tid; i < cnt; i += kBlock) {     // perfectly coalesced val/col stream
+                const double vv = A.val[base + i];
+                const Z3 z = Zc[A.col[base + i]];
+                pw[i] = vv * z.w; p1[i] = vv * z.v1; p2[i] = vv * z.v2;
+            }
+            __syncthreads();
+            if (row < nr) {
+                const int lo = max(sptr[row], base), hi = min(sptr[row + 1], base + cnt);
+                for (int q = lo + sub; q < hi; q += TPR) { sw += pw[q - base]; s1 += p1[q - base]; s2 += p2[q - base]; }
+            }
+            __syncthreads();
+        }
+        sw = group_sum<TPR>(sw); s1 = group_sum<TPR>(s1); s2 = group_sum<TPR>(s2);
+        if (row < nr && sub == 0) pr.finish(alpha, betap, mu, inv, zr, sw, s1, s2, vj, Zn, r0 + row);
+    }
+    pr.template store<kBlock>(L, jrel, smw);
+}
+
+// Start a sequence from u0: Z0 = (u0, 0, 0); partials such that step 0 normalises u0.
+__global__ __launch_bounds__(kBlock) void k_pipe_init(PipeView L, const double* __restrict__ u0) {
+    __shared__ double sm[4];
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = blockIdx.x * kBlock + threadIdx.x; r < L.n; r += gridDim.x * kBlock) {
+        const double t = u0[r];
+        Z3 o; o.w = t; o.v1 = 0.0; o.v2 = 0.0;
+        L.Z0[r] = o;
+        s1 += t; s2 += t * t;
+    }
+    s1 = block_sum(s1, sm); s2 = block_sum(s2, sm);
+    if (threadIdx.x == 0) {
+        for (int q = 0; q < kNP; ++q) L.part[q * kMaxGrid + blockIdx.x] = 0.0;
+        L.part[0 * kMaxGrid + blockIdx.x] = s2;
+        L.part[6 * kMaxGrid + blockIdx.x] = s1;
+        if (blockIdx.x == 0) { L.st->jA = 0; L.st->jB = 0; L.cb[0] = 0.0; }
+    }
+}
+// One wave, end of a chunk of `adv` steps: finish (alpha_{J-1}, beta_J, l1_{J-1}) for J = jA + adv
+// so the host can test convergence, advance the chunk base jA and hand beta_{J-1} to the first
+// launch of the next chunk.  The step kernels only read jA / cb[jrel]; this kernel is alone in
+// its launch.
+__global__ __launch_bounds__(64) void k_pipe_tail(PipeView L, int adv) {
+    __shared__ double scoef[8];
+    pipe_prologue_wave0(L, adv, adv, scoef);
+}
+
 // Partial sums (sum, sum of squares, sum of abs) of a vector -> part_u layout.
 __global__ __launch_bounds__(kBlock) void k_vec_sums(const double* __restrict__ u, int n,
                                                      double* __restrict__ part) {
@@ -398,15 +671,23 @@ __global__ __launch_bounds__(kBlock) void k_ritz_partial(const double* __restric
                                                          const double* __restrict__ s,
                                                          double* __restrict__ ypart) {
     const int KS = gridDim.y, ks = blockIdx.y;
+    constexpr int U = 8;   // columns in flight per thread: the basis columns are n*8 bytes apart, so
+                           // every load is a fresh DRAM page / TLB entry -- keep many outstanding
     for (int r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
-        double a0 = 0.0, a1 = 0.0;
-        int k = ks;
-        for (; k + KS < J; k += 2 * KS) {
-            a0 += V[(size_t)k * n + r] * s[k];
-            a1 += V[(size_t)(k + KS) * n + r] * s[k + KS];
+        double acc = 0.0;
+        for (int k0 = ks; k0 < J; k0 += U * KS) {
+            double v[U], c[U];
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+                const int k = k0 + q * KS;
+                const bool ok = k < J;
+                v[q] = ok ? V[(size_t)k * n + r] : 0.0;
+                c[q] = ok ? s[k] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < U; ++q) acc += v[q] * c[q];
         }
-        if (k < J) a0 += V[(size_t)k * n + r] * s[k];
-        ypart[(size_t)ks * n + r] = a0 + a1;
+        ypart[(size_t)ks * n + r] = acc;
     }
 }
 // y = sum over the KS slices, plus the (sum, sum^2, sum|.|) partials of y.
@@ -452,10 +733,11 @@ __global__ __launch_bounds__(kBlock) void k_resid_l1(const double* __restrict__ 
 __global__ __launch_bounds__(kBlock) void k_grad(const int* __restrict__ ci, const int* __restrict__ cj,
                                                  const double* __restrict__ cw, const double* __restrict__ v,
                                                  long lo, long hi, double* __restrict__ g) {
-#pragma clang fp contract(off)   // HIP's __dmul_rn is a plain '*': keep the compiler from fusing
+#pragma clang fp contract(off)   // plain operators under 'contract off': every op rounds once
     for (long k = lo + (long)blockIdx.x * kBlock + threadIdx.x; k < hi; k += (long)gridDim.x * kBlock) {
         const double d = v[ci[k]] - v[cj[k]];
-        g[k] = __dmul_rn(__dmul_rn(cw[k], d), d);
+        const double t = cw[k] * d;
+        g[k] = t * d;
     }
 }
 
@@ -610,7 +892,10 @@ __global__ __launch_bounds__(kBlock) void k_fw_final(const double* __restrict__ 
             const double diff = s - xi;
             d += gi * diff;
             q += gi * gi;
-            if (x_next) x_next[i] = __dadd_rn(xi, __dmul_rn(gamma, diff));
+            if (x_next) {
+                const double step = gamma * diff;   // two roundings (contract off above)
+                x_next[i] = xi + step;
+            }
         }
     }
     d = block_sum(d, sm);

@@ -3,11 +3,15 @@
 // Algorithm (replaces nx:151-256 TraceMIN + SuperLU, which the reference calls at
 // mac/utils/fiedler.py:42): plain Lanczos on L restricted to 1-perp (the mean is projected out
 // of every new vector, as nx:209-213 does), no re-orthogonalisation, the whole basis kept in HBM
-// (288 GB makes that free) so the Ritz vector is one tall-skinny pass at the end.  The host only
-// sees O(J) scalars per chunk of steps and runs the tridiagonal analysis (tridiag.h).
-// Convergence is declared by the reference's own rule evaluated explicitly on the device:
-//     || L v - lambda v ||_1 / || L ||_inf < tol          (nx:232, nx:246)
+// (288 GB makes that free) so the Ritz vector is one tall-skinny pass at the end.  One kernel
+// launch per Lanczos step (kernels.h, "pipelined" form); chunks of steps are replayed from cached
+// hipGraphs and run one chunk AHEAD of the host, which meanwhile analyses the previous chunk's
+// O(J) scalars (tridiag.h).  Convergence is declared by the reference's own rule evaluated
+// explicitly on the device:   || L v - lambda v ||_1 / || L ||_inf < tol     (nx:232, nx:246)
 #pragma once
+#include <deque>
+#include <map>
+#include <tuple>
 #include <vector>
 
 #include "kernels.h"
@@ -29,11 +33,19 @@ struct SpmvPlan {
     int variant = kVec;   // kStream or kVec
     int width = 8;        // TPR for stream, G for vec
     int grid = 1;
+    int block = kBlock;   // threads per workgroup of the fused step kernel (256 or 1024)
 };
 
 inline int env_int(const char* name, int dflt) {
     const char* s = getenv(name);
     return (s && *s) ? atoi(s) : dflt;
+}
+
+// Every workgroup of a step kernel re-reduces the previous step's per-workgroup partials, so
+// that traffic grows with grid^2: cap the grid (grid-stride loops cover the rest of the rows).
+inline int grid_cap() {
+    static const int cap = std::max(1, std::min(kMaxGrid, env_int("MACHIP_MAXGRID", 256)));
+    return cap;
 }
 
 inline SpmvPlan plan_spmv(int n, long nnz, int forced_variant) {
@@ -49,20 +61,42 @@ inline SpmvPlan plan_spmv(int n, long nnz, int forced_variant) {
     pl.variant = variant;
     if (variant == kStream) {
         int tpr = 16;
-        while (tpr > 1 && ((long)n * tpr / kBlock > kMaxGrid || tpr > std::max(2.0, mean))) tpr >>= 1;
+        while (tpr > 1 && ((long)n * tpr / kBlock > 4L * grid_cap() || tpr > std::max(2.0, mean))) tpr >>= 1;
         tpr = env_int("MACHIP_TPR", tpr);
         pl.width = tpr;
         const int R = kBlock / tpr;
-        pl.grid = (int)std::min<long>(kMaxGrid, ((long)n + R - 1) / R);
+        pl.grid = (int)std::min<long>(grid_cap(), ((long)n + R - 1) / R);
     } else {
         int g = 4;
         while (g < 64 && g < mean * 0.75) g <<= 1;
         g = env_int("MACHIP_G", g);
         pl.width = g;
         const int gpb = kBlock / g;
-        pl.grid = (int)std::min<long>(kMaxGrid, ((long)n + gpb - 1) / gpb);
+        pl.grid = (int)std::min<long>(grid_cap(), ((long)n + gpb - 1) / gpb);
     }
     if (pl.grid < 1) pl.grid = 1;
+    return pl;
+}
+
+// Launch shape of the fused Lanczos-step kernel (tools/ubench.hip ablations, MI355X):
+// sub-wave groups of 4 lanes per row up to ~40 nnz/row, 16 beyond; at most grid_cap() workgroups
+// (each re-reads every workgroup's partials), so large n gets 1024-thread workgroups instead of
+// more of them.
+inline SpmvPlan plan_pipe(int n, long nnz) {
+    SpmvPlan pl;
+    const double mean = n > 0 ? (double)nnz / (double)n : 1.0;
+    const char* e = getenv("MACHIP_SPMV");
+    if (e && !strcmp(e, "stream")) {
+        pl = plan_spmv(n, nnz, kStream);
+        pl.block = kBlock;
+        return pl;
+    }
+    pl.variant = kVec;
+    pl.width = env_int("MACHIP_G", mean < 16.0 ? 4 : 16);
+    const long tiles256 = ((long)n + (256 / pl.width) - 1) / (256 / pl.width);
+    pl.block = env_int("MACHIP_BLOCK", tiles256 > grid_cap() ? 1024 : 256);
+    const int gpb = pl.block / pl.width;
+    pl.grid = (int)std::max<long>(1, std::min<long>(grid_cap(), ((long)n + gpb - 1) / gpb));
     return pl;
 }
 
@@ -88,30 +122,67 @@ inline void launch_spmv(const SpmvPlan& pl, hipStream_t s, const CsrView& A, con
     }
 }
 
+inline void launch_pipe(const SpmvPlan& pl, hipStream_t s, const CsrView& A, const PipeView& L, int jrel) {
+    if (pl.variant == kStream) {
+        switch (pl.width) {
+            case 1: k_pipe_stream<1><<<pl.grid, kBlock, 0, s>>>(A, L, jrel); break;
+            case 2: k_pipe_stream<2><<<pl.grid, kBlock, 0, s>>>(A, L, jrel); break;
+            case 4: k_pipe_stream<4><<<pl.grid, kBlock, 0, s>>>(A, L, jrel); break;
+            case 8: k_pipe_stream<8><<<pl.grid, kBlock, 0, s>>>(A, L, jrel); break;
+            default: k_pipe_stream<16><<<pl.grid, kBlock, 0, s>>>(A, L, jrel); break;
+        }
+    } else if (pl.block == 1024) {
+        switch (pl.width) {
+            case 4: k_pipe_vec<1024, 4><<<pl.grid, 1024, 0, s>>>(A, L, jrel); break;
+            case 8: k_pipe_vec<1024, 8><<<pl.grid, 1024, 0, s>>>(A, L, jrel); break;
+            case 16: k_pipe_vec<1024, 16><<<pl.grid, 1024, 0, s>>>(A, L, jrel); break;
+            case 32: k_pipe_vec<1024, 32><<<pl.grid, 1024, 0, s>>>(A, L, jrel); break;
+            default: k_pipe_vec<1024, 64><<<pl.grid, 1024, 0, s>>>(A, L, jrel); break;
+        }
+    } else {
+        switch (pl.width) {
+            case 4: k_pipe_vec<256, 4><<<pl.grid, 256, 0, s>>>(A, L, jrel); break;
+            case 8: k_pipe_vec<256, 8><<<pl.grid, 256, 0, s>>>(A, L, jrel); break;
+            case 16: k_pipe_vec<256, 16><<<pl.grid, 256, 0, s>>>(A, L, jrel); break;
+            case 32: k_pipe_vec<256, 32><<<pl.grid, 256, 0, s>>>(A, L, jrel); break;
+            default: k_pipe_vec<256, 64><<<pl.grid, 256, 0, s>>>(A, L, jrel); break;
+        }
+    }
+}
+
 struct Solver {
     int n = 0;
     hipStream_t stream = nullptr;
     size_t vcap = 0;            // Lanczos vectors that fit in V
     // Krylov state
-    double *u = nullptr, *w = nullptr, *V = nullptr, *alpha = nullptr, *beta = nullptr, *l1 = nullptr;
-    double *part_u = nullptr, *part_a = nullptr;
+    double *u = nullptr, *V = nullptr, *tri = nullptr, *part = nullptr, *cb = nullptr;
+    Z3 *Z0 = nullptr, *Z1 = nullptr;
     LanState* st = nullptr;
-    // explicit-check / result state
+    // explicit-check / result state (OpLanczos "column 0" machinery)
     double *y_raw = nullptr, *w2 = nullptr, *yvec = nullptr, *ypart = nullptr, *sdev = nullptr;
     double *part_c = nullptr, *part_a2 = nullptr, *part_r = nullptr, *scratch3 = nullptr, *rq_dev = nullptr;
     LanState* st2 = nullptr;
+    // classic (two-kernel) Lanczos state: the accurate fallback for tiny / nearly exhausted Krylov spaces
+    double *wc = nullptr, *ctri = nullptr, *part_u = nullptr, *part_a = nullptr;
+    LanState* stc = nullptr;
     double* start = nullptr;    // persistent cold-start vector
     bool have_start = false, have_prev = false;
     int ks_max = 16;
     // pinned host staging
-    double* h_pin = nullptr;
-    size_t h_pin_cap = 0;
+    double* h_tri = nullptr;    // mirror of tri
+    double* h_pin = nullptr;    // misc
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> ev_pool;
+    // cached chunk graphs: (variant, width, grid, steps) -> exec
+    std::map<std::tuple<int, int, int, int, int>, hipGraphExec_t> graphs;
+    const void* graph_csr_key = nullptr;
+    bool use_graph = true;
     // host copies of T
     std::vector<double> ha, hb, hl1;
     std::vector<double> wk, guess;
     tri::Smallest sm;
     int J_last = 0;             // dimension of the Krylov space behind the current yvec
+    long last_steps = 0;        // steps the previous solve needed (chunk sizing hint)
 
     int init(int n_, hipStream_t s) {
         n = n_;
@@ -120,38 +191,44 @@ struct Solver {
         vcap = budget / (sizeof(double) * (size_t)std::max(n, 1));
         vcap = std::max<size_t>(std::min<size_t>(vcap, 16384), 64);
         vcap = (size_t)env_int("MACHIP_VCAP", (int)vcap);
-        ST_TRY(dev_alloc(&u, n)); ST_TRY(dev_alloc(&w, n));
+        use_graph = env_int("MACHIP_GRAPH", 1) != 0;
+        ST_TRY(dev_alloc(&u, n));
         ST_TRY(dev_alloc(&V, (size_t)n * vcap));
-        ST_TRY(dev_alloc(&alpha, vcap + 2)); ST_TRY(dev_alloc(&beta, vcap + 2)); ST_TRY(dev_alloc(&l1, vcap + 2));
-        ST_TRY(dev_alloc(&part_u, 3 * kMaxGrid)); ST_TRY(dev_alloc(&part_a, kMaxGrid));
+        ST_TRY(dev_alloc(&tri, 3 * (vcap + 2)));
+        ST_TRY(dev_alloc(&part, 2 * kNP * kMaxGrid));
+        ST_TRY(dev_alloc(&cb, kMaxChunk + 2));
+        ST_TRY(dev_alloc(&Z0, n)); ST_TRY(dev_alloc(&Z1, n));
         ST_TRY(dev_alloc(&st, 1)); ST_TRY(dev_alloc(&st2, 1));
         ST_TRY(dev_alloc(&y_raw, n)); ST_TRY(dev_alloc(&w2, n)); ST_TRY(dev_alloc(&yvec, n));
         ST_TRY(dev_alloc(&ypart, (size_t)n * ks_max)); ST_TRY(dev_alloc(&sdev, vcap + 2));
         ST_TRY(dev_alloc(&part_c, 3 * kMaxGrid)); ST_TRY(dev_alloc(&part_a2, kMaxGrid));
         ST_TRY(dev_alloc(&part_r, kMaxGrid)); ST_TRY(dev_alloc(&scratch3, 8)); ST_TRY(dev_alloc(&rq_dev, 1));
         ST_TRY(dev_alloc(&start, n));
-        h_pin_cap = 3 * (vcap + 2) + 4 * kMaxGrid + 64;
-        HIP_TRY(hipHostMalloc((void**)&h_pin, h_pin_cap * sizeof(double), hipHostMallocDefault));
+        ST_TRY(dev_alloc(&wc, n)); ST_TRY(dev_alloc(&ctri, 3 * (vcap + 2)));
+        ST_TRY(dev_alloc(&part_u, 3 * kMaxGrid)); ST_TRY(dev_alloc(&part_a, kMaxGrid)); ST_TRY(dev_alloc(&stc, 1));
+        HIP_TRY(hipHostMalloc((void**)&h_tri, 3 * (vcap + 2) * sizeof(double), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&h_pin, (4 * (vcap + 2) + 2 * kMaxGrid + 64) * sizeof(double), hipHostMallocDefault));
         HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
         return MACHIP_OK;
     }
     void destroy() {
-        double* ptrs[] = {u, w, V, alpha, beta, l1, part_u, part_a, y_raw, w2, yvec, ypart, sdev,
-                          part_c, part_a2, part_r, scratch3, rq_dev, start};
-        for (double* p : ptrs) if (p) (void)hipFree(p);
-        if (st) (void)hipFree(st);
-        if (st2) (void)hipFree(st2);
+        for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+        graphs.clear();
+        void* ptrs[] = {u, V, tri, part, cb, Z0, Z1, st, st2, y_raw, w2, yvec, ypart, sdev,
+                        part_c, part_a2, part_r, scratch3, rq_dev, start, wc, ctri, part_u, part_a, stc};
+        for (void* p : ptrs) if (p) (void)hipFree(p);
+        if (h_tri) (void)hipHostFree(h_tri);
         if (h_pin) (void)hipHostFree(h_pin);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
+        for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
     }
 
     int vgrid() const { return (int)std::min<long>(kMaxGrid, ((long)n + kBlock - 1) / kBlock); }
 
-    LanView view(const SpmvPlan& pl) const {
-        LanView L;
-        L.n = n; L.st = st; L.u = u; L.w = w; L.V = V; L.alpha = alpha; L.beta = beta; L.l1 = l1;
-        L.part_u = part_u; L.P_u = vgrid(); L.part_a = part_a; L.P_a = pl.grid;
+    PipeView pview(const SpmvPlan& pl) const {
+        PipeView L;
+        L.n = n; L.st = st; L.Z0 = Z0; L.Z1 = Z1; L.V = V; L.tri = tri; L.cb = cb; L.part = part; L.P = pl.grid;
         return L;
     }
     LanView check_view(const SpmvPlan& pl) const {   // "column 0" machinery for the explicit check
@@ -161,16 +238,55 @@ struct Solver {
         return L;
     }
 
-    // Enqueue `steps` Lanczos steps + the tail kernel.
-    void enqueue_steps(const CsrView& A, const SpmvPlan& pl, const LanView& L, int steps) {
+    LanView classic_view(const SpmvPlan& pl) const {
+        LanView L;
+        L.n = n; L.st = stc; L.u = u; L.w = wc; L.V = V; L.alpha = ctri; L.beta = ctri + (vcap + 2);
+        L.l1 = ctri + 2 * (vcap + 2); L.part_u = part_u; L.P_u = vgrid(); L.part_a = part_a; L.P_a = pl.grid;
+        return L;
+    }
+    // Classic Lanczos chunk: per step one SpMV kernel (v_j = (u - mean)/||u|| with the norm taken
+    // from the vector itself, w = L v_j, alpha partials) and one update kernel (u <- w - alpha v_j
+    // - beta v_{j-1}).  Twice the launches of the pipelined form, but beta_j is computed from u_j
+    // directly, so it stays accurate when ||u_j|| << ||L v_j|| (restart from a good vector, Krylov
+    // space nearly exhausted), where the pipelined quadratic form has lost its digits.
+    void enqueue_classic(const CsrView& A, const SpmvPlan& pl, int steps) {
         OpLanczos op;
-        op.L = L;
+        op.L = classic_view(pl);
         const int g2 = vgrid();
         for (int s = 0; s < steps; ++s) {
-            launch_spmv(pl, stream, A, L.u, op);
-            k_lan_update<<<g2, kBlock, 0, stream>>>(L);
+            launch_spmv(pl, stream, A, op.L.u, op);
+            k_lan_update<<<g2, kBlock, 0, stream>>>(op.L);
         }
-        k_lan_tail<<<1, kBlock, 0, stream>>>(L);
+        k_lan_tail<<<1, kBlock, 0, stream>>>(op.L);
+    }
+
+    // ---- one chunk = `steps` step kernels + the tail kernel ------------------------------------
+    void launch_chunk(const CsrView& A, const SpmvPlan& pl, int steps) {
+        const PipeView L = pview(pl);
+        for (int s = 0; s < steps; ++s) launch_pipe(pl, stream, A, L, s);
+        k_pipe_tail<<<1, 64, 0, stream>>>(L, steps);
+    }
+    int enqueue_chunk(const CsrView& A, const SpmvPlan& pl, int steps) {
+        if (!use_graph) { launch_chunk(A, pl, steps); return MACHIP_OK; }
+        if (graph_csr_key != (const void*)A.val) {   // different matrix buffers: cached graphs are stale
+            for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+            graphs.clear();
+            graph_csr_key = (const void*)A.val;
+        }
+        const auto key = std::make_tuple(pl.variant, pl.width, pl.grid, pl.block, steps);
+        auto it = graphs.find(key);
+        if (it == graphs.end()) {
+            hipGraph_t g = nullptr;
+            hipGraphExec_t ge = nullptr;
+            HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+            launch_chunk(A, pl, steps);
+            HIP_TRY(hipStreamEndCapture(stream, &g));
+            HIP_TRY(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(g);
+            it = graphs.emplace(key, ge).first;
+        }
+        HIP_TRY(hipGraphLaunch(it->second, stream));
+        return MACHIP_OK;
     }
 
     // y = V[:, :J] s  -> normalised into yvec; w2 = L yvec; returns (rq, ||w2 - rq yvec||_1).
@@ -192,7 +308,7 @@ struct Solver {
         op.L = check_view(pl);
         launch_spmv(pl, stream, A, y_raw, op);
         k_resid_l1<<<g2, kBlock, 0, stream>>>(w2, yvec, n, part_a2, pl.grid, part_r, rq_dev);
-        double* hp = h_pin + 3 * (vcap + 2);
+        double* hp = h_pin + (vcap + 2);
         HIP_TRY(hipMemcpyAsync(hp, part_r, sizeof(double) * (size_t)g2, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(hp + kMaxGrid, rq_dev, sizeof(double), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
@@ -203,11 +319,20 @@ struct Solver {
         return MACHIP_OK;
     }
 
+    struct Pending { int jend; hipEvent_t ev; int jstart; bool classic; };
+
+    int get_event(hipEvent_t* e) {
+        if (!ev_pool.empty()) { *e = ev_pool.back(); ev_pool.pop_back(); return MACHIP_OK; }
+        HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        return MACHIP_OK;
+    }
+
     // start_mode: 0 = stored cold-start vector (or device pseudo-random if none), 1 = previous
     // Fiedler vector (warm start).
     int solve(const CsrView& A, long nnz, double lnorm, double tol, int max_steps, int start_mode,
               int forced_variant, double* lambda2, machip_solve_stats* stats) {
-        const SpmvPlan pl = plan_spmv(n, nnz, forced_variant);
+        const SpmvPlan pl = plan_spmv(n, nnz, forced_variant);   // explicit-check kernels
+        const SpmvPlan pp = plan_pipe(n, nnz);                   // fused Lanczos-step kernel
         const int g2 = vgrid();
         HIP_TRY(hipEventRecord(ev0, stream));
         if (max_steps <= 0) max_steps = 200000;
@@ -215,8 +340,7 @@ struct Solver {
         int status = MACHIP_NOT_CONVERGED;
         double lam = 0.0, res = 0.0;
         const double tiny_l = (lnorm > 0 ? lnorm : 1.0);
-
-        if (n == 1) { *lambda2 = 0.0; return fail(MACHIP_BAD_ARG, "graph with a single node has no Fiedler pair"); }
+        if (n < 2) { *lambda2 = 0.0; return fail(MACHIP_BAD_ARG, "graph with a single node has no Fiedler pair"); }
 
         // ---- start vector ----
         if (start_mode == 1 && have_prev) {
@@ -226,88 +350,128 @@ struct Solver {
         } else {
             k_fill_start<<<g2, kBlock, 0, stream>>>(u, n, 0x1234567ull);
         }
-        bool fresh = true;   // u holds the (re)start vector, sums not yet taken
 
-        const int min_chunk = std::max(1, env_int("MACHIP_CHUNK", 16));
+        const int chunk0 = std::min(kMaxChunk, std::max(2, env_int("MACHIP_CHUNK", 16) & ~1));   // even: Z parity = jrel & 1
+        if (max_steps & 1) ++max_steps;
         const double trigger_slack = 1.5;   // run the explicit check a little early rather than late
-        double last_check_est = 1e300;
+        const PipeView L = pview(pp);
+        std::deque<Pending> pend;
+        bool done = false;
 
-        while (steps_total < max_steps) {
+        bool classic = n <= env_int("MACHIP_CLASSIC_N", 256);
+        const bool debug = env_int("MACHIP_DEBUG", 0) != 0;
+        while (!done && steps_total < max_steps) {
             // ---- (re)start a Krylov sequence from u ----
-            if (fresh) {
+            if (classic) {
                 k_vec_sums<<<g2, kBlock, 0, stream>>>(u, n, part_u);
-                k_set_state<<<1, 64, 0, stream>>>(st, 0);
-                fresh = false;
+                k_set_state<<<1, 64, 0, stream>>>(stc, 0);
+            } else {
+                k_pipe_init<<<pp.grid, kBlock, 0, stream>>>(L, u);
             }
-            const LanView L = view(pl);
-            int J = 0;
+            int J_enq = 0;        // steps enqueued in this sequence
             ha.clear(); hb.assign(1, 0.0); hl1.assign(1, 0.0);
             guess.clear();
-            double theta_prev = 0.0;
+            double theta_prev = 0.0, last_check_est = 1e300;
             bool converged = false, need_restart = false;
-            const int jcap = (int)std::min<size_t>(vcap - 1, (size_t)std::max(2, n - 1) + 8);
-            last_check_est = 1e300;
-            while (!converged) {
-                int chunk = std::max(min_chunk, J / 8);
-                chunk = std::min(chunk, jcap - J);
-                chunk = (int)std::min<long>(chunk, max_steps - steps_total);
-                if (chunk <= 0) { need_restart = true; break; }
-                enqueue_steps(A, pl, L, chunk);
-                // scalars of this chunk: alpha[J..J+chunk), beta[J..J+chunk], l1[J..J+chunk]
-                double* hp = h_pin;
-                HIP_TRY(hipMemcpyAsync(hp, alpha + J, sizeof(double) * (size_t)chunk, hipMemcpyDeviceToHost, stream));
-                HIP_TRY(hipMemcpyAsync(hp + vcap + 2, beta + J, sizeof(double) * (size_t)(chunk + 1), hipMemcpyDeviceToHost, stream));
-                HIP_TRY(hipMemcpyAsync(hp + 2 * (vcap + 2), l1 + J, sizeof(double) * (size_t)(chunk + 1), hipMemcpyDeviceToHost, stream));
-                HIP_TRY(hipStreamSynchronize(stream));
-                ha.resize((size_t)J + chunk); hb.resize((size_t)J + chunk + 1); hl1.resize((size_t)J + chunk + 1);
-                for (int i = 0; i < chunk; ++i) ha[(size_t)J + i] = hp[i];
-                for (int i = 0; i <= chunk; ++i) {
-                    hb[(size_t)J + i] = hp[vcap + 2 + i];
-                    hl1[(size_t)J + i] = hp[2 * (vcap + 2) + i];
+            const int jcap = (int)std::min<size_t>(vcap - 2, (size_t)std::max(2, n - 1) + 8) & ~1;
+            const size_t cs = vcap + 2;   // stride of the classic alpha / beta / l1 arrays
+
+            while (!converged && !need_restart) {
+                // keep one chunk in flight beyond the one being analysed
+                while ((int)pend.size() < (classic ? 1 : 2) && J_enq < jcap && steps_total < max_steps) {
+                    int chunk = chunk0;
+                    chunk = std::min(chunk, jcap - J_enq);
+                    chunk = (int)std::min<long>(chunk, max_steps - steps_total);
+                    if (chunk <= 0) break;
+                    const int lo = std::max(0, J_enq - 1);
+                    const int hi = J_enq + chunk;           // records lo..hi inclusive
+                    if (classic) {
+                        enqueue_classic(A, pl, chunk);
+                        double* hp = h_pin + (vcap + 2) + 2 * kMaxGrid + 32;   // staging: 3 x (chunk+1)
+                        for (int q = 0; q < 3; ++q)
+                            HIP_TRY(hipMemcpyAsync(hp + q * (size_t)(kMaxChunk + 2), ctri + q * cs + (size_t)J_enq,
+                                                   sizeof(double) * (size_t)(chunk + 1), hipMemcpyDeviceToHost, stream));
+                    } else {
+                        ST_TRY(enqueue_chunk(A, pp, chunk));
+                        HIP_TRY(hipMemcpyAsync(h_tri + 3 * (size_t)lo, tri + 3 * (size_t)lo,
+                                               sizeof(double) * 3 * (size_t)(hi - lo + 1), hipMemcpyDeviceToHost, stream));
+                    }
+                    Pending p;
+                    p.jstart = J_enq;
+                    p.classic = classic;
+                    p.jend = hi;
+                    ST_TRY(get_event(&p.ev));
+                    HIP_TRY(hipEventRecord(p.ev, stream));
+                    pend.push_back(p);
+                    J_enq = hi;
+                    steps_total += chunk; spmv_total += chunk;
                 }
-                steps_total += chunk; spmv_total += chunk;
-                const int Jold = J;
-                J += chunk;
+                if (pend.empty()) { need_restart = true; break; }
+                const Pending p = pend.front();
+                pend.pop_front();
+                HIP_TRY(hipEventSynchronize(p.ev));
+                ev_pool.push_back(p.ev);
+                if (p.classic) {   // scatter the staged (alpha, beta, l1) into the interleaved mirror
+                    const double* hp = h_pin + (vcap + 2) + 2 * kMaxGrid + 32;
+                    for (int i = 0; i <= p.jend - p.jstart; ++i) {
+                        const size_t j = (size_t)(p.jstart + i);
+                        h_tri[3 * j] = hp[i];
+                        h_tri[3 * j + 1] = hp[(kMaxChunk + 2) + i];
+                        h_tri[3 * j + 2] = hp[2 * (kMaxChunk + 2) + i];
+                    }
+                }
+                const int Jold = (int)ha.size();
+                const int J = p.jend;
+                ha.resize((size_t)J); hb.resize((size_t)J + 1); hl1.resize((size_t)J + 1);
+                for (int j = std::max(0, Jold - 1); j < J; ++j) {
+                    ha[(size_t)j] = h_tri[3 * (size_t)j];
+                    hl1[(size_t)j] = h_tri[3 * (size_t)j + 2];
+                }
+                for (int j = Jold; j <= J; ++j) hb[(size_t)j] = h_tri[3 * (size_t)j + 1];
+                if (Jold == 0 && (hb[0] <= 0.0 || !(hb[0] == hb[0])))
+                    return fail(MACHIP_BAD_ARG, "start vector is constant, zero or not finite");
                 // ---- breakdown: beta_j ~ 0 means span(v_0..v_{j-1}) is invariant ----
                 int Jeff = J;
                 bool broke = false;
                 for (int j = std::max(1, Jold); j <= J; ++j) {
                     if (!(hb[(size_t)j] > 1e-13 * tiny_l)) { Jeff = j; broke = true; break; }
                 }
-                if (hb[0] <= 0.0 || !(hb[0] == hb[0])) {
-                    return fail(MACHIP_BAD_ARG, "start vector is constant, zero or not finite");
-                }
                 // ---- host: smallest Ritz pair of T_Jeff ----
                 tri::smallest_eigpair(ha.data(), hb.data(), Jeff, guess.data(), (int)guess.size(), theta_prev, sm, wk);
                 guess = sm.s;
                 theta_prev = sm.theta;
                 const double rho = broke ? 0.0 : std::fabs(hb[(size_t)Jeff] * sm.s[(size_t)Jeff - 1]);
-                const double est = rho * hl1[(size_t)Jeff];   // predicted ||r||_1
-                const bool at_cap = (J >= jcap) || (steps_total >= max_steps);
+                const double l1v = hl1[(size_t)Jeff - 1] > 0 ? hl1[(size_t)Jeff - 1] : std::sqrt((double)n);
+                const double est = rho * l1v;   // predicted ||r||_1 (r = rho v_J; ||v_J||_1 ~ ||v_{J-1}||_1)
+                const bool at_cap = (J >= jcap) || (steps_total >= max_steps && pend.empty());
                 const bool trig = broke || est < trigger_slack * tol * lnorm;
+                if (debug) fprintf(stderr, "[machip] %s J=%d Jeff=%d theta=%.15g est=%.3e broke=%d pend=%zu passes=%d\n", classic ? "classic" : "pipe", J, Jeff, sm.theta, lnorm > 0 ? est / lnorm : est, (int)broke, pend.size(), sm.passes);
                 if ((trig && est < 0.5 * last_check_est) || broke || at_cap) {
                     double rq = 0.0, r1 = 0.0;
-                    ST_TRY(explicit_check(A, pl, Jeff, sm.s.data(), &rq, &r1));
-                    J_last = Jeff;
+                    ST_TRY(explicit_check(A, pl, Jeff, sm.s.data(), &rq, &r1));   // syncs the stream
                     spmv_total += 1;
+                    J_last = Jeff;
                     last_check_est = std::max(est, 1e-300);
                     lam = rq;
                     res = lnorm > 0 ? r1 / lnorm : r1;
+                    if (debug) fprintf(stderr, "[machip]    check J=%d rq=%.15g res=%.3e (tol %.1e)\n", Jeff, rq, res, tol);
                     if (res < tol) { converged = true; status = MACHIP_OK; break; }
                     if (broke || at_cap) { need_restart = true; break; }
                 }
             }
-            if (converged) break;
-            if (need_restart) {
-                if (steps_total >= max_steps) break;
-                // restart from the best Ritz vector found so far (it sits normalised in yvec)
-                HIP_TRY(hipMemcpyAsync(u, yvec, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream));
-                fresh = true;
-                ++restarts;
-                if (restarts > 64) break;
-            }
+            // drain what is still in flight (its results are not needed)
+            for (const Pending& p : pend) { HIP_TRY(hipEventSynchronize(p.ev)); ev_pool.push_back(p.ev); }
+            pend.clear();
+            if (converged) { done = true; break; }
+            if (steps_total >= max_steps) break;
+            // restart from the best Ritz vector found so far (it sits normalised in yvec)
+            HIP_TRY(hipMemcpyAsync(u, yvec, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream));
+            ++restarts;
+            classic = true;   // refine with the accurate form (see enqueue_classic)
+            if (restarts > 64) break;
         }
         have_prev = true;
+        last_steps = steps_total;
         HIP_TRY(hipEventRecord(ev1, stream));
         HIP_TRY(hipEventSynchronize(ev1));
         float ms = 0.f;
@@ -316,17 +480,17 @@ struct Solver {
         if (stats) {
             stats->lanczos_steps = steps_total;
             stats->spmv_total = spmv_total;
-            stats->vec_passes = steps_total * 7;   // K1: u, v_{j-1} read; w, v_j written. K2: w, v_j, v_{j-1} read; u written
+            stats->vec_passes = steps_total * 8;   // per step and row: Z read (3) + Z write (3) + V write (1) ~ 7-8 doubles
             stats->restarts = restarts;
             stats->nnz = nnz;
             stats->residual = res;
             stats->lnorm = lnorm;
             stats->gpu_ms = ms;
         }
-        if (status == MACHIP_OK && lam < 1e-12 * tiny_l) {
+        if (status == MACHIP_OK && lam < 1e-12 * tiny_l)
             return fail(MACHIP_DISCONNECTED, "lambda_2 ~ 0: the graph is not connected");
-        }
-        if (status != MACHIP_OK) return fail(MACHIP_NOT_CONVERGED, "Lanczos hit the step cap before the residual test passed");
+        if (status != MACHIP_OK)
+            return fail(MACHIP_NOT_CONVERGED, "Lanczos hit the step cap before the residual test passed");
         return MACHIP_OK;
     }
 
@@ -343,6 +507,23 @@ struct Solver {
         HIP_TRY(hipStreamSynchronize(stream));
         int acc = 1;
         std::vector<double> col((size_t)n);
+        auto orth_accept = [&](double n0) -> bool {
+            for (int pass = 0; pass < 2; ++pass)
+                for (int p = 0; p < acc; ++p) {
+                    const double* xp = X_host + (size_t)p * n;
+                    double dot = 0.0;
+                    for (int i = 0; i < n; ++i) dot += xp[i] * col[(size_t)i];
+                    for (int i = 0; i < n; ++i) col[(size_t)i] -= dot * xp[i];
+                }
+            double n2 = 0.0;
+            for (int i = 0; i < n; ++i) n2 += col[(size_t)i] * col[(size_t)i];
+            if (!(n2 > 1e-6 * std::max(n0, 1e-300))) return false;   // ghost copy / dependent
+            const double inv = 1.0 / std::sqrt(n2);
+            double* dst = X_host + (size_t)acc * n;
+            for (int i = 0; i < n; ++i) dst[i] = col[(size_t)i] * inv;
+            ++acc;
+            return true;
+        };
         for (int c = 1; c < (int)th.size() && acc < q; ++c) {
             memcpy(h_pin, S.data() + (size_t)c * Jeff, sizeof(double) * (size_t)Jeff);
             HIP_TRY(hipMemcpyAsync(sdev, h_pin, sizeof(double) * (size_t)Jeff, hipMemcpyHostToDevice, stream));
@@ -355,26 +536,13 @@ struct Solver {
             for (int i = 0; i < n; ++i) mean += col[(size_t)i];
             mean /= n;
             for (int i = 0; i < n; ++i) { col[(size_t)i] -= mean; n0 += col[(size_t)i] * col[(size_t)i]; }
-            for (int pass = 0; pass < 2; ++pass)
-                for (int p = 0; p < acc; ++p) {
-                    const double* xp = X_host + (size_t)p * n;
-                    double dot = 0.0;
-                    for (int i = 0; i < n; ++i) dot += xp[i] * col[(size_t)i];
-                    for (int i = 0; i < n; ++i) col[(size_t)i] -= dot * xp[i];
-                }
-            double n2 = 0.0;
-            for (int i = 0; i < n; ++i) n2 += col[(size_t)i] * col[(size_t)i];
-            if (!(n2 > 1e-6 * std::max(n0, 1e-300))) continue;   // ghost copy of an accepted vector
-            const double inv = 1.0 / std::sqrt(n2);
-            double* dst = X_host + (size_t)acc * n;
-            for (int i = 0; i < n; ++i) dst[i] = col[(size_t)i] * inv;
-            ++acc;
+            (void)orth_accept(n0);
         }
         // Krylov space exhausted (tiny or highly symmetric graph): complete the block with
         // deterministic vectors orthogonal to 1 and to the accepted columns, so X is always an
         // orthonormal n x q block like the reference's (nx:238).
         for (unsigned long long seed = 1; acc < q && seed < 64; ++seed) {
-            double mean = 0.0;
+            double mean = 0.0, n0 = 0.0;
             for (int i = 0; i < n; ++i) {
                 unsigned long long z = seed * 0xD1B54A32D192ED03ull + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
                 z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -384,21 +552,8 @@ struct Solver {
                 mean += col[(size_t)i];
             }
             mean /= n;
-            for (int i = 0; i < n; ++i) col[(size_t)i] -= mean;
-            for (int pass = 0; pass < 2; ++pass)
-                for (int p = 0; p < acc; ++p) {
-                    const double* xp = X_host + (size_t)p * n;
-                    double dot = 0.0;
-                    for (int i = 0; i < n; ++i) dot += xp[i] * col[(size_t)i];
-                    for (int i = 0; i < n; ++i) col[(size_t)i] -= dot * xp[i];
-                }
-            double n2 = 0.0;
-            for (int i = 0; i < n; ++i) n2 += col[(size_t)i] * col[(size_t)i];
-            if (!(n2 > 1e-12)) continue;
-            const double inv = 1.0 / std::sqrt(n2);
-            double* dst = X_host + (size_t)acc * n;
-            for (int i = 0; i < n; ++i) dst[i] = col[(size_t)i] * inv;
-            ++acc;
+            for (int i = 0; i < n; ++i) { col[(size_t)i] -= mean; n0 += col[(size_t)i] * col[(size_t)i]; }
+            (void)orth_accept(n0);
         }
         for (; acc < q; ++acc) {
             double* dst = X_host + (size_t)acc * n;
