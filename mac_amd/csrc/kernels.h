@@ -61,14 +61,13 @@ struct LanView {
 template <int G>
 __global__ __launch_bounds__(kBlock) void k_asm_count(PatternView P, const double* __restrict__ x,
                                                       double tol, int rows_per_block,
-                                                      int* __restrict__ cnt, int* __restrict__ blk_sum,
-                                                      int* __restrict__ blk_supp) {
+                                                      int* __restrict__ cnt, int* __restrict__ blk_sum) {
     __shared__ int sm[4];
     constexpr int GPB = kBlock / G;
     const int lane = threadIdx.x % G, g = threadIdx.x / G;
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(P.n, r0 + rows_per_block);
-    int local = 0, supp = 0;
+    int local = 0, supp = 0, mx = 0;
     for (int r = r0 + g; r < r1; r += GPB) {
         const int b = P.prow[r], e = P.prow[r + 1];
         int c = 0, sc = 0;
@@ -85,13 +84,20 @@ __global__ __launch_bounds__(kBlock) void k_asm_count(PatternView P, const doubl
             cnt[r] = c + 1;
             local += c + 1;
             supp += sc;
+            mx = max(mx, c + 1);
         }
     }
     const int tot = block_sum_i(local, sm);
     const int stot = block_sum_i(supp, sm);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, kWave));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mx;
+    __syncthreads();
     if (threadIdx.x == 0) {
         blk_sum[blockIdx.x] = tot;
-        blk_supp[blockIdx.x] = stot;
+        blk_sum[kMaxGrid + blockIdx.x] = stot;                                   // active candidates
+        blk_sum[2 * kMaxGrid + blockIdx.x] = max(max(sm[0], sm[1]), max(sm[2], sm[3]));   // longest row
     }
 }
 
@@ -392,6 +398,9 @@ struct PipeView {
     double* V;
     double* tri;      // interleaved (alpha_j, beta_j, ||v_j||_1) records: one D2H copy per chunk
     double* cb;       // kMaxChunk+1 slots: cb[s] = beta_{j-1} for the launch with jrel = s
+    double* htri;     // host-pinned mirror of tri, written by the tail kernel (zero-copy): the host
+                      // polls hflag instead of issuing a stream-ordered copy between chunks
+    unsigned long long* hflag;   // (epoch << 32) | J once records < J (and beta_J) are in htri
     double* part;     // 2 x kNP x kMaxGrid, ping-ponged like Z: a step reads half (jrel & 1) and
                       // writes the other, so a late-starting workgroup never sees partials that a
                       // fast workgroup of the SAME launch has already replaced
@@ -448,7 +457,7 @@ __device__ __forceinline__ PipeCoef pipe_coefs(const double (&a)[kNP], double be
 // Prologue, run by wave 0 only: sum the P (<= 256) partials of each quantity, derive the
 // coefficients, publish them to the workgroup through LDS (scoef) and -- workgroup 0 -- to the
 // host-visible tridiagonal record.  The other waves go straight to their CSR loads.
-__device__ __forceinline__ void pipe_prologue_wave0(const PipeView& L, int jrel, int adv_jA, double* scoef) {
+__device__ __forceinline__ PipeCoef pipe_prologue_wave0(const PipeView& L, int jrel, int adv_jA, double* scoef, int* j_out) {
     const int lane = threadIdx.x;   // caller guarantees threadIdx.x < 64
     const int jA = L.st->jA;
     const double betap = L.cb[jrel];
@@ -473,6 +482,8 @@ __device__ __forceinline__ void pipe_prologue_wave0(const PipeView& L, int jrel,
             else L.cb[jrel + 1] = c.beta;
         }
     }
+    *j_out = j;
+    return c;
 }
 
 struct PipeRow {   // per-thread accumulation of the next step's partial sums
@@ -521,7 +532,7 @@ __global__ __launch_bounds__(BLOCK) void k_pipe_vec(CsrView A, PipeView L, int j
     __shared__ double scoef[8];
     constexpr int GPB = BLOCK / G;
     const int lane = threadIdx.x % G, g = threadIdx.x / G;
-    if (threadIdx.x < 64) pipe_prologue_wave0(L, jrel, -1, scoef);
+    if (threadIdx.x < 64) { int jdummy; (void)pipe_prologue_wave0(L, jrel, -1, scoef, &jdummy); }
     const Z3* __restrict__ Zc = (jrel & 1) ? L.Z1 : L.Z0;
     Z3* __restrict__ Zn = (jrel & 1) ? L.Z0 : L.Z1;
     PipeRow pr;
@@ -566,7 +577,7 @@ __global__ __launch_bounds__(kBlock) void k_pipe_stream(CsrView A, PipeView L, i
     constexpr int R = kBlock / TPR;
     const int tid = threadIdx.x;
     const int row = tid / TPR, sub = tid % TPR;
-    if (tid < 64) pipe_prologue_wave0(L, jrel, -1, scoef);
+    if (tid < 64) { int jdummy; (void)pipe_prologue_wave0(L, jrel, -1, scoef, &jdummy); }
     const Z3* __restrict__ Zc = (jrel & 1) ? L.Z1 : L.Z0;
     Z3* __restrict__ Zn = (jrel & 1) ? L.Z0 : L.Z1;
     PipeRow pr;
@@ -607,7 +618,7 @@ __global__ __launch_bounds__(kBlock) void k_pipe_stream(CsrView A, PipeView L, i
 }
 
 // Start a sequence from u0: Z0 = (u0, 0, 0); partials such that step 0 normalises u0.
-__global__ __launch_bounds__(kBlock) void k_pipe_init(PipeView L, const double* __restrict__ u0) {
+__global__ __launch_bounds__(kBlock) void k_pipe_init(PipeView L, const double* __restrict__ u0, int epoch) {
     __shared__ double sm[4];
     double s1 = 0.0, s2 = 0.0;
     for (int r = blockIdx.x * kBlock + threadIdx.x; r < L.n; r += gridDim.x * kBlock) {
@@ -621,7 +632,7 @@ __global__ __launch_bounds__(kBlock) void k_pipe_init(PipeView L, const double* 
         for (int q = 0; q < kNP; ++q) L.part[q * kMaxGrid + blockIdx.x] = 0.0;
         L.part[0 * kMaxGrid + blockIdx.x] = s2;
         L.part[6 * kMaxGrid + blockIdx.x] = s1;
-        if (blockIdx.x == 0) { L.st->jA = 0; L.st->jB = 0; L.cb[0] = 0.0; }
+        if (blockIdx.x == 0) { L.st->jA = 0; L.st->jB = epoch; L.cb[0] = 0.0; }   // jB carries the sequence epoch
     }
 }
 // One wave, end of a chunk of `adv` steps: finish (alpha_{J-1}, beta_J, l1_{J-1}) for J = jA + adv
@@ -630,7 +641,23 @@ __global__ __launch_bounds__(kBlock) void k_pipe_init(PipeView L, const double* 
 // its launch.
 __global__ __launch_bounds__(64) void k_pipe_tail(PipeView L, int adv) {
     __shared__ double scoef[8];
-    pipe_prologue_wave0(L, adv, adv, scoef);
+    int j = 0;
+    const PipeCoef c = pipe_prologue_wave0(L, adv, adv, scoef, &j);
+    // zero-copy hand-off to the host: records [j-adv-1, j] of tri -> pinned host memory, then the
+    // flag.  The three values this kernel has just produced go from registers (lane 0).
+    const int lo = max(0, j - adv - 1);
+    const int cnt = 3 * (j - lo + 1);
+    for (int i = threadIdx.x; i < cnt; i += 64) L.htri[3 * lo + i] = L.tri[3 * lo + i];
+    if (threadIdx.x == 0) {
+        if (j > 0) { L.htri[3 * (j - 1)] = c.alpha; L.htri[3 * (j - 1) + 2] = c.l1prev; }
+        L.htri[3 * j + 1] = c.beta;
+    }
+    __threadfence_system();
+    if (threadIdx.x == 0) {
+        const unsigned long long epoch = (unsigned long long)(unsigned int)L.st->jB;
+        __hip_atomic_store(L.hflag, (epoch << 32) | (unsigned long long)(unsigned int)j, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // Partial sums (sum, sum of squares, sum of abs) of a vector -> part_u layout.
@@ -779,21 +806,34 @@ __global__ __launch_bounds__(kBlock) void k_sel_pass(const double* __restrict__ 
     const int sh = sel_shift(pass), nb = sel_bits(pass);
     const unsigned long long prefix = pass ? st->prefix : 0ull;
     const unsigned int mask = (1u << nb) - 1u;
+    // the high digits of a gradient vector fall into a handful of bins: count runs of equal
+    // digits in registers and touch the LDS histogram once per run, not once per key
+    unsigned int cur = 0xffffffffu, run = 0;
     for (long i = (long)blockIdx.x * kBlock + tid; i < m; i += (long)gridDim.x * kBlock) {
         const unsigned long long key = f64_key(g[i]);
         const bool match = pass == 0 || (key >> (sh + nb)) == prefix;
-        if (match) atomicAdd(&lh[(unsigned int)(key >> sh) & mask], 1u);
+        if (match) {
+            const unsigned int bin = (unsigned int)(key >> sh) & mask;
+            if (bin == cur) ++run;
+            else {
+                if (run) atomicAdd(&lh[cur], run);
+                cur = bin; run = 1;
+            }
+        }
     }
+    if (run) atomicAdd(&lh[cur], run);
     __syncthreads();
     unsigned int* gh = hist + pass * kBins;
     for (int i = tid; i < kBins; i += kBlock)
         if (lh[i]) atomicAdd(&gh[i], lh[i]);
-    __threadfence();
+    // the histogram lives in device-scope atomics (performed at the memory side, never cached);
+    // __syncthreads() drains this workgroup's atomics, then ONE lane takes the arrival ticket with
+    // release/acquire semantics (a fence per thread costs several microseconds here)
     __syncthreads();
-    if (tid == 0) s_last = (atomicAdd(&st->ticket[pass], 1u) == gridDim.x - 1);
+    if (tid == 0)
+        s_last = (__hip_atomic_fetch_add(&st->ticket[pass], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1);
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     // last workgroup: walk the bins from the top until the cumulative count reaches kk
     const long long kk = pass ? st->kk : st->k;
     const int nbins = 1 << nb;

@@ -35,9 +35,10 @@ struct machip_problem {
     double* cw = nullptr;
     double *x = nullptr, *x_next = nullptr, *g = nullptr, *s = nullptr;
     // assembled CSR (device)
-    int *cnt = nullptr, *blk_sum = nullptr, *blk_supp = nullptr, *rowptr = nullptr, *col = nullptr;
+    int *cnt = nullptr, *blk_sum = nullptr, *rowptr = nullptr, *col = nullptr;
     double *val = nullptr, *blk_lnorm = nullptr;
     long nnz = 0, support = 0;
+    int maxlen = 0;           // longest row of the assembled L(x)
     double lnorm = 0.0;
     bool assembled = false, have_vec = false, csr_only = false;
     // select / FW scalars
@@ -144,8 +145,7 @@ int build_pattern(machip_problem* p, int64_t nf, const int32_t* fi, const int32_
 template <int G>
 void launch_asm(machip_problem* p) {
     const PatternView P = p->pattern();
-    k_asm_count<G><<<p->asm_grid, kBlock, 0, p->stream>>>(P, p->x, p->tol_sel, p->asm_rpb, p->cnt, p->blk_sum,
-                                                          p->blk_supp);
+    k_asm_count<G><<<p->asm_grid, kBlock, 0, p->stream>>>(P, p->x, p->tol_sel, p->asm_rpb, p->cnt, p->blk_sum);
     const size_t lds = sizeof(int) * ((size_t)p->asm_rpb + 1);
     k_asm_fill<G><<<p->asm_grid, kBlock, lds, p->stream>>>(P, p->x, p->tol_sel, p->asm_rpb, p->cnt, p->blk_sum,
                                                            p->rowptr, p->col, p->val, p->blk_lnorm);
@@ -161,21 +161,24 @@ int assemble(machip_problem* p) {
         default: launch_asm<64>(p); break;
     }
     const int gb = p->asm_grid;
-    HIP_TRY(hipMemcpyAsync(p->h_int, p->blk_sum, sizeof(int) * (size_t)gb, hipMemcpyDeviceToHost, p->stream));
-    HIP_TRY(hipMemcpyAsync(p->h_int + kMaxGrid, p->blk_supp, sizeof(int) * (size_t)gb, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipMemcpyAsync(p->h_int, p->blk_sum, sizeof(int) * 3 * kMaxGrid, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipMemcpyAsync(p->h_dbl, p->blk_lnorm, sizeof(double) * (size_t)gb, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
     long nnz = 0, supp = 0;
+    int maxlen = 0;
     double ln = 0.0;
-    for (int b = 0; b < gb; ++b) { nnz += p->h_int[b]; supp += p->h_int[kMaxGrid + b]; ln = std::max(ln, p->h_dbl[b]); }
-    p->nnz = nnz; p->support = supp; p->lnorm = ln;
+    for (int b = 0; b < gb; ++b) {
+        nnz += p->h_int[b]; supp += p->h_int[kMaxGrid + b]; maxlen = std::max(maxlen, p->h_int[2 * kMaxGrid + b]);
+        ln = std::max(ln, p->h_dbl[b]);
+    }
+    p->nnz = nnz; p->support = supp; p->lnorm = ln; p->maxlen = maxlen;
     p->assembled = true;
     return MACHIP_OK;
 }
 
 int alloc_common(machip_problem* p) {
     ST_TRY(p->sol.init(p->n, p->stream));
-    HIP_TRY(hipHostMalloc((void**)&p->h_int, sizeof(int) * 2 * kMaxGrid, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&p->h_int, sizeof(int) * 3 * kMaxGrid, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void**)&p->h_dbl, sizeof(double) * 4 * kMaxGrid, hipHostMallocDefault));
     return MACHIP_OK;
 }
@@ -225,6 +228,7 @@ int run_fiedler(machip_problem* p, double tol, int max_steps, const double* x0, 
     }
     machip_solve_stats local;
     memset(&local, 0, sizeof(local));
+    p->sol.maxlen_hint = p->maxlen;
     const int st = p->sol.solve(p->csr(), p->nnz, p->lnorm, tol, max_steps, (x0 == nullptr && warm_start) ? 1 : 0,
                                 kAuto, lambda2, &local);
     local.support = p->support;
@@ -282,7 +286,7 @@ int machip_create(int device, int64_t n, int64_t n_fixed, const int32_t* fi, con
         HIP_TRY(hipMemset(p->x, 0, sizeof(double) * mp));
         HIP_TRY(hipMemset(p->g, 0, sizeof(double) * mp));
         const size_t cap = (size_t)p->P + (size_t)n + 8;
-        ST_TRY(dev_alloc(&p->cnt, (size_t)n + 1)); ST_TRY(dev_alloc(&p->blk_sum, kMaxGrid)); ST_TRY(dev_alloc(&p->blk_supp, kMaxGrid));
+        ST_TRY(dev_alloc(&p->cnt, (size_t)n + 1)); ST_TRY(dev_alloc(&p->blk_sum, 3 * kMaxGrid));
         ST_TRY(dev_alloc(&p->rowptr, (size_t)n + 1)); ST_TRY(dev_alloc(&p->col, cap)); ST_TRY(dev_alloc(&p->val, cap));
         ST_TRY(dev_alloc(&p->blk_lnorm, kMaxGrid));
         ST_TRY(dev_alloc(&p->hist, 6 * kBins)); ST_TRY(dev_alloc(&p->sel, 1)); ST_TRY(dev_alloc(&p->part_fw, 2 * kMaxGrid));
@@ -302,7 +306,7 @@ void machip_destroy(machip_problem* p) {
     if (p->comm) (void)ncclCommDestroy(p->comm);
     p->sol.destroy();
     void* ptrs[] = {p->prow, p->pcol, p->pk, p->pw, p->ci, p->cj, p->cw, p->x, p->x_next, p->g, p->s, p->cnt,
-                    p->blk_sum, p->blk_supp, p->rowptr, p->col, p->val, p->blk_lnorm, p->hist, p->sel, p->part_fw};
+                    p->blk_sum, p->rowptr, p->col, p->val, p->blk_lnorm, p->hist, p->sel, p->part_fw};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     if (p->h_int) (void)hipHostFree(p->h_int);
     if (p->h_dbl) (void)hipHostFree(p->h_dbl);
@@ -432,6 +436,7 @@ int machip_fiedler_csr(int device, int64_t n, const int32_t* indptr, const int32
     const long nnz = indptr[n];
     if (indptr[0] != 0 || nnz < 0) return fail(MACHIP_BAD_ARG, "bad indptr");
     double lnorm = 0.0;
+    int maxlen_csr = 0;
     for (int64_t r = 0; r < n; ++r) {
         if (indptr[r + 1] < indptr[r]) return fail(MACHIP_BAD_ARG, "indptr not monotone");
         double s = 0.0;
@@ -440,6 +445,7 @@ int machip_fiedler_csr(int device, int64_t n, const int32_t* indptr, const int32
             s += std::fabs(data[pp]);
         }
         lnorm = std::max(lnorm, s);   // nx:232
+        maxlen_csr = std::max(maxlen_csr, (int)(indptr[r + 1] - indptr[r]));
     }
     machip_problem* p = new machip_problem();
     p->device = device; p->n = (int)n; p->csr_only = true;
@@ -452,7 +458,7 @@ int machip_fiedler_csr(int device, int64_t n, const int32_t* indptr, const int32
             HIP_TRY(hipMemcpy(p->val, data, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
         }
         ST_TRY(alloc_common(p));
-        p->nnz = nnz; p->lnorm = lnorm; p->assembled = true;
+        p->nnz = nnz; p->lnorm = lnorm; p->maxlen = maxlen_csr; p->assembled = true;
         return MACHIP_OK;
     };
     int st = body();
@@ -481,13 +487,13 @@ int machip_profile_spmv(machip_problem* p, int reps, double* avg_us, double* byt
     HIP_TRY(hipSetDevice(p->device));
     if (!p->assembled) ST_TRY(assemble(p));
     Solver& S = p->sol;
-    const SpmvPlan pl = plan_pipe(p->n, p->nnz);
+    const SpmvPlan pl = plan_pipe(p->n, p->nnz, p->maxlen);
     // The dominant kernel of the path: one fused Lanczos step (k_pipe_*).  Re-launching step 1 of
     // a scratch sequence is idempotent (same Z read, same Z/V column written), so `reps`
     // back-to-back launches time exactly the kernel the solve runs, on the same L(x).
     k_fill_start<<<S.vgrid(), kBlock, 0, p->stream>>>(S.u, p->n, 77ull);
     const PipeView L = S.pview(pl);
-    k_pipe_init<<<pl.grid, kBlock, 0, p->stream>>>(L, S.u);
+    k_pipe_init<<<pl.grid, kBlock, 0, p->stream>>>(L, S.u, (int)(++S.epoch));
     launch_pipe(pl, p->stream, p->csr(), L, 0);
     launch_pipe(pl, p->stream, p->csr(), L, 1);
     k_pipe_tail<<<1, 64, 0, p->stream>>>(L, 2);      // jA = 2

@@ -82,7 +82,7 @@ inline SpmvPlan plan_spmv(int n, long nnz, int forced_variant) {
 // sub-wave groups of 4 lanes per row up to ~40 nnz/row, 16 beyond; at most grid_cap() workgroups
 // (each re-reads every workgroup's partials), so large n gets 1024-thread workgroups instead of
 // more of them.
-inline SpmvPlan plan_pipe(int n, long nnz) {
+inline SpmvPlan plan_pipe(int n, long nnz, int maxlen) {
     SpmvPlan pl;
     const double mean = n > 0 ? (double)nnz / (double)n : 1.0;
     const char* e = getenv("MACHIP_SPMV");
@@ -92,7 +92,9 @@ inline SpmvPlan plan_pipe(int n, long nnz) {
         return pl;
     }
     pl.variant = kVec;
-    pl.width = env_int("MACHIP_G", mean < 16.0 ? 4 : 16);
+    // hub rows (Frank-Wolfe vertices concentrate the selected edges on few nodes) serialise a
+    // 4-lane group: widen the groups when the longest row is far above the mean
+    pl.width = env_int("MACHIP_G", (mean < 16.0 && maxlen <= 48) ? 4 : 16);
     const long tiles256 = ((long)n + (256 / pl.width) - 1) / (256 / pl.width);
     pl.block = env_int("MACHIP_BLOCK", tiles256 > grid_cap() ? 1024 : 256);
     const int gpb = pl.block / pl.width;
@@ -169,7 +171,11 @@ struct Solver {
     bool have_start = false, have_prev = false;
     int ks_max = 16;
     // pinned host staging
-    double* h_tri = nullptr;    // mirror of tri
+    double* h_tri = nullptr;    // mirror of tri (pinned, device-mapped: the tail kernel writes it)
+    double* d_htri = nullptr;   // device view of h_tri
+    unsigned long long* h_flag = nullptr;   // pinned completion flag polled by the host
+    unsigned long long* d_hflag = nullptr;
+    unsigned int epoch = 0;
     double* h_pin = nullptr;    // misc
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> ev_pool;
@@ -183,6 +189,7 @@ struct Solver {
     tri::Smallest sm;
     int J_last = 0;             // dimension of the Krylov space behind the current yvec
     long last_steps = 0;        // steps the previous solve needed (chunk sizing hint)
+    int maxlen_hint = 0;        // longest row of the matrix about to be solved (0 = unknown)
 
     int init(int n_, hipStream_t s) {
         n = n_;
@@ -206,7 +213,11 @@ struct Solver {
         ST_TRY(dev_alloc(&start, n));
         ST_TRY(dev_alloc(&wc, n)); ST_TRY(dev_alloc(&ctri, 3 * (vcap + 2)));
         ST_TRY(dev_alloc(&part_u, 3 * kMaxGrid)); ST_TRY(dev_alloc(&part_a, kMaxGrid)); ST_TRY(dev_alloc(&stc, 1));
-        HIP_TRY(hipHostMalloc((void**)&h_tri, 3 * (vcap + 2) * sizeof(double), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&h_tri, 3 * (vcap + 2) * sizeof(double), hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void**)&d_htri, h_tri, 0));
+        HIP_TRY(hipHostMalloc((void**)&h_flag, 64, hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void**)&d_hflag, h_flag, 0));
+        *h_flag = 0;
         HIP_TRY(hipHostMalloc((void**)&h_pin, (4 * (vcap + 2) + 2 * kMaxGrid + 64) * sizeof(double), hipHostMallocDefault));
         HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
         return MACHIP_OK;
@@ -218,6 +229,7 @@ struct Solver {
                         part_c, part_a2, part_r, scratch3, rq_dev, start, wc, ctri, part_u, part_a, stc};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (h_tri) (void)hipHostFree(h_tri);
+        if (h_flag) (void)hipHostFree(h_flag);
         if (h_pin) (void)hipHostFree(h_pin);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -228,7 +240,7 @@ struct Solver {
 
     PipeView pview(const SpmvPlan& pl) const {
         PipeView L;
-        L.n = n; L.st = st; L.Z0 = Z0; L.Z1 = Z1; L.V = V; L.tri = tri; L.cb = cb; L.part = part; L.P = pl.grid;
+        L.n = n; L.st = st; L.Z0 = Z0; L.Z1 = Z1; L.V = V; L.tri = tri; L.cb = cb; L.htri = d_htri; L.hflag = d_hflag; L.part = part; L.P = pl.grid;
         return L;
     }
     LanView check_view(const SpmvPlan& pl) const {   // "column 0" machinery for the explicit check
@@ -321,6 +333,27 @@ struct Solver {
 
     struct Pending { int jend; hipEvent_t ev; int jstart; bool classic; };
 
+    // Spin on the pinned flag the tail kernel publishes; fall back to a stream query now and then so
+    // a device fault cannot hang the host.
+    int wait_flag(unsigned long long want) {
+        volatile unsigned long long* f = h_flag;
+        for (unsigned long spins = 0;; ++spins) {
+            const unsigned long long v = *f;
+            if ((v >> 32) == (want >> 32) && (v & 0xffffffffull) >= (want & 0xffffffffull)) return MACHIP_OK;
+            if ((spins & 0xfffff) == 0xfffff) {
+                const hipError_t q = hipStreamQuery(stream);
+                if (q != hipSuccess && q != hipErrorNotReady)
+                    return fail(MACHIP_HIP_ERROR, std::string("stream error while waiting for a Lanczos chunk: ") + hipGetErrorString(q));
+                if (q == hipSuccess) {   // stream drained: the flag must be there now
+                    const unsigned long long v2 = *f;
+                    if ((v2 >> 32) == (want >> 32) && (v2 & 0xffffffffull) >= (want & 0xffffffffull)) return MACHIP_OK;
+                    return fail(MACHIP_HIP_ERROR, "Lanczos chunk finished without publishing its flag");
+                }
+            }
+            __builtin_ia32_pause();
+        }
+    }
+
     int get_event(hipEvent_t* e) {
         if (!ev_pool.empty()) { *e = ev_pool.back(); ev_pool.pop_back(); return MACHIP_OK; }
         HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -332,7 +365,7 @@ struct Solver {
     int solve(const CsrView& A, long nnz, double lnorm, double tol, int max_steps, int start_mode,
               int forced_variant, double* lambda2, machip_solve_stats* stats) {
         const SpmvPlan pl = plan_spmv(n, nnz, forced_variant);   // explicit-check kernels
-        const SpmvPlan pp = plan_pipe(n, nnz);                   // fused Lanczos-step kernel
+        const SpmvPlan pp = plan_pipe(n, nnz, maxlen_hint);      // fused Lanczos-step kernel
         const int g2 = vgrid();
         HIP_TRY(hipEventRecord(ev0, stream));
         if (max_steps <= 0) max_steps = 200000;
@@ -351,7 +384,8 @@ struct Solver {
             k_fill_start<<<g2, kBlock, 0, stream>>>(u, n, 0x1234567ull);
         }
 
-        const int chunk0 = std::min(kMaxChunk, std::max(2, env_int("MACHIP_CHUNK", 16) & ~1));   // even: Z parity = jrel & 1
+        const int chunk0 = std::min(kMaxChunk, std::max(2, env_int("MACHIP_CHUNK", 32) & ~1));   // even: Z parity = jrel & 1
+        const int chunk_near = std::min(chunk0, std::max(2, env_int("MACHIP_CHUNK_NEAR", 8) & ~1));   // once the residual estimate is within 1e3 of the target
         if (max_steps & 1) ++max_steps;
         const double trigger_slack = 1.5;   // run the explicit check a little early rather than late
         const PipeView L = pview(pp);
@@ -366,12 +400,13 @@ struct Solver {
                 k_vec_sums<<<g2, kBlock, 0, stream>>>(u, n, part_u);
                 k_set_state<<<1, 64, 0, stream>>>(stc, 0);
             } else {
-                k_pipe_init<<<pp.grid, kBlock, 0, stream>>>(L, u);
+                ++epoch;
+                k_pipe_init<<<pp.grid, kBlock, 0, stream>>>(L, u, (int)epoch);
             }
             int J_enq = 0;        // steps enqueued in this sequence
             ha.clear(); hb.assign(1, 0.0); hl1.assign(1, 0.0);
             guess.clear();
-            double theta_prev = 0.0, last_check_est = 1e300;
+            double theta_prev = 0.0, last_check_est = 1e300, est_latest = 1e300;
             bool converged = false, need_restart = false;
             const int jcap = (int)std::min<size_t>(vcap - 2, (size_t)std::max(2, n - 1) + 8) & ~1;
             const size_t cs = vcap + 2;   // stride of the classic alpha / beta / l1 arrays
@@ -379,7 +414,8 @@ struct Solver {
             while (!converged && !need_restart) {
                 // keep one chunk in flight beyond the one being analysed
                 while ((int)pend.size() < (classic ? 1 : 2) && J_enq < jcap && steps_total < max_steps) {
-                    int chunk = chunk0;
+                    int chunk = (est_latest < 1e3 * tol * lnorm) ? chunk_near : chunk0;
+                    if (classic) chunk = std::min(chunk, 16);
                     chunk = std::min(chunk, jcap - J_enq);
                     chunk = (int)std::min<long>(chunk, max_steps - steps_total);
                     if (chunk <= 0) break;
@@ -393,15 +429,17 @@ struct Solver {
                                                    sizeof(double) * (size_t)(chunk + 1), hipMemcpyDeviceToHost, stream));
                     } else {
                         ST_TRY(enqueue_chunk(A, pp, chunk));
-                        HIP_TRY(hipMemcpyAsync(h_tri + 3 * (size_t)lo, tri + 3 * (size_t)lo,
-                                               sizeof(double) * 3 * (size_t)(hi - lo + 1), hipMemcpyDeviceToHost, stream));
                     }
+                    (void)lo;
                     Pending p;
                     p.jstart = J_enq;
                     p.classic = classic;
                     p.jend = hi;
-                    ST_TRY(get_event(&p.ev));
-                    HIP_TRY(hipEventRecord(p.ev, stream));
+                    p.ev = nullptr;
+                    if (classic) {
+                        ST_TRY(get_event(&p.ev));
+                        HIP_TRY(hipEventRecord(p.ev, stream));
+                    }
                     pend.push_back(p);
                     J_enq = hi;
                     steps_total += chunk; spmv_total += chunk;
@@ -409,8 +447,12 @@ struct Solver {
                 if (pend.empty()) { need_restart = true; break; }
                 const Pending p = pend.front();
                 pend.pop_front();
-                HIP_TRY(hipEventSynchronize(p.ev));
-                ev_pool.push_back(p.ev);
+                if (p.classic) {
+                    HIP_TRY(hipEventSynchronize(p.ev));
+                    ev_pool.push_back(p.ev);
+                } else {
+                    ST_TRY(wait_flag(((unsigned long long)epoch << 32) | (unsigned long long)(unsigned int)p.jend));
+                }
                 if (p.classic) {   // scatter the staged (alpha, beta, l1) into the interleaved mirror
                     const double* hp = h_pin + (vcap + 2) + 2 * kMaxGrid + 32;
                     for (int i = 0; i <= p.jend - p.jstart; ++i) {
@@ -443,6 +485,7 @@ struct Solver {
                 const double rho = broke ? 0.0 : std::fabs(hb[(size_t)Jeff] * sm.s[(size_t)Jeff - 1]);
                 const double l1v = hl1[(size_t)Jeff - 1] > 0 ? hl1[(size_t)Jeff - 1] : std::sqrt((double)n);
                 const double est = rho * l1v;   // predicted ||r||_1 (r = rho v_J; ||v_J||_1 ~ ||v_{J-1}||_1)
+                est_latest = est;
                 const bool at_cap = (J >= jcap) || (steps_total >= max_steps && pend.empty());
                 const bool trig = broke || est < trigger_slack * tol * lnorm;
                 if (debug) fprintf(stderr, "[machip] %s J=%d Jeff=%d theta=%.15g est=%.3e broke=%d pend=%zu passes=%d\n", classic ? "classic" : "pipe", J, Jeff, sm.theta, lnorm > 0 ? est / lnorm : est, (int)broke, pend.size(), sm.passes);
@@ -460,7 +503,10 @@ struct Solver {
                 }
             }
             // drain what is still in flight (its results are not needed)
-            for (const Pending& p : pend) { HIP_TRY(hipEventSynchronize(p.ev)); ev_pool.push_back(p.ev); }
+            for (const Pending& p : pend) {
+                if (p.ev) { HIP_TRY(hipEventSynchronize(p.ev)); ev_pool.push_back(p.ev); }
+            }
+            if (!pend.empty()) HIP_TRY(hipStreamSynchronize(stream));
             pend.clear();
             if (converged) { done = true; break; }
             if (steps_total >= max_steps) break;

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(kBlock) void k_var(CsrView A, PipeView L, const dou
     int jA = 0;
     __shared__ double scoef[8];
     if (PRO) {
-        if (threadIdx.x < 64) pipe_prologue_wave0(L, jrel, -1, scoef);
+        if (threadIdx.x < 64) { int jd; (void)pipe_prologue_wave0(L, jrel, -1, scoef, &jd); }
         __syncthreads();
         jA = (int)scoef[4];
     }
