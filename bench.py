@@ -160,11 +160,8 @@ def main():
     from mac_amd.utils.fiedler import reference_start_block
     P.set_start(reference_start_block(n)[:, 0].copy())
     if world > 1:
-        import torch
-        uid = [_lib.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        P.comm_init(rank, world, uid[0])
-        del torch
+        from mac_amd.dist import attach
+        attach(P, dist, rank, world)      # ncclCommInitRank inside libmachip; gloo only carries the id
 
     # ---- warmup (untimed) ----
     run_fw(P, k, args.warmup, w["x0"])
@@ -220,10 +217,17 @@ def main():
             us = float(np.sum(wts * np.array([r["spmv_us"] for r in prof])) / wts.sum())
             by = float(np.sum(wts * np.array([r["spmv_bytes"] for r in prof])) / wts.sum())
             ach = by / (us * 1e-6) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "k_spmv_{stream,vec}<OpLanczos>", "achieved": ach,
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                               "avg_launch_us": us, "algorithmic_bytes_per_launch": by,
-                               "note": "working set (CSR + vectors) is L2/Infinity-Cache resident at this size"}
+            traffic, tnote = None, "PMC traffic not collected for this config (tools/profile_round.sh)"
+            pj = os.path.join(ROOT, "profiles", f"r1_{args.config}_summary.json")
+            if os.path.exists(pj):      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+                dom = json.load(open(pj))["dominant"]
+                traffic = dom["hbm_bytes_per_launch"]
+                tnote = (f"traffic = 2*FETCH_SIZE + WRITE_SIZE per launch from profiles/r1_{args.config}_summary.json "
+                         f"(rocprofv3 --pmc passes of this command; rocprof avg launch {dom['avg_us']:.2f} us)")
+            out["roofline"] = {"bound": "hbm", "kernel": "k_pipe_vec (fused Lanczos step: CSR SpMV + all vector work of one step)",
+                               "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                               "traffic": traffic, "avg_launch_us": us, "algorithmic_bytes_per_launch": by,
+                               "note": "launch-latency bound: ~6-12 MB per launch, working set is Infinity-Cache resident; " + tnote}
     if rank == 0 and world == 1 and not args.no_cpu:
         cb = cpu_baseline(w)
         ft = cb.pop("f_traj")

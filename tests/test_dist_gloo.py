@@ -1,0 +1,85 @@
+"""World-size-2 CPU test (gloo) of the multi-GPU host logic: shard bounds / padding exactly as
+libmachip computes them, the unique-id rendezvous, and that the sharded-gradient protocol
+(each rank evaluates its candidate range, all-gather, everything else replicated) reproduces the
+single-process Frank-Wolfe trajectory bit for bit.  The arithmetic here is the CPU oracle; on GPUs
+the same protocol runs inside machip_fw_step with ncclAllGather."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+from mac_amd.dist import shard_bounds
+
+
+def test_shard_bounds_cover_and_pad():
+    for m in [0, 1, 7, 64, 500534, 2001737]:
+        for R in [1, 2, 3, 8]:
+            got = []
+            for r in range(R):
+                lo, hi, shard = shard_bounds(m, r, R)
+                assert 0 <= lo <= hi <= m and hi - lo <= shard
+                got.extend(range(lo, hi)) if m < 100 else got.append((lo, hi))
+                assert shard * R >= m and shard * R - m < R
+            if m < 100:
+                assert got == list(range(m))
+            else:
+                assert got[0][0] == 0 and got[-1][1] == m and all(a[1] == b[0] for a, b in zip(got, got[1:]))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    import oracle
+    from mac_amd.dist import exchange_unique_id, shard_bounds as sb
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        uid = exchange_unique_id(dist, rank, lambda: bytes(range(128)))
+        g = load_golden("er300_solve")
+        n, k = int(g["n"]), int(g["k"])
+        mo = oracle.MacOracle(g["fi"], g["fj"], g["fw"], g["ci"], g["cj"], g["cw"], n)
+        m = len(g["cw"])
+        lo, hi, shard = sb(m, rank, world)
+        x = g["x_init"].copy()
+        fs = []
+        for it in range(int(g["max_iters"])):
+            f, v, _ = oracle.find_fiedler_pair(mo.laplacian(x))          # replicated eigen-solve
+            mine = np.zeros(shard)
+            mine[:hi - lo] = oracle.supergradient(v, mo.ci[lo:hi], mo.cj[lo:hi], mo.cw[lo:hi])
+            parts = [torch.zeros(shard, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(parts, torch.from_numpy(mine))               # the one collective per iteration
+            grad = torch.cat(parts).numpy()[:m]
+            s = oracle.solve_subset_box_lp(grad, k)
+            x = x + oracle.naive_stepsize(it) * (s - x)
+            fs.append(float(f))
+        dist.barrier()
+        q.put((rank, uid == bytes(range(128)), fs, x))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_gradient_matches_single_process():
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = load_golden("er300_solve")
+    res.sort(key=lambda t: t[0])
+    for rank, uid_ok, fs, x in res:
+        assert uid_ok
+        assert np.allclose(fs, g["f_traj"], rtol=1e-9)
+        assert np.allclose(x, g["unrounded"], atol=1e-12)
+    assert np.array_equal(res[0][3], res[1][3])        # replicas stay bit-identical

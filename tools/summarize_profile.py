@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/<tag>/ (tools/profile_round.sh) into profiles/<tag>_summary.md + .json.
+HBM traffic per launch = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes): MI355X_MICROARCH.md section HBM says
+FETCH_SIZE on gfx950 counts 128-B requests at 64 B (x2 for wide coalesced reads; other widths and
+WRITE_SIZE uncalibrated), both counters come from separate --pmc passes."""
+import csv, json, os, sys, collections
+tag = sys.argv[1]
+src = os.path.join("gpurun_out", tag)
+out_md = os.path.join("profiles", tag + "_summary.md")
+out_js = os.path.join("profiles", tag + "_summary.json")
+
+def short(n):
+    n = n.replace("machip::", "").replace("void ", "")
+    return n.split("(")[0]
+
+stats = []
+with open(os.path.join(src, "trace", "t_kernel_stats.csv")) as fh:
+    for r in csv.DictReader(fh):
+        stats.append((short(r["Name"]), int(r["Calls"]), float(r["TotalDurationNs"]), float(r["AverageNs"]),
+                      float(r["Percentage"]), float(r["MinNs"]), float(r["MaxNs"])))
+
+def pmc(path, counter):
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    with open(path) as fh:
+        for r in csv.DictReader(fh):
+            if r["Counter_Name"] != counter:
+                continue
+            a = acc[short(r["Kernel_Name"])]
+            a[0] += 1; a[1] += float(r["Counter_Value"])
+    return {k: (v[0], v[1] / max(1, v[0])) for k, v in acc.items()}
+
+fetch = pmc(os.path.join(src, "pmc_fetch", "f_counter_collection.csv"), "FETCH_SIZE")
+write = pmc(os.path.join(src, "pmc_write", "w_counter_collection.csv"), "WRITE_SIZE")
+bench_line = None
+for line in open(os.path.join(src, "trace.log")):
+    if line.startswith('{"metric'):
+        bench_line = json.loads(line)
+rows = []
+for (n, calls, tot, avg, pct, mn, mx) in stats:
+    f = fetch.get(n, (0, 0.0))[1]; w = write.get(n, (0, 0.0))[1]
+    rows.append(dict(kernel=n, calls=calls, total_ms=tot / 1e6, avg_us=avg / 1e3, pct=pct, min_us=mn / 1e3, max_us=mx / 1e3,
+                     fetch_kib=f, write_kib=w, hbm_bytes_per_launch=(2.0 * f + w) * 1024.0))
+pipe = [r for r in rows if r["kernel"].startswith("k_pipe_vec") or r["kernel"].startswith("k_pipe_stream")]
+calls = sum(r["calls"] for r in pipe)
+dom = dict(kernel="k_pipe_{vec,stream} (fused Lanczos step)", calls=calls,
+           avg_us=sum(r["avg_us"] * r["calls"] for r in pipe) / max(1, calls),
+           hbm_bytes_per_launch=sum(r["hbm_bytes_per_launch"] * r["calls"] for r in pipe) / max(1, calls))
+js = dict(tag=tag, bench=bench_line, dominant=dom, kernels=rows)
+json.dump(js, open(out_js, "w"), indent=1)
+with open(out_md, "w") as fh:
+    fh.write(f"# rocprofv3 summary `{tag}`\n\nCommand: `rocprofv3 --kernel-trace --stats -- python bench.py ...` plus two `--pmc` passes "
+             "(FETCH_SIZE, WRITE_SIZE); raw CSVs were in `gpurun_out/" + tag + "/` (scratch).\n\n")
+    if bench_line:
+        fh.write("bench line of the traced run (profiler attached, so slower than the un-profiled number):\n\n```\n" + json.dumps(bench_line) + "\n```\n\n")
+    fh.write(f"Dominant kernel: **{dom['kernel']}**, {dom['calls']} launches, average {dom['avg_us']:.2f} us, "
+             f"HBM traffic/launch (2*FETCH+WRITE) {dom['hbm_bytes_per_launch']/1e6:.2f} MB.\n\n")
+    fh.write("| kernel | calls | total ms | avg us | min us | max us | % | FETCH KiB/launch | WRITE KiB/launch |\n|---|---|---|---|---|---|---|---|---|\n")
+    for r in rows:
+        fh.write(f"| `{r['kernel'][:60]}` | {r['calls']} | {r['total_ms']:.2f} | {r['avg_us']:.2f} | {r['min_us']:.2f} | {r['max_us']:.2f} | "
+                 f"{r['pct']:.2f} | {r['fetch_kib']:.1f} | {r['write_kib']:.1f} |\n")
+print(open(out_md).read()[:3000])
