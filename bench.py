@@ -14,8 +14,8 @@ workload is run with the candidates sharded over the ranks
 the supergradient of its contiguous candidate range, one RCCL all-gather rebuilds the m-vector
 on every rank, the eigen-solve is replicated.  "scaling": "strong".
 
-Prints ONE JSON line (rank 0).  torch is used only for the gloo rendezvous/barrier of N > 1
-runs; the data path is libmachip.so (HIP + RCCL) through ctypes.
+Prints ONE JSON line (rank 0).  No torch anywhere: ranks launched by torch.distributed.run find each
+other through mac_amd.dist.FileGroup (single node), the data path is libmachip.so (HIP + RCCL) via ctypes.
 """
 import argparse
 import json
@@ -145,10 +145,10 @@ def main():
     _lib.load()
     _lib.require_device()
     dist = None
-    if world > 1:
-        import torch.distributed as dist  # noqa: F811  (gloo: rendezvous / barrier / max only)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ     # under torch.distributed.run
+    if world > 1 or launched:
+        from mac_amd.dist import FileGroup     # rendezvous / barrier / max only; data path is RCCL
+        dist = FileGroup(rank, world)
 
     def barrier():
         if dist is not None:
@@ -159,7 +159,7 @@ def main():
     P = _lib.Problem(n, w["fi"], w["fj"], w["fw"], w["ci"], w["cj"], w["cw"], device=local_rank % max(1, _lib.device_count()))
     from mac_amd.utils.fiedler import reference_start_block
     P.set_start(reference_start_block(n)[:, 0].copy())
-    if world > 1:
+    if dist is not None:
         from mac_amd.dist import attach
         attach(P, dist, rank, world)      # ncclCommInitRank inside libmachip; gloo only carries the id
 
@@ -180,10 +180,7 @@ def main():
     barrier()
     el = time.perf_counter() - t0
     if dist is not None:
-        import torch
-        t = torch.tensor([el], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t[0])
+        el = dist.max(el)
 
     out = None
     if rank == 0:
@@ -203,7 +200,7 @@ def main():
             "data": "synthetic" if args.config in ("c2", "c4") else "dataset (tests/golden/data)",
             "config": {"workload": w["name"], "N": n, "m_candidates": m, "K": k, "fixed_edges": int(len(w["fw"])),
                        "fw_iters": args.steps, "fiedler_tol": 1e-8,
-                       "parallelism": "single GPU" if world == 1 else f"candidate shard x{world} + RCCL all-gather of the gradient, eigen-solve replicated"},
+                       "parallelism": ("single GPU" + (" (RCCL communicator of 1 rank)" if dist is not None else "")) if world == 1 else f"candidate shard x{world} + RCCL all-gather of the gradient, eigen-solve replicated"},
             "lanczos_steps_per_iter": float(steps.mean()),
             "lambda2_first_last": [rec[0][0], rec[-1][0]],
             "nnz_first_last": [rec[0][2], rec[-1][2]],
@@ -236,9 +233,9 @@ def main():
         out["speedup_vs_cpu"] = out["value"] / cb["value"]
     if rank == 0:
         print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
     P.close()
+    if dist is not None:
+        dist.close()
 
 
 if __name__ == "__main__":

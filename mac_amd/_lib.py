@@ -234,7 +234,18 @@ class Problem:
 
     def comm_init(self, rank, nranks, unique_id: bytes):
         buf = C.create_string_buffer(unique_id, 128)
-        check(self._lib.machip_comm_init(self._h, int(rank), int(nranks), buf))
+        # RCCL prints a version banner on stdout at communicator creation; keep stdout clean for
+        # callers that emit machine-readable output (bench.py's single JSON line)
+        import sys
+        sys.stdout.flush()
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            st = self._lib.machip_comm_init(self._h, int(rank), int(nranks), buf)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+        check(st)
 
     def synchronize(self):
         check(self._lib.machip_synchronize(self._h))

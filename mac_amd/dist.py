@@ -5,6 +5,9 @@ broadcast) and for timing barriers -- any object with torch.distributed's ``broa
 ``barrier`` works (gloo in bench.py and in the CPU tests)."""
 from __future__ import annotations
 
+import os
+import pickle
+import time
 from typing import Tuple
 
 
@@ -34,3 +37,69 @@ def attach(problem, dist, rank: int, nranks: int):
     uid = exchange_unique_id(dist, rank, _lib.comm_unique_id)
     problem.comm_init(rank, nranks, uid)
     return shard_bounds(problem.m, rank, nranks)
+
+
+class FileGroup:
+    """Single-node process group over a shared temp directory: rendezvous / barrier / max only.
+
+    bench.py uses it instead of torch.distributed so that no second HIP runtime (the one bundled
+    with the PyTorch wheel) is ever loaded next to libmachip's -- the data path is RCCL inside
+    libmachip either way.  The directory key is MASTER_PORT + the launcher's PID (all ranks of one
+    ``torch.distributed.run`` share their parent), so concurrent or stale jobs cannot collide.
+    Offers the subset of torch.distributed's interface that mac_amd.dist needs."""
+
+    def __init__(self, rank: int, world: int, key: str = None, root: str = "/tmp", timeout: float = 600.0):
+        self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
+        if key is None:
+            key = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+        self.dir = os.path.join(root, f"machip_rdzv_{key}")
+        os.makedirs(self.dir, exist_ok=True)
+        self._seq = 0
+
+    def _path(self, tag, r):
+        return os.path.join(self.dir, f"{tag}.{r}")
+
+    def _put(self, tag, obj):
+        tmp = self._path(tag, self.rank) + ".tmp"
+        with open(tmp, "wb") as fh:
+            pickle.dump(obj, fh)
+        os.replace(tmp, self._path(tag, self.rank))      # atomic publish
+
+    def _get(self, tag, r):
+        p = self._path(tag, r)
+        t0 = time.monotonic()
+        while not os.path.exists(p):
+            if time.monotonic() - t0 > self.timeout:
+                raise TimeoutError(f"rank {self.rank}: waited {self.timeout}s for rank {r} at '{tag}'")
+            time.sleep(0.0005)
+        with open(p, "rb") as fh:
+            return pickle.load(fh)
+
+    def all_gather_object(self, obj):
+        self._seq += 1
+        tag = f"s{self._seq}"
+        self._put(tag, obj)
+        return [self._get(tag, r) for r in range(self.world)]
+
+    def barrier(self):
+        self.all_gather_object(None)
+
+    def broadcast_object_list(self, box, src=0):
+        vals = self.all_gather_object(box[0] if self.rank == src else None)
+        box[0] = vals[src]
+
+    def max(self, value: float) -> float:
+        return max(self.all_gather_object(float(value)))
+
+    def close(self):
+        self.barrier()
+        if self.rank == 0:
+            for f in os.listdir(self.dir):
+                try:
+                    os.remove(os.path.join(self.dir, f))
+                except OSError:
+                    pass
+            try:
+                os.rmdir(self.dir)
+            except OSError:
+                pass

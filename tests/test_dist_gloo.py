@@ -83,3 +83,33 @@ def test_two_rank_sharded_gradient_matches_single_process():
         assert np.allclose(fs, g["f_traj"], rtol=1e-9)
         assert np.allclose(x, g["unrounded"], atol=1e-12)
     assert np.array_equal(res[0][3], res[1][3])        # replicas stay bit-identical
+
+
+def _fg_worker(rank, world, key, q):
+    sys.path.insert(0, ROOT)
+    from mac_amd.dist import FileGroup, exchange_unique_id
+    g = FileGroup(rank, world, key=key, timeout=60)
+    uid = exchange_unique_id(g, rank, lambda: bytes([7]) * 128)
+    g.barrier()
+    mx = g.max(10.0 + rank)
+    got = g.all_gather_object(("r", rank))
+    g.close()
+    q.put((rank, uid == bytes([7]) * 128, mx, got))
+
+
+def test_file_group_two_ranks():
+    """The torch-free single-node process group bench.py uses under torch.distributed.run."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    key = f"test_{os.getpid()}"
+    procs = [ctx.Process(target=_fg_worker, args=(r, 2, key, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    for rank, ok, mx, got in res:
+        assert ok and mx == 11.0 and got == [("r", 0), ("r", 1)]
+    assert not os.path.exists(os.path.join("/tmp", f"machip_rdzv_{key}"))
