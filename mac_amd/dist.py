@@ -93,7 +93,10 @@ class FileGroup:
 
     def close(self):
         self.barrier()
+        self._put("bye", None)          # nobody reads anything of mine after this
         if self.rank == 0:
+            for r in range(self.world):  # only now is it safe to remove the directory
+                self._get("bye", r)
             for f in os.listdir(self.dir):
                 try:
                     os.remove(os.path.join(self.dir, f))

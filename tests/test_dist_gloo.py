@@ -65,7 +65,7 @@ def _worker(rank, world, port, q):
 
 
 def test_two_rank_sharded_gradient_matches_single_process():
-    import torch.multiprocessing as mp
+    import multiprocessing as mp      # plain spawn: torch is imported in the children only
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
