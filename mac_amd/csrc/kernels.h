@@ -369,35 +369,37 @@ __global__ __launch_bounds__(kBlock) void k_lan_tail(LanView L) {
 }
 
 // ------------------------------------------------------------------------------------------
-// One-kernel Lanczos step ("pipelined" form).  A kernel boundary costs ~2 us on this chip, every
+// One-kernel Lanczos step ("pipelined" form).  A kernel boundary costs ~2.3 us on this chip, every
 // kernel here starts with a cold L2 (the per-XCD L2s are written back / invalidated at launch
-// boundaries) and is latency-bound, so a Lanczos step is ONE launch whose dependent-load chain
-// is as short as CSR allows:
-//   * step j finishes the reductions of step j-1 (alpha_{j-1}, beta_j, mean) from per-workgroup
-//     partials itself, and uses v_j without materialising it:
-//         v_j[c] = ( w_{j-1}[c] - alpha_{j-1} v_{j-1}[c] - beta_{j-1} v_{j-2}[c] - mu ) / beta_j
-//     The three sources sit interleaved in one 24-byte record Z[c] (same cache line a plain x[c]
-//     gather would touch).  By linearity the SpMV accumulates the three raw sums
-//     (L w_{j-1}, L v_{j-1}, L v_{j-2})[r] and combines them afterwards, so the matrix/gather
-//     phase does not depend on the reduction at all and the two overlap (L 1 = 0 removes mu).
-//   * beta_j = ||u_j|| comes from the exact quadratic form in the six inner products of
-//     (w, v1, v2) -- no orthogonality assumed -- which each step accumulates for the next one.
+// boundaries) and is latency-bound, so a Lanczos step is ONE launch:
+//   * step j first finishes the reductions of step j-1 (alpha_{j-1}, beta_j, mean) from per-
+//     workgroup partials (wave 0 of every workgroup, overlapping the other waves' CSR loads),
+//   * and uses v_j without materialising it.  With Paige's intermediate
+//         t_{j-1} = L v_{j-1} - beta_{j-1} v_{j-2}          (stored by step j-1, which knows beta_{j-1})
+//     the new vector is   v_j[c] = ( t_{j-1}[c] - alpha_{j-1} v_{j-1}[c] - mu ) / beta_j ,
+//     so the gather operand is ONE aligned 16-byte record Z[c] = {t_{j-1}, v_{j-1}}.  By linearity
+//     the SpMV accumulates the two raw sums (L t)[r], (L v)[r] and combines them afterwards
+//     (L 1 = 0 removes mu): the matrix/gather phase does not depend on the reduction at all.
+//   * alpha_{j-1} = v.t and beta_j^2 = t.t - 2 alpha v.t + alpha^2 v.v - n mu^2 come from inner
+//     products that are all MEASURED, nothing is assumed orthonormal: the quadratic form is exact
+//     for the vectors actually stored, so a rounding error in beta only rescales v_j and is
+//     accounted for one step later.  (Assuming |v| = 1 or dropping "tiny" terms turns that into an
+//     error-feedback loop that blows up in ~20 steps -- found by emulation.)
 //   * no per-step host arguments: j = jA (chunk base, device memory) + jrel (baked into the graph
-//     node); chunks have an even number of steps so the Z ping-pong parity is jrel & 1.
+//     node); chunks have an even number of steps so the Z / partial ping-pong parity is jrel & 1.
 // ------------------------------------------------------------------------------------------
-struct Z3 { double w, v1, v2; };
-constexpr int kNP = 10;   // partial sums per workgroup: ww wv1 wv2 v1v1 v1v2 v2v2 sw s1 s2 |v1|_1
+struct __attribute__((aligned(16))) Z2 { double t, v; };
+constexpr int kNP = 6;    // partial sums per workgroup: t.t  t.v  v.v  sum(t)  sum(v)  |v|_1
 constexpr int kMaxChunk = 64;
 constexpr int kMaxWaves = 16;
 
 struct PipeView {
     int n;
     LanState* st;
-    Z3* Z0;
-    Z3* Z1;
+    Z2* Z0;
+    Z2* Z1;
     double* V;
-    double* tri;      // interleaved (alpha_j, beta_j, ||v_j||_1) records: one D2H copy per chunk
-    double* cb;       // kMaxChunk+1 slots: cb[s] = beta_{j-1} for the launch with jrel = s
+    double* tri;      // interleaved (alpha_j, beta_j, ||v_j||_1) records
     double* htri;     // host-pinned mirror of tri, written by the tail kernel (zero-copy): the host
                       // polls hflag instead of issuing a stream-ordered copy between chunks
     unsigned long long* hflag;   // (epoch << 32) | J once records < J (and beta_J) are in htri
@@ -407,7 +409,7 @@ struct PipeView {
     int P;            // valid partials per quantity (= grid of the step kernel, <= 256)
 };
 
-struct PipeCoef { double alpha, betap, mu, beta, inv, l1prev; };
+struct PipeCoef { double alpha, mu, beta, inv, l1prev; };
 
 // ---- wave64 sum on the VALU (DPP row shifts + row broadcasts), ~5x faster than the
 // ds_bpermute butterfly; the total lands in lane 63 and is broadcast through an SGPR. ----------
@@ -431,36 +433,29 @@ __device__ __forceinline__ double wave_total(double v) {
 }
 
 // Finish step j-1's reductions from the summed partials.  Identical on every workgroup.
-// All six inner products and three sums are MEASURED, nothing is assumed orthonormal: the
-// quadratic form is then exact for the vectors actually stored, so a rounding error in beta_j
-// only rescales v_j and is accounted for one step later.  (Dropping the "tiny" terms v1.v2,
-// sum(v) or assuming |v2| = 1 turns that into an error-feedback loop that blows up in ~20 steps.)
-__device__ __forceinline__ PipeCoef pipe_coefs(const double (&a)[kNP], double betap, int n) {
+__device__ __forceinline__ PipeCoef pipe_coefs(const double (&a)[kNP], int n) {
     PipeCoef c;
-    const double ww = a[0], wv1 = a[1], wv2 = a[2], v1v1 = a[3], v1v2 = a[4], v2v2 = a[5];
-    c.betap = betap;                          // couples v_{j-2}, v_{j-1}
-    c.alpha = wv1 - betap * v1v2;             // Paige: v1.(w - beta v2); 0 at j = 0 (v1 = 0)
-    const double al = c.alpha, bp = c.betap;
-    const double uu = ww + al * al * v1v1 + bp * bp * v2v2 - 2.0 * al * wv1 - 2.0 * bp * wv2 + 2.0 * al * bp * v1v2;
-    const double su = a[6] - al * a[7] - bp * a[8];
-    c.mu = su / (double)n;
+    const double tt = a[0], tv = a[1], vv = a[2];
+    c.alpha = tv;                             // Paige: v.(L v - beta v_prev); 0 at j = 0 (v = 0)
+    const double al = c.alpha;
+    const double uu = tt - 2.0 * al * tv + al * al * vv;
+    c.mu = (a[3] - al * a[4]) / (double)n;
     const double nrm2 = uu - (double)n * c.mu * c.mu;
-    // ||u||^2 is a difference of O(||w||^2) terms: below ~1e-10 of their size it is rounding
+    // ||u||^2 is a difference of O(||t||^2) terms: below ~1e-10 of their size it is rounding
     // noise, i.e. the Krylov space is (numerically) invariant -> report an exact breakdown.
-    const double scale = ww + al * al * v1v1 + bp * bp * v2v2;
+    const double scale = tt + al * al * vv;
     c.beta = (nrm2 > 1e-10 * scale) ? sqrt(nrm2) : 0.0;
     c.inv = c.beta > 1e-290 ? 1.0 / c.beta : 0.0;
-    c.l1prev = a[9];
+    c.l1prev = a[5];
     return c;
 }
 
 // Prologue, run by wave 0 only: sum the P (<= 256) partials of each quantity, derive the
 // coefficients, publish them to the workgroup through LDS (scoef) and -- workgroup 0 -- to the
-// host-visible tridiagonal record.  The other waves go straight to their CSR loads.
+// tridiagonal record.  The other waves go straight to their CSR loads.
 __device__ __forceinline__ PipeCoef pipe_prologue_wave0(const PipeView& L, int jrel, int adv_jA, double* scoef, int* j_out) {
     const int lane = threadIdx.x;   // caller guarantees threadIdx.x < 64
     const int jA = L.st->jA;
-    const double betap = L.cb[jrel];
     const double* __restrict__ pin = L.part + (size_t)(jrel & 1) * (kNP * kMaxGrid);
     double a[kNP];
 #pragma unroll
@@ -471,15 +466,14 @@ __device__ __forceinline__ PipeCoef pipe_prologue_wave0(const PipeView& L, int j
     }
 #pragma unroll
     for (int q = 0; q < kNP; ++q) a[q] = wave_total(a[q]);
-    const PipeCoef c = pipe_coefs(a, betap, L.n);
+    const PipeCoef c = pipe_coefs(a, L.n);
     const int j = jA + jrel;
     if (lane == 0) {
-        scoef[0] = c.alpha; scoef[1] = c.betap; scoef[2] = c.mu; scoef[3] = c.inv; scoef[4] = (double)j;
+        scoef[0] = c.alpha; scoef[1] = c.beta; scoef[2] = c.mu; scoef[3] = c.inv; scoef[4] = (double)j;
         if (blockIdx.x == 0) {
             if (j > 0) { L.tri[3 * (j - 1)] = c.alpha; L.tri[3 * (j - 1) + 2] = c.l1prev; }
             L.tri[3 * j + 1] = c.beta;
-            if (adv_jA >= 0) { L.st->jA = j; L.cb[0] = betap; }   // tail kernel: new chunk base
-            else L.cb[jrel + 1] = c.beta;
+            if (adv_jA >= 0) L.st->jA = j;   // tail kernel: new chunk base
         }
     }
     *j_out = j;
@@ -492,17 +486,17 @@ struct PipeRow {   // per-thread accumulation of the next step's partial sums
 #pragma unroll
         for (int q = 0; q < kNP; ++q) acc[q] = 0.0;
     }
-    // raw sums (L w)[r], (L v1)[r], (L v2)[r] -> w_j[r]; v_j[r] from Z[r]; store V, next Z.
-    __device__ __forceinline__ void finish(double alpha, double betap, double mu, double inv, const Z3& z,
-                                           double sw, double s1, double s2, double* vj, Z3* Zn, int r) {
-        const double v = (((z.w - alpha * z.v1) - betap * z.v2) - mu) * inv;
-        const double w = ((sw - alpha * s1) - betap * s2) * inv;
+    // raw sums (L t)[r], (L v)[r] -> w_j[r]; v_j[r] from Z[r]; store V, next Z = {t_j, v_j}.
+    __device__ __forceinline__ void finish(double alpha, double beta, double mu, double inv, const Z2& z,
+                                           double st, double sv, double* vj, Z2* Zn, int r) {
+        const double v = ((z.t - alpha * z.v) - mu) * inv;
+        const double w = (st - alpha * sv) * inv;
+        const double t = w - beta * z.v;            // Paige's intermediate for the next step
         vj[r] = v;
-        Z3 o; o.w = w; o.v1 = v; o.v2 = z.v1;
+        Z2 o; o.t = t; o.v = v;
         Zn[r] = o;
-        acc[0] += w * w; acc[1] += w * v; acc[2] += w * z.v1;
-        acc[3] += v * v; acc[4] += v * z.v1; acc[5] += z.v1 * z.v1;
-        acc[6] += w; acc[7] += v; acc[8] += z.v1; acc[9] += fabs(v);
+        acc[0] += t * t; acc[1] += t * v; acc[2] += v * v;
+        acc[3] += t; acc[4] += v; acc[5] += fabs(v);
     }
     // one partial per quantity per workgroup; smw: kMaxWaves*kNP doubles
     template <int BLOCK>
@@ -533,97 +527,97 @@ __global__ __launch_bounds__(BLOCK) void k_pipe_vec(CsrView A, PipeView L, int j
     constexpr int GPB = BLOCK / G;
     const int lane = threadIdx.x % G, g = threadIdx.x / G;
     if (threadIdx.x < 64) { int jdummy; (void)pipe_prologue_wave0(L, jrel, -1, scoef, &jdummy); }
-    const Z3* __restrict__ Zc = (jrel & 1) ? L.Z1 : L.Z0;
-    Z3* __restrict__ Zn = (jrel & 1) ? L.Z0 : L.Z1;
+    const Z2* __restrict__ Zc = (jrel & 1) ? L.Z1 : L.Z0;
+    Z2* __restrict__ Zn = (jrel & 1) ? L.Z0 : L.Z1;
     PipeRow pr;
     pr.clear();
     bool have = false;
-    double alpha = 0.0, betap = 0.0, mu = 0.0, inv = 0.0;
+    double alpha = 0.0, beta = 0.0, mu = 0.0, inv = 0.0;
     double* vj = nullptr;
     for (int r0 = blockIdx.x * GPB; r0 < A.n; r0 += gridDim.x * GPB) {   // workgroup-uniform trip count
         const int r = r0 + g;
-        double sw = 0.0, s1 = 0.0, s2 = 0.0;
-        Z3 zr; zr.w = 0.0; zr.v1 = 0.0; zr.v2 = 0.0;
+        double st = 0.0, sv = 0.0;
+        Z2 zr; zr.t = 0.0; zr.v = 0.0;
         if (r < A.n) {
             const int b = A.rowptr[r], e = A.rowptr[r + 1];
             if (lane == 0) zr = Zc[r];
             for (int p = b + lane; p < e; p += G) {
                 const double vv = A.val[p];
-                const Z3 z = Zc[A.col[p]];
-                sw += vv * z.w; s1 += vv * z.v1; s2 += vv * z.v2;
+                const Z2 z = Zc[A.col[p]];
+                st += vv * z.t; sv += vv * z.v;
             }
-            sw = group_sum<G>(sw); s1 = group_sum<G>(s1); s2 = group_sum<G>(s2);
+            st = group_sum<G>(st); sv = group_sum<G>(sv);
         }
         if (!have) {   // first tile: the prologue of wave 0 overlapped with the loads above
             __syncthreads();
-            alpha = scoef[0]; betap = scoef[1]; mu = scoef[2]; inv = scoef[3];
+            alpha = scoef[0]; beta = scoef[1]; mu = scoef[2]; inv = scoef[3];
             vj = L.V + (size_t)scoef[4] * (size_t)L.n;
             have = true;
         }
-        if (r < A.n && lane == 0) pr.finish(alpha, betap, mu, inv, zr, sw, s1, s2, vj, Zn, r);
+        if (r < A.n && lane == 0) pr.finish(alpha, beta, mu, inv, zr, st, sv, vj, Zn, r);
     }
     pr.template store<BLOCK>(L, jrel, smw);
 }
 
 // ---- LDS row-tile ("CSR-stream") form ------------------------------------------------------------
-constexpr int kPipeTile = 1024;   // staged products per LDS tile, x3 arrays (24 KB)
+constexpr int kPipeTile = 1024;   // staged products per LDS tile, x2 arrays (16 KB)
 
 template <int TPR>
 __global__ __launch_bounds__(kBlock) void k_pipe_stream(CsrView A, PipeView L, int jrel) {
     __shared__ double smw[kMaxWaves * kNP];
     __shared__ double scoef[8];
-    __shared__ double pw[kPipeTile], p1[kPipeTile], p2[kPipeTile];
+    __shared__ double pt[kPipeTile], pv[kPipeTile];
     __shared__ int sptr[kBlock / TPR + 1];
     constexpr int R = kBlock / TPR;
     const int tid = threadIdx.x;
     const int row = tid / TPR, sub = tid % TPR;
     if (tid < 64) { int jdummy; (void)pipe_prologue_wave0(L, jrel, -1, scoef, &jdummy); }
-    const Z3* __restrict__ Zc = (jrel & 1) ? L.Z1 : L.Z0;
-    Z3* __restrict__ Zn = (jrel & 1) ? L.Z0 : L.Z1;
+    const Z2* __restrict__ Zc = (jrel & 1) ? L.Z1 : L.Z0;
+    Z2* __restrict__ Zn = (jrel & 1) ? L.Z0 : L.Z1;
     PipeRow pr;
     pr.clear();
-    double alpha = 0.0, betap = 0.0, mu = 0.0, inv = 0.0;
+    double alpha = 0.0, beta = 0.0, mu = 0.0, inv = 0.0;
     double* vj = nullptr;
     for (int tile = blockIdx.x; tile * R < A.n; tile += gridDim.x) {
         const int r0 = tile * R;
         const int nr = min(R, A.n - r0);
         if (tid <= nr) sptr[tid] = A.rowptr[r0 + tid];
-        Z3 zr; zr.w = 0.0; zr.v1 = 0.0; zr.v2 = 0.0;
+        Z2 zr; zr.t = 0.0; zr.v = 0.0;
         if (row < nr && sub == 0) zr = Zc[r0 + row];
         __syncthreads();
         if (!vj) {   // coefficients from wave 0 (published before the barrier above)
-            alpha = scoef[0]; betap = scoef[1]; mu = scoef[2]; inv = scoef[3];
+            alpha = scoef[0]; beta = scoef[1]; mu = scoef[2]; inv = scoef[3];
             vj = L.V + (size_t)scoef[4] * (size_t)L.n;
         }
         const int q0 = sptr[0], q1 = sptr[nr];
-        double sw = 0.0, s1 = 0.0, s2 = 0.0;
+        double st = 0.0, sv = 0.0;
         for (int base = q0; base < q1; base += kPipeTile) {
             const int cnt = min(kPipeTile, q1 - base);
             for (int i = tid; i < cnt; i += kBlock) {     // perfectly coalesced val/col stream
                 const double vv = A.val[base + i];
-                const Z3 z = Zc[A.col[base + i]];
-                pw[i] = vv * z.w; p1[i] = vv * z.v1; p2[i] = vv * z.v2;
+                const Z2 z = Zc[A.col[base + i]];
+                pt[i] = vv * z.t; pv[i] = vv * z.v;
             }
             __syncthreads();
             if (row < nr) {
                 const int lo = max(sptr[row], base), hi = min(sptr[row + 1], base + cnt);
-                for (int q = lo + sub; q < hi; q += TPR) { sw += pw[q - base]; s1 += p1[q - base]; s2 += p2[q - base]; }
+                for (int q = lo + sub; q < hi; q += TPR) { st += pt[q - base]; sv += pv[q - base]; }
             }
             __syncthreads();
         }
-        sw = group_sum<TPR>(sw); s1 = group_sum<TPR>(s1); s2 = group_sum<TPR>(s2);
-        if (row < nr && sub == 0) pr.finish(alpha, betap, mu, inv, zr, sw, s1, s2, vj, Zn, r0 + row);
+        st = group_sum<TPR>(st); sv = group_sum<TPR>(sv);
+        if (row < nr && sub == 0) pr.finish(alpha, beta, mu, inv, zr, st, sv, vj, Zn, r0 + row);
     }
     pr.template store<kBlock>(L, jrel, smw);
 }
 
-// Start a sequence from u0: Z0 = (u0, 0, 0); partials such that step 0 normalises u0.
+// Start a sequence from u0: Z0 = (u0, 0); partials such that step 0 normalises u0.
 __global__ __launch_bounds__(kBlock) void k_pipe_init(PipeView L, const double* __restrict__ u0, int epoch) {
     __shared__ double sm[4];
     double s1 = 0.0, s2 = 0.0;
     for (int r = blockIdx.x * kBlock + threadIdx.x; r < L.n; r += gridDim.x * kBlock) {
         const double t = u0[r];
-        Z3 o; o.w = t; o.v1 = 0.0; o.v2 = 0.0;
+        Z2 o; o.t = t; o.v = 0.0;
         L.Z0[r] = o;
         s1 += t; s2 += t * t;
     }
@@ -631,24 +625,22 @@ __global__ __launch_bounds__(kBlock) void k_pipe_init(PipeView L, const double* 
     if (threadIdx.x == 0) {
         for (int q = 0; q < kNP; ++q) L.part[q * kMaxGrid + blockIdx.x] = 0.0;
         L.part[0 * kMaxGrid + blockIdx.x] = s2;
-        L.part[6 * kMaxGrid + blockIdx.x] = s1;
-        if (blockIdx.x == 0) { L.st->jA = 0; L.st->jB = epoch; L.cb[0] = 0.0; }   // jB carries the sequence epoch
+        L.part[3 * kMaxGrid + blockIdx.x] = s1;
+        if (blockIdx.x == 0) { L.st->jA = 0; L.st->jB = epoch; }   // jB carries the sequence epoch
     }
 }
 // One wave, end of a chunk of `adv` steps: finish (alpha_{J-1}, beta_J, l1_{J-1}) for J = jA + adv
-// so the host can test convergence, advance the chunk base jA and hand beta_{J-1} to the first
-// launch of the next chunk.  The step kernels only read jA / cb[jrel]; this kernel is alone in
-// its launch.
+// so the host can test convergence, and advance the chunk base jA.  The step kernels only read
+// jA; this kernel is alone in its launch.  Zero-copy hand-off to the host: records [J-adv-1, J]
+// of tri -> pinned host memory, then the flag.
 __global__ __launch_bounds__(64) void k_pipe_tail(PipeView L, int adv) {
     __shared__ double scoef[8];
     int j = 0;
     const PipeCoef c = pipe_prologue_wave0(L, adv, adv, scoef, &j);
-    // zero-copy hand-off to the host: records [j-adv-1, j] of tri -> pinned host memory, then the
-    // flag.  The three values this kernel has just produced go from registers (lane 0).
     const int lo = max(0, j - adv - 1);
     const int cnt = 3 * (j - lo + 1);
     for (int i = threadIdx.x; i < cnt; i += 64) L.htri[3 * lo + i] = L.tri[3 * lo + i];
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) {   // the three values this kernel has just produced go from registers
         if (j > 0) { L.htri[3 * (j - 1)] = c.alpha; L.htri[3 * (j - 1) + 2] = c.l1prev; }
         L.htri[3 * j + 1] = c.beta;
     }

@@ -507,9 +507,9 @@ int machip_profile_spmv(machip_problem* p, int reps, double* avg_us, double* byt
     *avg_us = 1e3 * (double)ms / reps;
     if (bytes_per_launch) {
         // SURVEY 8(d) B_spmv = nnz*(8+4) + (n+1)*4 + n*8 [x] + n*8 [y], with the fused vector
-        // work on top: the gathered operand is the 24-byte record Z[c] (counted once per row),
-        // own-row Z read 24 B, next Z written 24 B, Lanczos vector v_j written 8 B.
-        *bytes_per_launch = (double)p->nnz * 12.0 + ((double)p->n + 1.0) * 4.0 + (double)p->n * 80.0;
+        // work on top: the gathered operand is the 16-byte record Z[c] (counted once per row),
+        // own-row Z read 16 B, next Z written 16 B, Lanczos vector v_j written 8 B.
+        *bytes_per_launch = (double)p->nnz * 12.0 + ((double)p->n + 1.0) * 4.0 + (double)p->n * 56.0;
     }
     return MACHIP_OK;
 }

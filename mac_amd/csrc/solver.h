@@ -157,8 +157,8 @@ struct Solver {
     hipStream_t stream = nullptr;
     size_t vcap = 0;            // Lanczos vectors that fit in V
     // Krylov state
-    double *u = nullptr, *V = nullptr, *tri = nullptr, *part = nullptr, *cb = nullptr;
-    Z3 *Z0 = nullptr, *Z1 = nullptr;
+    double *u = nullptr, *V = nullptr, *tri = nullptr, *part = nullptr;
+    Z2 *Z0 = nullptr, *Z1 = nullptr;
     LanState* st = nullptr;
     // explicit-check / result state (OpLanczos "column 0" machinery)
     double *y_raw = nullptr, *w2 = nullptr, *yvec = nullptr, *ypart = nullptr, *sdev = nullptr;
@@ -203,7 +203,6 @@ struct Solver {
         ST_TRY(dev_alloc(&V, (size_t)n * vcap));
         ST_TRY(dev_alloc(&tri, 3 * (vcap + 2)));
         ST_TRY(dev_alloc(&part, 2 * kNP * kMaxGrid));
-        ST_TRY(dev_alloc(&cb, kMaxChunk + 2));
         ST_TRY(dev_alloc(&Z0, n)); ST_TRY(dev_alloc(&Z1, n));
         ST_TRY(dev_alloc(&st, 1)); ST_TRY(dev_alloc(&st2, 1));
         ST_TRY(dev_alloc(&y_raw, n)); ST_TRY(dev_alloc(&w2, n)); ST_TRY(dev_alloc(&yvec, n));
@@ -225,7 +224,7 @@ struct Solver {
     void destroy() {
         for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
         graphs.clear();
-        void* ptrs[] = {u, V, tri, part, cb, Z0, Z1, st, st2, y_raw, w2, yvec, ypart, sdev,
+        void* ptrs[] = {u, V, tri, part, Z0, Z1, st, st2, y_raw, w2, yvec, ypart, sdev,
                         part_c, part_a2, part_r, scratch3, rq_dev, start, wc, ctri, part_u, part_a, stc};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (h_tri) (void)hipHostFree(h_tri);
@@ -240,7 +239,7 @@ struct Solver {
 
     PipeView pview(const SpmvPlan& pl) const {
         PipeView L;
-        L.n = n; L.st = st; L.Z0 = Z0; L.Z1 = Z1; L.V = V; L.tri = tri; L.cb = cb; L.htri = d_htri; L.hflag = d_hflag; L.part = part; L.P = pl.grid;
+        L.n = n; L.st = st; L.Z0 = Z0; L.Z1 = Z1; L.V = V; L.tri = tri; L.htri = d_htri; L.hflag = d_hflag; L.part = part; L.P = pl.grid;
         return L;
     }
     LanView check_view(const SpmvPlan& pl) const {   // "column 0" machinery for the explicit check
@@ -526,7 +525,7 @@ struct Solver {
         if (stats) {
             stats->lanczos_steps = steps_total;
             stats->spmv_total = spmv_total;
-            stats->vec_passes = steps_total * 8;   // per step and row: Z read (3) + Z write (3) + V write (1) ~ 7-8 doubles
+            stats->vec_passes = steps_total * 7;   // per step and row: Z gathered (2) + Z own-row read (2) + Z written (2) + V written (1)
             stats->restarts = restarts;
             stats->nnz = nnz;
             stats->residual = res;
