@@ -520,7 +520,7 @@ struct PipeRow {   // per-thread accumulation of the next step's partial sums
 };
 
 // ---- sub-wave vector form: G lanes per row, BLOCK threads per workgroup -------------------------
-template <int BLOCK, int G>
+template <int BLOCK, int G, int UNR = 1>
 __global__ __launch_bounds__(BLOCK) void k_pipe_vec(CsrView A, PipeView L, int jrel) {
     __shared__ double smw[kMaxWaves * kNP];
     __shared__ double scoef[8];
@@ -541,7 +541,21 @@ __global__ __launch_bounds__(BLOCK) void k_pipe_vec(CsrView A, PipeView L, int j
         if (r < A.n) {
             const int b = A.rowptr[r], e = A.rowptr[r + 1];
             if (lane == 0) zr = Zc[r];
-            for (int p = b + lane; p < e; p += G) {
+            int p = b + lane;
+            if (UNR > 1) {   // several independent (val, col, gather) chains in flight per lane
+                for (; p + (UNR - 1) * G < e; p += UNR * G) {
+                    double vv[UNR];
+                    int cc[UNR];
+                    Z2 zz[UNR];
+#pragma unroll
+                    for (int q = 0; q < UNR; ++q) { vv[q] = A.val[p + q * G]; cc[q] = A.col[p + q * G]; }
+#pragma unroll
+                    for (int q = 0; q < UNR; ++q) zz[q] = Zc[cc[q]];
+#pragma unroll
+                    for (int q = 0; q < UNR; ++q) { st += vv[q] * zz[q].t; sv += vv[q] * zz[q].v; }
+                }
+            }
+            for (; p < e; p += G) {
                 const double vv = A.val[p];
                 const Z2 z = Zc[A.col[p]];
                 st += vv * z.t; sv += vv * z.v;
@@ -818,12 +832,13 @@ __global__ __launch_bounds__(kBlock) void k_sel_pass(const double* __restrict__ 
     unsigned int* gh = hist + pass * kBins;
     for (int i = tid; i < kBins; i += kBlock)
         if (lh[i]) atomicAdd(&gh[i], lh[i]);
-    // the histogram lives in device-scope atomics (performed at the memory side, never cached);
-    // __syncthreads() drains this workgroup's atomics, then ONE lane takes the arrival ticket with
-    // release/acquire semantics (a fence per thread costs several microseconds here)
+    // the histogram lives in device-scope atomics (performed at the coherence point, never cached)
+    // and is read back below with device-scope atomic loads; __syncthreads() drains this
+    // workgroup's atomics (s_waitcnt vmcnt(0) counts them on gfx950) before ONE lane takes the
+    // arrival ticket, so no cache write-back / invalidate is needed at all
     __syncthreads();
     if (tid == 0)
-        s_last = (__hip_atomic_fetch_add(&st->ticket[pass], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1);
+        s_last = (__hip_atomic_fetch_add(&st->ticket[pass], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1);
     __syncthreads();
     if (!s_last) return;
     // last workgroup: walk the bins from the top until the cumulative count reaches kk

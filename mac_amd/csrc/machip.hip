@@ -190,7 +190,8 @@ int select_topk(machip_problem* p, long k) {
     HIP_TRY(hipMemsetAsync(p->hist, 0, sizeof(unsigned int) * 6 * kBins, p->stream));
     k_sel_init<<<1, 64, 0, p->stream>>>(p->sel, (long long)k);
     if (k > 0) {
-        const int grid = (int)std::min<long>(kMaxGrid, (m + kBlock * 4 - 1) / (kBlock * 4));
+        // <= 256 workgroups: every arrival is one serialized device-scope atomic on the ticket word
+        const int grid = (int)std::min<long>(256, (m + kBlock * 4 - 1) / (kBlock * 4));
         for (int pass = 0; pass < 6; ++pass)
             k_sel_pass<<<std::max(grid, 1), kBlock, 0, p->stream>>>(p->g, m, pass, p->hist, p->sel);
         k_sel_ties<<<1, 1024, 0, p->stream>>>(p->g, m, p->sel);

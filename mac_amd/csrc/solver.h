@@ -33,7 +33,8 @@ struct SpmvPlan {
     int variant = kVec;   // kStream or kVec
     int width = 8;        // TPR for stream, G for vec
     int grid = 1;
-    int block = kBlock;   // threads per workgroup of the fused step kernel (256 or 1024)
+    int block = kBlock;   // threads per workgroup of the fused step kernel (256, 512 or 1024)
+    int unroll = 1;       // independent (val, col, gather) chains per lane
 };
 
 inline int env_int(const char* name, int dflt) {
@@ -92,11 +93,20 @@ inline SpmvPlan plan_pipe(int n, long nnz, int maxlen) {
         return pl;
     }
     pl.variant = kVec;
-    // hub rows (Frank-Wolfe vertices concentrate the selected edges on few nodes) serialise a
-    // 4-lane group: widen the groups when the longest row is far above the mean
-    pl.width = env_int("MACHIP_G", (mean < 16.0 && maxlen <= 48) ? 4 : 16);
-    const long tiles256 = ((long)n + (256 / pl.width) - 1) / (256 / pl.width);
-    pl.block = env_int("MACHIP_BLOCK", tiles256 > grid_cap() ? 1024 : 256);
+    // tools/ubench.hip, MI355X: 4 lanes per row up to ~16 nnz/row, 8 up to ~32 (and for every
+    // n <= 32k, where the gather operand is cache resident), 16 beyond; two independent load chains
+    // per lane from 8 lanes up.  Hub rows (Frank-Wolfe vertices concentrate the selected edges on
+    // few nodes) would serialise a narrow group: widen when the longest row is far above the mean.
+    int g = mean < 16.0 ? 4 : ((mean < 32.0 || n <= 32768) ? 8 : 16);
+    if (g == 4 && maxlen > 48) g = 16;
+    if (g == 8 && maxlen > 8 * mean && maxlen > 128) g = 16;
+    pl.width = env_int("MACHIP_G", g);
+    pl.unroll = env_int("MACHIP_UNROLL", pl.width >= 8 ? 2 : 1);
+    // at most grid_cap() workgroups (each re-reads every workgroup's partials): grow the
+    // workgroup instead of the grid
+    int blk = 256;
+    while (blk < 1024 && ((long)n + (blk / pl.width) - 1) / (blk / pl.width) > grid_cap()) blk <<= 1;
+    pl.block = env_int("MACHIP_BLOCK", blk);
     const int gpb = pl.block / pl.width;
     pl.grid = (int)std::max<long>(1, std::min<long>(grid_cap(), ((long)n + gpb - 1) / gpb));
     return pl;
@@ -124,6 +134,23 @@ inline void launch_spmv(const SpmvPlan& pl, hipStream_t s, const CsrView& A, con
     }
 }
 
+template <int BLOCK>
+inline void launch_pipe_b(const SpmvPlan& pl, hipStream_t s, const CsrView& A, const PipeView& L, int jrel) {
+    const int key = pl.width * 10 + pl.unroll;
+    switch (key) {
+        case 41: k_pipe_vec<BLOCK, 4, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 42: k_pipe_vec<BLOCK, 4, 2><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 81: k_pipe_vec<BLOCK, 8, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 82: k_pipe_vec<BLOCK, 8, 2><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 161: k_pipe_vec<BLOCK, 16, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 162: k_pipe_vec<BLOCK, 16, 2><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 321: k_pipe_vec<BLOCK, 32, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 322: k_pipe_vec<BLOCK, 32, 2><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 641: k_pipe_vec<BLOCK, 64, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        default: k_pipe_vec<BLOCK, 64, 2><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+    }
+}
+
 inline void launch_pipe(const SpmvPlan& pl, hipStream_t s, const CsrView& A, const PipeView& L, int jrel) {
     if (pl.variant == kStream) {
         switch (pl.width) {
@@ -133,23 +160,9 @@ inline void launch_pipe(const SpmvPlan& pl, hipStream_t s, const CsrView& A, con
             case 8: k_pipe_stream<8><<<pl.grid, kBlock, 0, s>>>(A, L, jrel); break;
             default: k_pipe_stream<16><<<pl.grid, kBlock, 0, s>>>(A, L, jrel); break;
         }
-    } else if (pl.block == 1024) {
-        switch (pl.width) {
-            case 4: k_pipe_vec<1024, 4><<<pl.grid, 1024, 0, s>>>(A, L, jrel); break;
-            case 8: k_pipe_vec<1024, 8><<<pl.grid, 1024, 0, s>>>(A, L, jrel); break;
-            case 16: k_pipe_vec<1024, 16><<<pl.grid, 1024, 0, s>>>(A, L, jrel); break;
-            case 32: k_pipe_vec<1024, 32><<<pl.grid, 1024, 0, s>>>(A, L, jrel); break;
-            default: k_pipe_vec<1024, 64><<<pl.grid, 1024, 0, s>>>(A, L, jrel); break;
-        }
-    } else {
-        switch (pl.width) {
-            case 4: k_pipe_vec<256, 4><<<pl.grid, 256, 0, s>>>(A, L, jrel); break;
-            case 8: k_pipe_vec<256, 8><<<pl.grid, 256, 0, s>>>(A, L, jrel); break;
-            case 16: k_pipe_vec<256, 16><<<pl.grid, 256, 0, s>>>(A, L, jrel); break;
-            case 32: k_pipe_vec<256, 32><<<pl.grid, 256, 0, s>>>(A, L, jrel); break;
-            default: k_pipe_vec<256, 64><<<pl.grid, 256, 0, s>>>(A, L, jrel); break;
-        }
-    }
+    } else if (pl.block == 1024) launch_pipe_b<1024>(pl, s, A, L, jrel);
+    else if (pl.block == 512) launch_pipe_b<512>(pl, s, A, L, jrel);
+    else launch_pipe_b<256>(pl, s, A, L, jrel);
 }
 
 struct Solver {
@@ -284,7 +297,7 @@ struct Solver {
             graphs.clear();
             graph_csr_key = (const void*)A.val;
         }
-        const auto key = std::make_tuple(pl.variant, pl.width, pl.grid, pl.block, steps);
+        const auto key = std::make_tuple(pl.variant, pl.width * 10 + pl.unroll, pl.grid, pl.block, steps);
         auto it = graphs.find(key);
         if (it == graphs.end()) {
             hipGraph_t g = nullptr;
