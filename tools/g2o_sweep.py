@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Budget sweep over a g2o pose graph -- the loop of the reference's experiment driver
+(examples/g2o_experiment.py:240-336) without plotting / SE-Sync: for 10%..100% of the loop closures,
+NaiveGreedy init -> MAC.solve(max_iters=20, rounding="nearest", use_cache=True) -> Madow rounding,
+printing lambda_2 of each selection.  One MAC object (one device-resident problem) serves all budgets.
+
+    python tools/g2o_sweep.py tests/golden/data/intel.g2o
+"""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from mac_amd.solvers import MAC, NaiveGreedy          # noqa: E402
+from mac_amd.utils.g2o import read_g2o_file, split_edges  # noqa: E402
+from mac_amd.utils.rounding import round_madow        # noqa: E402
+
+
+def main(path):
+    edges, n = read_g2o_file(path)
+    odom, lc = split_edges(edges)
+    print(f"{path}: {n} poses, {len(odom)} odometry edges, {len(lc)} loop closures")
+    mac = MAC(odom, lc, n, fiedler_method="tracemin_cholesky")      # reference string, runs on HIP
+    naive = NaiveGreedy(lc)
+    print(f"{'pct':>5} {'k':>6} {'naive':>12} {'unrounded':>12} {'nearest':>12} {'madow':>12} {'upper':>12} {'solve_s':>8}")
+    for pct in [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 1.0]:
+        k = int(pct * len(lc))
+        w_init = naive.subset(k)
+        t0 = time.perf_counter()
+        result, unrounded, upper, rtime = mac.solve(k, w_init, max_iters=20, rounding="nearest",
+                                                    return_rounding_time=True, use_cache=True)
+        dt = time.perf_counter() - t0
+        madow = round_madow(unrounded, k, seed=np.random.RandomState(42)) if k < len(lc) else result
+        ev = mac.evaluate_objective
+        print(f"{pct:5.1f} {k:6d} {ev(w_init):12.8f} {ev(unrounded):12.8f} {ev(result):12.8f} {ev(madow):12.8f} {upper:12.8f} {dt:8.3f}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "tests/golden/data/intel.g2o")
