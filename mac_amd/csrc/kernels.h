@@ -33,9 +33,10 @@ struct PatternView {
 };
 
 struct LanState {   // device-resident step counters: kernels take no per-step arguments,
-    int jA;         // so a chunk of steps can be replayed from a hipGraph.
-    int jB;         // jA is read by k_lan_spmv*, jB by k_lan_update (see those kernels).
-    int pad0, pad1;
+    int jA;         // so a chunk of steps can be replayed from a hipGraph.  Fused form: jA = first
+    int jB;         // step of the current chunk (only k_pipe_tail writes it).  Classic form: jA is
+    int epoch;      // read by the SpMV kernel, jB by k_lan_update.  epoch tags the host flag.
+    int pad;
 };
 
 struct LanView {
@@ -640,7 +641,7 @@ __global__ __launch_bounds__(kBlock) void k_pipe_init(PipeView L, const double* 
         for (int q = 0; q < kNP; ++q) L.part[q * kMaxGrid + blockIdx.x] = 0.0;
         L.part[0 * kMaxGrid + blockIdx.x] = s2;
         L.part[3 * kMaxGrid + blockIdx.x] = s1;
-        if (blockIdx.x == 0) { L.st->jA = 0; L.st->jB = epoch; }   // jB carries the sequence epoch
+        if (blockIdx.x == 0) { L.st->jA = 0; L.st->epoch = epoch; }
     }
 }
 // One wave, end of a chunk of `adv` steps: finish (alpha_{J-1}, beta_J, l1_{J-1}) for J = jA + adv
@@ -660,7 +661,7 @@ __global__ __launch_bounds__(64) void k_pipe_tail(PipeView L, int adv) {
     }
     __threadfence_system();
     if (threadIdx.x == 0) {
-        const unsigned long long epoch = (unsigned long long)(unsigned int)L.st->jB;
+        const unsigned long long epoch = (unsigned long long)(unsigned int)L.st->epoch;
         __hip_atomic_store(L.hflag, (epoch << 32) | (unsigned long long)(unsigned int)j, __ATOMIC_RELEASE,
                            __HIP_MEMORY_SCOPE_SYSTEM);
     }

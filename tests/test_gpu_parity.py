@@ -8,12 +8,14 @@ Tolerances (BASELINE.json north_star: fp64, lambda_2 within 1e-8 relative):
   BIT-EXACT given the same vector;  assembly: structure exact, values exact off-diagonal,
   diagonal to 1e-14 relative;  top-k / x update: bit-exact.
 """
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
 
 import oracle
-from conftest import load_golden, sign_align
+from conftest import ROOT, load_golden, sign_align
 from mac_amd import _lib
 from mac_amd.solvers import MAC, NaiveGreedy
 from mac_amd.utils.fiedler import find_fiedler_pair, reference_start_block
@@ -425,3 +427,40 @@ def test_full_size_config4_properties():
     x = P.get_x()
     assert x.min() >= 0 and x.max() <= 1 and x.sum() <= k * (1 + 1e-12)
     P.close()
+
+
+@pytest.mark.parametrize("env", [
+    {"MACHIP_SPMV": "stream", "MACHIP_TPR": "4"}, {"MACHIP_SPMV": "stream", "MACHIP_TPR": "16"},
+    {"MACHIP_G": "4", "MACHIP_BLOCK": "256", "MACHIP_UNROLL": "2"}, {"MACHIP_G": "16", "MACHIP_BLOCK": "1024"},
+    {"MACHIP_G": "64", "MACHIP_BLOCK": "512"}, {"MACHIP_G": "32", "MACHIP_MAXGRID": "64"},
+    {"MACHIP_GRAPH": "0", "MACHIP_CHUNK": "6", "MACHIP_CHUNK_NEAR": "2"}, {"MACHIP_CLASSIC_N": "100000"},
+    {"MACHIP_VCAP": "80"},
+])
+def test_solver_variants_agree(env):
+    """Every launch shape / row mapping of the fused step kernel, eager vs graph launches, odd chunk
+    sizes, the classic two-kernel form and a basis so small that it forces restarts must all give the
+    reference's lambda_2 (each variant runs in its own process: the knobs are read once)."""
+    import subprocess
+    import sys
+    code = r'''
+import sys; sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import numpy as np
+from conftest import load_golden, sign_align
+from mac_amd import _lib
+from mac_amd.utils.fiedler import reference_start_block
+out = []
+for nm in ["er2000_xfrac", "er300_x0"]:
+    g = load_golden(nm)
+    P = _lib.Problem(int(g["n"]), g["fi"], g["fj"], g["fw"], g["ci"], g["cj"], g["cw"])
+    P.set_x(g["x"])
+    lam, v, _ = P.fiedler(tol=1e-8, x0=reference_start_block(int(g["n"]))[:, 0].copy())
+    out.append((abs(lam - float(g["lam"])) / float(g["lam"]), float(np.abs(sign_align(v, g["v"]) - g["v"]).max()), P.stats.residual))
+    P.close()
+print("RESULT", out)
+'''
+    e = dict(os.environ); e.update(env)
+    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0]
+    for rel, dv, res in eval(line[len("RESULT"):]):
+        assert rel <= LAM_RTOL and dv <= 2e-6 and res < 1e-8
