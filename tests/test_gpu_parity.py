@@ -464,3 +464,50 @@ print("RESULT", out)
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0]
     for rel, dv, res in eval(line[len("RESULT"):]):
         assert rel <= LAM_RTOL and dv <= 2e-6 and res < 1e-8
+
+
+def test_degenerate_inputs():
+    # n = 2: single fixed edge, no candidates (the smallest problem the reference's asserts admit)
+    mac = MAC([Edge(0, 1, 2.5)], [], 2)
+    assert abs(mac.evaluate_objective(np.zeros(0)) - 5.0) < 1e-9        # lambda_2 of w*[[1,-1],[-1,1]] = 2w
+    r, w, val = mac.solve(0, np.zeros(0))
+    assert r.shape == (0,) and abs(val - 5.0) < 1e-9
+    # fixed edges alone are disconnected; the candidates connect the graph
+    fixed = [Edge(0, 1, 1.0), Edge(2, 3, 1.0)]
+    cand = [Edge(1, 2, 2.0), Edge(0, 3, 0.5)]
+    mac = MAC(fixed, cand, 4)
+    with pytest.raises(_lib.Disconnected):
+        mac.evaluate_objective(np.zeros(2))
+    mo = oracle.MacOracle([0, 2], [1, 3], [1., 1.], [1, 0], [2, 3], [2.0, 0.5], 4)
+    for x in (np.array([1.0, 0.0]), np.array([0.3, 0.9]), np.ones(2)):
+        assert abs(mac.evaluate_objective(x) - oracle.dense_fiedler(mo.laplacian(x))[0]) < 1e-9
+    f, g = mac.problem(np.array([0.3, 0.9]))
+    fo, go = mo.problem(np.array([0.3, 0.9]))
+    assert abs(f - fo) < 1e-9 and np.allclose(g, go, rtol=1e-6, atol=1e-12)
+    # x entries at / below the selection threshold are dropped exactly like mac.py:85
+    lam_thr = mac.evaluate_objective(np.array([1.0, 1e-10]))
+    assert abs(lam_thr - oracle.dense_fiedler(mo.laplacian(np.array([1.0, 0.0])))[0]) < 1e-9
+    lam_above = mac.evaluate_objective(np.array([1.0, 2e-10]))
+    assert lam_above > lam_thr
+
+
+def test_wide_weight_range_and_large_ids():
+    """Weights spanning 8 decades and a sparse id space (isolated-looking high ids are still nodes)."""
+    rng = np.random.default_rng(11)
+    n = 500
+    fi = np.arange(n - 1); fj = fi + 1
+    fw = 10.0 ** rng.uniform(-3, 3, n - 1)
+    ci = rng.integers(0, n, 3000); cj = rng.integers(0, n, 3000)
+    keep = ci != cj
+    ci, cj = ci[keep], cj[keep]
+    cw = 10.0 ** rng.uniform(-4, 4, len(ci))
+    x = rng.random(len(ci))
+    P = _lib.Problem(n, fi, fj, fw, ci, cj, cw)
+    P.set_x(x)
+    lam, v, _ = P.fiedler(x0=reference_start_block(n)[:, 0].copy())
+    mo = oracle.MacOracle(fi, fj, fw, ci, cj, cw, n)
+    lam_d, v_d, _ = oracle.dense_fiedler(mo.laplacian(x))
+    assert abs(lam - lam_d) <= LAM_RTOL * lam_d
+    assert P.stats.residual < 1e-8
+    assert np.array_equal(P.gradient(), oracle.supergradient(v, ci, cj, cw))
+    P.close()
