@@ -75,9 +75,55 @@ def fiedler_case(name, fixed, cand, n, x):
          L_indptr=Lc.indptr, L_indices=Lc.indices, L_data=Lc.data)
 
 
-def main():
-    meta = {"numpy": np.__version__, "scipy": scipy.__version__,
-            "networkx": nx.__version__, "python": sys.version.split()[0]}
+def g2o_cases(meta, cases):
+    # ---- G5-G7: pose graphs through the reference's own g2o reader ----------
+    for mod in ["evo", "evo.core", "evo.core.trajectory", "evo.core.sync",
+                "evo.core.metrics"]:
+        sys.modules.setdefault(mod, types.ModuleType(mod))
+    sys.modules["evo.core.trajectory"].PoseTrajectory3D = object
+    sys.modules["evo.core"].sync = sys.modules["evo.core.sync"]
+    sys.modules["evo.core"].metrics = sys.modules["evo.core.metrics"]
+    sys.modules["evo.core.metrics"].PoseRelation = object
+    sys.modules["evo.core.metrics"].Unit = object
+    import matplotlib
+    matplotlib.use("Agg")
+    from pose_graph_utils import read_g2o_file, split_edges, rpm_to_mac
+
+    for nm, iters in cases:
+        meas, n = read_g2o_file(os.path.join(REF, "data", nm + ".g2o"))
+        odom, lc = split_edges(meas)
+        fixed, cand = rpm_to_mac(odom), rpm_to_mac(lc)
+        k = int(0.2 * len(cand))
+        import io, contextlib
+        with contextlib.redirect_stdout(io.StringIO()):
+            x0 = NaiveGreedy(cand).subset(k)
+        mac, rounded, w, u, fs, gs, xs = run_solve(fixed, cand, n, k, x0, iters,
+                                                   rounding="nearest", use_cache=True)
+        madow = round_madow(w, k, seed=np.random.RandomState(42))
+        u42 = np.random.RandomState(42).rand()
+        m0 = MAC(fixed, cand, n)
+        lam_all = m0.evaluate_objective(np.ones(len(cand)))
+        lam0, v0, X0 = find_fiedler_pair(m0.laplacian(x0))
+        fi, fj, fwt = edges_to_arrays(fixed); ci, cj, cw = edges_to_arrays(cand)
+        save("g2o_" + nm, n=n, fi=fi, fj=fj, fw=fwt, ci=ci, cj=cj, cw=cw, k=k,
+             x_init=x0, max_iters=iters, rounded=rounded, unrounded=w, upper=u,
+             f_traj=fs, supp=np.array([(x > 1e-10).sum() for x in xs]),
+             lam_init=lam0, v_init=np.array(v0), grad_init=gs[0], lam_all=lam_all,
+             lam_rounded=m0.evaluate_objective(rounded), madow=madow, madow_u=u42)
+        meta["g2o_" + nm] = {"n": int(n), "fixed": len(fixed), "cand": len(cand), "k": k}
+
+
+
+def main(only=None):
+    meta_path = os.path.join(OUT, "golden_meta.json")
+    if only and os.path.exists(meta_path):
+        meta = json.load(open(meta_path))
+    else:
+        meta = {}
+    meta.update({"numpy": np.__version__, "scipy": scipy.__version__,
+            "networkx": nx.__version__, "python": sys.version.split()[0]})
+    if only == "g2o_extra":
+        return g2o_cases(meta, [("kitti_05", 20)]), json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
 
     # ---- G1: K5 (tests/utils/test_fiedler.py:26-33) and G2: paths ----------
     for nm, G in [("k5", nx.complete_graph(5)), ("p2", nx.path_graph(2)),
@@ -150,41 +196,7 @@ def main():
              f_traj=fs, x_traj_last=xs[-1], g_traj_last=gs[-1],
              supp=np.array([(x > 1e-10).sum() for x in xs]))
 
-    # ---- G5-G7: pose graphs through the reference's own g2o reader ----------
-    for mod in ["evo", "evo.core", "evo.core.trajectory", "evo.core.sync",
-                "evo.core.metrics"]:
-        sys.modules.setdefault(mod, types.ModuleType(mod))
-    sys.modules["evo.core.trajectory"].PoseTrajectory3D = object
-    sys.modules["evo.core"].sync = sys.modules["evo.core.sync"]
-    sys.modules["evo.core"].metrics = sys.modules["evo.core.metrics"]
-    sys.modules["evo.core.metrics"].PoseRelation = object
-    sys.modules["evo.core.metrics"].Unit = object
-    import matplotlib
-    matplotlib.use("Agg")
-    from pose_graph_utils import read_g2o_file, split_edges, rpm_to_mac
-
-    for nm, iters in [("intel", 20), ("sphere2500", 20), ("city10000", 20)]:
-        meas, n = read_g2o_file(os.path.join(REF, "data", nm + ".g2o"))
-        odom, lc = split_edges(meas)
-        fixed, cand = rpm_to_mac(odom), rpm_to_mac(lc)
-        k = int(0.2 * len(cand))
-        import io, contextlib
-        with contextlib.redirect_stdout(io.StringIO()):
-            x0 = NaiveGreedy(cand).subset(k)
-        mac, rounded, w, u, fs, gs, xs = run_solve(fixed, cand, n, k, x0, iters,
-                                                   rounding="nearest", use_cache=True)
-        madow = round_madow(w, k, seed=np.random.RandomState(42))
-        u42 = np.random.RandomState(42).rand()
-        m0 = MAC(fixed, cand, n)
-        lam_all = m0.evaluate_objective(np.ones(len(cand)))
-        lam0, v0, X0 = find_fiedler_pair(m0.laplacian(x0))
-        fi, fj, fwt = edges_to_arrays(fixed); ci, cj, cw = edges_to_arrays(cand)
-        save("g2o_" + nm, n=n, fi=fi, fj=fj, fw=fwt, ci=ci, cj=cj, cw=cw, k=k,
-             x_init=x0, max_iters=iters, rounded=rounded, unrounded=w, upper=u,
-             f_traj=fs, supp=np.array([(x > 1e-10).sum() for x in xs]),
-             lam_init=lam0, v_init=np.array(v0), grad_init=gs[0], lam_all=lam_all,
-             lam_rounded=m0.evaluate_objective(rounded), madow=madow, madow_u=u42)
-        meta["g2o_" + nm] = {"n": int(n), "fixed": len(fixed), "cand": len(cand), "k": k}
+    g2o_cases(meta, [("intel", 20), ("sphere2500", 20), ("city10000", 20)])
 
     # ---- G8: ER N=10k (BASELINE.json configs[1]) one Fiedler solve ---------
     n = 10000
@@ -225,4 +237,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else None)

@@ -130,7 +130,7 @@ def test_fiedler_pair_and_gradient_vs_reference(nm):
     P.close()
 
 
-@pytest.mark.parametrize("nm", ["intel", "sphere2500", "city10000"])
+@pytest.mark.parametrize("nm", ["intel", "sphere2500", "city10000", "kitti_05"])
 def test_pose_graph_fiedler(nm):
     g = load_golden("g2o_" + nm)
     mac = MAC(edges_of(g, "f"), edges_of(g, "c"), int(g["n"]))
@@ -235,7 +235,7 @@ def test_er_solve_trajectory(nm):
     assert abs(u - g["upper"]) <= 1e-6 * abs(g["upper"])
 
 
-@pytest.mark.parametrize("nm", ["intel", "sphere2500"])
+@pytest.mark.parametrize("nm", ["intel", "sphere2500", "kitti_05"])
 def test_pose_graph_solve_trajectory(nm):
     g = load_golden("g2o_" + nm)
     mac = MAC(edges_of(g, "f"), edges_of(g, "c"), int(g["n"]))
@@ -511,3 +511,17 @@ def test_wide_weight_range_and_large_ids():
     assert P.stats.residual < 1e-8
     assert np.array_equal(P.gradient(), oracle.supergradient(v, ci, cj, cw))
     P.close()
+
+
+def test_madow_rounding_with_objective_reruns():
+    """rounding="madow" with random_rounding_max_iters > 1 re-evaluates lambda_2 per draw
+    (mac/utils/rounding.py:63-75 -> MAC.evaluate_objective); exact-K selection must hold."""
+    g = load_golden("g2o_intel")
+    mac = MAC(edges_of(g, "f"), edges_of(g, "c"), int(g["n"]))
+    k = int(g["k"])
+    np.random.seed(3)
+    rounded, w, u = mac.solve(k, g["x_init"], max_iters=6, rounding="madow", random_rounding_max_iters=3)
+    assert rounded.sum() == k and set(np.unique(rounded)) <= {0.0, 1.0}
+    assert mac.evaluate_objective(rounded) <= u + 1e-9
+    r2, w2, u2, rt = mac.solve(k, g["x_init"], max_iters=6, return_rounding_time=True, fallback=True)
+    assert rt >= 0 and r2.sum() == k and np.allclose(w, w2, atol=1e-12)

@@ -126,7 +126,7 @@ def test_unknown_method_raises_like_reference():
         find_fiedler_pair(sp.identity(4, format="csr"), method="bogus")
 
 
-@pytest.mark.parametrize("nm", ["intel", "sphere2500", "city10000"])
+@pytest.mark.parametrize("nm", ["intel", "sphere2500", "city10000", "kitti_05"])
 def test_g2o_reader_matches_reference_golden(nm):
     """Edge arrays produced by the reference's own reader (examples/pose_graph_utils.py) were
     captured in tests/golden/g2o_*.npz; the product parser must reproduce them."""

@@ -87,7 +87,7 @@ def test_er_fw_trajectory(nm):
     assert np.array_equal(rounded, g["rounded"])
 
 
-@pytest.mark.parametrize("nm", ["intel", "sphere2500"])
+@pytest.mark.parametrize("nm", ["intel", "sphere2500", "kitti_05"])
 def test_pose_graph_goldens(nm):
     g = load_golden("g2o_" + nm)
     i, j, kap, n = oracle.parse_g2o_edges(os.path.join(GOLDEN, "data", nm + ".g2o"))
