@@ -521,12 +521,16 @@ struct PipeRow {   // per-thread accumulation of the next step's partial sums
 };
 
 // ---- sub-wave vector form: G lanes per row, BLOCK threads per workgroup -------------------------
-template <int BLOCK, int G, int UNR = 1>
+template <int BLOCK, int G, int UNR = 1, bool DED = false>
 __global__ __launch_bounds__(BLOCK) void k_pipe_vec(CsrView A, PipeView L, int jrel) {
     __shared__ double smw[kMaxWaves * kNP];
     __shared__ double scoef[8];
-    constexpr int GPB = BLOCK / G;
-    const int lane = threadIdx.x % G, g = threadIdx.x / G;
+    // DED: wave 0 does nothing but the prologue (its reduction chain is then off the critical
+    // path of the row work); the other waves own the rows.
+    constexpr int WORK = DED ? BLOCK - 64 : BLOCK;
+    constexpr int GPB = WORK / G;
+    const int wt = DED ? (int)threadIdx.x - 64 : (int)threadIdx.x;
+    const int lane = wt >= 0 ? wt % G : 0, g = wt >= 0 ? wt / G : 0;
     if (threadIdx.x < 64) { int jdummy; (void)pipe_prologue_wave0(L, jrel, -1, scoef, &jdummy); }
     const Z2* __restrict__ Zc = (jrel & 1) ? L.Z1 : L.Z0;
     Z2* __restrict__ Zn = (jrel & 1) ? L.Z0 : L.Z1;
@@ -537,9 +541,10 @@ __global__ __launch_bounds__(BLOCK) void k_pipe_vec(CsrView A, PipeView L, int j
     double* vj = nullptr;
     for (int r0 = blockIdx.x * GPB; r0 < A.n; r0 += gridDim.x * GPB) {   // workgroup-uniform trip count
         const int r = r0 + g;
+        const bool mine = wt >= 0 && r < A.n;
         double st = 0.0, sv = 0.0;
         Z2 zr; zr.t = 0.0; zr.v = 0.0;
-        if (r < A.n) {
+        if (mine) {
             const int b = A.rowptr[r], e = A.rowptr[r + 1];
             if (lane == 0) zr = Zc[r];
             int p = b + lane;
@@ -569,7 +574,7 @@ __global__ __launch_bounds__(BLOCK) void k_pipe_vec(CsrView A, PipeView L, int j
             vj = L.V + (size_t)scoef[4] * (size_t)L.n;
             have = true;
         }
-        if (r < A.n && lane == 0) pr.finish(alpha, beta, mu, inv, zr, st, sv, vj, Zn, r);
+        if (mine && lane == 0) pr.finish(alpha, beta, mu, inv, zr, st, sv, vj, Zn, r);
     }
     pr.template store<BLOCK>(L, jrel, smw);
 }

@@ -104,10 +104,11 @@ inline SpmvPlan plan_pipe(int n, long nnz, int maxlen) {
     pl.unroll = env_int("MACHIP_UNROLL", pl.width >= 8 ? 2 : 1);
     // at most grid_cap() workgroups (each re-reads every workgroup's partials): grow the
     // workgroup instead of the grid
+    // (wave 0 of every workgroup only runs the prologue: BLOCK - 64 threads own rows)
     int blk = 256;
-    while (blk < 1024 && ((long)n + (blk / pl.width) - 1) / (blk / pl.width) > grid_cap()) blk <<= 1;
+    while (blk < 1024 && ((long)n + ((blk - 64) / pl.width) - 1) / ((blk - 64) / pl.width) > grid_cap()) blk <<= 1;
     pl.block = env_int("MACHIP_BLOCK", blk);
-    const int gpb = pl.block / pl.width;
+    const int gpb = (pl.block - 64) / pl.width;
     pl.grid = (int)std::max<long>(1, std::min<long>(grid_cap(), ((long)n + gpb - 1) / gpb));
     return pl;
 }
@@ -138,16 +139,16 @@ template <int BLOCK>
 inline void launch_pipe_b(const SpmvPlan& pl, hipStream_t s, const CsrView& A, const PipeView& L, int jrel) {
     const int key = pl.width * 10 + pl.unroll;
     switch (key) {
-        case 41: k_pipe_vec<BLOCK, 4, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 42: k_pipe_vec<BLOCK, 4, 2><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 81: k_pipe_vec<BLOCK, 8, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 82: k_pipe_vec<BLOCK, 8, 2><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 161: k_pipe_vec<BLOCK, 16, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 162: k_pipe_vec<BLOCK, 16, 2><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 321: k_pipe_vec<BLOCK, 32, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 322: k_pipe_vec<BLOCK, 32, 2><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 641: k_pipe_vec<BLOCK, 64, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        default: k_pipe_vec<BLOCK, 64, 2><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 41: k_pipe_vec<BLOCK, 4, 1, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 42: k_pipe_vec<BLOCK, 4, 2, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 81: k_pipe_vec<BLOCK, 8, 1, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 82: k_pipe_vec<BLOCK, 8, 2, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 161: k_pipe_vec<BLOCK, 16, 1, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 162: k_pipe_vec<BLOCK, 16, 2, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 321: k_pipe_vec<BLOCK, 32, 1, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 322: k_pipe_vec<BLOCK, 32, 2, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 641: k_pipe_vec<BLOCK, 64, 1, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        default: k_pipe_vec<BLOCK, 64, 2, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
     }
 }
 

@@ -31,13 +31,13 @@ double time_us(F&& launch, int reps, hipStream_t s) {
     return 1e3 * ms / reps;
 }
 
-template <int BLOCK, int G, int UNR>
+template <int BLOCK, int G, int UNR, bool DED = false>
 void run_pipe(const CsrView& A, PipeView L, int cap, hipStream_t s, long nnz) {
-    const int gpb = BLOCK / G;
+    const int gpb = (DED ? BLOCK - 64 : BLOCK) / G;
     const int grid = std::min(cap, (A.n + gpb - 1) / gpb);
     L.P = grid;
-    const double us = time_us([&] { k_pipe_vec<BLOCK, G, UNR><<<grid, BLOCK, 0, s>>>(A, L, 0); }, 400, s);
-    printf("  k_pipe_vec blk=%-4d G=%-2d unr=%d grid=%-4d : %7.2f us  (%6.0f GB/s on 12*nnz+56*n)\n", BLOCK, G, UNR, grid, us,
+    const double us = time_us([&] { k_pipe_vec<BLOCK, G, UNR, DED><<<grid, BLOCK, 0, s>>>(A, L, 0); }, 400, s);
+    printf("  k_pipe_vec blk=%-4d G=%-2d unr=%d ded=%d grid=%-4d : %7.2f us  (%6.0f GB/s on 12*nnz+56*n)\n", BLOCK, G, UNR, (int)DED, grid, us,
            (nnz * 12.0 + 56.0 * A.n) / us / 1e3);
 }
 template <int G>
@@ -82,13 +82,13 @@ int main() {
             printf("== n=%d mean row %.1f nnz=%ld (%.2f MB csr)\n", n, (double)nnz / n, nnz, nnz * 12.0 / 1e6);
             printf("  empty kernel, 256 workgroups                  : %7.2f us\n", time_us([&] { k_empty<<<256, kBlock, 0, s>>>(nullptr); }, 400, s));
             run_plain<4>(A, x, y, 1024, s, nnz); run_plain<16>(A, x, y, 1024, s, nnz);
-            for (int cap : {256, 512}) {
-                run_pipe<256, 4, 1>(A, L, cap, s, nnz); run_pipe<256, 4, 2>(A, L, cap, s, nnz); run_pipe<256, 4, 4>(A, L, cap, s, nnz);
-                run_pipe<256, 16, 1>(A, L, cap, s, nnz); run_pipe<256, 16, 2>(A, L, cap, s, nnz);
-                run_pipe<1024, 4, 1>(A, L, cap, s, nnz); run_pipe<1024, 4, 2>(A, L, cap, s, nnz);
-                run_pipe<1024, 16, 1>(A, L, cap, s, nnz); run_pipe<1024, 16, 2>(A, L, cap, s, nnz); run_pipe<1024, 16, 4>(A, L, cap, s, nnz);
-                run_pipe<1024, 8, 1>(A, L, cap, s, nnz); run_pipe<1024, 8, 2>(A, L, cap, s, nnz);
-                run_pipe<512, 16, 2>(A, L, cap, s, nnz); run_pipe<512, 8, 2>(A, L, cap, s, nnz);
+            for (int cap : {256}) {
+                run_pipe<256, 4, 1>(A, L, cap, s, nnz); run_pipe<256, 4, 1, true>(A, L, cap, s, nnz);
+                run_pipe<512, 4, 1>(A, L, cap, s, nnz); run_pipe<512, 4, 1, true>(A, L, cap, s, nnz);
+                run_pipe<512, 8, 2>(A, L, cap, s, nnz); run_pipe<512, 8, 2, true>(A, L, cap, s, nnz);
+                run_pipe<1024, 8, 2>(A, L, cap, s, nnz); run_pipe<1024, 8, 2, true>(A, L, cap, s, nnz);
+                run_pipe<1024, 4, 1>(A, L, cap, s, nnz); run_pipe<1024, 4, 1, true>(A, L, cap, s, nnz);
+                run_pipe<1024, 16, 2>(A, L, cap, s, nnz); run_pipe<1024, 16, 2, true>(A, L, cap, s, nnz);
             }
             CK(hipFree(drp)); CK(hipFree(dcol)); CK(hipFree(dval)); CK(hipFree(x)); CK(hipFree(y));
             CK(hipFree(L.st)); CK(hipFree(L.Z0)); CK(hipFree(L.Z1)); CK(hipFree(L.V)); CK(hipFree(L.tri)); CK(hipFree(L.part));
