@@ -117,6 +117,13 @@ int machip_fw_step(machip_problem* p, int64_t k, int iter, double tol, int max_s
                    double* f, double* dual, double* gnorm, machip_solve_stats* stats);
 int machip_fw_commit(machip_problem* p);
 
+/* round_nearest(w, k, weights, break_ties_decimal_tol) on the device-resident x
+ * (mac/utils/rounding.py:7-42, called at mac/solvers/mac.py:209): indicator of the k largest
+ * entries under the lexicographic key (round(x, decimals), candidate weight); decimals < 0 =
+ * plain top-k of x (rounding.py:21-28).  Full ties (equal rounded x and equal weight) go to the
+ * highest indices (the reference's argpartition leaves them unspecified).  rounded_out: m doubles. */
+int machip_round_nearest(machip_problem* p, int64_t k, int decimals, double* rounded_out);
+
 /* find_fiedler_pair(L) for an arbitrary scipy CSR Laplacian
  * (mac/utils/fiedler.py:9, called that way by tests/utils/test_fiedler.py:32). */
 int machip_fiedler_csr(int device, int64_t n, const int32_t* indptr, const int32_t* indices,

@@ -60,6 +60,7 @@ SIGNATURES = {
     "machip_fw_step": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_int, C.c_int, _f64p, _f64p,
                                  _f64p, C.POINTER(SolveStats)]),
     "machip_fw_commit": (C.c_int, [C.c_void_p]),
+    "machip_round_nearest": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, _f64p]),
     "machip_fiedler_csr": (C.c_int, [C.c_int, C.c_int64, _i32p, _i32p, _f64p, C.c_double, C.c_int, _f64p, _f64p,
                                      _f64p, _f64p, C.c_int, C.POINTER(SolveStats)]),
     "machip_spmv": (C.c_int, [C.c_void_p, _f64p, _f64p, C.c_int]),
@@ -226,6 +227,12 @@ class Problem:
 
     def fw_commit(self):
         check(self._lib.machip_fw_commit(self._h))
+
+    def round_nearest(self, k, decimals=10):
+        """Device round_nearest of the resident x; decimals=None -> plain top-k."""
+        out = np.empty(self.m)
+        check(self._lib.machip_round_nearest(self._h, int(k), -1 if decimals is None else int(decimals), p_f64(out)))
+        return out
 
     def profile_spmv(self, reps=200):
         us, by = C.c_double(), C.c_double()

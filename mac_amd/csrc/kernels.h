@@ -891,20 +891,24 @@ __global__ __launch_bounds__(kBlock) void k_sel_pass(const double* __restrict__ 
 
 // Ties at the k-th value: select the lowest indices.  One workgroup; exits at once in the
 // common case (every key equal to T is needed).
-__global__ __launch_bounds__(1024) void k_sel_ties(const double* __restrict__ g, long m, SelState* st) {
+// prefer_high = 0: ties with index <= tie_limit are selected (lowest indices first);
+// prefer_high = 1: ties with index >= tie_limit (highest indices first; matches the stable
+// lexsort order the rounding oracle uses).
+__global__ __launch_bounds__(1024) void k_sel_ties(const double* __restrict__ g, long m, SelState* st, int prefer_high) {
     __shared__ int s_cnt[16];
     __shared__ long long s_found;
     const long long need = st->kk;        // ties to take (>= 1 when k >= 1)
     const long long eq = st->cnt_eq;
-    if (st->k <= 0) { if (threadIdx.x == 0) st->tie_limit = -1; return; }
-    if (need >= eq) { if (threadIdx.x == 0) st->tie_limit = 0x7fffffffffffffffll; return; }
+    if (st->k <= 0) { if (threadIdx.x == 0) st->tie_limit = prefer_high ? 0x7fffffffffffffffll : -1; return; }
+    if (need >= eq) { if (threadIdx.x == 0) st->tie_limit = prefer_high ? -1 : 0x7fffffffffffffffll; return; }
     const unsigned long long T = st->T;
     const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
     if (tid == 0) s_found = -1;
     long long run = 0;
     for (long base = 0; base < m; base += 1024) {
-        const long i = base + tid;
-        const bool is = i < m && f64_key(g[i]) == T;
+        const long ii = base + tid;                         // position in scan order
+        const long i = prefer_high ? m - 1 - ii : ii;       // element index
+        const bool is = ii < m && f64_key(g[i]) == T;
         const unsigned long long bal = __ballot(is);
         __syncthreads();
         if (ln == 0) s_cnt[wv] = __popcll(bal);
@@ -920,7 +924,7 @@ __global__ __launch_bounds__(1024) void k_sel_ties(const double* __restrict__ g,
         }
         run += tot;
     }
-    if (tid == 0) st->tie_limit = 0x7fffffffffffffffll;
+    if (tid == 0) st->tie_limit = prefer_high ? -1 : 0x7fffffffffffffffll;
 }
 
 // Final fused Frank-Wolfe pass (mac/optimization/frankwolfe.py:59-76): s from the threshold,
@@ -954,6 +958,52 @@ __global__ __launch_bounds__(kBlock) void k_fw_final(const double* __restrict__ 
     d = block_sum(d, sm);
     q = block_sum(q, sm);
     if (threadIdx.x == 0) { part[blockIdx.x] = d; part[kMaxGrid + blockIdx.x] = q; }
+}
+
+// ------------------------------------------------------------------------------------------
+// round_nearest with tie-break (mac/utils/rounding.py:30-42), SURVEY section 8(f) rank 2:
+// top-k under the lexicographic key (round(w, decimals), edge weight).
+// ------------------------------------------------------------------------------------------
+// r = rint(x * f) / f  -- exactly NumPy's ndarray.round(decimals) for decimals > 0
+__global__ __launch_bounds__(kBlock) void k_round_keys(const double* __restrict__ x, long m, double f,
+                                                       double* __restrict__ r) {
+#pragma clang fp contract(off)
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < m; i += (long)gridDim.x * kBlock) {
+        const double t = x[i] * f;
+        r[i] = rint(t) / f;
+    }
+}
+// second-level keys: the edge weight where the rounded value ties with the k-th one, -inf elsewhere
+__global__ __launch_bounds__(kBlock) void k_tie_keys(const double* __restrict__ r, const double* __restrict__ cw,
+                                                     long m, const SelState* __restrict__ st1,
+                                                     double* __restrict__ keys2) {
+    const unsigned long long T = st1->T;
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < m; i += (long)gridDim.x * kBlock)
+        keys2[i] = f64_key(r[i]) == T ? cw[i] : -__builtin_huge_val();
+}
+// out = 1 where r > T1, or r == T1 and (no second level: index rule of st1 | second level: weight
+// > T2, or == T2 with index >= st2.tie_limit)
+__global__ __launch_bounds__(kBlock) void k_round_mark(const double* __restrict__ r, const double* __restrict__ keys2,
+                                                       long m, const SelState* __restrict__ st1,
+                                                       const SelState* __restrict__ st2, int two_level,
+                                                       double* __restrict__ out) {
+    const unsigned long long T1 = st1->T;
+    const bool none = st1->k <= 0;
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < m; i += (long)gridDim.x * kBlock) {
+        const unsigned long long k1 = f64_key(r[i]);
+        bool sel = false;
+        if (!none) {
+            if (k1 > T1) sel = true;
+            else if (k1 == T1) {
+                if (!two_level) sel = (long long)i >= st1->tie_limit;
+                else {
+                    const unsigned long long k2 = f64_key(keys2[i]);
+                    sel = k2 > st2->T || (k2 == st2->T && (long long)i >= st2->tie_limit);
+                }
+            }
+        }
+        out[i] = sel ? 1.0 : 0.0;
+    }
 }
 
 __global__ void k_sel_init(SelState* st, long long k) {

@@ -2,6 +2,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <cmath>
 #include <numeric>
 #include <vector>
 
@@ -33,7 +34,7 @@ struct machip_problem {
     // candidates (device)
     int *ci = nullptr, *cj = nullptr;
     double* cw = nullptr;
-    double *x = nullptr, *x_next = nullptr, *g = nullptr, *s = nullptr;
+    double *x = nullptr, *x_next = nullptr, *g = nullptr, *s = nullptr, *scratch_m = nullptr;
     // assembled CSR (device)
     int *cnt = nullptr, *blk_sum = nullptr, *rowptr = nullptr, *col = nullptr;
     double *val = nullptr, *blk_lnorm = nullptr;
@@ -183,21 +184,24 @@ int alloc_common(machip_problem* p) {
     return MACHIP_OK;
 }
 
-int select_topk(machip_problem* p, long k) {
+// k-th largest of keys[0..m): threshold, remaining rank and tie rule into *st.
+int select_on(machip_problem* p, const double* keys, long k, SelState* st, int prefer_high) {
     const long m = p->m;
     if (k < 0) k = 0;
     if (k > m) k = m;
     HIP_TRY(hipMemsetAsync(p->hist, 0, sizeof(unsigned int) * 6 * kBins, p->stream));
-    k_sel_init<<<1, 64, 0, p->stream>>>(p->sel, (long long)k);
+    k_sel_init<<<1, 64, 0, p->stream>>>(st, (long long)k);
     if (k > 0) {
         // <= 256 workgroups: every arrival is one serialized device-scope atomic on the ticket word
         const int grid = (int)std::min<long>(256, (m + kBlock * 4 - 1) / (kBlock * 4));
         for (int pass = 0; pass < 6; ++pass)
-            k_sel_pass<<<std::max(grid, 1), kBlock, 0, p->stream>>>(p->g, m, pass, p->hist, p->sel);
-        k_sel_ties<<<1, 1024, 0, p->stream>>>(p->g, m, p->sel);
+            k_sel_pass<<<std::max(grid, 1), kBlock, 0, p->stream>>>(keys, m, pass, p->hist, st);
     }
+    k_sel_ties<<<1, 1024, 0, p->stream>>>(keys, m, st, prefer_high);
     return MACHIP_OK;
 }
+
+int select_topk(machip_problem* p, long k) { return select_on(p, p->g, k, p->sel, 0); }
 
 int compute_gradient(machip_problem* p) {
     if (!p->have_vec) return fail(MACHIP_BAD_ARG, "no Fiedler vector on the device: call machip_fiedler first");
@@ -290,7 +294,7 @@ int machip_create(int device, int64_t n, int64_t n_fixed, const int32_t* fi, con
         ST_TRY(dev_alloc(&p->cnt, (size_t)n + 1)); ST_TRY(dev_alloc(&p->blk_sum, 3 * kMaxGrid));
         ST_TRY(dev_alloc(&p->rowptr, (size_t)n + 1)); ST_TRY(dev_alloc(&p->col, cap)); ST_TRY(dev_alloc(&p->val, cap));
         ST_TRY(dev_alloc(&p->blk_lnorm, kMaxGrid));
-        ST_TRY(dev_alloc(&p->hist, 6 * kBins)); ST_TRY(dev_alloc(&p->sel, 1)); ST_TRY(dev_alloc(&p->part_fw, 2 * kMaxGrid));
+        ST_TRY(dev_alloc(&p->hist, 6 * kBins)); ST_TRY(dev_alloc(&p->sel, 2)); ST_TRY(dev_alloc(&p->part_fw, 2 * kMaxGrid));
         ST_TRY(alloc_common(p));
         return MACHIP_OK;
     };
@@ -306,7 +310,7 @@ void machip_destroy(machip_problem* p) {
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     if (p->comm) (void)ncclCommDestroy(p->comm);
     p->sol.destroy();
-    void* ptrs[] = {p->prow, p->pcol, p->pk, p->pw, p->ci, p->cj, p->cw, p->x, p->x_next, p->g, p->s, p->cnt,
+    void* ptrs[] = {p->prow, p->pcol, p->pk, p->pw, p->ci, p->cj, p->cw, p->x, p->x_next, p->g, p->s, p->scratch_m, p->cnt,
                     p->blk_sum, p->rowptr, p->col, p->val, p->blk_lnorm, p->hist, p->sel, p->part_fw};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     if (p->h_int) (void)hipHostFree(p->h_int);
@@ -416,6 +420,36 @@ int machip_fw_step(machip_problem* p, int64_t k, int iter, double tol, int max_s
     *f = lam;
     *dual = lam + d;
     *gnorm = std::sqrt(q2);
+    return MACHIP_OK;
+}
+
+int machip_round_nearest(machip_problem* p, int64_t k, int decimals, double* rounded_out) {
+    if (!p || p->csr_only || !rounded_out) return fail(MACHIP_BAD_ARG, "bad argument");
+    if (decimals > 15) return fail(MACHIP_BAD_ARG, "decimals must be <= 15");
+    HIP_TRY(hipSetDevice(p->device));
+    const long m = p->m;
+    if (m == 0) return MACHIP_OK;
+    if (!p->scratch_m) ST_TRY(dev_alloc(&p->scratch_m, (size_t)m + 64));
+    const int grid = std::max(1, (int)std::min<long>(kMaxGrid, (m + kBlock - 1) / kBlock));
+    double* r = p->s;                       // rounded selection weights (or x itself)
+    const bool tb = decimals >= 0;
+    if (tb) k_round_keys<<<grid, kBlock, 0, p->stream>>>(p->x, m, std::pow(10.0, decimals), r);
+    else HIP_TRY(hipMemcpyAsync(r, p->x, sizeof(double) * (size_t)m, hipMemcpyDeviceToDevice, p->stream));
+    ST_TRY(select_on(p, r, (long)k, p->sel, 1));
+    int two = 0;
+    if (tb && k > 0 && k < m) {
+        SelState h;
+        HIP_TRY(hipMemcpyAsync(&h, p->sel, sizeof(SelState), hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        if (h.kk < h.cnt_eq) {              // more candidates tie at the k-th rounded value than fit
+            k_tie_keys<<<grid, kBlock, 0, p->stream>>>(r, p->cw, m, p->sel, p->scratch_m);
+            ST_TRY(select_on(p, p->scratch_m, (long)h.kk, p->sel + 1, 1));
+            two = 1;
+        }
+    }
+    k_round_mark<<<grid, kBlock, 0, p->stream>>>(r, p->scratch_m, m, p->sel, p->sel + 1, two, r);
+    HIP_TRY(hipMemcpyAsync(rounded_out, r, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
     return MACHIP_OK;
 }
 

@@ -123,7 +123,8 @@ class MAC:
         if rounding == "madow":
             rounded = round_madow(w, k, value_fn=self.evaluate_objective, max_iters=random_rounding_max_iters)
         else:
-            rounded = round_nearest(w, k, weights=self.weights, break_ties_decimal_tol=10)
+            # rounding == "nearest" (mac.py:209), on the device-resident x (machip_round_nearest)
+            rounded = dev.round_nearest(k, decimals=10)
         rounding_time = timer() - start
 
         if fallback:

@@ -15,9 +15,25 @@ def round_nearest(w, k, weights=None, break_ties_decimal_tol=None):
     if weights is None or break_ties_decimal_tol is None:
         rounded[np.argpartition(w, -k)[-k:]] = 1.0
         return rounded
+    # Top-k under the lexicographic key (round(w, tol), weight), as the reference's structured
+    # argpartition (rounding.py:33-38).  O(m): one partition for the k-th rounded value, then only
+    # the entries tied with it are ordered by weight (stable, so equal weights keep index order --
+    # the same set np.lexsort((weights, tw))[-k:] selects).
     tw = w.round(decimals=break_ties_decimal_tol)
-    order = np.lexsort((np.asarray(weights, dtype=np.float64), tw))
-    rounded[order[-k:]] = 1.0
+    m = len(tw)
+    if k >= m:
+        rounded[:] = 1.0
+        return rounded
+    thr = np.partition(tw, m - k)[m - k]
+    above = tw > thr
+    rounded[above] = 1.0
+    need = k - int(above.sum())
+    if need > 0:
+        ties = np.nonzero(tw == thr)[0]
+        if need < len(ties):
+            wt = np.asarray(weights, dtype=np.float64)[ties]
+            ties = ties[np.argsort(wt, kind="stable")[-need:]]
+        rounded[ties] = 1.0
     return rounded
 
 

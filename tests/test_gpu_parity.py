@@ -525,3 +525,38 @@ def test_madow_rounding_with_objective_reruns():
     assert mac.evaluate_objective(rounded) <= u + 1e-9
     r2, w2, u2, rt = mac.solve(k, g["x_init"], max_iters=6, return_rounding_time=True, fallback=True)
     assert rt >= 0 and r2.sum() == k and np.allclose(w, w2, atol=1e-12)
+
+
+def test_device_round_nearest_matches_oracle():
+    """machip_round_nearest == oracle.round_nearest (the reference's tie-broken top-k, rounding.py:30-42)
+    bit for bit, including heavy ties in the rounded selection weights and in the edge weights."""
+    rng = np.random.default_rng(21)
+    g = load_golden("er2000_solve")
+    n, m = int(g["n"]), len(g["cw"])
+    cases = []
+    cw_tied = np.round(g["cw"], 1)                       # many equal edge weights
+    for cw in (g["cw"], cw_tied, np.ones(m)):
+        P = _lib.Problem(n, g["fi"], g["fj"], g["fw"], g["ci"], g["cj"], cw)
+        xs = [g["unrounded"], np.round(rng.random(m), 1), np.round(rng.random(m), 2) * (rng.random(m) < 0.3),
+              np.zeros(m), np.full(m, 0.5), rng.random(m)]
+        for x in xs:
+            P.set_x(x)
+            for k in (0, 1, 17, int(g["k"]), m // 2, m - 1, m):
+                got = P.round_nearest(k, decimals=10)
+                exp = oracle.round_nearest(x, k, cw, 10)
+                assert np.array_equal(got, exp), (k,)
+                cases.append(k)
+            got = P.round_nearest(int(g["k"]), decimals=None)     # plain top-k branch (rounding.py:21-28)
+            assert got.sum() == int(g["k"])
+            kth = np.sort(x)[-int(g["k"])]
+            assert np.all(got[x > kth] == 1) and np.all(got[x < kth] == 0)
+        P.close()
+    assert len(cases) == 3 * 6 * 7
+
+
+def test_solve_rounding_matches_reference_goldens():
+    for nm in ("g2o_intel", "g2o_sphere2500", "er2000_solve"):
+        g = load_golden(nm)
+        mac = MAC(edges_of(g, "f"), edges_of(g, "c"), int(g["n"]))
+        mac._dev.set_x(g["unrounded"])
+        assert np.array_equal(mac._dev.round_nearest(int(g["k"]), decimals=10), g["rounded"])
