@@ -1,14 +1,15 @@
-"""NaiveGreedy (mac/solvers/baseline.py:3-14): top-k candidates by weight; the usual
-x_init of MAC.solve (examples/g2o_experiment.py:312-315)."""
+"""Weight-greedy baseline with the reference's class name and method (mac/solvers/baseline.py:3-14):
+keep the k heaviest candidate edges.  It doubles as the usual sparse initial point of ``MAC.solve``
+(examples/g2o_experiment.py:312-315)."""
 import numpy as np
+
+from mac_amd.utils.rounding import round_nearest
 
 
 class NaiveGreedy:
     def __init__(self, edges):
-        self.weights = np.array([e.weight for e in edges])
+        self.weights = np.fromiter((e[2] for e in edges), dtype=np.float64, count=len(edges))
 
     def subset(self, k):
-        solution = np.zeros(len(self.weights))
-        if k > 0:
-            solution[np.argpartition(self.weights, -k)[-k:]] = 1.0
-        return solution
+        """0/1 vector with ones on the k largest weights (ties resolved as numpy.argpartition does)."""
+        return round_nearest(self.weights, k)
