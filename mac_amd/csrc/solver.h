@@ -426,7 +426,11 @@ struct Solver {
 
             while (!converged && !need_restart) {
                 // keep one chunk in flight beyond the one being analysed
-                while ((int)pend.size() < (classic ? 1 : 2) && J_enq < jcap && steps_total < max_steps) {
+                // one chunk runs ahead of the host -- except in the end game (same threshold as the
+                // short chunks), where the chunk in flight is likely the last one and a speculative
+                // successor would only delay the explicit residual check queued behind it
+                const int depth = (classic || est_latest < 1e3 * tol * lnorm) ? 1 : 2;
+                while ((int)pend.size() < depth && J_enq < jcap && steps_total < max_steps) {
                     int chunk = (est_latest < 1e3 * tol * lnorm) ? chunk_near : chunk0;
                     if (classic) chunk = std::min(chunk, 16);
                     chunk = std::min(chunk, jcap - J_enq);
