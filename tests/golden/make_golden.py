@@ -114,6 +114,24 @@ def g2o_cases(meta, cases):
 
 
 
+def er10k_solve(meta):
+    """BASELINE.json configs[1] through the real reference: 20 Frank-Wolfe iterations from the bench's
+    x0 (stop tests effectively disabled), the per-iteration lambda_2 / support and the end point."""
+    n = 10000
+    G = nx.fast_gnp_random_graph(n, 0.01, seed=0)
+    fixed = [Edge(a, a + 1, 1.0) for a in range(n - 1)]
+    cand = [Edge(min(a, b), max(a, b), 1.0) for (a, b) in G.edges() if abs(a - b) != 1]
+    m_ = len(cand); k = m_ // 10
+    x0 = np.zeros(m_); x0[np.random.default_rng(0).choice(m_, k, replace=False)] = 1.0
+    mac, rounded, w, u, fs, gs, xs = run_solve(fixed, cand, n, k, x0, 20, relative_duality_gap_tol=0.0,
+                                               grad_norm_tol=0.0)
+    save("er10k_solve", n=n, m=m_, k=k, f_traj=fs, supp=np.array([(x > 1e-10).sum() for x in xs]), upper=u,
+         unrounded_sum=w.sum(), unrounded_head=w[:2048], unrounded_nnz=np.count_nonzero(w),
+         rounded_idx=np.nonzero(rounded)[0].astype(np.int64), g_last_head=gs[-1][:512],
+         x0_idx=np.nonzero(x0)[0].astype(np.int64))
+    meta["er10k_solve"] = {"iters": len(fs), "upper": float(u)}
+
+
 def main(only=None):
     meta_path = os.path.join(OUT, "golden_meta.json")
     if only and os.path.exists(meta_path):
@@ -122,6 +140,8 @@ def main(only=None):
         meta = {}
     meta.update({"numpy": np.__version__, "scipy": scipy.__version__,
             "networkx": nx.__version__, "python": sys.version.split()[0]})
+    if only == "er10k_solve":
+        return er10k_solve(meta), json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
     if only == "g2o_extra":
         return g2o_cases(meta, [("kitti_05", 20)]), json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
 
