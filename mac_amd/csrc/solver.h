@@ -9,6 +9,9 @@
 // O(J) scalars (tridiag.h).  Convergence is declared by the reference's own rule evaluated
 // explicitly on the device:   || L v - lambda v ||_1 / || L ||_inf < tol     (nx:232, nx:246)
 #pragma once
+#include <dlfcn.h>
+
+#include <array>
 #include <deque>
 #include <map>
 #include <tuple>
@@ -194,7 +197,8 @@ struct Solver {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> ev_pool;
     // cached chunk graphs: (variant, width, grid, steps) -> exec
-    std::map<std::tuple<int, int, int, int, int>, hipGraphExec_t> graphs;
+    std::map<std::tuple<int, int, int, int, int>, std::array<hipGraphExec_t, 2>> graphs;
+    unsigned graph_flip = 0;
     const void* graph_csr_key = nullptr;
     bool use_graph = true;
     // host copies of T
@@ -212,7 +216,13 @@ struct Solver {
         vcap = budget / (sizeof(double) * (size_t)std::max(n, 1));
         vcap = std::max<size_t>(std::min<size_t>(vcap, 16384), 64);
         vcap = (size_t)env_int("MACHIP_VCAP", (int)vcap);
-        use_graph = env_int("MACHIP_GRAPH", 1) != 0;
+        // rocprofiler-sdk (ROCm 7.2) segfaults inside its HSA interception when short graphs are
+        // launched in quick succession (reproduced under rocprofv3 --kernel-trace on the pose-graph
+        // tests; eager launches of the same kernels are fine): with a profiler attached fall back to
+        // eager launches unless MACHIP_GRAPH says otherwise.
+        const bool profiled = dlopen("librocprofiler-sdk.so", RTLD_NOLOAD | RTLD_LAZY) != nullptr ||
+                              dlopen("librocprofiler-sdk.so.1", RTLD_NOLOAD | RTLD_LAZY) != nullptr;
+        use_graph = env_int("MACHIP_GRAPH", profiled ? 0 : 1) != 0;
         ST_TRY(dev_alloc(&u, n));
         ST_TRY(dev_alloc(&V, (size_t)n * vcap));
         ST_TRY(dev_alloc(&tri, 3 * (vcap + 2)));
@@ -236,7 +246,7 @@ struct Solver {
         return MACHIP_OK;
     }
     void destroy() {
-        for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+        for (auto& kv : graphs) for (hipGraphExec_t ge : kv.second) if (ge) (void)hipGraphExecDestroy(ge);
         graphs.clear();
         void* ptrs[] = {u, V, tri, part, Z0, Z1, st, st2, y_raw, w2, yvec, ypart, sdev,
                         part_c, part_a2, part_r, scratch3, rq_dev, start, wc, ctri, part_u, part_a, stc};
@@ -294,23 +304,25 @@ struct Solver {
     int enqueue_chunk(const CsrView& A, const SpmvPlan& pl, int steps) {
         if (!use_graph) { launch_chunk(A, pl, steps); return MACHIP_OK; }
         if (graph_csr_key != (const void*)A.val) {   // different matrix buffers: cached graphs are stale
-            for (auto& kv : graphs) (void)hipGraphExecDestroy(kv.second);
+            for (auto& kv : graphs) for (hipGraphExec_t ge : kv.second) if (ge) (void)hipGraphExecDestroy(ge);
             graphs.clear();
             graph_csr_key = (const void*)A.val;
         }
         const auto key = std::make_tuple(pl.variant, pl.width * 10 + pl.unroll, pl.grid, pl.block, steps);
         auto it = graphs.find(key);
-        if (it == graphs.end()) {
+        if (it == graphs.end()) it = graphs.emplace(key, std::array<hipGraphExec_t, 2>{nullptr, nullptr}).first;
+        // two executables per shape, used alternately: with one chunk running ahead, the same
+        // hipGraphExec is never in flight twice
+        hipGraphExec_t& ge = it->second[(size_t)(graph_flip++ & 1)];
+        if (!ge) {
             hipGraph_t g = nullptr;
-            hipGraphExec_t ge = nullptr;
             HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
             launch_chunk(A, pl, steps);
             HIP_TRY(hipStreamEndCapture(stream, &g));
             HIP_TRY(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
             (void)hipGraphDestroy(g);
-            it = graphs.emplace(key, ge).first;
         }
-        HIP_TRY(hipGraphLaunch(it->second, stream));
+        HIP_TRY(hipGraphLaunch(ge, stream));
         return MACHIP_OK;
     }
 

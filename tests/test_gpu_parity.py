@@ -434,7 +434,7 @@ def test_full_size_config4_properties():
     {"MACHIP_G": "4", "MACHIP_BLOCK": "256", "MACHIP_UNROLL": "2"}, {"MACHIP_G": "16", "MACHIP_BLOCK": "1024"},
     {"MACHIP_G": "64", "MACHIP_BLOCK": "512"}, {"MACHIP_G": "32", "MACHIP_MAXGRID": "64"},
     {"MACHIP_GRAPH": "0", "MACHIP_CHUNK": "6", "MACHIP_CHUNK_NEAR": "2"}, {"MACHIP_CLASSIC_N": "100000"},
-    {"MACHIP_VCAP": "80"},
+    {"MACHIP_VCAP": "80"}, {"MACHIP_ASM_G": "8"}, {"MACHIP_ASM_G": "32", "MACHIP_G": "8", "MACHIP_UNROLL": "1"},
 ])
 def test_solver_variants_agree(env):
     """Every launch shape / row mapping of the fused step kernel, eager vs graph launches, odd chunk
@@ -560,3 +560,34 @@ def test_solve_rounding_matches_reference_goldens():
         mac = MAC(edges_of(g, "f"), edges_of(g, "c"), int(g["n"]))
         mac._dev.set_x(g["unrounded"])
         assert np.array_equal(mac._dev.round_nearest(int(g["k"]), decimals=10), g["rounded"])
+
+
+def test_config2_twenty_iterations_match_reference_trajectory():
+    """The bench workload itself (BASELINE.json configs[1], 20 Frank-Wolfe iterations from the bench's
+    x0, stop tests off) against the trajectory the REAL reference produced (tests/golden/er10k_solve.npz,
+    ~15 CPU-minutes there): lambda_2 per iteration to 1e-8, identical supports, same rounded set."""
+    g = load_golden("er10k_solve")
+    n = 10000
+    ci, cj = make_er(n, 0.01, 0)
+    m, k = len(ci), int(g["k"])
+    assert m == int(g["m"])
+    fi = np.arange(n - 1, dtype=np.int32)
+    P = _lib.Problem(n, fi, fi + 1, np.ones(n - 1), ci, cj, np.ones(m))
+    P.set_start(reference_start_block(n)[:, 0].copy())
+    x0 = np.zeros(m); x0[g["x0_idx"]] = 1.0
+    P.set_x(x0)
+    fs, supp, u = [], [], np.inf
+    for it in range(len(g["f_traj"])):
+        f, dual, gn = P.fw_step(k, it)
+        u = min(u, dual)
+        fs.append(f); supp.append(int(P.stats.support))
+        P.fw_commit()
+    assert np.allclose(fs, g["f_traj"], rtol=LAM_RTOL, atol=0)
+    assert np.array_equal(supp, g["supp"])
+    assert abs(u - float(g["upper"])) <= 1e-7 * abs(float(g["upper"]))
+    w = P.get_x()
+    assert np.count_nonzero(w) == int(g["unrounded_nnz"])
+    assert np.allclose(w[:2048], g["unrounded_head"], atol=1e-12) and abs(w.sum() - float(g["unrounded_sum"])) < 1e-6
+    rounded = P.round_nearest(k, decimals=10)
+    assert np.array_equal(np.nonzero(rounded)[0], g["rounded_idx"])
+    P.close()
