@@ -241,26 +241,35 @@ class Problem:
 
     def comm_init(self, rank, nranks, unique_id: bytes):
         buf = C.create_string_buffer(unique_id, 128)
-        # RCCL prints a version banner on stdout at communicator creation; keep stdout clean for
-        # callers that emit machine-readable output (bench.py's single JSON line)
-        import sys
-        sys.stdout.flush()
-        saved = os.dup(1)
-        try:
-            os.dup2(2, 1)
+        with _stdout_to_stderr():
             st = self._lib.machip_comm_init(self._h, int(rank), int(nranks), buf)
-        finally:
-            os.dup2(saved, 1)
-            os.close(saved)
         check(st)
 
     def synchronize(self):
         check(self._lib.machip_synchronize(self._h))
 
 
+class _stdout_to_stderr:
+    """RCCL prints a version banner on stdout the first time it is touched; keep stdout clean for
+    callers that emit machine-readable output (bench.py's single JSON line)."""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def comm_unique_id() -> bytes:
     buf = C.create_string_buffer(128)
-    check(load().machip_comm_unique_id(buf))
+    lib = load()
+    with _stdout_to_stderr():
+        st = lib.machip_comm_unique_id(buf)
+    check(st)
     return buf.raw
 
 
