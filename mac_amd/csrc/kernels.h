@@ -860,20 +860,16 @@ __global__ __launch_bounds__(kBlock) void k_sel_pass(const double* __restrict__ 
     }
     s_scan[tid] = tsum;
     __syncthreads();
-    if (tid == 0) {
-        unsigned long long run = 0;
-        int t = 0;
-        for (; t < kBlock; ++t) {
-            if ((long long)(run + s_scan[t]) >= kk) break;
-            run += s_scan[t];
-        }
-        s_scan[0] = (unsigned int)t;            // owning thread
-        st->kk = kk - (long long)run;           // provisional: rank inside thread t's bins
+    // inclusive prefix over the 256 per-thread sums (Hillis-Steele in LDS; counts fit 32 bits)
+    for (int off = 1; off < kBlock; off <<= 1) {
+        const unsigned int add = tid >= off ? s_scan[tid - off] : 0u;
+        __syncthreads();
+        s_scan[tid] += add;
+        __syncthreads();
     }
-    __syncthreads();
-    const int owner = (int)s_scan[0];
-    if (tid == owner) {
-        long long rem = st->kk;
+    const long long pre = (long long)s_scan[tid];
+    if (pre >= kk && pre - (long long)tsum < kk) {      // exactly one thread owns the kk-th key
+        long long rem = kk - (pre - (long long)tsum);
         int q = 0;
         for (; q < per; ++q) {
             if ((long long)c[q] >= rem) break;
