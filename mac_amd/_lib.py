@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmachip.so")
+LIB_PATH = os.environ.get("MACHIP_LIB") or os.path.join(_HERE, "libmachip.so")   # MACHIP_LIB: developer override (sanitizer builds)
 
 OK, NOT_CONVERGED, DISCONNECTED, BAD_ARG, HIP_ERROR, RCCL_ERROR, NO_DEVICE = range(7)
 STATUS_NAMES = ["OK", "NOT_CONVERGED", "DISCONNECTED", "BAD_ARG", "HIP_ERROR", "RCCL_ERROR", "NO_DEVICE"]
