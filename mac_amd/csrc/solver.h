@@ -433,6 +433,13 @@ struct Solver {
             guess.clear();
             double theta_prev = 0.0, last_check_est = 1e300, est_latest = 1e300;
             bool converged = false, need_restart = false;
+            // convergence-rate tracking: (J, ln est) over a >= 64-step window predicts the steps still
+            // needed, which sizes the chunks and the speculation depth (stiff chain-like graphs spend
+            // thousands of steps within 1e3 of the target; random graphs a few dozen)
+            std::deque<std::pair<int, double>> hist;
+            double to_go = 1e18;
+            const bool sched = env_int("MACHIP_SCHED", 1) != 0;
+            const double ltarget = std::log(std::max(tol * tiny_l, 1e-300));
             const int jcap = (int)std::min<size_t>(vcap - 2, (size_t)std::max(2, n - 1) + 8) & ~1;
             const size_t cs = vcap + 2;   // stride of the classic alpha / beta / l1 arrays
 
@@ -441,9 +448,13 @@ struct Solver {
                 // one chunk runs ahead of the host -- except in the end game (same threshold as the
                 // short chunks), where the chunk in flight is likely the last one and a speculative
                 // successor would only delay the explicit residual check queued behind it
-                const int depth = (classic || est_latest < 1e3 * tol * lnorm) ? 1 : 2;
+                const bool near = sched ? (to_go < 2.0 * chunk0 || (to_go >= 1e17 && est_latest < 1e3 * tol * lnorm))
+                                        : est_latest < 1e3 * tol * lnorm;
+                const int depth = (classic || near) ? 1 : ((sched && to_go > 8.0 * chunk0) ? 3 : 2);
                 while ((int)pend.size() < depth && J_enq < jcap && steps_total < max_steps) {
-                    int chunk = (est_latest < 1e3 * tol * lnorm) ? chunk_near : chunk0;
+                    int chunk = near ? chunk_near : chunk0;
+                    if (near && sched && to_go < 1e17)   // aim a little short of the predicted crossing
+                        chunk = std::min(chunk0, std::max(chunk_near, ((int)(0.75 * to_go) + 1) & ~1));
                     if (classic) chunk = std::min(chunk, 16);
                     chunk = std::min(chunk, jcap - J_enq);
                     chunk = (int)std::min<long>(chunk, max_steps - steps_total);
@@ -474,13 +485,20 @@ struct Solver {
                     steps_total += chunk; spmv_total += chunk;
                 }
                 if (pend.empty()) { need_restart = true; break; }
-                const Pending p = pend.front();
+                Pending p = pend.front();
                 pend.pop_front();
                 if (p.classic) {
                     HIP_TRY(hipEventSynchronize(p.ev));
                     ev_pool.push_back(p.ev);
                 } else {
                     ST_TRY(wait_flag(((unsigned long long)epoch << 32) | (unsigned long long)(unsigned int)p.jend));
+                    // a slow host (T_J analysis is O(J)) skips to the newest chunk that has already landed
+                    while (!pend.empty() && !pend.front().classic) {
+                        const unsigned long long v = *(volatile unsigned long long*)h_flag;
+                        if ((v >> 32) != (unsigned long long)epoch || (int)(v & 0xffffffffull) < pend.front().jend) break;
+                        p.jend = pend.front().jend;
+                        pend.pop_front();
+                    }
                 }
                 if (p.classic) {   // scatter the staged (alpha, beta, l1) into the interleaved mirror
                     const double* hp = h_pin + (vcap + 2) + 2 * kMaxGrid + 32;
@@ -515,9 +533,18 @@ struct Solver {
                 const double l1v = hl1[(size_t)Jeff - 1] > 0 ? hl1[(size_t)Jeff - 1] : std::sqrt((double)n);
                 const double est = rho * l1v;   // predicted ||r||_1 (r = rho v_J; ||v_J||_1 ~ ||v_{J-1}||_1)
                 est_latest = est;
+                if (!broke && est > 0.0) {
+                    hist.emplace_back(J, std::log(est));
+                    while (hist.size() > 2 && hist[1].first <= J - 64) hist.pop_front();
+                    to_go = 1e18;
+                    if (hist.front().first < J) {
+                        const double slope = (hist.front().second - hist.back().second) / (double)(J - hist.front().first);
+                        if (slope > 1e-7) to_go = std::max(0.0, (hist.back().second - ltarget) / slope);
+                    }
+                }
                 const bool at_cap = (J >= jcap) || (steps_total >= max_steps && pend.empty());
                 const bool trig = broke || est < trigger_slack * tol * lnorm;
-                if (debug) fprintf(stderr, "[machip] %s J=%d Jeff=%d theta=%.15g est=%.3e broke=%d pend=%zu passes=%d\n", classic ? "classic" : "pipe", J, Jeff, sm.theta, lnorm > 0 ? est / lnorm : est, (int)broke, pend.size(), sm.passes);
+                if (debug) fprintf(stderr, "[machip] %s J=%d Jeff=%d theta=%.15g est=%.3e to_go=%.0f broke=%d pend=%zu passes=%d\n", classic ? "classic" : "pipe", J, Jeff, sm.theta, lnorm > 0 ? est / lnorm : est, std::min(to_go, 1e9), (int)broke, pend.size(), sm.passes);
                 if ((trig && est < 0.5 * last_check_est) || broke || at_cap) {
                     double rq = 0.0, r1 = 0.0;
                     ST_TRY(explicit_check(A, pl, Jeff, sm.s.data(), &rq, &r1));   // syncs the stream

@@ -123,7 +123,7 @@ def er10k_solve(meta):
     cand = [Edge(min(a, b), max(a, b), 1.0) for (a, b) in G.edges() if abs(a - b) != 1]
     m_ = len(cand); k = m_ // 10
     x0 = np.zeros(m_); x0[np.random.default_rng(0).choice(m_, k, replace=False)] = 1.0
-    iters = int(os.environ.get("ER10K_ITERS", "20"))     # 20 takes ~2 h of SuperLU here; 8 about 15 min
+    iters = int(os.environ.get("ER10K_ITERS", "20"))     # 20 take about two hours of SuperLU here
     mac, rounded, w, u, fs, gs, xs = run_solve(fixed, cand, n, k, x0, iters, relative_duality_gap_tol=0.0,
                                                grad_norm_tol=0.0)
     save("er10k_solve" if iters == 20 else f"er10k_solve{iters}", n=n, m=m_, k=k, f_traj=fs, supp=np.array([(x > 1e-10).sum() for x in xs]), upper=u,
