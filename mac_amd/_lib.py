@@ -67,6 +67,7 @@ SIGNATURES = {
     "machip_profile_spmv": (C.c_int, [C.c_void_p, C.c_int, _f64p, _f64p]),
     "machip_comm_unique_id": (C.c_int, [C.c_void_p]),
     "machip_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "machip_set_solver": (C.c_int, [C.c_void_p, C.c_int]),
     "machip_synchronize": (C.c_int, [C.c_void_p]),
 }
 _EXTRA = {"machip_host_tridiag_smallest": (C.c_int, [_f64p, _f64p, C.c_int, _f64p, _f64p])}
@@ -244,6 +245,10 @@ class Problem:
         with _stdout_to_stderr():
             st = self._lib.machip_comm_init(self._h, int(rank), int(nranks), buf)
         check(st)
+
+    def set_solver(self, mode):
+        """0 = automatic, 1 = Lanczos, 2 = preconditioned (LOBPCG + tridiagonal chain solve)."""
+        check(self._lib.machip_set_solver(self._h, int(mode)))
 
     def synchronize(self):
         check(self._lib.machip_synchronize(self._h))

@@ -234,6 +234,7 @@ int run_fiedler(machip_problem* p, double tol, int max_steps, const double* x0, 
     machip_solve_stats local;
     memset(&local, 0, sizeof(local));
     p->sol.maxlen_hint = p->maxlen;
+    p->sol.support_hint = p->csr_only ? -1 : p->support;
     const int st = p->sol.solve(p->csr(), p->nnz, p->lnorm, tol, max_steps, (x0 == nullptr && warm_start) ? 1 : 0,
                                 kAuto, lambda2, &local);
     local.support = p->support;
@@ -296,6 +297,18 @@ int machip_create(int device, int64_t n, int64_t n_fixed, const int32_t* fi, con
         ST_TRY(dev_alloc(&p->blk_lnorm, kMaxGrid));
         ST_TRY(dev_alloc(&p->hist, 6 * kBins)); ST_TRY(dev_alloc(&p->sel, 2)); ST_TRY(dev_alloc(&p->part_fw, 2 * kMaxGrid));
         ST_TRY(alloc_common(p));
+        // pose-graph shape: do the fixed edges contain (nearly) the whole chain (i, i+1)?  Decides
+        // whether the preconditioned eigen-solver mode is considered (solver.h, precond.h).
+        {
+            std::vector<char> has((size_t)n, 0);
+            for (int64_t e = 0; e < n_fixed; ++e) {
+                const int a = std::min(fi[e], fj[e]), b = std::max(fi[e], fj[e]);
+                if (a >= 0 && b < n && b == a + 1 && fw[e] > 0.0) has[(size_t)a] = 1;
+            }
+            long cnt = 0;
+            for (int64_t i = 0; i + 1 < n; ++i) cnt += has[(size_t)i];
+            p->sol.chain_like = cnt >= (long)(0.98 * (double)(n - 1));
+        }
         return MACHIP_OK;
     };
     st = body();
@@ -568,6 +581,12 @@ int machip_comm_init(machip_problem* p, int rank, int nranks, const void* id128)
     p->rank = rank; p->nranks = nranks;
     const long shard = (p->m + nranks - 1) / nranks;
     p->m_pad = shard * nranks;   // <= m + 63 < allocation slack
+    return MACHIP_OK;
+}
+
+int machip_set_solver(machip_problem* p, int mode) {
+    if (!p || mode < 0 || mode > 2) return fail(MACHIP_BAD_ARG, "machip_set_solver: mode must be 0 (auto), 1 (Lanczos) or 2 (preconditioned)");
+    p->sol.solver_mode = mode;
     return MACHIP_OK;
 }
 

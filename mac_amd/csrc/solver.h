@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "precond.h"
 #include "tridiag.h"
 
 namespace machip {
@@ -208,6 +209,19 @@ struct Solver {
     int J_last = 0;             // dimension of the Krylov space behind the current yvec
     long last_steps = 0;        // steps the previous solve needed (chunk sizing hint)
     int maxlen_hint = 0;        // longest row of the matrix about to be solved (0 = unknown)
+    // preconditioned mode (precond.h): allocated on first use
+    double *lx_x = nullptr, *lx_Lx = nullptr, *lx_p = nullptr, *lx_Lp = nullptr, *lx_Lw = nullptr;
+    double *lx_rT = nullptr, *lx_wT = nullptr, *lx_tl = nullptr, *lx_tdinv = nullptr, *lx_tcu = nullptr;
+    double *lx_part = nullptr, *lx_partR = nullptr;
+    int *lx_colT = nullptr, *lx_bad = nullptr;
+    size_t lx_colT_cap = 0;
+    LobState* lx_st = nullptr;
+    double *h_lrec = nullptr, *d_hlrec = nullptr;
+    bool lob_ready = false, last_was_lob = false;
+    int solver_mode = 0;        // 0 = auto, 1 = Lanczos, 2 = preconditioned (LOBPCG + tridiagonal solve)
+    bool chain_like = false;    // the fixed edges contain (nearly) the whole chain (i, i+1)
+    long support_hint = -1;     // active candidate edges of the matrix about to be solved (-1 = unknown)
+    static constexpr int kLobCap = 20000;
 
     int init(int n_, hipStream_t s) {
         n = n_;
@@ -249,7 +263,10 @@ struct Solver {
         for (auto& kv : graphs) for (hipGraphExec_t ge : kv.second) if (ge) (void)hipGraphExecDestroy(ge);
         graphs.clear();
         void* ptrs[] = {u, V, tri, part, Z0, Z1, st, st2, y_raw, w2, yvec, ypart, sdev,
-                        part_c, part_a2, part_r, scratch3, rq_dev, start, wc, ctri, part_u, part_a, stc};
+                        part_c, part_a2, part_r, scratch3, rq_dev, start, wc, ctri, part_u, part_a, stc,
+                        lx_x, lx_Lx, lx_p, lx_Lp, lx_Lw, lx_rT, lx_wT, lx_tl, lx_tdinv, lx_tcu, lx_part, lx_partR,
+                        lx_colT, lx_bad, lx_st};
+        if (h_lrec) (void)hipHostFree(h_lrec);
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (h_tri) (void)hipHostFree(h_tri);
         if (h_flag) (void)hipHostFree(h_flag);
@@ -385,10 +402,216 @@ struct Solver {
         return MACHIP_OK;
     }
 
+    // ---- preconditioned mode (precond.h) ------------------------------------------------------
+    void drop_graphs() {
+        for (auto& kv : graphs) for (hipGraphExec_t ge : kv.second) if (ge) (void)hipGraphExecDestroy(ge);
+        graphs.clear();
+    }
+    int lob_alloc(long nnz) {
+        if (!lob_ready) {
+            ST_TRY(dev_alloc(&lx_x, n)); ST_TRY(dev_alloc(&lx_Lx, n)); ST_TRY(dev_alloc(&lx_p, n));
+            ST_TRY(dev_alloc(&lx_Lp, n)); ST_TRY(dev_alloc(&lx_Lw, n));
+            double** tr[] = {&lx_rT, &lx_wT, &lx_tl, &lx_tdinv, &lx_tcu};
+            for (double** q : tr) {
+                ST_TRY(dev_alloc(q, (size_t)kTriMaxN));
+                HIP_TRY(hipMemsetAsync(*q, 0, sizeof(double) * (size_t)kTriMaxN, stream));
+            }
+            ST_TRY(dev_alloc(&lx_part, (size_t)kLobNS * kMaxGrid)); ST_TRY(dev_alloc(&lx_partR, 2 * kMaxGrid));
+            ST_TRY(dev_alloc(&lx_bad, 1)); ST_TRY(dev_alloc(&lx_st, 1));
+            HIP_TRY(hipHostMalloc((void**)&h_lrec, sizeof(double) * 2 * (size_t)(kLobCap + kLobMaxChunk + 4), hipHostMallocMapped));
+            HIP_TRY(hipHostGetDevicePointer((void**)&d_hlrec, h_lrec, 0));
+            lob_ready = true;
+        }
+        if ((size_t)nnz > lx_colT_cap) {
+            if (lx_colT) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(lx_colT); lx_colT = nullptr; drop_graphs(); }
+            lx_colT_cap = (size_t)nnz + (size_t)nnz / 2 + 1024;
+            ST_TRY(dev_alloc(&lx_colT, lx_colT_cap));
+        }
+        return MACHIP_OK;
+    }
+    LobView lview(const SpmvPlan& pl) const {
+        LobView L;
+        L.n = n; L.c = (n + kTriThreads - 1) / kTriThreads;
+        L.x = lx_x; L.Lx = lx_Lx; L.p = lx_p; L.Lp = lx_Lp; L.Lw = lx_Lw; L.rT = lx_rT; L.wT = lx_wT;
+        L.tl = lx_tl; L.tdinv = lx_tdinv; L.tcu = lx_tcu; L.part = lx_part; L.partR = lx_partR;
+        L.P_c = pl.grid; L.P_a = vgrid(); L.st = lx_st; L.hrec = d_hlrec; L.hflag = d_hflag;
+        return L;
+    }
+    template <int CMAX>
+    void lob_launch_chunk_t(const CsrView& AT, const SpmvPlan& pl, const LobView& L, int steps) {
+        OpLob op;
+        op.L = L;
+        for (int s = 0; s < steps; ++s) {
+            k_tri_solve<CMAX><<<1, kTriThreads, 0, stream>>>(L, s);
+            launch_spmv(pl, stream, AT, L.wT, op);
+            k_lob_update<<<L.P_a, kBlock, 0, stream>>>(L, s);
+        }
+        k_lob_tail<<<1, 64, 0, stream>>>(L, steps);
+    }
+    void lob_launch_chunk(const CsrView& AT, const SpmvPlan& pl, const LobView& L, int steps) {
+        switch (L.c) {   // the solver kernel is instantiated per chunk length: no guards, everything in registers
+#define MACHIP_LOB_CASE(C) case C: lob_launch_chunk_t<C>(AT, pl, L, steps); break;
+            MACHIP_LOB_CASE(1) MACHIP_LOB_CASE(2) MACHIP_LOB_CASE(3) MACHIP_LOB_CASE(4) MACHIP_LOB_CASE(5) MACHIP_LOB_CASE(6)
+            MACHIP_LOB_CASE(7) MACHIP_LOB_CASE(8) MACHIP_LOB_CASE(9) MACHIP_LOB_CASE(10) MACHIP_LOB_CASE(11) MACHIP_LOB_CASE(12)
+            MACHIP_LOB_CASE(13) MACHIP_LOB_CASE(14) MACHIP_LOB_CASE(15)
+#undef MACHIP_LOB_CASE
+            default: lob_launch_chunk_t<16>(AT, pl, L, steps); break;
+        }
+    }
+    int lob_enqueue_chunk(const CsrView& A, const CsrView& AT, const SpmvPlan& pl, const LobView& L, int steps) {
+        if (!use_graph) { lob_launch_chunk(AT, pl, L, steps); return MACHIP_OK; }
+        if (graph_csr_key != (const void*)A.val) { drop_graphs(); graph_csr_key = (const void*)A.val; }
+        const auto key = std::make_tuple(1000 + pl.variant, pl.width, pl.grid, L.c, steps);
+        auto it = graphs.find(key);
+        if (it == graphs.end()) it = graphs.emplace(key, std::array<hipGraphExec_t, 2>{nullptr, nullptr}).first;
+        hipGraphExec_t& ge = it->second[(size_t)(graph_flip++ & 1)];
+        if (!ge) {
+            hipGraph_t g = nullptr;
+            HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+            lob_launch_chunk(AT, pl, L, steps);
+            HIP_TRY(hipStreamEndCapture(stream, &g));
+            HIP_TRY(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(g);
+        }
+        HIP_TRY(hipGraphLaunch(ge, stream));
+        return MACHIP_OK;
+    }
+    // Returns MACHIP_OK (converged: yvec, *lam, *res set), MACHIP_NOT_CONVERGED (caller falls back to
+    // Lanczos) or an error.
+    int solve_lob(const CsrView& A, long nnz, double lnorm, double tol, int max_steps, int start_mode,
+                  double* lam, double* res, long* iters, long* spmvs, long* restarts_out) {
+        ST_TRY(lob_alloc(nnz));
+        const SpmvPlan pl = plan_spmv(n, nnz, kAuto);
+        const LobView L = lview(pl);
+        const int g2 = vgrid();
+        const bool debug = env_int("MACHIP_DEBUG", 0) != 0;
+        const double scale = lnorm > 0 ? lnorm : 1.0;
+        // ---- T = tridiag(L) + sigma I, factored on the device; gather indices in the solver's layout ----
+        const double sigma = 2.5e-7 * scale;
+        HIP_TRY(hipMemsetAsync(lx_bad, 0, sizeof(int), stream));
+        if (L.c <= 4) k_tri_factor<4><<<1, kTriThreads, 0, stream>>>(A, L.c, sigma, lx_tl, lx_tdinv, lx_tcu, lx_bad);
+        else if (L.c <= 8) k_tri_factor<8><<<1, kTriThreads, 0, stream>>>(A, L.c, sigma, lx_tl, lx_tdinv, lx_tcu, lx_bad);
+        else k_tri_factor<16><<<1, kTriThreads, 0, stream>>>(A, L.c, sigma, lx_tl, lx_tdinv, lx_tcu, lx_bad);
+        k_lob_perm_cols<<<(int)std::min<long>(kMaxGrid, (nnz + kBlock - 1) / kBlock), kBlock, 0, stream>>>(A.col, nnz, L.c, lx_colT);
+        CsrView AT = A;
+        AT.col = lx_colT;
+        // ---- start vector: normalised into yvec, w2 = L yvec, Rayleigh quotient ----
+        const double* src = (start_mode == 1 && have_prev) ? yvec : (have_start ? start : nullptr);
+        if (!src) { k_fill_start<<<g2, kBlock, 0, stream>>>(u, n, 0x1234567ull); src = u; }
+        HIP_TRY(hipMemcpyAsync(y_raw, src, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream));
+        k_vec_sums<<<g2, kBlock, 0, stream>>>(y_raw, n, part_c);
+        double rq = 0.0, r1 = 0.0;
+        ST_TRY(check_vector(A, pl, &rq, &r1));
+        *spmvs = 1; *iters = 0; *restarts_out = 0;
+        int hbad = 0;
+        HIP_TRY(hipMemcpy(&hbad, lx_bad, sizeof(int), hipMemcpyDeviceToHost));
+        if (hbad || !(rq == rq)) return MACHIP_NOT_CONVERGED;
+        *lam = rq; *res = r1 / scale;
+        if (*res < tol) return MACHIP_OK;
+        const int cap = std::min(kLobCap, max_steps > 0 ? max_steps : kLobCap);
+        const int chunk0 = std::min(kLobMaxChunk, std::max(1, env_int("MACHIP_LOB_CHUNK", 16)));
+        const double ltarget = std::log(std::max(tol * scale, 1e-300));
+        int it_enq = 0, restarts = 0;
+        double best = r1;
+        int best_it = 0;
+        while (true) {
+            ++epoch;
+            k_lob_start<<<g2, kBlock, 0, stream>>>(L, yvec, w2, rq_dev, it_enq, epoch);
+            std::deque<int> pend;
+            std::deque<std::pair<int, double>> hist;
+            double to_go = 1e18, est = 1e300;
+            bool check = false, bad = false;
+            while (!check) {
+                const bool near = to_go < 2.0 * chunk0;
+                const int depth = near ? 1 : 2;
+                while ((int)pend.size() < depth && it_enq < cap) {
+                    int chunk = chunk0;
+                    if (near) chunk = std::min(chunk0, std::max(2, (int)(0.75 * to_go) + 1));
+                    chunk = std::min(chunk, cap - it_enq);
+                    ST_TRY(lob_enqueue_chunk(A, AT, pl, L, chunk));
+                    it_enq += chunk;
+                    *spmvs += chunk;
+                    pend.push_back(it_enq);
+                }
+                if (pend.empty()) { check = true; break; }
+                int jend = pend.front();
+                pend.pop_front();
+                ST_TRY(wait_flag(((unsigned long long)epoch << 32) | (unsigned long long)(unsigned int)jend));
+                const unsigned long long fv = *(volatile unsigned long long*)h_flag;
+                bad = (fv & 0x80000000ull) != 0;
+                est = h_lrec[2 * (size_t)jend + 1];
+                if (debug) fprintf(stderr, "[machip] lobpcg it=%d theta=%.15g est=%.3e to_go=%.0f bad=%d pend=%zu\n", jend, h_lrec[2 * (size_t)jend], est / scale, std::min(to_go, 1e9), (int)bad, pend.size());
+                if (est < best) { best = est; best_it = jend; }
+                if (est > 0.0) {
+                    hist.emplace_back(jend, std::log(est));
+                    while (hist.size() > 2 && hist[1].first <= jend - 48) hist.pop_front();
+                    to_go = 1e18;
+                    if (hist.front().first < jend) {
+                        const double slope = (hist.front().second - hist.back().second) / (double)(jend - hist.front().first);
+                        if (slope > 1e-7) to_go = std::max(0.0, (hist.back().second - ltarget) / slope);
+                    }
+                }
+                if (bad || !(est == est) || est < tol * scale || jend >= cap || jend - best_it > 1500) check = true;
+            }
+            // ---- explicit check of the current x (fresh SpMV), also the refresh point of a restart ----
+            HIP_TRY(hipStreamSynchronize(stream));
+            HIP_TRY(hipMemcpyAsync(y_raw, lx_x, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream));
+            k_vec_sums<<<g2, kBlock, 0, stream>>>(y_raw, n, part_c);
+            ST_TRY(check_vector(A, pl, &rq, &r1));
+            *spmvs += 1;
+            *iters = it_enq;
+            *restarts_out = restarts;
+            if (debug) fprintf(stderr, "[machip]    lobpcg check it=%d rq=%.15g res=%.3e (tol %.1e)\n", it_enq, rq, r1 / scale, tol);
+            if (!(rq == rq)) return MACHIP_NOT_CONVERGED;
+            *lam = rq; *res = r1 / scale;
+            if (*res < tol) return MACHIP_OK;
+            if (it_enq >= cap || ++restarts > 12 || it_enq - best_it > 1500) return MACHIP_NOT_CONVERGED;
+        }
+    }
+
     // start_mode: 0 = stored cold-start vector (or device pseudo-random if none), 1 = previous
     // Fiedler vector (warm start).
     int solve(const CsrView& A, long nnz, double lnorm, double tol, int max_steps, int start_mode,
               int forced_variant, double* lambda2, machip_solve_stats* stats) {
+        int mode = solver_mode;
+        if (const char* e = getenv("MACHIP_SOLVER")) {
+            if (!strcmp(e, "lanczos")) mode = 1;
+            else if (!strcmp(e, "lobpcg")) mode = 2;
+            else if (!strcmp(e, "auto")) mode = 0;
+        }
+        // auto: chain-dominated graphs with few active closures per node (measured cross-over)
+        const bool eligible = n > 256 && n <= kTriMaxN;
+        const bool want = mode == 2 || (mode == 0 && chain_like && support_hint >= 0 &&
+                                        (double)support_hint <= env_int("MACHIP_LOB_DENSITY_PCT", 12) * 0.01 * (double)n);
+        last_was_lob = false;
+        if (eligible && want) {
+            HIP_TRY(hipEventRecord(ev0, stream));
+            double lam = 0.0, res = 0.0;
+            long iters = 0, spmvs = 0, rst = 0;
+            const int st = solve_lob(A, nnz, lnorm, tol, max_steps, start_mode, &lam, &res, &iters, &spmvs, &rst);
+            if (st == MACHIP_OK) {
+                HIP_TRY(hipEventRecord(ev1, stream));
+                HIP_TRY(hipEventSynchronize(ev1));
+                float ms = 0.f;
+                HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+                have_prev = true; last_was_lob = true; last_steps = iters; J_last = 0;
+                *lambda2 = lam;
+                if (stats) {
+                    stats->lanczos_steps = iters; stats->spmv_total = spmvs; stats->vec_passes = iters * 16;
+                    stats->restarts = rst; stats->nnz = nnz; stats->residual = res; stats->lnorm = lnorm; stats->gpu_ms = ms;
+                }
+                if (lam < 1e-12 * (lnorm > 0 ? lnorm : 1.0))
+                    return fail(MACHIP_DISCONNECTED, "lambda_2 ~ 0: the graph is not connected");
+                return MACHIP_OK;
+            }
+            if (st != MACHIP_NOT_CONVERGED) return st;
+            // stagnated / T not positive definite: the Lanczos path takes over from its own start
+        }
+        return solve_lanczos(A, nnz, lnorm, tol, max_steps, start_mode, forced_variant, lambda2, stats);
+    }
+
+    int solve_lanczos(const CsrView& A, long nnz, double lnorm, double tol, int max_steps, int start_mode,
+                      int forced_variant, double* lambda2, machip_solve_stats* stats) {
         const SpmvPlan pl = plan_spmv(n, nnz, forced_variant);   // explicit-check kernels
         const SpmvPlan pp = plan_pipe(n, nnz, maxlen_hint);      // fused Lanczos-step kernel
         const int g2 = vgrid();
@@ -603,7 +826,7 @@ struct Solver {
         const int Jeff = std::max(1, std::min(J_last, (int)ha.size()));
         const int ncand = std::min(Jeff, q + 6);
         std::vector<double> th, S;
-        tri::smallest_block(ha.data(), hb.data(), Jeff, ncand, th, S, wk);
+        if (!last_was_lob) tri::smallest_block(ha.data(), hb.data(), Jeff, ncand, th, S, wk);   // (no Krylov basis after the preconditioned mode: X is completed with orthonormal filler)
         const int g2 = vgrid();
         HIP_TRY(hipMemcpyAsync(X_host, yvec, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));

@@ -52,6 +52,7 @@ class MAC:
                                  min_selection_weight_tol=min_selection_weight_tol, device=device)
         # every cold eigen-solve starts from column 0 of the reference's block (fiedler.py:27-32)
         self._dev.set_start(_fiedler.reference_start_block(num_nodes)[:, 0].copy())
+        self._dev.set_solver(_fiedler.solver_mode(fiedler_method))
         self.last_stats = None
 
     # -------------------------------------------------------------------------------

@@ -8,7 +8,7 @@ from scipy.sparse import csr_matrix
 
 from mac_amd import _lib
 
-HIP_METHODS = ("hip", "hip_lanczos")
+HIP_METHODS = ("hip", "hip_lanczos", "hip_lobpcg")
 # method strings of the reference (fiedler.py:38-42 / nx:215-229): accepted so existing call
 # sites run unchanged; the eigen-solve is still the HIP one.
 REFERENCE_METHODS = ("tracemin_lu", "tracemin_cholesky", "tracemin_pcg")
@@ -26,6 +26,15 @@ class UnknownFiedlerMethod(_BaseErr):
 def check_method(method):
     if method not in HIP_METHODS and method not in REFERENCE_METHODS:
         raise UnknownFiedlerMethod(f"Unknown linear system solver: {method}")
+
+
+def solver_mode(method):
+    """libmachip eigen-solver mode for a method string (machip_set_solver): 'hip' and the reference's
+    direct-solver flavours pick automatically, 'hip_lanczos' forces the Lanczos path, and the
+    reference's preconditioned flavour 'tracemin_pcg' (nx:22-76) -- like 'hip_lobpcg' -- asks for the
+    preconditioned mode (LOBPCG + tridiagonal chain solve; needs n <= 16384, else Lanczos runs)."""
+    check_method(method)
+    return {"hip_lanczos": 1, "hip_lobpcg": 2, "tracemin_pcg": 2}.get(method, 0)
 
 
 def reference_start_block(n, seed=None):

@@ -133,6 +133,35 @@ def er10k_solve(meta):
     meta["er10k_solve"] = {"iters": len(fs), "upper": float(u)}
 
 
+def er10k_exact_topk(meta):
+    """Where the C2 trajectories can fork: the first two LP vertices of the reference run next to the
+    EXACT ones (dense numpy eigh of the reference's own MAC.laplacian(x), gradient formula of
+    mac.py:117-124, stable descending sort).  ~10 CPU-minutes."""
+    from mac.optimization.constraints import solve_subset_box_lp
+    n = 10000
+    G = nx.fast_gnp_random_graph(n, 0.01, seed=0)
+    fixed = [Edge(a, a + 1, 1.0) for a in range(n - 1)]
+    cand = [Edge(min(a, b), max(a, b), 1.0) for (a, b) in G.edges() if abs(a - b) != 1]
+    m_ = len(cand); k = m_ // 10
+    x = np.zeros(m_); x[np.random.default_rng(0).choice(m_, k, replace=False)] = 1.0
+    mac = MAC(fixed, cand, n)
+    out = {}
+    for it in range(2):
+        f, g = mac.problem(x)
+        s = solve_subset_box_lp(g, k)
+        w, V = np.linalg.eigh(mac.laplacian(x).toarray())
+        v = V[:, 1]
+        gx = mac.weights * (v[mac.edge_list[:, 0]] - v[mac.edge_list[:, 1]]) ** 2
+        order = np.argsort(-gx, kind="stable")
+        out[f"ref_s{it}"] = np.nonzero(s)[0].astype(np.int32)
+        out[f"exact_s{it}"] = np.sort(order[:k]).astype(np.int32)
+        out[f"ref_f{it}"] = f; out[f"exact_lam{it}"] = w[1]; out[f"exact_lam3_{it}"] = w[2]
+        out[f"boundary_gap_rel{it}"] = (gx[order[k - 1]] - gx[order[k]]) / gx[order[k - 1]]
+        x = x + 2.0 / (it + 2) * (s - x)
+    save("er10k_exact_topk", n=n, m=m_, k=k, **out)
+    meta["er10k_exact_topk"] = {kk: float(out[kk]) for kk in out if not kk.endswith(("s0", "s1"))}
+
+
 def main(only=None):
     meta_path = os.path.join(OUT, "golden_meta.json")
     if only and os.path.exists(meta_path):
@@ -143,6 +172,8 @@ def main(only=None):
             "networkx": nx.__version__, "python": sys.version.split()[0]})
     if only == "er10k_solve":
         return er10k_solve(meta), json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
+    if only == "er10k_exact_topk":
+        return er10k_exact_topk(meta), json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
     if only == "g2o_extra":
         return g2o_cases(meta, [("kitti_05", 20)]), json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
 

@@ -143,6 +143,89 @@ def test_pose_graph_fiedler(nm):
     assert abs(lam_all - g["lam_all"]) <= LAM_RTOL * g["lam_all"]
 
 
+# ---- preconditioned eigen-solver mode (LOBPCG + tridiagonal chain solve, precond.h) ----------
+@pytest.mark.parametrize("nm", ["intel", "sphere2500", "city10000", "kitti_05"])
+def test_preconditioned_mode_on_pose_graphs(nm):
+    """fiedler_method='tracemin_pcg' (the reference's preconditioned flavour) routes to the
+    preconditioned HIP mode; same pair as the reference / the Lanczos mode to the same tolerances."""
+    g = load_golden("g2o_" + nm)
+    mac = MAC(edges_of(g, "f"), edges_of(g, "c"), int(g["n"]), fiedler_method="tracemin_pcg")
+    ref = MAC(edges_of(g, "f"), edges_of(g, "c"), int(g["n"]), fiedler_method="hip_lanczos")
+    for x, key in [(g["x_init"], "lam_init"), (np.ones(len(g["cw"])), "lam_all")]:
+        lam = mac.evaluate_objective(x)
+        assert abs(lam - g[key]) <= LAM_RTOL * g[key]
+        assert mac.last_stats["residual"] < 1e-8
+    f, grad = mac.problem(g["x_init"])
+    f2, grad2 = ref.problem(g["x_init"])
+    assert abs(f - f2) <= LAM_RTOL * f2
+    assert np.abs(grad - grad2).max() <= 2e-4 * np.abs(grad2).max()   # both eigenvectors carry the 1e-8 residual
+    assert np.abs(grad - g["grad_init"]).max() <= 2e-4 * np.abs(g["grad_init"]).max()
+    v = mac._dev.fiedler()[1]
+    assert abs(np.linalg.norm(v) - 1) < 1e-12 and abs(v.sum()) < 1e-9
+
+
+def test_preconditioned_mode_full_solve_matches_reference_trajectory():
+    g = load_golden("g2o_kitti_05")
+    mac = MAC(edges_of(g, "f"), edges_of(g, "c"), int(g["n"]), fiedler_method="tracemin_pcg")
+    rounded, w, u = mac.solve(int(g["k"]), g["x_init"], max_iters=20, use_cache=False)
+    ft = np.array([t[0] for t in mac.trace])
+    assert np.allclose(ft, g["f_traj"][:len(ft)], rtol=1e-6)
+    assert np.array_equal([t[3] for t in mac.trace], g["supp"][:len(ft)])
+    assert abs(u - g["upper"]) <= 1e-5 * abs(g["upper"])
+    # warm start through the same mode
+    mac2 = MAC(edges_of(g, "f"), edges_of(g, "c"), int(g["n"]), fiedler_method="tracemin_pcg")
+    mac2.solve(int(g["k"]), g["x_init"], max_iters=20, use_cache=True)
+    assert np.allclose([t[0] for t in mac2.trace], ft, rtol=1e-6)
+
+
+def test_preconditioned_mode_fallbacks_and_errors():
+    rng = np.random.default_rng(11)
+    # (a) no chain at all (random graph): T = diag + sigma, still a valid preconditioner or a clean fallback
+    n = 3000
+    ci, cj = make_er(n, 0.004, 3)
+    fi = np.arange(n - 1, dtype=np.int32)
+    P = _lib.Problem(n, fi[::7], fi[::7] + 1, np.ones(len(fi[::7])), ci, cj, rng.random(len(ci)) + 0.5)
+    P.set_x(np.ones(len(ci)))
+    P.set_solver(1); lam1, v1, _ = P.fiedler()
+    P.set_solver(2); lam2, v2, _ = P.fiedler()
+    assert abs(lam1 - lam2) <= LAM_RTOL * lam1 and P.stats.residual < 1e-8
+    P.close()
+    # (b) n above the register-resident solver's limit: mode 2 silently runs the Lanczos path
+    n = 20000
+    fi = np.arange(n - 1, dtype=np.int32)
+    ci = rng.integers(0, n - 50, 4000).astype(np.int32); cj = (ci + rng.integers(2, 50, 4000)).astype(np.int32)
+    P = _lib.Problem(n, fi, fi + 1, np.full(n - 1, 50.0), ci, cj, np.full(4000, 20.0))
+    P.set_x(np.ones(4000))
+    P.set_solver(2); lam2, _, _ = P.fiedler()
+    P.set_solver(1); lam1, _, _ = P.fiedler()
+    assert lam1 == lam2
+    P.close()
+    # (c) disconnected graph: same status as the Lanczos mode
+    n = 600
+    fi = np.concatenate([np.arange(0, 299), np.arange(300, 599)]).astype(np.int32)
+    P = _lib.Problem(n, fi, fi + 1, np.ones(len(fi)), np.array([5], np.int32), np.array([50], np.int32), np.ones(1))
+    P.set_x(np.ones(1))
+    P.set_solver(2)
+    with pytest.raises(_lib.Disconnected):
+        P.fiedler()
+    with pytest.raises(AssertionError):
+        P.set_solver(7)
+    P.close()
+
+
+def test_auto_mode_picks_preconditioned_solver_on_sparse_chain_graphs():
+    """Automatic selection: a chain with few closures runs the preconditioned mode (an order of
+    magnitude fewer dependent launches), a dense-closure graph the Lanczos mode; same lambda_2."""
+    g = load_golden("g2o_kitti_05")
+    P = problem_of(g)
+    P.set_x(g["x_init"])
+    P.set_solver(1); lam_l, _, _ = P.fiedler(); steps_l = P.stats.lanczos_steps
+    P.set_solver(0); lam_a, _, _ = P.fiedler(); steps_a = P.stats.lanczos_steps
+    assert abs(lam_l - lam_a) <= LAM_RTOL * lam_l
+    assert steps_a * 5 < steps_l
+    P.close()
+
+
 # --------------------------------------------------------------------------------------------
 def test_topk_matches_oracle_and_handles_ties():
     g = load_golden("er2000_x0")
