@@ -645,6 +645,33 @@ def test_solve_rounding_matches_reference_goldens():
         assert np.array_equal(mac._dev.round_nearest(int(g["k"]), decimals=10), g["rounded"])
 
 
+def test_config2_first_lp_vertices_equal_the_exact_ones():
+    """Where the C2 trajectories fork (see the next test): the top-K sets s_0, s_1 of the HIP path equal
+    the ones an exact dense eigen-solve gives (tests/golden/er10k_exact_topk.npz: numpy eigh of the
+    reference's own L(x)), element for element; the reference's own s_1 misses one of 50 053."""
+    g = load_golden("er10k_exact_topk")
+    n = 10000
+    ci, cj = make_er(n, 0.01, 0)
+    m, k = len(ci), int(g["k"])
+    assert m == int(g["m"])
+    assert k - len(np.intersect1d(g["ref_s0"], g["exact_s0"])) == 0
+    assert k - len(np.intersect1d(g["ref_s1"], g["exact_s1"])) == 1      # the fork
+    fi = np.arange(n - 1, dtype=np.int32)
+    P = _lib.Problem(n, fi, fi + 1, np.ones(n - 1), ci, cj, np.ones(m))
+    P.set_start(reference_start_block(n)[:, 0].copy())
+    x = np.zeros(m); x[np.random.default_rng(0).choice(m, k, replace=False)] = 1.0
+    for it in range(2):
+        P.set_x(x)
+        lam, _, _ = P.fiedler()
+        assert abs(lam - float(g[f"exact_lam{it}"])) <= 1e-11 * lam
+        assert abs(float(g[f"ref_f{it}"]) - float(g[f"exact_lam{it}"])) <= LAM_RTOL * lam
+        P.gradient(want=False)
+        s = P.lp_topk(k)
+        assert np.array_equal(np.nonzero(s)[0], g[f"exact_s{it}"])
+        x = x + 2.0 / (it + 2) * (s - x)
+    P.close()
+
+
 def test_config2_twenty_iterations_match_reference_trajectory():
     """The bench workload itself (BASELINE.json configs[1], 20 Frank-Wolfe iterations from the bench's
     x0, stop tests off) against the trajectory the REAL reference produced (tests/golden/er10k_solve.npz,
