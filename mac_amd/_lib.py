@@ -241,6 +241,7 @@ class Problem:
         return us.value, by.value
 
     def comm_init(self, rank, nranks, unique_id: bytes):
+        _single_node_bootstrap()
         buf = C.create_string_buffer(unique_id, 128)
         with _stdout_to_stderr():
             st = self._lib.machip_comm_init(self._h, int(rank), int(nranks), buf)
@@ -269,7 +270,15 @@ class _stdout_to_stderr:
         os.close(self._saved)
 
 
+def _single_node_bootstrap():
+    """The ranks of one job share a node (one process per GPU, xGMI between them): keep RCCL's socket
+    bootstrap on the loopback interface unless the caller chose one.  (On the test boxes the only other
+    interface is a container veth, over which ncclCommInitRank was once seen to hang.)"""
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+
+
 def comm_unique_id() -> bytes:
+    _single_node_bootstrap()
     buf = C.create_string_buffer(128)
     lib = load()
     with _stdout_to_stderr():

@@ -308,6 +308,7 @@ int machip_create(int device, int64_t n, int64_t n_fixed, const int32_t* fi, con
             long cnt = 0;
             for (int64_t i = 0; i + 1 < n; ++i) cnt += has[(size_t)i];
             p->sol.chain_like = cnt >= (long)(0.98 * (double)(n - 1));
+            p->sol.chain_edges = cnt;
         }
         return MACHIP_OK;
     };

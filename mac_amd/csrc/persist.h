@@ -1,0 +1,259 @@
+// mac_amd/csrc/persist.h -- single-workgroup, LDS-resident Lanczos for small graphs.
+//
+// On the pose graphs of BASELINE.json configs[2] and [4] (intel: n = 1 728, sphere2500: n = 2 500;
+// also kitti_05) the whole matrix is a few tens of KB and a Lanczos step of the multi-workgroup
+// path is nothing but launch latency (~4.5 us for ~0.2 us of work).  Here one workgroup (4 waves)
+// keeps the gather operand and the off-band entries in LDS (148 of the CU's 160 KB), every thread
+// owns up to 12 rows in registers, and a chunk of Lanczos steps runs inside ONE launch: the two
+// global reductions of a step are workgroup reductions (DPP wave totals + 16 LDS words + a barrier).
+// Classic three-term form (beta_j from the vector itself), so it also serves restarts.  Same
+// records / flag protocol towards the host as k_pipe_tail, same basis V in HBM for the Ritz vector.
+#pragma once
+#include "kernels.h"
+
+namespace machip {
+
+#ifdef PERSIST_CLOCKS   // tools/ubench_persist.hip: shader-clock stamps of thread 0
+#define PCLK(cond, i) do { if (t == 0 && (cond)) L.clk[i] = clock64(); } while (0)
+#else
+#define PCLK(cond, i) do { } while (0)
+#endif
+
+constexpr int kPersistThreads = 256;      // 4 waves, one per SIMD: the kernel is FP64-issue bound, and every extra
+                                           // wave repeats the reduction epilogues (1 024 threads: 3.1 us/step at n = 1 728)
+constexpr int kPersistPool = 148 * 1024;   // bytes of LDS for val, col, rowptr and the gather operand
+constexpr int kPersistMaxSteps = 256;      // steps per launch (records staged in LDS)
+constexpr int kPersistMaxRows = 12;        // rows per thread held in registers (instantiated for 4, 8, 12): n <= 3072;
+                                           // beyond that the register file spills and one CU's FP64 issue rate loses
+                                           // to the multi-workgroup path (n = 4 661: 4.0 us/step either way)
+
+struct PersistView {
+    int n;
+    LanState* st;
+    double* u;      // un-normalised next Lanczos vector (state between chunks)
+    double* vprev;  // v_{J-1}
+    double* V;      // basis, column-major
+    double* tri;    // (alpha_j, beta_j, ||v_j||_1) triples
+    double* htri;   // pinned mirror
+    unsigned long long* hflag;
+#ifdef PERSIST_CLOCKS
+    long long* clk;   // tools/ubench_persist.hip: phase stamps of thread 0
+#endif
+};
+
+// nc_max: upper bound of the entries outside the tridiagonal band (the band itself lives in registers)
+inline bool persist_fits(int n, long nc_max) {
+    return n <= kPersistThreads * kPersistMaxRows && nc_max >= 0 &&
+           (size_t)nc_max * 12 + (size_t)n * 8 + ((size_t)n + 2) * 4 + 64 <= (size_t)kPersistPool;
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
+// queue (s_waitcnt vmcnt(0)), i.e. it would wait ~1 us per step for the basis column v_j just stored
+// to HBM, which nothing in this kernel ever reads back.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Sum two values over the workgroup; `red` = 2 x kPersistThreads/64 doubles, two of them used alternately.
+__device__ __forceinline__ void persist_sum2(double& a, double& b, double* red) {
+    a = wave_total(a); b = wave_total(b);
+    const int w = threadIdx.x >> 6;
+    constexpr int W = kPersistThreads / 64;
+    if ((threadIdx.x & 63) == 0) { red[w] = a; red[W + w] = b; }
+    lds_barrier();
+    double sa = 0.0, sb = 0.0;
+#pragma unroll
+    for (int k = 0; k < W; ++k) { sa += red[k]; sb += red[W + k]; }
+    a = sa; b = sb;
+}
+
+__global__ void k_persist_begin(PersistView L, int epoch) {
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < L.n; r += gridDim.x * blockDim.x) L.vprev[r] = 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { L.st->jA = 0; L.st->epoch = epoch; }
+}
+
+// Matrix layout inside the workgroup (pose graph = odometry chain + loop closures): the tridiagonal
+// band of every owned row (diag, sub, super) sits in REGISTERS and its operands v[r-1], v[r], v[r+1]
+// are consecutive LDS words for consecutive lanes -- conflict free.  Only the entries outside the band
+// (the closures) are split: the first two of every row also sit in registers, further ones -- rare hub
+// rows -- are kept as a CSR in LDS next to the gather operand.  (A plain
+// thread-per-row CSR in LDS was tried first: rows of ~4 entries put the 64 lanes of a load on 4 banks
+// and the step cost 4 us, LDS-bound.)
+template <int RPT>
+__global__ __launch_bounds__(kPersistThreads) void k_lan_persist(CsrView A, PersistView L, int steps) {
+    __shared__ __align__(16) unsigned char pool[kPersistPool];
+    __shared__ double red1[2 * kPersistThreads / 64], red2[2 * kPersistThreads / 64];
+    __shared__ double srec[3 * (kPersistMaxSteps + 1)];   // (alpha, beta, l1) of this chunk
+    __shared__ int s_scan[kPersistThreads];
+    const int t = threadIdx.x, n = A.n;
+    PCLK(true, 0);
+#ifdef PERSIST_CLOCKS
+    if (t == 0) L.clk[10] = wall_clock64();
+#endif
+    double* svec = reinterpret_cast<double*>(pool);
+    int* crow = reinterpret_cast<int*>(svec + n);          // n + 1 offsets of the out-of-band entries
+    // ---- band and the first two off-band entries -> registers; count the overflow of every row ----
+    double dg[RPT], lo[RPT], up[RPT], c0v[RPT], c1v[RPT];
+    int c0c[RPT], c1c[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int r = t + k * kPersistThreads;
+        dg[k] = 0.0; lo[k] = 0.0; up[k] = 0.0; c0v[k] = 0.0; c1v[k] = 0.0; c0c[k] = 0; c1c[k] = 0;
+        if (r < n) {
+            int c = 0;
+            for (int p = A.rowptr[r]; p < A.rowptr[r + 1]; ++p) {
+                const int col = A.col[p];
+                const double x = A.val[p];
+                if (col == r) dg[k] += x;
+                else if (col == r - 1) lo[k] += x;
+                else if (col == r + 1) up[k] += x;
+                else {
+                    if (c == 0) { c0c[k] = col; c0v[k] = x; }
+                    else if (c == 1) { c1c[k] = col; c1v[k] = x; }
+                    ++c;
+                }
+            }
+            crow[r + 1] = max(0, c - 2);
+        }
+    }
+    if (t == 0) crow[0] = 0;
+    __syncthreads();
+    // inclusive prefix sum of crow[1..n]: contiguous segment per thread, then a scan of the segment totals
+    {
+        const int seg = (n + kPersistThreads - 1) / kPersistThreads;
+        const int b0 = 1 + t * seg, e0 = min(n + 1, b0 + seg);
+        int tot = 0;
+        for (int i = b0; i < e0; ++i) tot += crow[i];
+        s_scan[t] = tot;
+        __syncthreads();
+        for (int o = 1; o < kPersistThreads; o <<= 1) {
+            const int add = t >= o ? s_scan[t - o] : 0;
+            __syncthreads();
+            s_scan[t] += add;
+            __syncthreads();
+        }
+        int run = s_scan[t] - tot;
+        for (int i = b0; i < e0; ++i) { run += crow[i]; crow[i] = run; }
+        __syncthreads();
+    }
+    const int nc = crow[n];
+    int* ccol = crow + (n + 1);
+    double* cval = reinterpret_cast<double*>(pool + (((size_t)n * 8 + ((size_t)n + 1 + (size_t)nc) * 4 + 7) & ~(size_t)7));
+    bool any_over = false;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int r = t + k * kPersistThreads;
+        if (r < n) {
+            int q = crow[r], c = 0;
+            any_over = any_over || crow[r + 1] > q;
+            for (int p = A.rowptr[r]; p < A.rowptr[r + 1]; ++p) {
+                const int col = A.col[p];
+                if (col < r - 1 || col > r + 1) {
+                    if (c >= 2) { ccol[q] = col; cval[q] = A.val[p]; ++q; }
+                    ++c;
+                }
+            }
+        }
+    }
+    const int J0 = L.st->jA;
+    double u[RPT], vp[RPT], v[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int r = t + k * kPersistThreads;
+        u[k] = r < n ? L.u[r] : 0.0;
+        vp[k] = r < n ? L.vprev[r] : 0.0;
+    }
+    const double dn = (double)n;
+    __syncthreads();
+    PCLK(true, 1);
+    for (int s = 0; s <= steps; ++s) {
+        const int j = J0 + s;
+        PCLK(s == 1, 8);
+        // ---- beta_j = ||u - mean||, v_j = (u - mean) / beta_j  (nx:209-213 project()) ----
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) { s1 += u[k]; s2 += u[k] * u[k]; }
+        persist_sum2(s1, s2, red1);
+        PCLK(s == 0, 2);
+        const double mu = s1 / dn;
+        const double nrm2 = s2 - dn * mu * mu;
+        const double beta = nrm2 > 0.0 ? sqrt(nrm2) : 0.0;
+        if (s == steps) {              // chunk end: only beta_J is needed (the host's residual estimate)
+            if (t == 0) { srec[3 * s] = 0.0; srec[3 * s + 1] = beta; }
+            break;
+        }
+        const double inv = beta > 1e-290 ? 1.0 / beta : 0.0;
+        double l1 = 0.0, al = 0.0;
+        double* vj = L.V + (size_t)j * (size_t)n;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int r = t + k * kPersistThreads;
+            v[k] = (u[k] - mu) * inv;
+            if (r < n) { svec[r] = v[k]; vj[r] = v[k]; l1 += fabs(v[k]); } else v[k] = 0.0;
+        }
+        PCLK(s == 0, 3);
+        lds_barrier();
+        PCLK(s == 0, 4);
+        // ---- w = L v_j: band and two closures per row from registers (independent LDS gathers, no
+        // loops), the rare rows with more closures add theirs from the LDS CSR; alpha_j = v_j . w ----
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int r = t + k * kPersistThreads;
+            const int rm = max(r - 1, 0), rp = min(r + 1, n - 1);     // lo/up are 0 where the neighbour does not exist
+            double w = dg[k] * v[k];
+            if (r < n) w += lo[k] * svec[rm] + up[k] * svec[rp] + c0v[k] * svec[c0c[k]] + c1v[k] * svec[c1c[k]];
+            u[k] = w;
+        }
+        if (any_over) {
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int r = t + k * kPersistThreads;
+                if (r < n) {
+                    const int b = crow[r], e = crow[r + 1];
+                    for (int p = b; p < e; ++p) u[k] += cval[p] * svec[ccol[p]];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) al += v[k] * u[k];
+        PCLK(s == 0, 5);
+        persist_sum2(al, l1, red2);
+        PCLK(s == 0, 6);
+        // ---- u_{j+1} = w - alpha_j v_j - beta_j v_{j-1} ----
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            u[k] = (u[k] - al * v[k]) - beta * vp[k];
+            vp[k] = v[k];
+        }
+        if (t == 0) { srec[3 * s] = al; srec[3 * s + 1] = beta; srec[3 * s + 2] = l1; }
+        PCLK(s == 0, 7);
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int r = t + k * kPersistThreads;
+        if (r < n) { L.u[r] = u[k]; L.vprev[r] = vp[k]; }
+    }
+    // ---- hand the chunk's records to the host (as k_pipe_tail does): triples J0..J-1 and beta_J ----
+    __syncthreads();
+    const int J = J0 + steps;
+    const int cnt = 3 * steps + 2;
+    for (int i = t; i < cnt; i += kPersistThreads) {
+        const double x = srec[i];
+        L.tri[3 * (size_t)J0 + i] = x;
+        L.htri[3 * (size_t)J0 + i] = x;
+    }
+    __threadfence_system();
+    __syncthreads();
+    PCLK(true, 9);
+#ifdef PERSIST_CLOCKS
+    if (t == 0) L.clk[11] = wall_clock64();
+#endif
+    if (t == 0) {
+        L.st->jA = J;
+        const unsigned long long epoch = (unsigned long long)(unsigned int)L.st->epoch;
+        __hip_atomic_store(L.hflag, (epoch << 32) | (unsigned long long)(unsigned int)J, __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+}  // namespace machip

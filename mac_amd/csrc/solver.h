@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "persist.h"
 #include "precond.h"
 #include "tridiag.h"
 
@@ -220,6 +221,7 @@ struct Solver {
     bool lob_ready = false, last_was_lob = false;
     int solver_mode = 0;        // 0 = auto, 1 = Lanczos, 2 = preconditioned (LOBPCG + tridiagonal solve)
     bool chain_like = false;    // the fixed edges contain (nearly) the whole chain (i, i+1)
+    long chain_edges = 0;       // how many of them
     long support_hint = -1;     // active candidate edges of the matrix about to be solved (-1 = unknown)
     static constexpr int kLobCap = 20000;
 
@@ -310,6 +312,21 @@ struct Solver {
             k_lan_update<<<g2, kBlock, 0, stream>>>(op.L);
         }
         k_lan_tail<<<1, kBlock, 0, stream>>>(op.L);
+    }
+
+    // ---- small graphs: a whole chunk of Lanczos steps in one single-workgroup launch (persist.h) ----
+    PersistView persist_view() const {
+        PersistView L;
+        L.n = n; L.st = st; L.u = u; L.vprev = wc; L.V = V; L.tri = tri; L.htri = d_htri; L.hflag = d_hflag;
+        return L;
+    }
+    void launch_persist(const CsrView& A, int steps) {
+        const PersistView L = persist_view();
+        switch ((n + 4 * kPersistThreads - 1) / (4 * kPersistThreads)) {   // rows per thread, rounded up to 4
+            case 1: k_lan_persist<4><<<1, kPersistThreads, 0, stream>>>(A, L, steps); break;
+            case 2: k_lan_persist<8><<<1, kPersistThreads, 0, stream>>>(A, L, steps); break;
+            default: k_lan_persist<12><<<1, kPersistThreads, 0, stream>>>(A, L, steps); break;
+        }
     }
 
     // ---- one chunk = `steps` step kernels + the tail kernel ------------------------------------
@@ -641,10 +658,16 @@ struct Solver {
         bool done = false;
 
         bool classic = n <= env_int("MACHIP_CLASSIC_N", 256);
+        // LDS-resident single-workgroup form when the matrix fits (classic recurrence: also fine after restarts)
+        const bool pmode = env_int("MACHIP_PERSIST", 1) != 0 && chain_like && persist_fits(n, nnz - n - 2 * chain_edges);
+        const int pchunk0 = std::min(kPersistMaxSteps, std::max(2, env_int("MACHIP_PCHUNK", 64)));
         const bool debug = env_int("MACHIP_DEBUG", 0) != 0;
         while (!done && steps_total < max_steps) {
             // ---- (re)start a Krylov sequence from u ----
-            if (classic) {
+            if (pmode) {
+                ++epoch;
+                k_persist_begin<<<g2, kBlock, 0, stream>>>(persist_view(), (int)epoch);
+            } else if (classic) {
                 k_vec_sums<<<g2, kBlock, 0, stream>>>(u, n, part_u);
                 k_set_state<<<1, 64, 0, stream>>>(stc, 0);
             } else {
@@ -673,18 +696,25 @@ struct Solver {
                 // successor would only delay the explicit residual check queued behind it
                 const bool near = sched ? (to_go < 2.0 * chunk0 || (to_go >= 1e17 && est_latest < 1e3 * tol * lnorm))
                                         : est_latest < 1e3 * tol * lnorm;
-                const int depth = (classic || near) ? 1 : ((sched && to_go > 8.0 * chunk0) ? 3 : 2);
+                const bool use_classic = classic && !pmode;
+                const int depth = (use_classic || near) ? 1 : ((sched && to_go > 8.0 * chunk0) ? 3 : 2);
                 while ((int)pend.size() < depth && J_enq < jcap && steps_total < max_steps) {
                     int chunk = near ? chunk_near : chunk0;
                     if (near && sched && to_go < 1e17)   // aim a little short of the predicted crossing
                         chunk = std::min(chunk0, std::max(chunk_near, ((int)(0.75 * to_go) + 1) & ~1));
-                    if (classic) chunk = std::min(chunk, 16);
+                    if (pmode) {   // steps cost ~0.5 us here: long chunks, so the O(J) host analysis keeps up
+                        chunk = pchunk0;
+                        if (to_go < 1e17) chunk = std::min(pchunk0, std::max(16, ((int)(0.9 * to_go) + 1) & ~1));
+                    }
+                    if (use_classic) chunk = std::min(chunk, 16);
                     chunk = std::min(chunk, jcap - J_enq);
                     chunk = (int)std::min<long>(chunk, max_steps - steps_total);
                     if (chunk <= 0) break;
                     const int lo = std::max(0, J_enq - 1);
                     const int hi = J_enq + chunk;           // records lo..hi inclusive
-                    if (classic) {
+                    if (pmode) {
+                        launch_persist(A, chunk);
+                    } else if (classic) {
                         enqueue_classic(A, pl, chunk);
                         double* hp = h_pin + (vcap + 2) + 2 * kMaxGrid + 32;   // staging: 3 x (chunk+1)
                         for (int q = 0; q < 3; ++q)
@@ -696,10 +726,10 @@ struct Solver {
                     (void)lo;
                     Pending p;
                     p.jstart = J_enq;
-                    p.classic = classic;
+                    p.classic = use_classic;
                     p.jend = hi;
                     p.ev = nullptr;
-                    if (classic) {
+                    if (use_classic) {
                         ST_TRY(get_event(&p.ev));
                         HIP_TRY(hipEventRecord(p.ev, stream));
                     }
@@ -767,7 +797,7 @@ struct Solver {
                 }
                 const bool at_cap = (J >= jcap) || (steps_total >= max_steps && pend.empty());
                 const bool trig = broke || est < trigger_slack * tol * lnorm;
-                if (debug) fprintf(stderr, "[machip] %s J=%d Jeff=%d theta=%.15g est=%.3e to_go=%.0f broke=%d pend=%zu passes=%d\n", classic ? "classic" : "pipe", J, Jeff, sm.theta, lnorm > 0 ? est / lnorm : est, std::min(to_go, 1e9), (int)broke, pend.size(), sm.passes);
+                if (debug) fprintf(stderr, "[machip] %s J=%d Jeff=%d theta=%.15g est=%.3e to_go=%.0f broke=%d pend=%zu passes=%d\n", pmode ? "persist" : (classic ? "classic" : "pipe"), J, Jeff, sm.theta, lnorm > 0 ? est / lnorm : est, std::min(to_go, 1e9), (int)broke, pend.size(), sm.passes);
                 if ((trig && est < 0.5 * last_check_est) || broke || at_cap) {
                     double rq = 0.0, r1 = 0.0;
                     ST_TRY(explicit_check(A, pl, Jeff, sm.s.data(), &rq, &r1));   // syncs the stream
