@@ -223,6 +223,7 @@ struct Solver {
     bool chain_like = false;    // the fixed edges contain (nearly) the whole chain (i, i+1)
     long chain_edges = 0;       // how many of them
     long support_hint = -1;     // active candidate edges of the matrix about to be solved (-1 = unknown)
+    long hist_lan_steps = -1, hist_lob_iters = -1;   // steps / iterations of the last solve in each mode
     static constexpr int kLobCap = 20000;
 
     int init(int n_, hipStream_t s) {
@@ -598,8 +599,16 @@ struct Solver {
         }
         // auto: chain-dominated graphs with few active closures per node (measured cross-over)
         const bool eligible = n > 256 && n <= kTriMaxN;
-        const bool want = mode == 2 || (mode == 0 && chain_like && support_hint >= 0 &&
-                                        (double)support_hint <= env_int("MACHIP_LOB_DENSITY_PCT", 12) * 0.01 * (double)n);
+        // One preconditioned iteration costs about `ratio` Lanczos steps (three launches, one of them a
+        // single workgroup).  Sparse closures: preconditioned.  Denser closures: only when the last
+        // Lanczos solve of this problem was long (a stiff x) and the preconditioned mode has not been seen
+        // to need more than 1/ratio of those steps.  Counts only -- never timings -- so the choice, and
+        // with it every rounding of the trajectory, is reproducible run to run.
+        const long ratio = n <= kPersistThreads * kPersistMaxRows ? 9 : 6;
+        const bool sparse = (double)support_hint <= env_int("MACHIP_LOB_DENSITY_PCT", 12) * 0.01 * (double)n;
+        const bool stiff = hist_lan_steps > 2500 && (hist_lob_iters < 0 || hist_lob_iters * ratio < hist_lan_steps);
+        const bool slow_lob = hist_lan_steps > 0 && hist_lob_iters > 0 && hist_lob_iters * ratio > 2 * hist_lan_steps;
+        const bool want = mode == 2 || (mode == 0 && chain_like && support_hint >= 0 && ((sparse && !slow_lob) || stiff));
         last_was_lob = false;
         if (eligible && want) {
             HIP_TRY(hipEventRecord(ev0, stream));
@@ -612,6 +621,7 @@ struct Solver {
                 float ms = 0.f;
                 HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
                 have_prev = true; last_was_lob = true; last_steps = iters; J_last = 0;
+                hist_lob_iters = iters;
                 *lambda2 = lam;
                 if (stats) {
                     stats->lanczos_steps = iters; stats->spmv_total = spmvs; stats->vec_passes = iters * 16;
@@ -624,7 +634,9 @@ struct Solver {
             if (st != MACHIP_NOT_CONVERGED) return st;
             // stagnated / T not positive definite: the Lanczos path takes over from its own start
         }
-        return solve_lanczos(A, nnz, lnorm, tol, max_steps, start_mode, forced_variant, lambda2, stats);
+        const int st = solve_lanczos(A, nnz, lnorm, tol, max_steps, start_mode, forced_variant, lambda2, stats);
+        if (st == MACHIP_OK) hist_lan_steps = last_steps;
+        return st;
     }
 
     int solve_lanczos(const CsrView& A, long nnz, double lnorm, double tol, int max_steps, int start_mode,

@@ -213,6 +213,58 @@ def test_preconditioned_mode_fallbacks_and_errors():
     P.close()
 
 
+def test_auto_mode_learns_a_stiff_problem_from_step_counts():
+    """city10000 with the first 20 % of the closures selected is stiff (~10^4 Lanczos steps) although its
+    closure density is above the static threshold: the automatic mode sees that from the first solve's step
+    count and runs the preconditioned mode from then on (deterministic: counts, not timings)."""
+    g = load_golden("g2o_city10000")
+    P = problem_of(g)
+    m = len(g["cw"])
+    x = np.zeros(m); x[: m // 5] = 1.0
+    P.set_x(x)
+    P.set_solver(0)
+    lam1, _, _ = P.fiedler(); s1 = int(P.stats.lanczos_steps)
+    lam2, _, _ = P.fiedler(); s2 = int(P.stats.lanczos_steps)
+    lam3, _, _ = P.fiedler(); s3 = int(P.stats.lanczos_steps)
+    assert s1 > 2500 and s2 * 6 < s1 and s3 == s2
+    assert abs(lam1 - lam2) <= LAM_RTOL * lam1 and lam2 == lam3
+    P.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_solver_modes_agree_on_random_chain_graphs(seed):
+    """Seeded sweep over pose-graph-like inputs (chain with weights over three decades, random closures,
+    sizes on both sides of the single-workgroup / register-resident limits): Lanczos, preconditioned and
+    automatic modes against a dense eigen-solve (n <= 2500) and against each other."""
+    rng = np.random.default_rng(100 + seed)
+    n = int([300, 1024, 1025, 2500, 3073, 6000, 16384, 16400][seed])
+    ncl = int(rng.integers(3, max(4, n // 5)))
+    fi = np.arange(n - 1, dtype=np.int32)
+    fw = 10.0 ** rng.uniform(0, 3, n - 1)
+    a = rng.integers(0, n, ncl); b = rng.integers(0, n, ncl)
+    keep = np.abs(a - b) > 1
+    ci = np.minimum(a, b)[keep].astype(np.int32); cj = np.maximum(a, b)[keep].astype(np.int32)
+    cw = 10.0 ** rng.uniform(0, 2.5, len(ci))
+    x = rng.random(len(ci)); x[rng.random(len(ci)) < 0.3] = 0.0
+    P = _lib.Problem(n, fi, fi + 1, fw, ci, cj, cw)
+    P.set_x(x)
+    lams, vecs = [], []
+    for mode in (1, 2, 0):
+        P.set_solver(mode)
+        lam, v, _ = P.fiedler()
+        assert P.stats.residual < 1e-8 and abs(np.linalg.norm(v) - 1) < 1e-12 and abs(v.sum()) < 1e-8
+        lams.append(lam); vecs.append(v)
+    assert max(lams) - min(lams) <= LAM_RTOL * min(lams)
+    if n <= 2500:
+        L = oracle.mac_laplacian(oracle.laplacian_from_edges(fi, fi + 1, fw, n), ci.astype(np.int64), cj.astype(np.int64), cw, x, n)
+        w = np.linalg.eigvalsh(L.toarray())
+        assert abs(lams[0] - w[1]) <= LAM_RTOL * w[1]
+        if w[2] - w[1] > 1e-3 * w[1]:      # simple eigenvalue: the vectors agree too
+            for v in vecs[1:]:
+                assert min(np.abs(v - vecs[0]).max(), np.abs(v + vecs[0]).max()) < 1e-4
+    P.close()
+
+
 def test_auto_mode_picks_preconditioned_solver_on_sparse_chain_graphs():
     """Automatic selection: a chain with few closures runs the preconditioned mode (an order of
     magnitude fewer dependent launches), a dense-closure graph the Lanczos mode; same lambda_2."""
