@@ -106,7 +106,9 @@ inline SpmvPlan plan_pipe(int n, long nnz, int maxlen) {
     if (g == 4 && maxlen > 48) g = 16;
     if (g == 8 && maxlen > 8 * mean && maxlen > 128) g = 16;
     pl.width = env_int("MACHIP_G", g);
-    pl.unroll = env_int("MACHIP_UNROLL", pl.width >= 8 ? 2 : 1);
+    // in a real solve the gather operand was written by the previous launch from all XCDs (cold lines): more
+    // loads in flight per lane pay off there even where the warm replay says otherwise (config 2: +4 %)
+    pl.unroll = env_int("MACHIP_UNROLL", pl.width == 8 && mean >= 32.0 ? 4 : (pl.width >= 8 ? 2 : 1));
     // at most grid_cap() workgroups (each re-reads every workgroup's partials): grow the
     // workgroup instead of the grid
     // (wave 0 of every workgroup only runs the prologue: BLOCK - 64 threads own rows)
@@ -146,6 +148,9 @@ inline void launch_pipe_b(const SpmvPlan& pl, hipStream_t s, const CsrView& A, c
     switch (key) {
         case 41: k_pipe_vec<BLOCK, 4, 1, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
         case 42: k_pipe_vec<BLOCK, 4, 2, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 44: k_pipe_vec<BLOCK, 4, 4, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 84: k_pipe_vec<BLOCK, 8, 4, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 164: k_pipe_vec<BLOCK, 16, 4, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
         case 81: k_pipe_vec<BLOCK, 8, 1, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
         case 82: k_pipe_vec<BLOCK, 8, 2, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
         case 161: k_pipe_vec<BLOCK, 16, 1, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
