@@ -836,15 +836,21 @@ __global__ __launch_bounds__(kBlock) void k_sel_pass(const double* __restrict__ 
     if (run) atomicAdd(&lh[cur], run);
     __syncthreads();
     unsigned int* gh = hist + pass * kBins;
+    // The histogram lives in device-scope atomics (performed at the coherence point, never cached) and
+    // is read back below with device-scope atomic loads, so no cache write-back / invalidate is needed.
+    // The adds must have been PERFORMED before this workgroup takes its arrival ticket: they are issued
+    // as returning atomics and the returned values are consumed, which forces the wave to wait for the
+    // memory side's answer.  (Fire-and-forget adds followed by s_waitcnt vmcnt(0) were not enough: with
+    // hundreds of workgroups adding to the same one or two bins -- round_nearest keys are mostly ties --
+    // the last workgroup occasionally read a bin before every add had landed, and the selection came
+    // out a few elements too large.  Found by tools/round_check.py.)
+    unsigned int seen = 0;
     for (int i = tid; i < kBins; i += kBlock)
-        if (lh[i]) atomicAdd(&gh[i], lh[i]);
-    // the histogram lives in device-scope atomics (performed at the coherence point, never cached)
-    // and is read back below with device-scope atomic loads; __syncthreads() drains this
-    // workgroup's atomics (s_waitcnt vmcnt(0) counts them on gfx950) before ONE lane takes the
-    // arrival ticket, so no cache write-back / invalidate is needed at all
+        if (lh[i]) seen |= __hip_atomic_fetch_add(&gh[i], lh[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::"v"(seen));
     __syncthreads();
     if (tid == 0)
-        s_last = (__hip_atomic_fetch_add(&st->ticket[pass], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1);
+        s_last = (__hip_atomic_fetch_add(&st->ticket[pass], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1);
     __syncthreads();
     if (!s_last) return;
     // last workgroup: walk the bins from the top until the cumulative count reaches kk

@@ -697,6 +697,38 @@ def test_solve_rounding_matches_reference_goldens():
         assert np.array_equal(mac._dev.round_nearest(int(g["k"]), decimals=10), g["rounded"])
 
 
+def test_selection_is_deterministic_on_massive_ties():
+    """Regression for a race in the radix select: the last workgroup could read a histogram bin before
+    every workgroup's (fire-and-forget) add had been performed at the memory side; with rounded iterates
+    nearly all keys share one or two bins and the selection came out a few elements too large in ~20 % of
+    the calls right after a config-2 solve (tools/round_check.py).  Repeated calls must give exactly k
+    ones, identical to the oracle's."""
+    n = 10000
+    ci, cj = make_er(n, 0.01, 0)
+    m = len(ci); k = m // 10
+    fi = np.arange(n - 1, dtype=np.int32)
+    P = _lib.Problem(n, fi, fi + 1, np.ones(n - 1), ci, cj, np.ones(m))
+    P.set_start(reference_start_block(n)[:, 0].copy())
+    x0 = np.zeros(m); x0[np.random.default_rng(0).choice(m, k, replace=False)] = 1.0
+    P.set_x(x0)
+    for it in range(20):
+        P.fw_step(k, it); P.fw_commit()
+    w = P.get_x()
+    want = oracle.round_nearest(w, k, np.ones(m), 10)
+    assert int(want.sum()) == k
+    for rep in range(40):
+        r = P.round_nearest(k, decimals=10)
+        assert int(r.sum()) == k and np.array_equal(r, want), rep
+    # a synthetic all-ties input as well
+    rng = np.random.default_rng(3)
+    x = rng.choice(np.array([0.0, 0.0, 0.0, 1.0 / 3.0, 0.4, 0.4, 0.6, 2.0 / 3.0, 1.0]), size=m)
+    P.set_x(x)
+    want = oracle.round_nearest(x, k, np.ones(m), 10)
+    for rep in range(10):
+        assert np.array_equal(P.round_nearest(k, decimals=10), want), rep
+    P.close()
+
+
 def test_config2_first_lp_vertices_equal_the_exact_ones():
     """Where the C2 trajectories fork (see the next test): the top-K sets s_0, s_1 of the HIP path equal
     the ones an exact dense eigen-solve gives (tests/golden/er10k_exact_topk.npz: numpy eigh of the
