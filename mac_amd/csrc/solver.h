@@ -545,12 +545,14 @@ struct Solver {
             std::deque<std::pair<int, double>> hist;
             double to_go = 1e18, est = 1e300;
             bool check = false, bad = false;
+            int ramp = 4;
             while (!check) {
                 const bool near = to_go < 2.0 * chunk0;
                 const int depth = near ? 1 : 2;
                 while ((int)pend.size() < depth && it_enq < cap) {
-                    int chunk = chunk0;
-                    if (near) chunk = std::min(chunk0, std::max(2, (int)(0.75 * to_go) + 1));
+                    int chunk = std::min(chunk0, ramp);   // easy problems (T ~ L) converge in a handful of iterations
+                    ramp = std::min(chunk0, ramp * 2);
+                    if (near) chunk = std::min(chunk, std::max(2, (int)(0.75 * to_go) + 1));
                     chunk = std::min(chunk, cap - it_enq);
                     ST_TRY(lob_enqueue_chunk(A, AT, pl, L, chunk));
                     it_enq += chunk;
