@@ -153,8 +153,8 @@ int machip_comm_init(machip_problem* p, int rank, int nranks, const void* id128)
  * mac/utils/fiedler.py:38-42 dispatches 'tracemin_pcg' | 'tracemin_lu' | 'tracemin_cholesky', all
  * computing the same pair).  mode 0 = automatic (default), 1 = Lanczos on L restricted to 1-perp,
  * 2 = preconditioned (LOBPCG with a tridiagonal odometry-chain solve; the drop-in maps
- * 'tracemin_pcg' here).  Mode 2 needs n <= 16384 and falls back to mode 1 when it does not apply
- * or stagnates; results obey the same stop rule either way. */
+ * 'tracemin_pcg' here).  Mode 2 falls back to mode 1 when it does not apply (n <= 256) or
+ * stagnates; results obey the same stop rule either way. */
 int machip_set_solver(machip_problem* p, int mode);
 
 int machip_synchronize(machip_problem* p);

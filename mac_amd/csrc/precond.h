@@ -24,7 +24,8 @@ namespace machip {
 
 constexpr int kTriThreads = 1024;
 constexpr int kTriCMax = 16;                       // unknowns per thread held in registers
-constexpr int kTriMaxN = kTriThreads * kTriCMax;   // 16384
+constexpr int kTriMaxN = kTriThreads * kTriCMax;   // 16384: above it the chunk lives in global scratch (k_tri_*_big)
+constexpr int kTriBigMaxN = 1 << 21;
 constexpr int kLobNS = 15;                         // sums per Rayleigh-Ritz step
 constexpr int kLobMaxChunk = 32;
 
@@ -41,6 +42,7 @@ struct LobView {
     double *x, *Lx, *p, *Lp, *Lw;      // natural order
     double *rT, *wT;                   // chunk-transposed: element e = t*c + i sits at i*1024 + t
     double *tl, *tdinv, *tcu;          // LU of T, chunk-transposed (zero padded)
+    double *ys, *pas;                  // chunk scratch of the big-n solver (c > 16), same layout
     double* part;                      // [kLobNS][kMaxGrid] partial sums of the SpMV kernel
     double* partR;                     // [kMaxGrid] ||r||_1 partials of the update kernel
     int P_c, P_a;
@@ -185,6 +187,85 @@ __global__ __launch_bounds__(kTriThreads) void k_tri_factor(CsrView A, int c, do
         }
     }
     if (isbad) *bad = 1;
+}
+
+// ---- the same two kernels for c > 16 (n > 16 384): the per-thread chunk no longer fits in registers
+// and lives in global scratch (chunk-transposed, so still coalesced; every thread only re-reads what
+// it wrote itself).  One CU streams ~10 n doubles per application: 46 us at n = 10^5 -- slow for a
+// kernel, but it replaces ~10^4..10^5 dependent Lanczos launches on a stiff chain of that length.
+__global__ __launch_bounds__(kTriThreads) void k_tri_factor_big(CsrView A, int c, double sigma, double* tl, double* tdinv,
+                                                                double* tcu, double* as, double* bs, int* bad) {
+    __shared__ Mob sM[16];
+    const int t = threadIdx.x, n = A.n;
+    Mob M{1.0, 0.0, 0.0, 1.0};
+    for (int i = 0; i < c; ++i) {
+        const int e = t * c + i, k = i * kTriThreads + t;
+        double a = 0.0, b = 1.0;
+        if (e < n) {
+            b = 0.0;
+            for (int p = A.rowptr[e]; p < A.rowptr[e + 1]; ++p) {
+                const int col = A.col[p];
+                if (col == e) b += A.val[p];
+                else if (col == e - 1) a += A.val[p];
+            }
+            b += sigma;
+            M = mob_mul(Mob{b, -a * a, 1.0, 0.0}, M);
+        }
+        as[k] = a; bs[k] = b;
+    }
+    double p_in, q_in;
+    mob_carry_in(M, sM, &p_in, &q_in);
+    double rinv = (t == 0 || p_in == 0.0) ? 0.0 : q_in / p_in;
+    int isbad = 0;
+    for (int i = 0; i < c; ++i) {
+        const int e = t * c + i, k = i * kTriThreads + t;
+        double l = 0.0, dinv = 0.0;
+        if (e < n) {
+            const double a = as[k];
+            l = a * rinv;
+            const double u = bs[k] - a * a * rinv;
+            if (!(u > 0.0)) isbad = 1;
+            rinv = 1.0 / u;
+            dinv = rinv;
+        }
+        tl[k] = l; tdinv[k] = dinv;
+    }
+    __syncthreads();                     // as[] of the neighbouring thread (same CU: L1 is shared, stores drained)
+    for (int i = 0; i < c; ++i) {
+        const int e = t * c + i, k = i * kTriThreads + t;
+        double cu = 0.0;
+        if (e + 1 < n) cu = as[tri_perm(e + 1, c)] * tdinv[k];
+        tcu[k] = cu;
+    }
+    if (isbad) *bad = 1;
+}
+
+__global__ __launch_bounds__(kTriThreads) void k_tri_solve_big(LobView L, int jrel) {
+    __shared__ double sA[16], sB[16];
+    const int t = threadIdx.x, c = L.c;
+    (void)jrel;
+    double run = 0.0, prod = 1.0;
+    for (int i = 0; i < c; ++i) {
+        const int k = i * kTriThreads + t;
+        const double l = L.tl[k];
+        run = L.rT[k] - l * run;
+        prod = -l * prod;
+        L.ys[k] = run; L.pas[k] = prod;
+    }
+    const double carry = affine_carry_in<false>(prod, run, sA, sB);
+    double xr = 0.0, pb = 1.0;
+    for (int i = c - 1; i >= 0; --i) {
+        const int k = i * kTriThreads + t;
+        const double cu = L.tcu[k];
+        xr = (L.ys[k] + L.pas[k] * carry) * L.tdinv[k] - cu * xr;
+        pb = -cu * pb;
+        L.ys[k] = xr; L.pas[k] = pb;
+    }
+    const double carry2 = affine_carry_in<true>(pb, xr, sA, sB);
+    for (int i = 0; i < c; ++i) {
+        const int k = i * kTriThreads + t;
+        L.wT[k] = L.ys[k] + L.pas[k] * carry2;
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void k_lob_perm_cols(const int* __restrict__ col, long nnz, int c, int* __restrict__ colT) {

@@ -219,6 +219,7 @@ struct Solver {
     // preconditioned mode (precond.h): allocated on first use
     double *lx_x = nullptr, *lx_Lx = nullptr, *lx_p = nullptr, *lx_Lp = nullptr, *lx_Lw = nullptr;
     double *lx_rT = nullptr, *lx_wT = nullptr, *lx_tl = nullptr, *lx_tdinv = nullptr, *lx_tcu = nullptr;
+    double *lx_ys = nullptr, *lx_pas = nullptr, *lx_as = nullptr, *lx_bs = nullptr;   // big-n solver scratch
     double *lx_part = nullptr, *lx_partR = nullptr;
     int *lx_colT = nullptr, *lx_bad = nullptr;
     size_t lx_colT_cap = 0;
@@ -274,6 +275,7 @@ struct Solver {
         void* ptrs[] = {u, V, tri, part, Z0, Z1, st, st2, y_raw, w2, yvec, ypart, sdev,
                         part_c, part_a2, part_r, scratch3, rq_dev, start, wc, ctri, part_u, part_a, stc,
                         lx_x, lx_Lx, lx_p, lx_Lp, lx_Lw, lx_rT, lx_wT, lx_tl, lx_tdinv, lx_tcu, lx_part, lx_partR,
+                        lx_ys, lx_pas, lx_as, lx_bs,
                         lx_colT, lx_bad, lx_st};
         if (h_lrec) (void)hipHostFree(h_lrec);
         for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -435,10 +437,15 @@ struct Solver {
         if (!lob_ready) {
             ST_TRY(dev_alloc(&lx_x, n)); ST_TRY(dev_alloc(&lx_Lx, n)); ST_TRY(dev_alloc(&lx_p, n));
             ST_TRY(dev_alloc(&lx_Lp, n)); ST_TRY(dev_alloc(&lx_Lw, n));
+            const size_t tcap = (size_t)kTriThreads * (size_t)((n + kTriThreads - 1) / kTriThreads);   // zero padded past n
             double** tr[] = {&lx_rT, &lx_wT, &lx_tl, &lx_tdinv, &lx_tcu};
             for (double** q : tr) {
-                ST_TRY(dev_alloc(q, (size_t)kTriMaxN));
-                HIP_TRY(hipMemsetAsync(*q, 0, sizeof(double) * (size_t)kTriMaxN, stream));
+                ST_TRY(dev_alloc(q, tcap));
+                HIP_TRY(hipMemsetAsync(*q, 0, sizeof(double) * tcap, stream));
+            }
+            if (n > kTriMaxN) {
+                double** sc[] = {&lx_ys, &lx_pas, &lx_as, &lx_bs};
+                for (double** q : sc) ST_TRY(dev_alloc(q, tcap));
             }
             ST_TRY(dev_alloc(&lx_part, (size_t)kLobNS * kMaxGrid)); ST_TRY(dev_alloc(&lx_partR, 2 * kMaxGrid));
             ST_TRY(dev_alloc(&lx_bad, 1)); ST_TRY(dev_alloc(&lx_st, 1));
@@ -458,6 +465,7 @@ struct Solver {
         L.n = n; L.c = (n + kTriThreads - 1) / kTriThreads;
         L.x = lx_x; L.Lx = lx_Lx; L.p = lx_p; L.Lp = lx_Lp; L.Lw = lx_Lw; L.rT = lx_rT; L.wT = lx_wT;
         L.tl = lx_tl; L.tdinv = lx_tdinv; L.tcu = lx_tcu; L.part = lx_part; L.partR = lx_partR;
+        L.ys = lx_ys; L.pas = lx_pas;
         L.P_c = pl.grid; L.P_a = vgrid(); L.st = lx_st; L.hrec = d_hlrec; L.hflag = d_hflag;
         return L;
     }
@@ -473,6 +481,17 @@ struct Solver {
         k_lob_tail<<<1, 64, 0, stream>>>(L, steps);
     }
     void lob_launch_chunk(const CsrView& AT, const SpmvPlan& pl, const LobView& L, int steps) {
+        if (L.c > kTriCMax) {
+            OpLob op;
+            op.L = L;
+            for (int s = 0; s < steps; ++s) {
+                k_tri_solve_big<<<1, kTriThreads, 0, stream>>>(L, s);
+                launch_spmv(pl, stream, AT, L.wT, op);
+                k_lob_update<<<L.P_a, kBlock, 0, stream>>>(L, s);
+            }
+            k_lob_tail<<<1, 64, 0, stream>>>(L, steps);
+            return;
+        }
         switch (L.c) {   // the solver kernel is instantiated per chunk length: no guards, everything in registers
 #define MACHIP_LOB_CASE(C) case C: lob_launch_chunk_t<C>(AT, pl, L, steps); break;
             MACHIP_LOB_CASE(1) MACHIP_LOB_CASE(2) MACHIP_LOB_CASE(3) MACHIP_LOB_CASE(4) MACHIP_LOB_CASE(5) MACHIP_LOB_CASE(6)
@@ -513,7 +532,8 @@ struct Solver {
         // ---- T = tridiag(L) + sigma I, factored on the device; gather indices in the solver's layout ----
         const double sigma = 2.5e-7 * scale;
         HIP_TRY(hipMemsetAsync(lx_bad, 0, sizeof(int), stream));
-        if (L.c <= 4) k_tri_factor<4><<<1, kTriThreads, 0, stream>>>(A, L.c, sigma, lx_tl, lx_tdinv, lx_tcu, lx_bad);
+        if (L.c > kTriCMax) k_tri_factor_big<<<1, kTriThreads, 0, stream>>>(A, L.c, sigma, lx_tl, lx_tdinv, lx_tcu, lx_as, lx_bs, lx_bad);
+        else if (L.c <= 4) k_tri_factor<4><<<1, kTriThreads, 0, stream>>>(A, L.c, sigma, lx_tl, lx_tdinv, lx_tcu, lx_bad);
         else if (L.c <= 8) k_tri_factor<8><<<1, kTriThreads, 0, stream>>>(A, L.c, sigma, lx_tl, lx_tdinv, lx_tcu, lx_bad);
         else k_tri_factor<16><<<1, kTriThreads, 0, stream>>>(A, L.c, sigma, lx_tl, lx_tdinv, lx_tcu, lx_bad);
         k_lob_perm_cols<<<(int)std::min<long>(kMaxGrid, (nnz + kBlock - 1) / kBlock), kBlock, 0, stream>>>(A.col, nnz, L.c, lx_colT);
@@ -606,7 +626,7 @@ struct Solver {
             else if (!strcmp(e, "auto")) mode = 0;
         }
         // auto: chain-dominated graphs with few active closures per node (measured cross-over)
-        const bool eligible = n > 256 && n <= kTriMaxN;
+        const bool eligible = n > 256 && n <= kTriBigMaxN;
         // One preconditioned iteration costs about `ratio` Lanczos steps (three launches, one of them a
         // single workgroup).  Sparse closures: preconditioned.  Denser closures: only when the last
         // Lanczos solve of this problem was long (a stiff x) and the preconditioned mode has not been seen

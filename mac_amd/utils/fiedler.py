@@ -32,7 +32,7 @@ def solver_mode(method):
     """libmachip eigen-solver mode for a method string (machip_set_solver): 'hip' and the reference's
     direct-solver flavours pick automatically, 'hip_lanczos' forces the Lanczos path, and the
     reference's preconditioned flavour 'tracemin_pcg' (nx:22-76) -- like 'hip_lobpcg' -- asks for the
-    preconditioned mode (LOBPCG + tridiagonal chain solve; needs n <= 16384, else Lanczos runs)."""
+    preconditioned mode (LOBPCG + tridiagonal chain solve)."""
     check_method(method)
     return {"hip_lanczos": 1, "hip_lobpcg": 2, "tracemin_pcg": 2}.get(method, 0)
 

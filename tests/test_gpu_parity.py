@@ -190,15 +190,23 @@ def test_preconditioned_mode_fallbacks_and_errors():
     P.set_solver(2); lam2, v2, _ = P.fiedler()
     assert abs(lam1 - lam2) <= LAM_RTOL * lam1 and P.stats.residual < 1e-8
     P.close()
-    # (b) n above the register-resident solver's limit: mode 2 silently runs the Lanczos path
+    # (b) n above the register-resident solver's limit (16 384): the global-scratch tridiagonal kernels run
     n = 20000
     fi = np.arange(n - 1, dtype=np.int32)
     ci = rng.integers(0, n - 50, 4000).astype(np.int32); cj = (ci + rng.integers(2, 50, 4000)).astype(np.int32)
     P = _lib.Problem(n, fi, fi + 1, np.full(n - 1, 50.0), ci, cj, np.full(4000, 20.0))
     P.set_x(np.ones(4000))
-    P.set_solver(2); lam2, _, _ = P.fiedler()
-    P.set_solver(1); lam1, _, _ = P.fiedler()
-    assert lam1 == lam2
+    P.set_solver(2); lam2, v2, _ = P.fiedler(); it2 = int(P.stats.lanczos_steps)
+    assert P.stats.residual < 1e-8
+    P.set_solver(1); lam1, v1, _ = P.fiedler(); it1 = int(P.stats.lanczos_steps)
+    assert abs(lam1 - lam2) <= LAM_RTOL * lam1 and it1 > 0 and it2 > 0
+    assert min(np.abs(v1 - v2).max(), np.abs(v1 + v2).max()) < 1e-4
+    P.close()
+    # a pure path of that size has the closed form 2 - 2 cos(pi / n)
+    P = _lib.Problem(n, fi, fi + 1, np.ones(n - 1), np.array([0], np.int32), np.array([2], np.int32), np.ones(1))
+    P.set_x(np.zeros(1))
+    lam, _, _ = P.fiedler()
+    assert abs(lam - (2 - 2 * np.cos(np.pi / n))) <= LAM_RTOL * lam and P.stats.lanczos_steps < 100
     P.close()
     # (c) disconnected graph: same status as the Lanczos mode
     n = 600
