@@ -2,9 +2,9 @@
 //
 // On the pose graphs of BASELINE.json configs[2] and [4] (intel: n = 1 728, sphere2500: n = 2 500;
 // also kitti_05) the whole matrix is a few tens of KB and a Lanczos step of the multi-workgroup
-// path is nothing but launch latency (~4.5 us for ~0.2 us of work).  Here one workgroup (4 waves)
+// path is nothing but launch latency (~4.5 us for ~0.2 us of work).  Here one workgroup (8 waves)
 // keeps the gather operand and the off-band entries in LDS (148 of the CU's 160 KB), every thread
-// owns up to 12 rows in registers, and a chunk of Lanczos steps runs inside ONE launch: the two
+// owns up to 6 rows in registers, and a chunk of Lanczos steps runs inside ONE launch: the two
 // global reductions of a step are workgroup reductions (DPP wave totals + 16 LDS words + a barrier).
 // Classic three-term form (beta_j from the vector itself), so it also serves restarts.  Same
 // records / flag protocol towards the host as k_pipe_tail, same basis V in HBM for the Ritz vector.
@@ -19,11 +19,13 @@ namespace machip {
 #define PCLK(cond, i) do { } while (0)
 #endif
 
-constexpr int kPersistThreads = 256;      // 4 waves, one per SIMD: the kernel is FP64-issue bound, and every extra
-                                           // wave repeats the reduction epilogues (1 024 threads: 3.1 us/step at n = 1 728)
+constexpr int kPersistThreads = 512;      // 8 waves, two per SIMD.  The kernel is FP64-issue / latency bound: a second
+                                           // wave per SIMD hides the dependent-op latency, more waves only repeat the
+                                           // reduction epilogues (intel / sphere2500 FW it/s: 256 threads 329 / 702,
+                                           // 512 threads 430 / 990, 1 024 threads 397 / 746)
 constexpr int kPersistPool = 148 * 1024;   // bytes of LDS for val, col, rowptr and the gather operand
 constexpr int kPersistMaxSteps = 256;      // steps per launch (records staged in LDS)
-constexpr int kPersistMaxRows = 12;        // rows per thread held in registers (instantiated for 4, 8, 12): n <= 3072;
+constexpr int kPersistMaxRows = 6;        // rows per thread held in registers (instantiated for 4, 8, 12): n <= 3072;
                                            // beyond that the register file spills and one CU's FP64 issue rate loses
                                            // to the multi-workgroup path (n = 4 661: 4.0 us/step either way)
 
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_lan_persist(CsrView A, Pers
         u[k] = r < n ? L.u[r] : 0.0;
         vp[k] = r < n ? L.vprev[r] : 0.0;
     }
-    const double dn = (double)n;
+    const double dn = (double)n, rdn = 1.0 / dn;
     __syncthreads();
     PCLK(true, 1);
     for (int s = 0; s <= steps; ++s) {
@@ -175,14 +177,15 @@ __global__ __launch_bounds__(kPersistThreads) void k_lan_persist(CsrView A, Pers
         for (int k = 0; k < RPT; ++k) { s1 += u[k]; s2 += u[k] * u[k]; }
         persist_sum2(s1, s2, red1);
         PCLK(s == 0, 2);
-        const double mu = s1 / dn;
+        const double mu = s1 * rdn;
         const double nrm2 = s2 - dn * mu * mu;
-        const double beta = nrm2 > 0.0 ? sqrt(nrm2) : 0.0;
+        const double rs = nrm2 > 1e-290 ? rsqrt(nrm2) : 0.0;
+        const double beta = nrm2 * rs;
         if (s == steps) {              // chunk end: only beta_J is needed (the host's residual estimate)
             if (t == 0) { srec[3 * s] = 0.0; srec[3 * s + 1] = beta; }
             break;
         }
-        const double inv = beta > 1e-290 ? 1.0 / beta : 0.0;
+        const double inv = rs;
         double l1 = 0.0, al = 0.0;
         double* vj = L.V + (size_t)j * (size_t)n;
 #pragma unroll

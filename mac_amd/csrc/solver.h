@@ -331,10 +331,10 @@ struct Solver {
     }
     void launch_persist(const CsrView& A, int steps) {
         const PersistView L = persist_view();
-        switch ((n + 4 * kPersistThreads - 1) / (4 * kPersistThreads)) {   // rows per thread, rounded up to 4
-            case 1: k_lan_persist<4><<<1, kPersistThreads, 0, stream>>>(A, L, steps); break;
-            case 2: k_lan_persist<8><<<1, kPersistThreads, 0, stream>>>(A, L, steps); break;
-            default: k_lan_persist<12><<<1, kPersistThreads, 0, stream>>>(A, L, steps); break;
+        switch ((n + 2 * kPersistThreads - 1) / (2 * kPersistThreads)) {   // rows per thread, rounded up to 2
+            case 1: k_lan_persist<2><<<1, kPersistThreads, 0, stream>>>(A, L, steps); break;
+            case 2: k_lan_persist<4><<<1, kPersistThreads, 0, stream>>>(A, L, steps); break;
+            default: k_lan_persist<6><<<1, kPersistThreads, 0, stream>>>(A, L, steps); break;
         }
     }
 

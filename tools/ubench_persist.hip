@@ -44,10 +44,10 @@ int main(int argc, char** argv) {
             CK(hipMemcpyAsync(L.u, u0.data(), n * 8, hipMemcpyHostToDevice, s));
             k_persist_begin<<<8, 256, 0, s>>>(L, 1);
             CK(hipEventRecord(e0, s));
-            switch ((n + 4 * kPersistThreads - 1) / (4 * kPersistThreads)) {
-                case 1: k_lan_persist<4><<<1, kPersistThreads, 0, s>>>(A, L, steps); break;
-                case 2: k_lan_persist<8><<<1, kPersistThreads, 0, s>>>(A, L, steps); break;
-                default: k_lan_persist<12><<<1, kPersistThreads, 0, s>>>(A, L, steps); break;
+            switch ((n + 2 * kPersistThreads - 1) / (2 * kPersistThreads)) {   // rows per thread, rounded up to 2
+                case 1: k_lan_persist<2><<<1, kPersistThreads, 0, s>>>(A, L, steps); break;
+                case 2: k_lan_persist<4><<<1, kPersistThreads, 0, s>>>(A, L, steps); break;
+                default: k_lan_persist<6><<<1, kPersistThreads, 0, s>>>(A, L, steps); break;
             }
             CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
