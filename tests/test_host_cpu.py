@@ -126,6 +126,18 @@ def test_unknown_method_raises_like_reference():
         find_fiedler_pair(sp.identity(4, format="csr"), method="bogus")
 
 
+def test_method_strings_map_to_solver_modes():
+    """fiedler_method -> machip_set_solver mode: the reference's direct-solver flavours and 'hip' pick
+    automatically, 'tracemin_pcg' (the reference's preconditioned flavour, nx:22-76) asks for the
+    preconditioned mode, the explicit 'hip_*' names force one."""
+    from mac_amd.utils.fiedler import solver_mode, UnknownFiedlerMethod
+    assert solver_mode("hip") == 0 and solver_mode("tracemin_lu") == 0 and solver_mode("tracemin_cholesky") == 0
+    assert solver_mode("hip_lanczos") == 1
+    assert solver_mode("tracemin_pcg") == 2 and solver_mode("hip_lobpcg") == 2
+    with pytest.raises(UnknownFiedlerMethod):
+        solver_mode("lobpcg")
+
+
 @pytest.mark.parametrize("nm", ["intel", "sphere2500", "city10000", "kitti_05"])
 def test_g2o_reader_matches_reference_golden(nm):
     """Edge arrays produced by the reference's own reader (examples/pose_graph_utils.py) were
