@@ -234,7 +234,7 @@ int run_fiedler(machip_problem* p, double tol, int max_steps, const double* x0, 
     machip_solve_stats local;
     memset(&local, 0, sizeof(local));
     p->sol.maxlen_hint = p->maxlen;
-    p->sol.support_hint = p->csr_only ? -1 : p->support;
+    p->sol.support_hint = (p->csr_only && !p->sol.chain_like) ? -1 : p->support;
     const int st = p->sol.solve(p->csr(), p->nnz, p->lnorm, tol, max_steps, (x0 == nullptr && warm_start) ? 1 : 0,
                                 kAuto, lambda2, &local);
     local.support = p->support;
@@ -486,12 +486,14 @@ int machip_fiedler_csr(int device, int64_t n, const int32_t* indptr, const int32
     if (indptr[0] != 0 || nnz < 0) return fail(MACHIP_BAD_ARG, "bad indptr");
     double lnorm = 0.0;
     int maxlen_csr = 0;
+    long chain_cnt = 0;   // super-diagonal entries: a pose-graph Laplacian carries the chain (i, i+1)
     for (int64_t r = 0; r < n; ++r) {
         if (indptr[r + 1] < indptr[r]) return fail(MACHIP_BAD_ARG, "indptr not monotone");
         double s = 0.0;
         for (int pp = indptr[r]; pp < indptr[r + 1]; ++pp) {
             if (indices[pp] < 0 || indices[pp] >= n) return fail(MACHIP_BAD_ARG, "column index out of range");
             s += std::fabs(data[pp]);
+            if (indices[pp] == r + 1 && data[pp] != 0.0) ++chain_cnt;
         }
         lnorm = std::max(lnorm, s);   // nx:232
         maxlen_csr = std::max(maxlen_csr, (int)(indptr[r + 1] - indptr[r]));
@@ -508,6 +510,11 @@ int machip_fiedler_csr(int device, int64_t n, const int32_t* indptr, const int32
         }
         ST_TRY(alloc_common(p));
         p->nnz = nnz; p->lnorm = lnorm; p->maxlen = maxlen_csr; p->assembled = true;
+        // same solver selection as a MAC handle gets (solver.h): chain-like matrices may run the
+        // single-workgroup / preconditioned modes; "support" = off-chain edges
+        p->sol.chain_like = chain_cnt >= (long)(0.98 * (double)(n - 1));
+        p->sol.chain_edges = chain_cnt;
+        p->support = std::max<long>(0, (nnz - n) / 2 - chain_cnt);
         return MACHIP_OK;
     };
     int st = body();

@@ -808,3 +808,18 @@ def test_config2_twenty_iterations_match_reference_trajectory():
     assert abs(w.sum() - k) < 1e-6 and abs(float(g["unrounded_sum"]) - k) < 1e-6
     assert int(P.round_nearest(k, decimals=10).sum()) == k == len(g["rounded_idx"])
     P.close()
+
+
+def test_find_fiedler_pair_on_pose_graph_laplacians_uses_the_structured_modes():
+    """The bare find_fiedler_pair(L) surface (mac/utils/fiedler.py:9-44) detects a chain-like Laplacian
+    from the CSR itself: same pair as the forced Lanczos path, far fewer dependent launches on a stiff one."""
+    g = load_golden("g2o_kitti_05")
+    mac = MAC(edges_of(g, "f"), edges_of(g, "c"), int(g["n"]), fiedler_method="hip_lanczos")
+    L = mac.laplacian(g["x_init"])
+    lam_ref = mac.evaluate_objective(g["x_init"]); steps_ref = mac.last_stats["lanczos_steps"]
+    lam, v, X = find_fiedler_pair(L)
+    assert abs(lam - lam_ref) <= LAM_RTOL * lam_ref and abs(lam - g["lam_init"]) <= LAM_RTOL * g["lam_init"]
+    assert X.shape == (int(g["n"]), 4) and np.abs(X.T @ X - np.eye(4)).max() < 1e-6 and np.allclose(X[:, 0], v)
+    indptr, indices, data = L.indptr, L.indices, L.data
+    _, _, _, st = _lib.fiedler_csr(indptr, indices, data, int(g["n"]))
+    assert st.lanczos_steps * 5 < steps_ref and st.residual < 1e-8
