@@ -51,7 +51,8 @@ def find_fiedler_pair(L, X=None, method="hip", tol=1e-8, seed=None):
 
     Returns ``(lambda_2, v_2, X)`` like the reference: X is n x q (q = min(4, n-1)), its
     column 0 is v_2 (unit norm, orthogonal to 1) and the other columns are the next Ritz
-    vectors of the Krylov space.  ``X`` (if given) supplies the start vector in column 0.
+    vectors of the Krylov space (after the preconditioned mode, which keeps no Krylov basis: an
+    orthonormal completion orthogonal to 1 and v_2).  ``X`` (if given) supplies the start vector in column 0.
     """
     check_method(method)
     L = csr_matrix(L, dtype=np.float64)
