@@ -632,8 +632,11 @@ struct Solver {
         // Lanczos solve of this problem was long (a stiff x) and the preconditioned mode has not been seen
         // to need more than 1/ratio of those steps.  Counts only -- never timings -- so the choice, and
         // with it every rounding of the trajectory, is reproducible run to run.
-        const long ratio = n <= kPersistThreads * kPersistMaxRows ? 9 : 6;
-        const bool sparse = (double)support_hint <= env_int("MACHIP_LOB_DENSITY_PCT", 12) * 0.01 * (double)n;
+        // (where the single-workgroup Lanczos applies a step costs ~2 us instead of ~4.5: higher bar there --
+        // measured: intel at 9 % closures/node 3.5 ms Lanczos vs 4.7 ms preconditioned, kitti_05 at 0.5 %: 8.6 vs 1.1)
+        const bool small = n <= kPersistThreads * kPersistMaxRows;
+        const long ratio = small ? 9 : 6;
+        const bool sparse = (double)support_hint <= env_int("MACHIP_LOB_DENSITY_PCT", small ? 3 : 12) * 0.01 * (double)n;
         const bool stiff = hist_lan_steps > 2500 && (hist_lob_iters < 0 || hist_lob_iters * ratio < hist_lan_steps);
         const bool slow_lob = hist_lan_steps > 0 && hist_lob_iters > 0 && hist_lob_iters * ratio > 2 * hist_lan_steps;
         const bool want = mode == 2 || (mode == 0 && chain_like && support_hint >= 0 && ((sparse && !slow_lob) || stiff));
