@@ -130,29 +130,27 @@ __device__ __forceinline__ void mob_carry_in(Mob M, Mob* sM, double* p_in, doubl
 // ---- T = tridiag(L) + sigma I = L U, pivots by the continued fraction u_e = b_e - a_e^2/u_{e-1}
 // (a_e = L[e, e-1]), parallelised as a scan of Moebius maps.  One workgroup of 1024 threads.
 // bad[0] <- 1 when a pivot is not positive (T not positive definite: caller falls back).
-template <int CMAX>
-__global__ __launch_bounds__(kTriThreads) void k_tri_factor(CsrView A, int c, double sigma, double* tl,
+template <int C>
+__global__ __launch_bounds__(kTriThreads) void k_tri_factor(CsrView A, double sigma, double* tl,
                                                             double* tdinv, double* tcu, int* bad) {
     __shared__ Mob sM[16];
     __shared__ double s_afirst[kTriThreads + 1];
-    const int t = threadIdx.x, n = A.n;
-    double av[CMAX], bv[CMAX];
+    const int t = threadIdx.x, n = A.n;   // thread t owns the unknowns e = t*C .. t*C + C-1 (zero padded past n)
+    double av[C], bv[C];
     Mob M{1.0, 0.0, 0.0, 1.0};
 #pragma unroll
-    for (int i = 0; i < CMAX; ++i) {
+    for (int i = 0; i < C; ++i) {
         av[i] = 0.0; bv[i] = 1.0;
-        if (i < c) {
-            const int e = t * c + i;
-            if (e < n) {
-                double a = 0.0, b = 0.0;
-                for (int p = A.rowptr[e]; p < A.rowptr[e + 1]; ++p) {
-                    const int col = A.col[p];
-                    if (col == e) b += A.val[p];
-                    else if (col == e - 1) a += A.val[p];
-                }
-                av[i] = a; bv[i] = b + sigma;
-                M = mob_mul(Mob{bv[i], -a * a, 1.0, 0.0}, M);
+        const int e = t * C + i;
+        if (e < n) {
+            double a = 0.0, b = 0.0;
+            for (int p = A.rowptr[e]; p < A.rowptr[e + 1]; ++p) {
+                const int col = A.col[p];
+                if (col == e) b += A.val[p];
+                else if (col == e - 1) a += A.val[p];
             }
+            av[i] = a; bv[i] = b + sigma;
+            M = mob_mul(Mob{bv[i], -a * a, 1.0, 0.0}, M);
         }
     }
     s_afirst[t] = av[0];
@@ -162,29 +160,25 @@ __global__ __launch_bounds__(kTriThreads) void k_tri_factor(CsrView A, int c, do
     double rinv = (t == 0 || p_in == 0.0) ? 0.0 : q_in / p_in;   // 1 / u_{e-1}
     int isbad = 0;
 #pragma unroll
-    for (int i = 0; i < CMAX; ++i) {
-        if (i < c) {
-            const int e = t * c + i, k = i * kTriThreads + t;
-            double l = 0.0, dinv = 0.0;
-            if (e < n) {
-                l = av[i] * rinv;
-                const double u = bv[i] - av[i] * av[i] * rinv;
-                if (!(u > 0.0)) isbad = 1;
-                rinv = 1.0 / u;
-                dinv = rinv;
-            }
-            tl[k] = l; tdinv[k] = dinv;
-            bv[i] = dinv;
+    for (int i = 0; i < C; ++i) {
+        const int e = t * C + i, k = i * kTriThreads + t;
+        double l = 0.0, dinv = 0.0;
+        if (e < n) {
+            l = av[i] * rinv;
+            const double u = bv[i] - av[i] * av[i] * rinv;
+            if (!(u > 0.0)) isbad = 1;
+            rinv = 1.0 / u;
+            dinv = rinv;
         }
+        tl[k] = l; tdinv[k] = dinv;
+        bv[i] = dinv;
     }
 #pragma unroll
-    for (int i = 0; i < CMAX; ++i) {
-        if (i < c) {
-            const int e = t * c + i, k = i * kTriThreads + t;
-            double anext = 0.0;   // a_{e+1}: next element of the chunk (constant index after unrolling) or of the next thread
-            if (e + 1 < n) anext = (i + 1 < c) ? av[i + 1 < CMAX ? i + 1 : CMAX - 1] : s_afirst[t + 1];
-            tcu[k] = (e < n) ? anext * bv[i] : 0.0;
-        }
+    for (int i = 0; i < C; ++i) {
+        const int e = t * C + i, k = i * kTriThreads + t;
+        double anext = 0.0;   // a_{e+1}: next element of the chunk (constant index after unrolling) or of the next thread
+        if (e + 1 < n) anext = (i + 1 < C) ? av[i + 1 < C ? i + 1 : C - 1] : s_afirst[t + 1];
+        tcu[k] = (e < n) ? anext * bv[i] : 0.0;
     }
     if (isbad) *bad = 1;
 }
@@ -358,37 +352,49 @@ struct OpLob {
 struct LobCoef { double z0, z1, z2, theta, mx, mw, mp; int bad; };
 
 // Fallback eigen-solver (cyclic Jacobi) for the rare case the Rayleigh-quotient iteration below did
-// not land on the smallest eigenvalue.  Kept out of line: its dynamically indexed arrays live in
-// scratch memory, which the common path must not pay for.
-__device__ __noinline__ void jacobi3_smallest(const double* Cin, double* theta, double* yv) {
-    double C[3][3], V[3][3] = {{1.0, 0.0, 0.0}, {0.0, 1.0, 0.0}, {0.0, 0.0, 1.0}};
-    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) C[a][b] = Cin[a * 3 + b];
-    for (int sweep = 0; sweep < 6; ++sweep) {
-        for (int a = 0; a < 2; ++a)
-            for (int b = a + 1; b < 3; ++b) {
-                const double apq = C[a][b];
-                if (fabs(apq) <= 1e-300) continue;
-                const double tau = (C[b][b] - C[a][a]) / (2.0 * apq);
-                const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                const double cs = rsqrt(1.0 + tt * tt), sn = tt * cs;
-                for (int q = 0; q < 3; ++q) {
-                    const double cqa = C[q][a], cqb = C[q][b];
-                    C[q][a] = cs * cqa - sn * cqb; C[q][b] = sn * cqa + cs * cqb;
-                }
-                for (int q = 0; q < 3; ++q) {
-                    const double caq = C[a][q], cbq = C[b][q];
-                    C[a][q] = cs * caq - sn * cbq; C[b][q] = sn * caq + cs * cbq;
-                }
-                for (int q = 0; q < 3; ++q) {
-                    const double vqa = V[q][a], vqb = V[q][b];
-                    V[q][a] = cs * vqa - sn * vqb; V[q][b] = sn * vqa + cs * vqb;
-                }
-            }
+// not land on the smallest eigenvalue.  Fully unrolled: every index is a compile-time constant, so the
+// matrices stay in registers (a kernel that touches scratch memory pays for it at every launch).
+template <int A, int B>
+__device__ __forceinline__ void jacobi3_rotate(double (&C)[3][3], double (&V)[3][3]) {
+    const double apq = C[A][B];
+    if (fabs(apq) <= 1e-300) return;
+    const double tau = (C[B][B] - C[A][A]) / (2.0 * apq);
+    const double tt = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+    const double cs = rsqrt(1.0 + tt * tt), sn = tt * cs;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const double cqa = C[q][A], cqb = C[q][B];
+        C[q][A] = cs * cqa - sn * cqb; C[q][B] = sn * cqa + cs * cqb;
     }
-    int best = 0;
-    for (int a = 1; a < 3; ++a) if (C[a][a] < C[best][best]) best = a;
-    *theta = C[best][best];
-    for (int q = 0; q < 3; ++q) yv[q] = V[q][best];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const double caq = C[A][q], cbq = C[B][q];
+        C[A][q] = cs * caq - sn * cbq; C[B][q] = sn * caq + cs * cbq;
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const double vqa = V[q][A], vqb = V[q][B];
+        V[q][A] = cs * vqa - sn * vqb; V[q][B] = sn * vqa + cs * vqb;
+    }
+}
+__device__ __forceinline__ void jacobi3_smallest(double c00, double c01, double c02, double c11, double c12, double c22,
+                                                 double* theta, double* y0, double* y1, double* y2) {
+    double C[3][3] = {{c00, c01, c02}, {c01, c11, c12}, {c02, c12, c22}};
+    double V[3][3] = {{1.0, 0.0, 0.0}, {0.0, 1.0, 0.0}, {0.0, 0.0, 1.0}};
+#pragma unroll
+    for (int sweep = 0; sweep < 6; ++sweep) {
+        jacobi3_rotate<0, 1>(C, V);
+        jacobi3_rotate<0, 2>(C, V);
+        jacobi3_rotate<1, 2>(C, V);
+    }
+    // selects, not branches: a data-dependent column index would put V in scratch memory
+    const bool s1 = C[1][1] < C[0][0];
+    double th = s1 ? C[1][1] : C[0][0];
+    double a0 = s1 ? V[0][1] : V[0][0], a1 = s1 ? V[1][1] : V[1][0], a2 = s1 ? V[2][1] : V[2][0];
+    const bool s2 = C[2][2] < th;
+    th = s2 ? C[2][2] : th;
+    a0 = s2 ? V[0][2] : a0; a1 = s2 ? V[1][2] : a1; a2 = s2 ? V[2][2] : a2;
+    *theta = th; *y0 = a0; *y1 = a1; *y2 = a2;
 }
 
 // All scalars: nothing here may be indexed dynamically (that would put it in scratch memory).
@@ -470,10 +476,7 @@ __device__ __forceinline__ LobCoef lob_rayleigh_ritz(const double* s, int n, boo
         const double min2 = m00 * m11 - C01 * C01;
         const double det = m00 * (m11 * m22 - C12 * C12) - C01 * (C01 * m22 - C12 * C02) + C02 * (C01 * C12 - m11 * C02);
         if (!(m00 > 0.0 && min2 > 0.0 && det > 0.0)) {   // not the smallest one
-            const double Cm[9] = {C00, C01, C02, C01, C11, C12, C02, C12, C22};
-            double yv[3];
-            jacobi3_smallest(Cm, &theta, yv);
-            y0 = yv[0]; y1 = yv[1]; y2 = yv[2];
+            jacobi3_smallest(C00, C01, C02, C11, C12, C22, &theta, &y0, &y1, &y2);
         }
     }
     // back to the coefficients of (x, w, p): z = D Ri y

@@ -533,9 +533,14 @@ struct Solver {
         const double sigma = 2.5e-7 * scale;
         HIP_TRY(hipMemsetAsync(lx_bad, 0, sizeof(int), stream));
         if (L.c > kTriCMax) k_tri_factor_big<<<1, kTriThreads, 0, stream>>>(A, L.c, sigma, lx_tl, lx_tdinv, lx_tcu, lx_as, lx_bs, lx_bad);
-        else if (L.c <= 4) k_tri_factor<4><<<1, kTriThreads, 0, stream>>>(A, L.c, sigma, lx_tl, lx_tdinv, lx_tcu, lx_bad);
-        else if (L.c <= 8) k_tri_factor<8><<<1, kTriThreads, 0, stream>>>(A, L.c, sigma, lx_tl, lx_tdinv, lx_tcu, lx_bad);
-        else k_tri_factor<16><<<1, kTriThreads, 0, stream>>>(A, L.c, sigma, lx_tl, lx_tdinv, lx_tcu, lx_bad);
+        else switch (L.c) {
+#define MACHIP_LOB_CASE(C) case C: k_tri_factor<C><<<1, kTriThreads, 0, stream>>>(A, sigma, lx_tl, lx_tdinv, lx_tcu, lx_bad); break;
+            MACHIP_LOB_CASE(1) MACHIP_LOB_CASE(2) MACHIP_LOB_CASE(3) MACHIP_LOB_CASE(4) MACHIP_LOB_CASE(5) MACHIP_LOB_CASE(6)
+            MACHIP_LOB_CASE(7) MACHIP_LOB_CASE(8) MACHIP_LOB_CASE(9) MACHIP_LOB_CASE(10) MACHIP_LOB_CASE(11) MACHIP_LOB_CASE(12)
+            MACHIP_LOB_CASE(13) MACHIP_LOB_CASE(14) MACHIP_LOB_CASE(15)
+#undef MACHIP_LOB_CASE
+            default: k_tri_factor<16><<<1, kTriThreads, 0, stream>>>(A, sigma, lx_tl, lx_tdinv, lx_tcu, lx_bad); break;
+        }
         k_lob_perm_cols<<<(int)std::min<long>(kMaxGrid, (nnz + kBlock - 1) / kBlock), kBlock, 0, stream>>>(A.col, nnz, L.c, lx_colT);
         CsrView AT = A;
         AT.col = lx_colT;
