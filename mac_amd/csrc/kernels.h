@@ -229,7 +229,7 @@ __device__ __forceinline__ void spmv_rows_stream(const CsrView& A, const double*
     for (int tile = blockIdx.x; tile * R < A.n; tile += gridDim.x) {
         const int r0 = tile * R;
         const int nr = min(R, A.n - r0);
-        if (tid <= nr) sptr[tid] = A.rowptr[r0 + tid];
+        for (int i = tid; i <= nr; i += kBlock) sptr[i] = A.rowptr[r0 + i];   // nr + 1 offsets (TPR = 1: 257 > 256 threads)
         __syncthreads();
         const int p0 = sptr[0], p1 = sptr[nr];
         double acc = 0.0;
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(kBlock) void k_pipe_stream(CsrView A, PipeView L, i
     for (int tile = blockIdx.x; tile * R < A.n; tile += gridDim.x) {
         const int r0 = tile * R;
         const int nr = min(R, A.n - r0);
-        if (tid <= nr) sptr[tid] = A.rowptr[r0 + tid];
+        for (int i = tid; i <= nr; i += kBlock) sptr[i] = A.rowptr[r0 + i];   // nr + 1 offsets (TPR = 1: 257 > 256 threads)
         Z2 zr; zr.t = 0.0; zr.v = 0.0;
         if (row < nr && sub == 0) zr = Zc[r0 + row];
         __syncthreads();

@@ -26,6 +26,7 @@ constexpr int kTriThreads = 1024;
 constexpr int kTriCMax = 16;                       // unknowns per thread held in registers
 constexpr int kTriMaxN = kTriThreads * kTriCMax;   // 16384: above it the chunk lives in global scratch (k_tri_*_big)
 constexpr int kTriBigMaxN = 1 << 21;
+constexpr int kTriBigC = 4;                        // unknowns per thread of the multi-workgroup solver (n > 16 384)
 constexpr int kLobNS = 15;                         // sums per Rayleigh-Ritz step
 constexpr int kLobMaxChunk = 32;
 
@@ -38,11 +39,12 @@ struct LobState {
 };
 
 struct LobView {
-    int n, c;                          // c = unknowns per thread of the tridiagonal solver
+    int n, c, stride;                  // c = unknowns per thread of the tridiagonal solver, stride = threads (padded)
     double *x, *Lx, *p, *Lp, *Lw;      // natural order
-    double *rT, *wT;                   // chunk-transposed: element e = t*c + i sits at i*1024 + t
+    double *rT, *wT;                   // chunk-transposed: element e = t*c + i sits at i*stride + t
     double *tl, *tdinv, *tcu;          // LU of T, chunk-transposed (zero padded)
-    double *ys, *pas;                  // chunk scratch of the big-n solver (c > 16), same layout
+    double *ys, *pas;                  // chunk scratch of the big-n solver (n > 16 384), same layout
+    double *mapA, *mapB, *mapA2, *mapB2;   // its per-WORKGROUP affine maps (forward / backward sweep)
     double* part;                      // [kLobNS][kMaxGrid] partial sums of the SpMV kernel
     double* partR;                     // [kMaxGrid] ||r||_1 partials of the update kernel
     int P_c, P_a;
@@ -51,13 +53,13 @@ struct LobView {
     unsigned long long* hflag;
 };
 
-__device__ __forceinline__ int tri_perm(int e, int c) { return (e % c) * kTriThreads + e / c; }
+__device__ __forceinline__ int tri_perm(int e, int c, int stride) { return (e % c) * stride + e / c; }
 
 // ---- scans over the 1024 threads of the solver workgroup --------------------------------------
 // Affine maps f(y) = A y + B, composed in thread order (REV: in reverse thread order).  Returns
 // the value the composition of all earlier maps gives to 0, i.e. the carry entering this thread.
 template <bool REV>
-__device__ __forceinline__ double affine_carry_in(double A, double B, double* sA, double* sB) {
+__device__ __forceinline__ double affine_carry_in(double A, double B, double* sA, double* sB, double c0 = 0.0) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -72,7 +74,7 @@ __device__ __forceinline__ double affine_carry_in(double A, double B, double* sA
     if (REV ? lane == 63 : lane == 0) { pA = 1.0; pB = 0.0; }
     if (REV ? lane == 0 : lane == 63) { sA[w] = A; sB[w] = B; }
     __syncthreads();
-    double carry = 0.0;                              // value entering this wave
+    double carry = c0;                               // value entering this wave (c0 enters the first one)
     if (REV) { for (int k = 15; k > w; --k) carry = sA[k] * carry + sB[k]; }
     else     { for (int k = 0; k < w; ++k) carry = sA[k] * carry + sB[k]; }
     __syncthreads();
@@ -183,14 +185,20 @@ __global__ __launch_bounds__(kTriThreads) void k_tri_factor(CsrView A, double si
     if (isbad) *bad = 1;
 }
 
-// ---- the same two kernels for c > 16 (n > 16 384): the per-thread chunk no longer fits in registers
-// and lives in global scratch (chunk-transposed, so still coalesced; every thread only re-reads what
-// it wrote itself).  One CU streams ~10 n doubles per application: 46 us at n = 10^5 -- slow for a
-// kernel, but it replaces ~10^4..10^5 dependent Lanczos launches on a stiff chain of that length.
-__global__ __launch_bounds__(kTriThreads) void k_tri_factor_big(CsrView A, int c, double sigma, double* tl, double* tdinv,
+// ---- n > 16 384: the same algorithm over several workgroups ----------------------------------------
+// Chunks of kTriBigC = 4 unknowns per thread, Q = ceil(n/4) threads in Q/1024 workgroups, the chunk in
+// global scratch (chunk-transposed with stride = padded Q, so still coalesced).  Three launches per
+// solve: (1) forward sweeps with a zero carry; every workgroup also publishes the composition of its
+// 1 024 chunk maps as ONE affine map; (2) every workgroup composes the maps of all EARLIER workgroups
+// itself (<= a few hundred, identical arithmetic everywhere, no inter-workgroup signalling), scans its
+// own chunks, fixes them up and runs the backward sweeps; (3) the same from the other end.
+// ~13 n doubles of traffic spread over n/4096 CUs.  The LU is computed once per solve by a single
+// workgroup (k_tri_factor_big) straight into this layout.
+__global__ __launch_bounds__(kTriThreads) void k_tri_factor_big(CsrView A, int stride, double sigma, double* tl, double* tdinv,
                                                                 double* tcu, double* as, double* bs, int* bad) {
     __shared__ Mob sM[16];
     const int t = threadIdx.x, n = A.n;
+    const int c = (n + kTriThreads - 1) / kTriThreads;     // unknowns per thread HERE (private scratch layout i*1024 + t)
     Mob M{1.0, 0.0, 0.0, 1.0};
     for (int i = 0; i < c; ++i) {
         const int e = t * c + i, k = i * kTriThreads + t;
@@ -213,57 +221,95 @@ __global__ __launch_bounds__(kTriThreads) void k_tri_factor_big(CsrView A, int c
     int isbad = 0;
     for (int i = 0; i < c; ++i) {
         const int e = t * c + i, k = i * kTriThreads + t;
-        double l = 0.0, dinv = 0.0;
         if (e < n) {
             const double a = as[k];
-            l = a * rinv;
             const double u = bs[k] - a * a * rinv;
             if (!(u > 0.0)) isbad = 1;
+            const int ko = tri_perm(e, kTriBigC, stride);
+            tl[ko] = a * rinv;
             rinv = 1.0 / u;
-            dinv = rinv;
+            tdinv[ko] = rinv;
+            bs[k] = rinv;
         }
-        tl[k] = l; tdinv[k] = dinv;
     }
     __syncthreads();                     // as[] of the neighbouring thread (same CU: L1 is shared, stores drained)
     for (int i = 0; i < c; ++i) {
         const int e = t * c + i, k = i * kTriThreads + t;
-        double cu = 0.0;
-        if (e + 1 < n) cu = as[tri_perm(e + 1, c)] * tdinv[k];
-        tcu[k] = cu;
+        if (e < n) {
+            const int e1 = e + 1;
+            const double anext = e1 < n ? as[(e1 % c) * kTriThreads + e1 / c] : 0.0;
+            tcu[tri_perm(e, kTriBigC, stride)] = anext * bs[k];
+        }
     }
     if (isbad) *bad = 1;
 }
 
-__global__ __launch_bounds__(kTriThreads) void k_tri_solve_big(LobView L, int jrel) {
+// Product of one value per thread over the 1 024 threads (shuffle tree + 16 LDS words).
+__device__ __forceinline__ double block_prod_1024(double a, double* sP) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a *= __shfl_xor(a, o, 64);
+    if ((threadIdx.x & 63) == 0) sP[threadIdx.x >> 6] = a;
+    __syncthreads();
+    double p = 1.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) p *= sP[k];
+    __syncthreads();
+    return p;
+}
+
+__global__ __launch_bounds__(kTriThreads) void k_tri_big_fwd(LobView L) {
     __shared__ double sA[16], sB[16];
-    const int t = threadIdx.x, c = L.c;
-    (void)jrel;
+    const int q = blockIdx.x * kTriThreads + threadIdx.x, S = L.stride;
     double run = 0.0, prod = 1.0;
-    for (int i = 0; i < c; ++i) {
-        const int k = i * kTriThreads + t;
+#pragma unroll
+    for (int i = 0; i < kTriBigC; ++i) {
+        const int k = i * S + q;
         const double l = L.tl[k];
         run = L.rT[k] - l * run;
         prod = -l * prod;
         L.ys[k] = run; L.pas[k] = prod;
     }
-    const double carry = affine_carry_in<false>(prod, run, sA, sB);
+    // this workgroup's 1 024 chunk maps as one map (A, B): B = value given to 0, A = product of the A's
+    const double cin = affine_carry_in<false>(prod, run, sA, sB);
+    const double Atot = block_prod_1024(prod, sA);
+    if (threadIdx.x == kTriThreads - 1) { L.mapA[blockIdx.x] = Atot; L.mapB[blockIdx.x] = prod * cin + run; }
+}
+__global__ __launch_bounds__(kTriThreads) void k_tri_big_mid(LobView L) {
+    __shared__ double sA[16], sB[16];
+    const int q = blockIdx.x * kTriThreads + threadIdx.x, S = L.stride;
+    double c0 = 0.0;                                   // carry entering this workgroup
+    for (int g = 0; g < (int)blockIdx.x; ++g) c0 = L.mapA[g] * c0 + L.mapB[g];
+    // own chunk maps are recomputed from the stored sweeps: A = pas at the chunk end, B = ys at the chunk end
+    const int kl = (kTriBigC - 1) * S + q;
+    const double carry = affine_carry_in<false>(L.pas[kl], L.ys[kl], sA, sB, c0);
     double xr = 0.0, pb = 1.0;
-    for (int i = c - 1; i >= 0; --i) {
-        const int k = i * kTriThreads + t;
+#pragma unroll
+    for (int i = kTriBigC - 1; i >= 0; --i) {
+        const int k = i * S + q;
         const double cu = L.tcu[k];
         xr = (L.ys[k] + L.pas[k] * carry) * L.tdinv[k] - cu * xr;
         pb = -cu * pb;
         L.ys[k] = xr; L.pas[k] = pb;
     }
-    const double carry2 = affine_carry_in<true>(pb, xr, sA, sB);
-    for (int i = 0; i < c; ++i) {
-        const int k = i * kTriThreads + t;
+    const double cin = affine_carry_in<true>(pb, xr, sA, sB);
+    const double Atot = block_prod_1024(pb, sA);
+    if (threadIdx.x == 0) { L.mapA2[blockIdx.x] = Atot; L.mapB2[blockIdx.x] = pb * cin + xr; }
+}
+__global__ __launch_bounds__(kTriThreads) void k_tri_big_fin(LobView L) {
+    __shared__ double sA[16], sB[16];
+    const int q = blockIdx.x * kTriThreads + threadIdx.x, S = L.stride;
+    double c0 = 0.0;
+    for (int g = (int)gridDim.x - 1; g > (int)blockIdx.x; --g) c0 = L.mapA2[g] * c0 + L.mapB2[g];
+    const double carry2 = affine_carry_in<true>(L.pas[q], L.ys[q], sA, sB, c0);   // chunk start = row 0 of the layout
+#pragma unroll
+    for (int i = 0; i < kTriBigC; ++i) {
+        const int k = i * S + q;
         L.wT[k] = L.ys[k] + L.pas[k] * carry2;
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_lob_perm_cols(const int* __restrict__ col, long nnz, int c, int* __restrict__ colT) {
-    for (long p = (long)blockIdx.x * kBlock + threadIdx.x; p < nnz; p += (long)gridDim.x * kBlock) colT[p] = tri_perm(col[p], c);
+__global__ __launch_bounds__(kBlock) void k_lob_perm_cols(const int* __restrict__ col, long nnz, int c, int stride, int* __restrict__ colT) {
+    for (long p = (long)blockIdx.x * kBlock + threadIdx.x; p < nnz; p += (long)gridDim.x * kBlock) colT[p] = tri_perm(col[p], c, stride);
 }
 
 // Reduce the ||r||_1 partials of iteration `it` (ping-pong halves of partR by parity: the update
@@ -324,7 +370,7 @@ struct OpLob {
     __device__ __forceinline__ double gather(const double* __restrict__ x, int c) const { return x[c]; }
     __device__ __forceinline__ void row(int r, double lw) {
         const double x = L.x[r], p = L.p[r], lx = L.Lx[r], lp = L.Lp[r];
-        const double w = L.wT[tri_perm(r, L.c)];
+        const double w = L.wT[tri_perm(r, L.c, L.stride)];
         L.Lw[r] = lw;
         s[0] += x * x; s[1] += x * w; s[2] += x * p; s[3] += w * w; s[4] += w * p; s[5] += p * p;
         s[6] += x * lx; s[7] += x * lw; s[8] += x * lp; s[9] += w * lw; s[10] += w * lp; s[11] += p * lp;
@@ -528,7 +574,7 @@ __global__ __launch_bounds__(kBlock) void k_lob_update(LobView L, int jrel) {
     const double z0 = sc[0], z1 = sc[1], z2 = sc[2], th = sc[3], mx = sc[4], mw = sc[5], mp = sc[6];
     double l1 = 0.0;
     for (int r = blockIdx.x * kBlock + threadIdx.x; r < L.n; r += gridDim.x * kBlock) {
-        const int k = tri_perm(r, L.c);
+        const int k = tri_perm(r, L.c, L.stride);
         const double w = L.wT[k] - mw;
         const double pn = z1 * w + z2 * (L.p[r] - mp);
         const double lpn = z1 * L.Lw[r] + z2 * L.Lp[r];
@@ -553,7 +599,7 @@ __global__ __launch_bounds__(kBlock) void k_lob_start(LobView L, const double* _
         const double x = xin[r], lx = lxin[r];
         L.x[r] = x; L.Lx[r] = lx; L.p[r] = 0.0; L.Lp[r] = 0.0;
         const double res = lx - th * x;
-        L.rT[tri_perm(r, L.c)] = res;
+        L.rT[tri_perm(r, L.c, L.stride)] = res;
         l1 += fabs(res);
     }
     l1 = block_sum(l1, sm);

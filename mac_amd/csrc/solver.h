@@ -220,6 +220,7 @@ struct Solver {
     double *lx_x = nullptr, *lx_Lx = nullptr, *lx_p = nullptr, *lx_Lp = nullptr, *lx_Lw = nullptr;
     double *lx_rT = nullptr, *lx_wT = nullptr, *lx_tl = nullptr, *lx_tdinv = nullptr, *lx_tcu = nullptr;
     double *lx_ys = nullptr, *lx_pas = nullptr, *lx_as = nullptr, *lx_bs = nullptr;   // big-n solver scratch
+    double* lx_maps = nullptr;   // 4 x stride chunk maps of the multi-workgroup tridiagonal solve
     double *lx_part = nullptr, *lx_partR = nullptr;
     int *lx_colT = nullptr, *lx_bad = nullptr;
     size_t lx_colT_cap = 0;
@@ -275,7 +276,7 @@ struct Solver {
         void* ptrs[] = {u, V, tri, part, Z0, Z1, st, st2, y_raw, w2, yvec, ypart, sdev,
                         part_c, part_a2, part_r, scratch3, rq_dev, start, wc, ctri, part_u, part_a, stc,
                         lx_x, lx_Lx, lx_p, lx_Lp, lx_Lw, lx_rT, lx_wT, lx_tl, lx_tdinv, lx_tcu, lx_part, lx_partR,
-                        lx_ys, lx_pas, lx_as, lx_bs,
+                        lx_ys, lx_pas, lx_as, lx_bs, lx_maps,
                         lx_colT, lx_bad, lx_st};
         if (h_lrec) (void)hipHostFree(h_lrec);
         for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -437,15 +438,17 @@ struct Solver {
         if (!lob_ready) {
             ST_TRY(dev_alloc(&lx_x, n)); ST_TRY(dev_alloc(&lx_Lx, n)); ST_TRY(dev_alloc(&lx_p, n));
             ST_TRY(dev_alloc(&lx_Lp, n)); ST_TRY(dev_alloc(&lx_Lw, n));
-            const size_t tcap = (size_t)kTriThreads * (size_t)((n + kTriThreads - 1) / kTriThreads);   // zero padded past n
+            const size_t tcap = (size_t)lob_c() * (size_t)lob_stride();   // chunk-transposed, zero padded past n
             double** tr[] = {&lx_rT, &lx_wT, &lx_tl, &lx_tdinv, &lx_tcu};
             for (double** q : tr) {
                 ST_TRY(dev_alloc(q, tcap));
                 HIP_TRY(hipMemsetAsync(*q, 0, sizeof(double) * tcap, stream));
             }
             if (n > kTriMaxN) {
-                double** sc[] = {&lx_ys, &lx_pas, &lx_as, &lx_bs};
-                for (double** q : sc) ST_TRY(dev_alloc(q, tcap));
+                const size_t fcap = (size_t)kTriThreads * (size_t)((n + kTriThreads - 1) / kTriThreads);
+                ST_TRY(dev_alloc(&lx_ys, tcap)); ST_TRY(dev_alloc(&lx_pas, tcap));
+                ST_TRY(dev_alloc(&lx_as, fcap)); ST_TRY(dev_alloc(&lx_bs, fcap));
+                ST_TRY(dev_alloc(&lx_maps, 4 * (size_t)kMaxGrid));   // one map per workgroup and direction
             }
             ST_TRY(dev_alloc(&lx_part, (size_t)kLobNS * kMaxGrid)); ST_TRY(dev_alloc(&lx_partR, 2 * kMaxGrid));
             ST_TRY(dev_alloc(&lx_bad, 1)); ST_TRY(dev_alloc(&lx_st, 1));
@@ -460,9 +463,19 @@ struct Solver {
         }
         return MACHIP_OK;
     }
+    // layout of the tridiagonal solver: up to n = 16 384 one workgroup, c = ceil(n/1024) unknowns per thread;
+    // beyond, 4 unknowns per thread and as many 1024-thread workgroups as that takes
+    int lob_c() const { return n > kTriMaxN ? kTriBigC : (n + kTriThreads - 1) / kTriThreads; }
+    int lob_stride() const {
+        if (n <= kTriMaxN) return kTriThreads;
+        const int q = (n + kTriBigC - 1) / kTriBigC;
+        return (q + kTriThreads - 1) / kTriThreads * kTriThreads;
+    }
     LobView lview(const SpmvPlan& pl) const {
         LobView L;
-        L.n = n; L.c = (n + kTriThreads - 1) / kTriThreads;
+        L.n = n; L.c = lob_c(); L.stride = lob_stride();
+        L.mapA = lx_maps; L.mapB = lx_maps ? lx_maps + kMaxGrid : nullptr;
+        L.mapA2 = lx_maps ? lx_maps + 2 * kMaxGrid : nullptr; L.mapB2 = lx_maps ? lx_maps + 3 * kMaxGrid : nullptr;
         L.x = lx_x; L.Lx = lx_Lx; L.p = lx_p; L.Lp = lx_Lp; L.Lw = lx_Lw; L.rT = lx_rT; L.wT = lx_wT;
         L.tl = lx_tl; L.tdinv = lx_tdinv; L.tcu = lx_tcu; L.part = lx_part; L.partR = lx_partR;
         L.ys = lx_ys; L.pas = lx_pas;
@@ -481,11 +494,14 @@ struct Solver {
         k_lob_tail<<<1, 64, 0, stream>>>(L, steps);
     }
     void lob_launch_chunk(const CsrView& AT, const SpmvPlan& pl, const LobView& L, int steps) {
-        if (L.c > kTriCMax) {
+        if (n > kTriMaxN) {
             OpLob op;
             op.L = L;
+            const int gw = L.stride / kTriThreads;
             for (int s = 0; s < steps; ++s) {
-                k_tri_solve_big<<<1, kTriThreads, 0, stream>>>(L, s);
+                k_tri_big_fwd<<<gw, kTriThreads, 0, stream>>>(L);
+                k_tri_big_mid<<<gw, kTriThreads, 0, stream>>>(L);
+                k_tri_big_fin<<<gw, kTriThreads, 0, stream>>>(L);
                 launch_spmv(pl, stream, AT, L.wT, op);
                 k_lob_update<<<L.P_a, kBlock, 0, stream>>>(L, s);
             }
@@ -504,7 +520,7 @@ struct Solver {
     int lob_enqueue_chunk(const CsrView& A, const CsrView& AT, const SpmvPlan& pl, const LobView& L, int steps) {
         if (!use_graph) { lob_launch_chunk(AT, pl, L, steps); return MACHIP_OK; }
         if (graph_csr_key != (const void*)A.val) { drop_graphs(); graph_csr_key = (const void*)A.val; }
-        const auto key = std::make_tuple(1000 + pl.variant, pl.width, pl.grid, L.c, steps);
+        const auto key = std::make_tuple(1000 + pl.variant, pl.width, pl.grid, L.c + (n > kTriMaxN ? 100 : 0), steps);
         auto it = graphs.find(key);
         if (it == graphs.end()) it = graphs.emplace(key, std::array<hipGraphExec_t, 2>{nullptr, nullptr}).first;
         hipGraphExec_t& ge = it->second[(size_t)(graph_flip++ & 1)];
@@ -532,7 +548,7 @@ struct Solver {
         // ---- T = tridiag(L) + sigma I, factored on the device; gather indices in the solver's layout ----
         const double sigma = 2.5e-7 * scale;
         HIP_TRY(hipMemsetAsync(lx_bad, 0, sizeof(int), stream));
-        if (L.c > kTriCMax) k_tri_factor_big<<<1, kTriThreads, 0, stream>>>(A, L.c, sigma, lx_tl, lx_tdinv, lx_tcu, lx_as, lx_bs, lx_bad);
+        if (n > kTriMaxN) k_tri_factor_big<<<1, kTriThreads, 0, stream>>>(A, L.stride, sigma, lx_tl, lx_tdinv, lx_tcu, lx_as, lx_bs, lx_bad);
         else switch (L.c) {
 #define MACHIP_LOB_CASE(C) case C: k_tri_factor<C><<<1, kTriThreads, 0, stream>>>(A, sigma, lx_tl, lx_tdinv, lx_tcu, lx_bad); break;
             MACHIP_LOB_CASE(1) MACHIP_LOB_CASE(2) MACHIP_LOB_CASE(3) MACHIP_LOB_CASE(4) MACHIP_LOB_CASE(5) MACHIP_LOB_CASE(6)
@@ -541,7 +557,7 @@ struct Solver {
 #undef MACHIP_LOB_CASE
             default: k_tri_factor<16><<<1, kTriThreads, 0, stream>>>(A, sigma, lx_tl, lx_tdinv, lx_tcu, lx_bad); break;
         }
-        k_lob_perm_cols<<<(int)std::min<long>(kMaxGrid, (nnz + kBlock - 1) / kBlock), kBlock, 0, stream>>>(A.col, nnz, L.c, lx_colT);
+        k_lob_perm_cols<<<(int)std::min<long>(kMaxGrid, (nnz + kBlock - 1) / kBlock), kBlock, 0, stream>>>(A.col, nnz, L.c, L.stride, lx_colT);
         CsrView AT = A;
         AT.col = lx_colT;
         // ---- start vector: normalised into yvec, w2 = L yvec, Rayleigh quotient ----

@@ -823,3 +823,33 @@ def test_find_fiedler_pair_on_pose_graph_laplacians_uses_the_structured_modes():
     indptr, indices, data = L.indptr, L.indices, L.data
     _, _, _, st = _lib.fiedler_csr(indptr, indices, data, int(g["n"]))
     assert st.lanczos_steps * 5 < steps_ref and st.residual < 1e-8
+
+
+def test_large_sparse_chain_spmv_and_preconditioned_solve():
+    """n = 200 000 rows of ~3 entries: the row-tile SpMV runs with one lane per row (257 row offsets staged by
+    256 threads -- a staging bug there went unnoticed until this size), the tridiagonal solve of the
+    preconditioned mode runs its multi-workgroup form (n > 16 384).  SpMV against SciPy for every variant,
+    lambda_2 through the stop rule and against SciPy's shift-invert Lanczos."""
+    import scipy.sparse.linalg as spla
+    n, nc = 200000, 3000
+    rng = np.random.default_rng(1)
+    fi = np.arange(n - 1, dtype=np.int32); fw = rng.uniform(100, 1000, n - 1)
+    a = rng.integers(0, n, nc); b = np.clip(a + rng.integers(-3000, 3000, nc), 0, n - 1)
+    keep = np.abs(a - b) > 1
+    ci = np.minimum(a, b)[keep].astype(np.int32); cj = np.maximum(a, b)[keep].astype(np.int32)
+    cw = rng.uniform(100, 300, len(ci))
+    P = _lib.Problem(n, fi, fi + 1, fw, ci, cj, cw)
+    P.set_x(np.ones(len(ci)))
+    L = oracle.mac_laplacian(oracle.laplacian_from_edges(fi, fi + 1, fw, n), ci.astype(np.int64), cj.astype(np.int64), cw, np.ones(len(ci)), n)
+    v = rng.standard_normal(n)
+    ref = L @ v
+    for variant in (0, 1, 2):
+        y = P.spmv(v, variant=variant)
+        assert np.abs(y - ref).max() <= 1e-12 * np.abs(ref).max(), variant
+    lam, vec, _ = P.fiedler()
+    assert P.stats.residual < 1e-8 and P.stats.lanczos_steps < 6000          # preconditioned mode (auto)
+    assert np.abs(L @ vec - lam * vec).sum() / abs(L).sum(axis=1).max() < 1e-8
+    w = spla.eigsh(L + 1e-3 * sp.identity(n, format="csr"), k=2, sigma=0, which="LM", return_eigenvectors=False)
+    lam_ref = np.sort(w)[1] - 1e-3
+    assert abs(lam - lam_ref) <= 1e-6 * lam_ref
+    P.close()
