@@ -49,11 +49,13 @@ struct LobView {
     double* partR;                     // [kMaxGrid] ||r||_1 partials of the update kernel
     int P_c, P_a;
     LobState* st;
-    double* hrec;                      // pinned, device-mapped: (theta, ||r||_1) per iteration
+    double* hrec;                      // pinned, device-mapped: (theta, ||r||_1, tag, -) per iteration; tag =
+                                       // lob_tag(epoch, it) lets the host tell a landed record from stale memory
     unsigned long long* hflag;
 };
 
 __device__ __forceinline__ int tri_perm(int e, int c, int stride) { return (e % c) * stride + e / c; }
+__host__ __device__ inline double lob_tag(unsigned int epoch, int it) { return (double)(epoch & 0xfffffu) * 16777216.0 + (double)it; }
 
 // ---- scans over the 1024 threads of the solver workgroup --------------------------------------
 // Affine maps f(y) = A y + B, composed in thread order (REV: in reverse thread order).  Returns
@@ -321,8 +323,9 @@ __device__ __forceinline__ void lob_publish(const LobView& L, int it) {
     for (int i = threadIdx.x; i < L.P_a; i += 64) a += pr[i];
     a = wave_total(a);
     if (threadIdx.x == 0) {
-        L.hrec[2 * (size_t)it] = L.st->theta;
-        L.hrec[2 * (size_t)it + 1] = a;
+        L.hrec[4 * (size_t)it] = L.st->theta;
+        L.hrec[4 * (size_t)it + 1] = a;
+        L.hrec[4 * (size_t)it + 2] = lob_tag(L.st->epoch, it);
     }
 }
 
@@ -548,8 +551,9 @@ __global__ __launch_bounds__(kBlock) void k_lob_update(LobView L, int jrel) {
         for (int i = threadIdx.x - 64; i < L.P_a; i += 64) a += pr[i];
         a = wave_total(a);
         if (threadIdx.x == 64) {
-            L.hrec[2 * (size_t)(itn - 1)] = L.st->theta;
-            L.hrec[2 * (size_t)(itn - 1) + 1] = a;
+            L.hrec[4 * (size_t)(itn - 1)] = L.st->theta;
+            L.hrec[4 * (size_t)(itn - 1) + 1] = a;
+            L.hrec[4 * (size_t)(itn - 1) + 2] = lob_tag(L.st->epoch, itn - 1);
         }
     }
     if (threadIdx.x < 64) {

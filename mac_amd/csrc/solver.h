@@ -13,6 +13,7 @@
 
 #include <array>
 #include <deque>
+#include <limits>
 #include <map>
 #include <tuple>
 #include <vector>
@@ -452,7 +453,8 @@ struct Solver {
             }
             ST_TRY(dev_alloc(&lx_part, (size_t)kLobNS * kMaxGrid)); ST_TRY(dev_alloc(&lx_partR, 2 * kMaxGrid));
             ST_TRY(dev_alloc(&lx_bad, 1)); ST_TRY(dev_alloc(&lx_st, 1));
-            HIP_TRY(hipHostMalloc((void**)&h_lrec, sizeof(double) * 2 * (size_t)(kLobCap + kLobMaxChunk + 4), hipHostMallocMapped));
+            HIP_TRY(hipHostMalloc((void**)&h_lrec, sizeof(double) * 4 * (size_t)(kLobCap + kLobMaxChunk + 4), hipHostMallocMapped));
+            memset(h_lrec, 0, sizeof(double) * 4 * (size_t)(kLobCap + kLobMaxChunk + 4));
             HIP_TRY(hipHostGetDevicePointer((void**)&d_hlrec, h_lrec, 0));
             lob_ready = true;
         }
@@ -606,8 +608,17 @@ struct Solver {
                 ST_TRY(wait_flag(((unsigned long long)epoch << 32) | (unsigned long long)(unsigned int)jend));
                 const unsigned long long fv = *(volatile unsigned long long*)h_flag;
                 bad = (fv & 0x80000000ull) != 0;
-                est = h_lrec[2 * (size_t)jend + 1];
-                if (debug) fprintf(stderr, "[machip] lobpcg it=%d theta=%.15g est=%.3e to_go=%.0f bad=%d pend=%zu\n", jend, h_lrec[2 * (size_t)jend], est / scale, std::min(to_go, 1e9), (int)bad, pend.size());
+                {   // the flag can overtake the record on its way to host memory (seen once in ~60 solves as a
+                    // stale residual that triggered premature checks): wait for the record's own tag
+                    volatile double* rec = h_lrec + 4 * (size_t)jend;
+                    const double want = lob_tag(epoch, jend);
+                    for (unsigned long spins = 0; rec[2] != want; ++spins) {
+                        if (spins > 200000000ul) return fail(MACHIP_HIP_ERROR, "preconditioned solve: iteration record never arrived");
+                        __builtin_ia32_pause();
+                    }
+                    est = rec[1];
+                }
+                if (debug) fprintf(stderr, "[machip] lobpcg it=%d theta=%.15g est=%.3e to_go=%.0f bad=%d pend=%zu\n", jend, h_lrec[4 * (size_t)jend], est / scale, std::min(to_go, 1e9), (int)bad, pend.size());
                 if (est < best) { best = est; best_it = jend; }
                 if (est > 0.0) {
                     hist.emplace_back(jend, std::log(est));
@@ -763,7 +774,9 @@ struct Solver {
                 const bool use_classic = classic && !pmode;
                 const int depth = (use_classic || near) ? 1 : ((sched && to_go > 8.0 * chunk0) ? 3 : 2);
                 while ((int)pend.size() < depth && J_enq < jcap && steps_total < max_steps) {
-                    int chunk = near ? chunk_near : chunk0;
+                    // (the O(J) host analysis must keep up with the GPU: longer chunks once J is large -- a function of
+                    // J only, so the step count at which convergence is noticed stays reproducible)
+                    int chunk = near ? chunk_near : (J_enq >= 4096 ? std::min(kMaxChunk, 2 * chunk0) : chunk0);
                     if (near && sched && to_go < 1e17)   // aim a little short of the predicted crossing
                         chunk = std::min(chunk0, std::max(chunk_near, ((int)(0.75 * to_go) + 1) & ~1));
                     if (pmode) {   // steps cost ~0.5 us here: long chunks, so the O(J) host analysis keeps up
@@ -776,6 +789,8 @@ struct Solver {
                     if (chunk <= 0) break;
                     const int lo = std::max(0, J_enq - 1);
                     const int hi = J_enq + chunk;           // records lo..hi inclusive
+                    if (pmode || !classic)   // zero-copy records: poison the beta slots only this chunk writes
+                        for (int j = J_enq ? J_enq + 1 : 0; j <= hi; ++j) h_tri[3 * (size_t)j + 1] = std::numeric_limits<double>::quiet_NaN();
                     if (pmode) {
                         launch_persist(A, chunk);
                     } else if (classic) {
@@ -809,12 +824,11 @@ struct Solver {
                     ev_pool.push_back(p.ev);
                 } else {
                     ST_TRY(wait_flag(((unsigned long long)epoch << 32) | (unsigned long long)(unsigned int)p.jend));
-                    // a slow host (T_J analysis is O(J)) skips to the newest chunk that has already landed
-                    while (!pend.empty() && !pend.front().classic) {
-                        const unsigned long long v = *(volatile unsigned long long*)h_flag;
-                        if ((v >> 32) != (unsigned long long)epoch || (int)(v & 0xffffffffull) < pend.front().jend) break;
-                        p.jend = pend.front().jend;
-                        pend.pop_front();
+                    // the flag can overtake the records on their way to host memory: the beta slots of this chunk
+                    // were poisoned before it was enqueued, wait until every one has landed
+                    for (int j = p.jstart ? p.jstart + 1 : 0; j <= p.jend; ++j) {
+                        volatile double* slot = h_tri + 3 * (size_t)j + 1;
+                        for (unsigned long spins = 0; *slot != *slot && spins < 50000000ul; ++spins) __builtin_ia32_pause();
                     }
                 }
                 if (p.classic) {   // scatter the staged (alpha, beta, l1) into the interleaved mirror

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Developer fuzz: random chain-like graphs of random size / closure density / weight spread, the three
+solver modes against each other (lambda_2 to 1e-8, residual rule, vector agreement when lambda_2 is simple)."""
+import sys, time
+import numpy as np
+sys.path.insert(0, ".")
+from mac_amd import _lib
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+bad = 0
+for s in range(seed0, seed0 + N):
+    rng = np.random.default_rng(1000 + s)
+    n = int(rng.choice([rng.integers(260, 3072), rng.integers(3072, 16384), rng.integers(16384, 60000)]))
+    ncl = int(rng.integers(1, max(2, int(n * rng.choice([0.005, 0.05, 0.3])))))
+    fi = np.arange(n - 1, dtype=np.int32)
+    fw = 10.0 ** rng.uniform(0, rng.choice([0.5, 2, 3]), n - 1)
+    a = rng.integers(0, n, ncl); span = int(rng.choice([50, 3000, n]))
+    b = np.clip(a + rng.integers(-span, span + 1, ncl), 0, n - 1)
+    keep = np.abs(a - b) > 1
+    if not keep.any():
+        continue
+    ci = np.minimum(a, b)[keep].astype(np.int32); cj = np.maximum(a, b)[keep].astype(np.int32)
+    cw = 10.0 ** rng.uniform(0, 2.5, len(ci))
+    x = rng.random(len(ci)); x[rng.random(len(ci)) < 0.3] = 0.0
+    P = _lib.Problem(n, fi, fi + 1, fw, ci, cj, cw)
+    P.set_x(x)
+    out = []
+    for mode in (1, 2, 0):
+        P.set_solver(mode)
+        t0 = time.perf_counter()
+        try:
+            lam, v, _ = P.fiedler()
+            out.append((lam, v, int(P.stats.lanczos_steps), P.stats.residual, time.perf_counter() - t0))
+        except Exception as e:      # noqa
+            out.append((float("nan"), None, -1, float("nan"), 0.0)); print("   seed", s, "mode", mode, type(e).__name__, e)
+    lams = np.array([o[0] for o in out])
+    ok = np.all(np.isfinite(lams)) and (lams.max() - lams.min()) <= 1e-8 * lams.min() and all(o[3] < 1e-8 for o in out)
+    tag = "ok " if ok else "BAD"
+    bad += (not ok)
+    print(f"{tag} seed={s} n={n} closures={len(ci)} lam={lams[0]:.6e} steps L/P/auto={out[0][2]}/{out[1][2]}/{out[2][2]} ms={out[0][4]*1e3:.1f}/{out[1][4]*1e3:.1f}/{out[2][4]*1e3:.1f}", flush=True)
+    P.close()
+print("fuzz bad =", bad)
