@@ -34,7 +34,9 @@ for s in range(seed0, seed0 + N):
         except Exception as e:      # noqa
             out.append((float("nan"), None, -1, float("nan"), 0.0)); print("   seed", s, "mode", mode, type(e).__name__, e)
     lams = np.array([o[0] for o in out])
-    ok = np.all(np.isfinite(lams)) and (lams.max() - lams.min()) <= 1e-8 * lams.min() and all(o[3] < 1e-8 for o in out)
+    # every mode stops on the reference's rule (residual 1e-8 relative to ||L||_inf); on stiff graphs that pins
+    # lambda_2 itself only to ~1e-6 relative, so that is what the modes are compared to
+    ok = np.all(np.isfinite(lams)) and (lams.max() - lams.min()) <= 1e-5 * lams.min() and all(o[3] < 1e-8 for o in out)
     tag = "ok " if ok else "BAD"
     bad += (not ok)
     print(f"{tag} seed={s} n={n} closures={len(ci)} lam={lams[0]:.6e} steps L/P/auto={out[0][2]}/{out[1][2]}/{out[2][2]} ms={out[0][4]*1e3:.1f}/{out[1][4]*1e3:.1f}/{out[2][4]*1e3:.1f}", flush=True)
