@@ -233,7 +233,7 @@ struct Solver {
     long chain_edges = 0;       // how many of them
     long support_hint = -1;     // active candidate edges of the matrix about to be solved (-1 = unknown)
     long hist_lan_steps = -1, hist_lob_iters = -1;   // steps / iterations of the last solve in each mode
-    static constexpr int kLobCap = 20000;
+    static constexpr int kLobCap = 100000;
 
     int init(int n_, hipStream_t s) {
         n = n_;
@@ -576,6 +576,7 @@ struct Solver {
         *lam = rq; *res = r1 / scale;
         if (*res < tol) return MACHIP_OK;
         const int cap = std::min(kLobCap, max_steps > 0 ? max_steps : kLobCap);
+        const int patience = std::max(64, env_int("MACHIP_LOB_PATIENCE", 10000));   // iterations without a new best residual
         const int chunk0 = std::min(kLobMaxChunk, std::max(1, env_int("MACHIP_LOB_CHUNK", 16)));
         const double ltarget = std::log(std::max(tol * scale, 1e-300));
         int it_enq = 0, restarts = 0;
@@ -629,7 +630,7 @@ struct Solver {
                         if (slope > 1e-7) to_go = std::max(0.0, (hist.back().second - ltarget) / slope);
                     }
                 }
-                if (bad || !(est == est) || est < tol * scale || jend >= cap || jend - best_it > 1500) check = true;
+                if (bad || !(est == est) || est < tol * scale || jend >= cap || jend - best_it > patience) check = true;
             }
             // ---- explicit check of the current x (fresh SpMV), also the refresh point of a restart ----
             HIP_TRY(hipStreamSynchronize(stream));
@@ -643,7 +644,7 @@ struct Solver {
             if (!(rq == rq)) return MACHIP_NOT_CONVERGED;
             *lam = rq; *res = r1 / scale;
             if (*res < tol) return MACHIP_OK;
-            if (it_enq >= cap || ++restarts > 12 || it_enq - best_it > 1500) return MACHIP_NOT_CONVERGED;
+            if (it_enq >= cap || ++restarts > 12 || it_enq - best_it > patience) return MACHIP_NOT_CONVERGED;
         }
     }
 
