@@ -318,6 +318,10 @@ def main():
                                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                "traffic": traffic, "avg_launch_us": us, "algorithmic_bytes_per_launch": by,
                                "note": "launch-latency bound: ~6-12 MB per launch, working set is Infinity-Cache resident; " + tnote}
+            if w["n"] <= 3072:   # small chain-like graphs run the single-workgroup solver, not this kernel
+                out["roofline"]["note"] = ("at this size the solve runs in the LDS/register-resident single-workgroup kernel k_lan_persist "
+                                           "(HBM traffic: one 8n-byte basis column per step); the figures here are the multi-workgroup "
+                                           "fused step replayed on the same matrices, for comparison only; " + tnote)
     if rank == 0 and world == 1 and not args.no_cpu:
         cb = cpu_baseline_bounded(args.config)
         ft = cb.pop("f_traj")
