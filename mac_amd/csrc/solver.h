@@ -827,9 +827,10 @@ struct Solver {
                     ST_TRY(wait_flag(((unsigned long long)epoch << 32) | (unsigned long long)(unsigned int)p.jend));
                     // the flag can overtake the records on their way to host memory: the beta slots of this chunk
                     // were poisoned before it was enqueued, wait until every one has landed
-                    for (int j = p.jstart ? p.jstart + 1 : 0; j <= p.jend; ++j) {
+                    unsigned long budget = 5000000ul;   // ~20 ms in total: a genuine NaN (non-finite input) must not stall the solve
+                    for (int j = p.jstart ? p.jstart + 1 : 0; j <= p.jend && budget; ++j) {
                         volatile double* slot = h_tri + 3 * (size_t)j + 1;
-                        for (unsigned long spins = 0; *slot != *slot && spins < 50000000ul; ++spins) __builtin_ia32_pause();
+                        while (*slot != *slot && budget) { --budget; __builtin_ia32_pause(); }
                     }
                 }
                 if (p.classic) {   // scatter the staged (alpha, beta, l1) into the interleaved mirror

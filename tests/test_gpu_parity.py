@@ -853,3 +853,29 @@ def test_large_sparse_chain_spmv_and_preconditioned_solve():
     lam_ref = np.sort(w)[1] - 1e-3
     assert abs(lam - lam_ref) <= 1e-6 * lam_ref
     P.close()
+
+
+def test_non_finite_input_fails_fast():
+    """A NaN edge weight poisons L(x): the solve must come back with an error within moments (the host waits
+    for poisoned record slots to be overwritten -- with a bounded budget), not hang.  (A NaN in x itself is
+    simply an inactive candidate, as in the reference: `x > tol` is False.)"""
+    import time
+    g = load_golden("er300_x0")
+    cw = np.array(g["cw"], dtype=float)
+    k = int(np.argmax(g["x"] > 0.5))
+    cw[k] = np.nan
+    P = _lib.Problem(int(g["n"]), g["fi"], g["fj"], g["fw"], g["ci"], g["cj"], cw)
+    P.set_x(g["x"])
+    t0 = time.perf_counter()
+    with pytest.raises((_lib.MachipError, AssertionError)):
+        P.fiedler(max_steps=2000)
+    assert time.perf_counter() - t0 < 30.0
+    P.close()
+    x = np.array(g["x"], dtype=float); x[3] = np.nan
+    P = problem_of(g)
+    P.set_x(x)
+    x0 = np.where(np.isnan(x), 0.0, x)
+    lam, _, _ = P.fiedler()
+    P.set_x(x0)
+    assert lam == P.fiedler()[0]
+    P.close()
