@@ -813,6 +813,9 @@ __global__ __launch_bounds__(kBlock) void k_sel_pass(const double* __restrict__ 
     __shared__ unsigned int s_last;
     __shared__ unsigned int s_scan[kBlock];
     const int tid = threadIdx.x;
+    // an earlier pass found a bucket that is needed completely: the remaining digits cannot change the
+    // selected set (ticket[7] is that pass's "done" mark; typical after 3 of the 6 passes on a gradient)
+    if (pass && st->ticket[7]) return;
     for (int i = tid; i < kBins; i += kBlock) lh[i] = 0;
     __syncthreads();
     const int sh = sel_shift(pass), nb = sel_bits(pass);
@@ -887,6 +890,10 @@ __global__ __launch_bounds__(kBlock) void k_sel_pass(const double* __restrict__ 
         if (pass == 5) {
             st->T = (prefix << nb) | (unsigned long long)bin;
             st->cnt_eq = (long long)c[q];
+        } else if ((long long)c[q] == rem) {   // the whole bucket is selected: T = its lowest key, every "tie" counts
+            st->T = ((prefix << nb) | (unsigned long long)bin) << sh;
+            st->cnt_eq = rem;
+            st->ticket[7] = 1u;
         }
     }
 }
