@@ -7,6 +7,7 @@ sys.path.insert(0, ".")
 from mac_amd import _lib
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+MODES = tuple(int(c) for c in (sys.argv[3] if len(sys.argv) > 3 else "120"))
 bad = 0
 for s in range(seed0, seed0 + N):
     rng = np.random.default_rng(1000 + s)
@@ -25,7 +26,7 @@ for s in range(seed0, seed0 + N):
     P = _lib.Problem(n, fi, fi + 1, fw, ci, cj, cw)
     P.set_x(x)
     out = []
-    for mode in (1, 2, 0):
+    for mode in MODES:
         P.set_solver(mode)
         t0 = time.perf_counter()
         try:
@@ -39,6 +40,7 @@ for s in range(seed0, seed0 + N):
     ok = np.all(np.isfinite(lams)) and (lams.max() - lams.min()) <= 1e-5 * lams.min() and all(o[3] < 1e-8 for o in out)
     tag = "ok " if ok else "BAD"
     bad += (not ok)
-    print(f"{tag} seed={s} n={n} closures={len(ci)} lam={lams[0]:.6e} steps L/P/auto={out[0][2]}/{out[1][2]}/{out[2][2]} ms={out[0][4]*1e3:.1f}/{out[1][4]*1e3:.1f}/{out[2][4]*1e3:.1f}", flush=True)
+    steps_s = "/".join(str(o[2]) for o in out); ms_s = "/".join("%.1f" % (o[4] * 1e3) for o in out)
+    print(f"{tag} seed={s} n={n} closures={len(ci)} lam={lams[0]:.6e} steps={steps_s} ms={ms_s} modes={MODES}", flush=True)
     P.close()
 print("fuzz bad =", bad)
