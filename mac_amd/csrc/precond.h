@@ -134,9 +134,11 @@ __device__ __forceinline__ void mob_carry_in(Mob M, Mob* sM, double* p_in, doubl
 // ---- T = tridiag(L) + sigma I = L U, pivots by the continued fraction u_e = b_e - a_e^2/u_{e-1}
 // (a_e = L[e, e-1]), parallelised as a scan of Moebius maps.  One workgroup of 1024 threads.
 // bad[0] <- 1 when a pivot is not positive (T not positive definite: caller falls back).
+// chain_only: T = (odometry-chain Laplacian) + sigma I, i.e. the diagonal counts the two band neighbours
+// only -- the closures are then added back exactly by the Woodbury correction (woodbury.h).
 template <int C>
 __global__ __launch_bounds__(kTriThreads) void k_tri_factor(CsrView A, double sigma, double* tl,
-                                                            double* tdinv, double* tcu, int* bad) {
+                                                            double* tdinv, double* tcu, int* bad, int chain_only) {
     __shared__ Mob sM[16];
     __shared__ double s_afirst[kTriThreads + 1];
     const int t = threadIdx.x, n = A.n;   // thread t owns the unknowns e = t*C .. t*C + C-1 (zero padded past n)
@@ -147,12 +149,14 @@ __global__ __launch_bounds__(kTriThreads) void k_tri_factor(CsrView A, double si
         av[i] = 0.0; bv[i] = 1.0;
         const int e = t * C + i;
         if (e < n) {
-            double a = 0.0, b = 0.0;
+            double a = 0.0, b = 0.0, up = 0.0;
             for (int p = A.rowptr[e]; p < A.rowptr[e + 1]; ++p) {
                 const int col = A.col[p];
                 if (col == e) b += A.val[p];
                 else if (col == e - 1) a += A.val[p];
+                else if (col == e + 1) up += A.val[p];
             }
+            if (chain_only) b = -(a + up);
             av[i] = a; bv[i] = b + sigma;
             M = mob_mul(Mob{bv[i], -a * a, 1.0, 0.0}, M);
         }
@@ -330,19 +334,18 @@ __device__ __forceinline__ void lob_publish(const LobView& L, int it) {
 }
 
 // ---- w = T^-1 r ------------------------------------------------------------------------------
-template <int CMAX>
-__global__ __launch_bounds__(kTriThreads) void k_tri_solve(LobView L, int jrel) {
-    __shared__ double sA[16], sB[16];
-    __shared__ double s_pa[CMAX * kTriThreads];   // carry coefficients (CMAX = 16: 128 of the 160 KB of LDS)
+// w = T^-1 rhs for one workgroup; rhs(k) supplies the right-hand side in the chunk-transposed layout.
+template <int CMAX, class Rhs>
+__device__ __forceinline__ void tri_solve_body(const LobView& L, Rhs rhs, double* __restrict__ out, double* sA, double* sB,
+                                               double* s_pa) {
     const int t = threadIdx.x;   // CMAX == L.c: every thread owns exactly CMAX unknowns (zero padded past n)
-    (void)jrel;
     double y[CMAX];
     double run = 0.0, prod = 1.0;
 #pragma unroll
     for (int i = 0; i < CMAX; ++i) {
         const int k = i * kTriThreads + t;
         const double l = L.tl[k];
-        run = L.rT[k] - l * run;
+        run = rhs(k) - l * run;
         prod = -l * prod;
         y[i] = run; s_pa[k] = prod;
     }
@@ -358,7 +361,16 @@ __global__ __launch_bounds__(kTriThreads) void k_tri_solve(LobView L, int jrel) 
     }
     const double carry2 = affine_carry_in<true>(pb, xr, sA, sB);
 #pragma unroll
-    for (int i = 0; i < CMAX; ++i) L.wT[i * kTriThreads + t] = y[i] + s_pa[i * kTriThreads + t] * carry2;
+    for (int i = 0; i < CMAX; ++i) out[i * kTriThreads + t] = y[i] + s_pa[i * kTriThreads + t] * carry2;
+}
+
+template <int CMAX>
+__global__ __launch_bounds__(kTriThreads) void k_tri_solve(LobView L, int jrel) {
+    __shared__ double sA[16], sB[16];
+    __shared__ double s_pa[CMAX * kTriThreads];   // carry coefficients (CMAX = 16: 128 of the 160 KB of LDS)
+    (void)jrel;
+    const double* __restrict__ r = L.rT;
+    tri_solve_body<CMAX>(L, [r](int k) { return r[k]; }, L.wT, sA, sB, s_pa);
 }
 
 // ---- Lw = L w and the inner products -----------------------------------------------------------

@@ -21,6 +21,7 @@
 #include "kernels.h"
 #include "persist.h"
 #include "precond.h"
+#include "woodbury.h"
 #include "tridiag.h"
 
 namespace machip {
@@ -222,6 +223,12 @@ struct Solver {
     double *lx_rT = nullptr, *lx_wT = nullptr, *lx_tl = nullptr, *lx_tdinv = nullptr, *lx_tcu = nullptr;
     double *lx_ys = nullptr, *lx_pas = nullptr, *lx_as = nullptr, *lx_bs = nullptr;   // big-n solver scratch
     double* lx_maps = nullptr;   // 4 x stride chunk maps of the multi-workgroup tridiagonal solve
+    // exact chain + closures preconditioner (woodbury.h)
+    int *wb_ui = nullptr, *wb_uj = nullptr, *wb_counts = nullptr;
+    double *wb_uc = nullptr, *wb_g = nullptr, *wb_h = nullptr, *wb_Zt = nullptr, *wb_Cm = nullptr;
+    size_t wb_Zt_cap = 0;
+    rocblas_handle wb_handle = nullptr;
+    WbView wb_active{};          // s > 0 while the running solve uses it
     double *lx_part = nullptr, *lx_partR = nullptr;
     int *lx_colT = nullptr, *lx_bad = nullptr;
     size_t lx_colT_cap = 0;
@@ -277,9 +284,10 @@ struct Solver {
         void* ptrs[] = {u, V, tri, part, Z0, Z1, st, st2, y_raw, w2, yvec, ypart, sdev,
                         part_c, part_a2, part_r, scratch3, rq_dev, start, wc, ctri, part_u, part_a, stc,
                         lx_x, lx_Lx, lx_p, lx_Lp, lx_Lw, lx_rT, lx_wT, lx_tl, lx_tdinv, lx_tcu, lx_part, lx_partR,
-                        lx_ys, lx_pas, lx_as, lx_bs, lx_maps,
+                        lx_ys, lx_pas, lx_as, lx_bs, lx_maps, wb_ui, wb_uj, wb_counts, wb_uc, wb_g, wb_h, wb_Zt, wb_Cm,
                         lx_colT, lx_bad, lx_st};
         if (h_lrec) (void)hipHostFree(h_lrec);
+        if (wb_handle) (void)rocblas_destroy_handle(wb_handle);
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (h_tri) (void)hipHostFree(h_tri);
         if (h_flag) (void)hipHostFree(h_flag);
@@ -490,6 +498,12 @@ struct Solver {
         op.L = L;
         for (int s = 0; s < steps; ++s) {
             k_tri_solve<CMAX><<<1, kTriThreads, 0, stream>>>(L, s);
+            if (wb_active.s > 0) {   // w <- y - Z C^-1 U^T y
+                const WbView& W = wb_active;
+                k_wb_g<<<(W.s + kBlock - 1) / kBlock, kBlock, 0, stream>>>(L, W);
+                k_wb_h<<<std::min(kMaxGrid, (W.s + 3) / 4), kBlock, 0, stream>>>(W);
+                k_wb_w<<<(int)std::min<size_t>(kMaxGrid, (W.cap + kBlock - 1) / kBlock), kBlock, 0, stream>>>(L, W);
+            }
             launch_spmv(pl, stream, AT, L.wT, op);
             k_lob_update<<<L.P_a, kBlock, 0, stream>>>(L, s);
         }
@@ -520,7 +534,7 @@ struct Solver {
         }
     }
     int lob_enqueue_chunk(const CsrView& A, const CsrView& AT, const SpmvPlan& pl, const LobView& L, int steps) {
-        if (!use_graph) { lob_launch_chunk(AT, pl, L, steps); return MACHIP_OK; }
+        if (!use_graph || wb_active.s > 0) { lob_launch_chunk(AT, pl, L, steps); return MACHIP_OK; }   // (closure count is baked into the launches)
         if (graph_csr_key != (const void*)A.val) { drop_graphs(); graph_csr_key = (const void*)A.val; }
         const auto key = std::make_tuple(1000 + pl.variant, pl.width, pl.grid, L.c + (n > kTriMaxN ? 100 : 0), steps);
         auto it = graphs.find(key);
@@ -537,6 +551,49 @@ struct Solver {
         HIP_TRY(hipGraphLaunch(ge, stream));
         return MACHIP_OK;
     }
+    int wb_alloc() {
+        if (wb_ui) return MACHIP_OK;
+        ST_TRY(dev_alloc(&wb_ui, kWbMaxS)); ST_TRY(dev_alloc(&wb_uj, kWbMaxS)); ST_TRY(dev_alloc(&wb_counts, 2));
+        ST_TRY(dev_alloc(&wb_uc, kWbMaxS)); ST_TRY(dev_alloc(&wb_g, kWbMaxS)); ST_TRY(dev_alloc(&wb_h, kWbMaxS));
+        ST_TRY(dev_alloc(&wb_Cm, (size_t)kWbMaxS * kWbMaxS));
+        if (rocblas_create_handle(&wb_handle) != rocblas_status_success) return fail(MACHIP_HIP_ERROR, "rocblas_create_handle failed");
+        if (rocblas_set_stream(wb_handle, stream) != rocblas_status_success) return fail(MACHIP_HIP_ERROR, "rocblas_set_stream failed");
+        return MACHIP_OK;
+    }
+    // Z = T^-1 U, C = D^-1 + U^T Z, C^-1 (rocSOLVER).  MACHIP_NOT_CONVERGED when C is not positive definite.
+    int wb_build(const LobView& L, int s) {
+        const size_t cap = (size_t)L.c * (size_t)L.stride;
+        if (cap * (size_t)s > wb_Zt_cap) {
+            if (wb_Zt) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(wb_Zt); wb_Zt = nullptr; }
+            wb_Zt_cap = cap * (size_t)std::min(kWbMaxS, std::max(s + s / 2, 64));
+            ST_TRY(dev_alloc(&wb_Zt, wb_Zt_cap));
+        }
+        WbView W;
+        W.s = s; W.cap = cap; W.ui = wb_ui; W.uj = wb_uj; W.uc = wb_uc; W.Zt = wb_Zt; W.Cm = wb_Cm; W.g = wb_g; W.h = wb_h;
+        switch (L.c) {
+#define MACHIP_LOB_CASE(C) case C: k_wb_cols<C><<<s, kTriThreads, 0, stream>>>(L, W); break;
+            MACHIP_LOB_CASE(1) MACHIP_LOB_CASE(2) MACHIP_LOB_CASE(3) MACHIP_LOB_CASE(4) MACHIP_LOB_CASE(5) MACHIP_LOB_CASE(6)
+            MACHIP_LOB_CASE(7) MACHIP_LOB_CASE(8) MACHIP_LOB_CASE(9) MACHIP_LOB_CASE(10) MACHIP_LOB_CASE(11) MACHIP_LOB_CASE(12)
+            MACHIP_LOB_CASE(13) MACHIP_LOB_CASE(14) MACHIP_LOB_CASE(15)
+#undef MACHIP_LOB_CASE
+            default: k_wb_cols<16><<<s, kTriThreads, 0, stream>>>(L, W); break;
+        }
+        const int g2s = (int)std::min<long>(kMaxGrid, ((long)s * s + kBlock - 1) / kBlock);
+        k_wb_cap<<<g2s, kBlock, 0, stream>>>(L, W);
+        int* info = wb_counts + 1;
+        if (rocsolver_dpotrf(wb_handle, rocblas_fill_lower, s, wb_Cm, s, info) != rocblas_status_success)
+            return fail(MACHIP_HIP_ERROR, "rocsolver_dpotrf failed");
+        int hinfo = 0;
+        HIP_TRY(hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (hinfo != 0) return MACHIP_NOT_CONVERGED;
+        if (rocsolver_dpotri(wb_handle, rocblas_fill_lower, s, wb_Cm, s, info) != rocblas_status_success)
+            return fail(MACHIP_HIP_ERROR, "rocsolver_dpotri failed");
+        k_wb_sym<<<g2s, kBlock, 0, stream>>>(W);
+        wb_active = W;
+        return MACHIP_OK;
+    }
+
     // Returns MACHIP_OK (converged: yvec, *lam, *res set), MACHIP_NOT_CONVERGED (caller falls back to
     // Lanczos) or an error.
     int solve_lob(const CsrView& A, long nnz, double lnorm, double tol, int max_steps, int start_mode,
@@ -547,21 +604,41 @@ struct Solver {
         const int g2 = vgrid();
         const bool debug = env_int("MACHIP_DEBUG", 0) != 0;
         const double scale = lnorm > 0 ? lnorm : 1.0;
-        // ---- T = tridiag(L) + sigma I, factored on the device; gather indices in the solver's layout ----
-        const double sigma = 2.5e-7 * scale;
+        // ---- exact preconditioner (woodbury.h) when the graph is chain + at most kWbMaxS closures ----
+        wb_active.s = 0;
+        int wb_s = 0;
+        if (env_int("MACHIP_WOODBURY", 1) != 0 && n <= kTriMaxN && chain_like && support_hint >= 0 && support_hint <= kWbMaxS) {
+            ST_TRY(wb_alloc());
+            HIP_TRY(hipMemsetAsync(lx_bad, 0, sizeof(int), stream));
+            k_wb_extract<<<1, kTriThreads, 0, stream>>>(A, L.c, kWbMaxS, wb_ui, wb_uj, wb_uc, wb_counts, lx_bad);
+            int hc[2] = {0, 0};
+            HIP_TRY(hipMemcpyAsync(&hc[0], wb_counts, sizeof(int), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(&hc[1], lx_bad, sizeof(int), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (hc[0] > 0 && hc[0] <= kWbMaxS && !hc[1]) wb_s = hc[0];
+        }
+        const int chain_only = wb_s > 0 ? 1 : 0;
+        // ---- T = tridiag(L) + sigma I (chain Laplacian + sigma I under the exact preconditioner), factored on
+        // the device; gather indices in the solver's layout ----
+        const double sigma = (wb_s > 0 ? 1e-8 : 2.5e-7) * scale;
         HIP_TRY(hipMemsetAsync(lx_bad, 0, sizeof(int), stream));
         if (n > kTriMaxN) k_tri_factor_big<<<1, kTriThreads, 0, stream>>>(A, L.stride, sigma, lx_tl, lx_tdinv, lx_tcu, lx_as, lx_bs, lx_bad);
         else switch (L.c) {
-#define MACHIP_LOB_CASE(C) case C: k_tri_factor<C><<<1, kTriThreads, 0, stream>>>(A, sigma, lx_tl, lx_tdinv, lx_tcu, lx_bad); break;
+#define MACHIP_LOB_CASE(C) case C: k_tri_factor<C><<<1, kTriThreads, 0, stream>>>(A, sigma, lx_tl, lx_tdinv, lx_tcu, lx_bad, chain_only); break;
             MACHIP_LOB_CASE(1) MACHIP_LOB_CASE(2) MACHIP_LOB_CASE(3) MACHIP_LOB_CASE(4) MACHIP_LOB_CASE(5) MACHIP_LOB_CASE(6)
             MACHIP_LOB_CASE(7) MACHIP_LOB_CASE(8) MACHIP_LOB_CASE(9) MACHIP_LOB_CASE(10) MACHIP_LOB_CASE(11) MACHIP_LOB_CASE(12)
             MACHIP_LOB_CASE(13) MACHIP_LOB_CASE(14) MACHIP_LOB_CASE(15)
 #undef MACHIP_LOB_CASE
-            default: k_tri_factor<16><<<1, kTriThreads, 0, stream>>>(A, sigma, lx_tl, lx_tdinv, lx_tcu, lx_bad); break;
+            default: k_tri_factor<16><<<1, kTriThreads, 0, stream>>>(A, sigma, lx_tl, lx_tdinv, lx_tcu, lx_bad, chain_only); break;
         }
         k_lob_perm_cols<<<(int)std::min<long>(kMaxGrid, (nnz + kBlock - 1) / kBlock), kBlock, 0, stream>>>(A.col, nnz, L.c, L.stride, lx_colT);
         CsrView AT = A;
         AT.col = lx_colT;
+        if (wb_s > 0) {
+            const int st = wb_build(L, wb_s);
+            if (st != MACHIP_OK && st != MACHIP_NOT_CONVERGED) return st;
+            if (st == MACHIP_NOT_CONVERGED) return MACHIP_NOT_CONVERGED;   // capacitance not SPD numerically: Lanczos takes over
+        }
         // ---- start vector: normalised into yvec, w2 = L yvec, Rayleigh quotient ----
         const double* src = (start_mode == 1 && have_prev) ? yvec : (have_start ? start : nullptr);
         if (!src) { k_fill_start<<<g2, kBlock, 0, stream>>>(u, n, 0x1234567ull); src = u; }
@@ -577,7 +654,9 @@ struct Solver {
         if (*res < tol) return MACHIP_OK;
         const int cap = std::min(kLobCap, max_steps > 0 ? max_steps : kLobCap);
         const int patience = std::max(64, env_int("MACHIP_LOB_PATIENCE", 10000));   // iterations without a new best residual
-        const int chunk0 = std::min(kLobMaxChunk, std::max(1, env_int("MACHIP_LOB_CHUNK", 16)));
+        // (exact preconditioner: a handful of iterations in all, each six launches -- short chunks, no speculation)
+        const bool wb = wb_active.s > 0;
+        const int chunk0 = wb ? 4 : std::min(kLobMaxChunk, std::max(1, env_int("MACHIP_LOB_CHUNK", 16)));
         const double ltarget = std::log(std::max(tol * scale, 1e-300));
         int it_enq = 0, restarts = 0;
         double best = r1;
@@ -589,10 +668,10 @@ struct Solver {
             std::deque<std::pair<int, double>> hist;
             double to_go = 1e18, est = 1e300;
             bool check = false, bad = false;
-            int ramp = 4;
+            int ramp = wb ? 2 : 4;
             while (!check) {
                 const bool near = to_go < 2.0 * chunk0;
-                const int depth = near ? 1 : 2;
+                const int depth = (near || wb) ? 1 : 2;
                 while ((int)pend.size() < depth && it_enq < cap) {
                     int chunk = std::min(chunk0, ramp);   // easy problems (T ~ L) converge in a handful of iterations
                     ramp = std::min(chunk0, ramp * 2);
@@ -669,7 +748,9 @@ struct Solver {
         // measured: intel at 9 % closures/node 3.5 ms Lanczos vs 4.7 ms preconditioned, kitti_05 at 0.5 %: 8.6 vs 1.1)
         const bool small = n <= kPersistThreads * kPersistMaxRows;
         const long ratio = small ? 9 : 6;
-        const bool sparse = (double)support_hint <= env_int("MACHIP_LOB_DENSITY_PCT", small ? 3 : 12) * 0.01 * (double)n;
+        const bool wb_ok = env_int("MACHIP_WOODBURY", 1) != 0 && n <= kTriMaxN;
+        const bool sparse = (double)support_hint <= env_int("MACHIP_LOB_DENSITY_PCT", small ? 3 : 12) * 0.01 * (double)n ||
+                            (wb_ok && small && support_hint <= 200);   // exact preconditioner: ~1.5 ms flat up to ~200 closures
         const bool stiff = hist_lan_steps > 2500 && (hist_lob_iters < 0 || hist_lob_iters * ratio < hist_lan_steps);
         const bool slow_lob = hist_lan_steps > 0 && hist_lob_iters > 0 && hist_lob_iters * ratio > 2 * hist_lan_steps;
         const bool want = mode == 2 || (mode == 0 && chain_like && support_hint >= 0 && ((sparse && !slow_lob) || stiff));
