@@ -13,6 +13,8 @@ import os
 import numpy as np
 import pytest
 import scipy.sparse as sp
+import subprocess
+import sys
 
 import oracle
 from conftest import ROOT, load_golden, sign_align
@@ -879,3 +881,44 @@ def test_non_finite_input_fails_fast():
     P.set_x(x0)
     assert lam == P.fiedler()[0]
     P.close()
+
+
+@pytest.mark.parametrize("nm", ["intel", "kitti_05", "city10000"])
+def test_exact_chain_plus_closures_preconditioner(nm):
+    """woodbury.h: with at most 2 048 active closures the preconditioned mode inverts L + sigma I exactly
+    (chain tridiagonal + low-rank closures, capacitance matrix by rocSOLVER) and converges in a handful of
+    iterations; same pair as the tridiagonal-preconditioned mode and as an independent SciPy solve."""
+    import scipy.sparse.linalg as spla
+    g = load_golden("g2o_" + nm)
+    code = r"""
+import sys; sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import numpy as np
+from test_gpu_parity import load_golden, problem_of
+from mac_amd.utils.fiedler import reference_start_block
+g = load_golden("g2o_%s")
+P = problem_of(g)
+P.set_start(reference_start_block(int(g["n"]))[:, 0].copy())
+x = np.zeros(len(g["cw"])); x[: min(len(x), 1000)] = 1.0          # <= 2 048 active closures
+x[::3] *= 0.37
+P.set_x(x)
+P.set_solver(2)
+lam, v, _ = P.fiedler()
+print(repr(lam), int(P.stats.lanczos_steps), repr(P.stats.residual), repr(float(np.abs(v).sum())))
+""" % nm
+    out = {}
+    for flag in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, MACHIP_WOODBURY=flag))
+        assert r.returncode == 0, r.stderr[-2000:]
+        lam, its, res, l1 = r.stdout.strip().split()[-4:]
+        out[flag] = (float(lam), int(its), float(res), float(l1))
+    x = np.zeros(len(g["cw"])); x[: min(len(x), 1000)] = 1.0
+    x[::3] *= 0.37
+    n = int(g["n"])
+    L = oracle.mac_laplacian(oracle.laplacian_from_edges(g["fi"], g["fj"], g["fw"], n), g["ci"].astype(np.int64), g["cj"].astype(np.int64), g["cw"], x, n)
+    w = spla.eigsh(L + 1e-3 * sp.identity(n, format="csr"), k=2, sigma=0, which="LM", return_eigenvectors=False)
+    lam_ref = np.sort(w)[1] - 1e-3
+    for flag in ("1", "0"):
+        assert abs(out[flag][0] - lam_ref) <= 1e-7 * lam_ref and out[flag][2] < 1e-8
+    assert abs(out["1"][0] - out["0"][0]) <= LAM_RTOL * lam_ref
+    assert out["1"][1] <= 40 and out["1"][1] < out["0"][1]          # a handful of iterations instead of dozens to hundreds
+    assert abs(out["1"][3] - out["0"][3]) <= 1e-5 * out["0"][3]      # same vector (its 1-norm)
