@@ -748,9 +748,7 @@ struct Solver {
         // measured: intel at 9 % closures/node 3.5 ms Lanczos vs 4.7 ms preconditioned, kitti_05 at 0.5 %: 8.6 vs 1.1)
         const bool small = n <= kPersistThreads * kPersistMaxRows;
         const long ratio = small ? 9 : 6;
-        const bool wb_ok = env_int("MACHIP_WOODBURY", 1) != 0 && n <= kTriMaxN;
-        const bool sparse = (double)support_hint <= env_int("MACHIP_LOB_DENSITY_PCT", small ? 3 : 12) * 0.01 * (double)n ||
-                            (wb_ok && small && support_hint <= 200);   // exact preconditioner: ~1.5 ms flat up to ~200 closures
+        const bool sparse = (double)support_hint <= env_int("MACHIP_LOB_DENSITY_PCT", small ? 3 : 12) * 0.01 * (double)n;
         const bool stiff = hist_lan_steps > 2500 && (hist_lob_iters < 0 || hist_lob_iters * ratio < hist_lan_steps);
         const bool slow_lob = hist_lan_steps > 0 && hist_lob_iters > 0 && hist_lob_iters * ratio > 2 * hist_lan_steps;
         const bool want = mode == 2 || (mode == 0 && chain_like && support_hint >= 0 && ((sparse && !slow_lob) || stiff));
