@@ -907,7 +907,8 @@ print(repr(lam), int(P.stats.lanczos_steps), repr(P.stats.residual), repr(float(
 """ % nm
     out = {}
     for flag in ("1", "0"):
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, MACHIP_WOODBURY=flag))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT,
+                           env=dict(os.environ, MACHIP_WOODBURY=flag))
         assert r.returncode == 0, r.stderr[-2000:]
         lam, its, res, l1 = r.stdout.strip().split()[-4:]
         out[flag] = (float(lam), int(its), float(res), float(l1))
