@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kTriThreads) void k_tri_factor(CsrView A, double si
 // ~13 n doubles of traffic spread over n/4096 CUs.  The LU is computed once per solve by a single
 // workgroup (k_tri_factor_big) straight into this layout.
 __global__ __launch_bounds__(kTriThreads) void k_tri_factor_big(CsrView A, int stride, double sigma, double* tl, double* tdinv,
-                                                                double* tcu, double* as, double* bs, int* bad) {
+                                                                double* tcu, double* as, double* bs, int* bad, int chain_only) {
     __shared__ Mob sM[16];
     const int t = threadIdx.x, n = A.n;
     const int c = (n + kTriThreads - 1) / kTriThreads;     // unknowns per thread HERE (private scratch layout i*1024 + t)
@@ -211,11 +211,14 @@ __global__ __launch_bounds__(kTriThreads) void k_tri_factor_big(CsrView A, int s
         double a = 0.0, b = 1.0;
         if (e < n) {
             b = 0.0;
+            double up = 0.0;
             for (int p = A.rowptr[e]; p < A.rowptr[e + 1]; ++p) {
                 const int col = A.col[p];
                 if (col == e) b += A.val[p];
                 else if (col == e - 1) a += A.val[p];
+                else if (col == e + 1) up += A.val[p];
             }
+            if (chain_only) b = -(a + up);
             b += sigma;
             M = mob_mul(Mob{b, -a * a, 1.0, 0.0}, M);
         }
@@ -263,55 +266,74 @@ __device__ __forceinline__ double block_prod_1024(double a, double* sP) {
     return p;
 }
 
-__global__ __launch_bounds__(kTriThreads) void k_tri_big_fwd(LobView L) {
-    __shared__ double sA[16], sB[16];
+// The three phases as device functions over explicit buffers, so that the batched form (one right-hand side per
+// blockIdx.y: woodbury.h) shares them: ys / pas = chunk scratch (chunk-transposed, stride S), mA/mB/mA2/mB2 =
+// one affine map per workgroup and direction, out = the solution.
+struct TriBigBuf { double *ys, *pas, *mA, *mB, *mA2, *mB2, *out; };
+
+template <class Rhs>
+__device__ __forceinline__ void tri_big_fwd(const LobView& L, const TriBigBuf& B, Rhs rhs, double* sA, double* sB) {
     const int q = blockIdx.x * kTriThreads + threadIdx.x, S = L.stride;
     double run = 0.0, prod = 1.0;
 #pragma unroll
     for (int i = 0; i < kTriBigC; ++i) {
         const int k = i * S + q;
         const double l = L.tl[k];
-        run = L.rT[k] - l * run;
+        run = rhs(k) - l * run;
         prod = -l * prod;
-        L.ys[k] = run; L.pas[k] = prod;
+        B.ys[k] = run; B.pas[k] = prod;
     }
     // this workgroup's 1 024 chunk maps as one map (A, B): B = value given to 0, A = product of the A's
     const double cin = affine_carry_in<false>(prod, run, sA, sB);
     const double Atot = block_prod_1024(prod, sA);
-    if (threadIdx.x == kTriThreads - 1) { L.mapA[blockIdx.x] = Atot; L.mapB[blockIdx.x] = prod * cin + run; }
+    if (threadIdx.x == kTriThreads - 1) { B.mA[blockIdx.x] = Atot; B.mB[blockIdx.x] = prod * cin + run; }
 }
-__global__ __launch_bounds__(kTriThreads) void k_tri_big_mid(LobView L) {
-    __shared__ double sA[16], sB[16];
+__device__ __forceinline__ void tri_big_mid(const LobView& L, const TriBigBuf& B, double* sA, double* sB) {
     const int q = blockIdx.x * kTriThreads + threadIdx.x, S = L.stride;
     double c0 = 0.0;                                   // carry entering this workgroup
-    for (int g = 0; g < (int)blockIdx.x; ++g) c0 = L.mapA[g] * c0 + L.mapB[g];
+    for (int g = 0; g < (int)blockIdx.x; ++g) c0 = B.mA[g] * c0 + B.mB[g];
     // own chunk maps are recomputed from the stored sweeps: A = pas at the chunk end, B = ys at the chunk end
     const int kl = (kTriBigC - 1) * S + q;
-    const double carry = affine_carry_in<false>(L.pas[kl], L.ys[kl], sA, sB, c0);
+    const double carry = affine_carry_in<false>(B.pas[kl], B.ys[kl], sA, sB, c0);
     double xr = 0.0, pb = 1.0;
 #pragma unroll
     for (int i = kTriBigC - 1; i >= 0; --i) {
         const int k = i * S + q;
         const double cu = L.tcu[k];
-        xr = (L.ys[k] + L.pas[k] * carry) * L.tdinv[k] - cu * xr;
+        xr = (B.ys[k] + B.pas[k] * carry) * L.tdinv[k] - cu * xr;
         pb = -cu * pb;
-        L.ys[k] = xr; L.pas[k] = pb;
+        B.ys[k] = xr; B.pas[k] = pb;
     }
     const double cin = affine_carry_in<true>(pb, xr, sA, sB);
     const double Atot = block_prod_1024(pb, sA);
-    if (threadIdx.x == 0) { L.mapA2[blockIdx.x] = Atot; L.mapB2[blockIdx.x] = pb * cin + xr; }
+    if (threadIdx.x == 0) { B.mA2[blockIdx.x] = Atot; B.mB2[blockIdx.x] = pb * cin + xr; }
 }
-__global__ __launch_bounds__(kTriThreads) void k_tri_big_fin(LobView L) {
-    __shared__ double sA[16], sB[16];
+__device__ __forceinline__ void tri_big_fin(const LobView& L, const TriBigBuf& B, double* sA, double* sB) {
     const int q = blockIdx.x * kTriThreads + threadIdx.x, S = L.stride;
     double c0 = 0.0;
-    for (int g = (int)gridDim.x - 1; g > (int)blockIdx.x; --g) c0 = L.mapA2[g] * c0 + L.mapB2[g];
-    const double carry2 = affine_carry_in<true>(L.pas[q], L.ys[q], sA, sB, c0);   // chunk start = row 0 of the layout
+    for (int g = (int)gridDim.x - 1; g > (int)blockIdx.x; --g) c0 = B.mA2[g] * c0 + B.mB2[g];
+    const double carry2 = affine_carry_in<true>(B.pas[q], B.ys[q], sA, sB, c0);   // chunk start = row 0 of the layout
 #pragma unroll
     for (int i = 0; i < kTriBigC; ++i) {
         const int k = i * S + q;
-        L.wT[k] = L.ys[k] + L.pas[k] * carry2;
+        B.out[k] = B.ys[k] + B.pas[k] * carry2;
     }
+}
+__device__ __forceinline__ TriBigBuf tri_big_buf(const LobView& L) {
+    return TriBigBuf{L.ys, L.pas, L.mapA, L.mapB, L.mapA2, L.mapB2, L.wT};
+}
+__global__ __launch_bounds__(kTriThreads) void k_tri_big_fwd(LobView L) {
+    __shared__ double sA[16], sB[16];
+    const double* __restrict__ r = L.rT;
+    tri_big_fwd(L, tri_big_buf(L), [r](int k) { return r[k]; }, sA, sB);
+}
+__global__ __launch_bounds__(kTriThreads) void k_tri_big_mid(LobView L) {
+    __shared__ double sA[16], sB[16];
+    tri_big_mid(L, tri_big_buf(L), sA, sB);
+}
+__global__ __launch_bounds__(kTriThreads) void k_tri_big_fin(LobView L) {
+    __shared__ double sA[16], sB[16];
+    tri_big_fin(L, tri_big_buf(L), sA, sB);
 }
 
 __global__ __launch_bounds__(kBlock) void k_lob_perm_cols(const int* __restrict__ col, long nnz, int c, int stride, int* __restrict__ colT) {

@@ -226,7 +226,8 @@ struct Solver {
     // exact chain + closures preconditioner (woodbury.h)
     int *wb_ui = nullptr, *wb_uj = nullptr, *wb_counts = nullptr;
     double *wb_uc = nullptr, *wb_g = nullptr, *wb_h = nullptr, *wb_Zt = nullptr, *wb_Cm = nullptr;
-    size_t wb_Zt_cap = 0;
+    size_t wb_Zt_cap = 0, wb_pas_cap = 0;
+    double *wb_pas = nullptr, *wb_maps = nullptr;   // batched multi-workgroup column solves (n > 16 384)
     rocblas_handle wb_handle = nullptr;
     WbView wb_active{};          // s > 0 while the running solve uses it
     double *lx_part = nullptr, *lx_partR = nullptr;
@@ -284,7 +285,7 @@ struct Solver {
         void* ptrs[] = {u, V, tri, part, Z0, Z1, st, st2, y_raw, w2, yvec, ypart, sdev,
                         part_c, part_a2, part_r, scratch3, rq_dev, start, wc, ctri, part_u, part_a, stc,
                         lx_x, lx_Lx, lx_p, lx_Lp, lx_Lw, lx_rT, lx_wT, lx_tl, lx_tdinv, lx_tcu, lx_part, lx_partR,
-                        lx_ys, lx_pas, lx_as, lx_bs, lx_maps, wb_ui, wb_uj, wb_counts, wb_uc, wb_g, wb_h, wb_Zt, wb_Cm,
+                        lx_ys, lx_pas, lx_as, lx_bs, lx_maps, wb_ui, wb_uj, wb_counts, wb_uc, wb_g, wb_h, wb_Zt, wb_Cm, wb_pas, wb_maps,
                         lx_colT, lx_bad, lx_st};
         if (h_lrec) (void)hipHostFree(h_lrec);
         if (wb_handle) (void)rocblas_destroy_handle(wb_handle);
@@ -518,6 +519,12 @@ struct Solver {
                 k_tri_big_fwd<<<gw, kTriThreads, 0, stream>>>(L);
                 k_tri_big_mid<<<gw, kTriThreads, 0, stream>>>(L);
                 k_tri_big_fin<<<gw, kTriThreads, 0, stream>>>(L);
+                if (wb_active.s > 0) {
+                    const WbView& W = wb_active;
+                    k_wb_g<<<(W.s + kBlock - 1) / kBlock, kBlock, 0, stream>>>(L, W);
+                    k_wb_h<<<std::min(kMaxGrid, (W.s + 3) / 4), kBlock, 0, stream>>>(W);
+                    k_wb_w<<<(int)std::min<size_t>(kMaxGrid, (W.cap + kBlock - 1) / kBlock), kBlock, 0, stream>>>(L, W);
+                }
                 launch_spmv(pl, stream, AT, L.wT, op);
                 k_lob_update<<<L.P_a, kBlock, 0, stream>>>(L, s);
             }
@@ -570,7 +577,19 @@ struct Solver {
         }
         WbView W;
         W.s = s; W.cap = cap; W.ui = wb_ui; W.uj = wb_uj; W.uc = wb_uc; W.Zt = wb_Zt; W.Cm = wb_Cm; W.g = wb_g; W.h = wb_h;
-        switch (L.c) {
+        if (n > kTriMaxN) {   // batched multi-workgroup solves: grid = (workgroups per system, closures)
+            const int gw = L.stride / kTriThreads;
+            if (cap * (size_t)s > wb_pas_cap) {
+                if (wb_pas) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(wb_pas); wb_pas = nullptr; }
+                wb_pas_cap = wb_Zt_cap;
+                ST_TRY(dev_alloc(&wb_pas, wb_pas_cap));
+            }
+            if (!wb_maps) ST_TRY(dev_alloc(&wb_maps, (size_t)4 * kMaxGrid * kWbMaxS));
+            WbBig Bg{wb_pas, wb_maps};
+            k_wb_big_fwd<<<dim3(gw, s), kTriThreads, 0, stream>>>(L, W, Bg);
+            k_wb_big_mid<<<dim3(gw, s), kTriThreads, 0, stream>>>(L, W, Bg);
+            k_wb_big_fin<<<dim3(gw, s), kTriThreads, 0, stream>>>(L, W, Bg);
+        } else switch (L.c) {
 #define MACHIP_LOB_CASE(C) case C: k_wb_cols<C><<<s, kTriThreads, 0, stream>>>(L, W); break;
             MACHIP_LOB_CASE(1) MACHIP_LOB_CASE(2) MACHIP_LOB_CASE(3) MACHIP_LOB_CASE(4) MACHIP_LOB_CASE(5) MACHIP_LOB_CASE(6)
             MACHIP_LOB_CASE(7) MACHIP_LOB_CASE(8) MACHIP_LOB_CASE(9) MACHIP_LOB_CASE(10) MACHIP_LOB_CASE(11) MACHIP_LOB_CASE(12)
@@ -607,10 +626,10 @@ struct Solver {
         // ---- exact preconditioner (woodbury.h) when the graph is chain + at most kWbMaxS closures ----
         wb_active.s = 0;
         int wb_s = 0;
-        if (env_int("MACHIP_WOODBURY", 1) != 0 && n <= kTriMaxN && chain_like && support_hint >= 0 && support_hint <= kWbMaxS) {
+        if (env_int("MACHIP_WOODBURY", 1) != 0 && chain_like && support_hint >= 0 && support_hint <= kWbMaxS) {
             ST_TRY(wb_alloc());
             HIP_TRY(hipMemsetAsync(lx_bad, 0, sizeof(int), stream));
-            k_wb_extract<<<1, kTriThreads, 0, stream>>>(A, L.c, kWbMaxS, wb_ui, wb_uj, wb_uc, wb_counts, lx_bad);
+            k_wb_extract<<<1, kTriThreads, 0, stream>>>(A, (n + kTriThreads - 1) / kTriThreads, kWbMaxS, wb_ui, wb_uj, wb_uc, wb_counts, lx_bad);
             int hc[2] = {0, 0};
             HIP_TRY(hipMemcpyAsync(&hc[0], wb_counts, sizeof(int), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipMemcpyAsync(&hc[1], lx_bad, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -622,7 +641,7 @@ struct Solver {
         // the device; gather indices in the solver's layout ----
         const double sigma = (wb_s > 0 ? 1e-8 : 2.5e-7) * scale;
         HIP_TRY(hipMemsetAsync(lx_bad, 0, sizeof(int), stream));
-        if (n > kTriMaxN) k_tri_factor_big<<<1, kTriThreads, 0, stream>>>(A, L.stride, sigma, lx_tl, lx_tdinv, lx_tcu, lx_as, lx_bs, lx_bad);
+        if (n > kTriMaxN) k_tri_factor_big<<<1, kTriThreads, 0, stream>>>(A, L.stride, sigma, lx_tl, lx_tdinv, lx_tcu, lx_as, lx_bs, lx_bad, chain_only);
         else switch (L.c) {
 #define MACHIP_LOB_CASE(C) case C: k_tri_factor<C><<<1, kTriThreads, 0, stream>>>(A, sigma, lx_tl, lx_tdinv, lx_tcu, lx_bad, chain_only); break;
             MACHIP_LOB_CASE(1) MACHIP_LOB_CASE(2) MACHIP_LOB_CASE(3) MACHIP_LOB_CASE(4) MACHIP_LOB_CASE(5) MACHIP_LOB_CASE(6)

@@ -82,6 +82,29 @@ __global__ __launch_bounds__(kTriThreads) void k_wb_cols(LobView L, WbView W) {
                          W.Zt + (size_t)b * W.cap, sA, sB, s_pa);
 }
 
+// n > 16 384: the multi-workgroup solve of precond.h, one right-hand side per blockIdx.y.  Z's own column is the
+// sweep scratch, `pas` a second n x s buffer, `maps` = 4 doubles per (column, workgroup).
+struct WbBig { double* pas; double* maps; };
+__device__ __forceinline__ TriBigBuf wb_big_buf(const LobView& L, const WbView& W, const WbBig& Bg) {
+    const size_t col = (size_t)blockIdx.y * W.cap;
+    double* m = Bg.maps + (size_t)blockIdx.y * 4 * gridDim.x;
+    return TriBigBuf{W.Zt + col, Bg.pas + col, m, m + gridDim.x, m + 2 * gridDim.x, m + 3 * gridDim.x, W.Zt + col};
+}
+__global__ __launch_bounds__(kTriThreads) void k_wb_big_fwd(LobView L, WbView W, WbBig Bg) {
+    __shared__ double sA[16], sB[16];
+    const int b = blockIdx.y;
+    const int pi = tri_perm(W.ui[b], L.c, L.stride), pj = tri_perm(W.uj[b], L.c, L.stride);
+    tri_big_fwd(L, wb_big_buf(L, W, Bg), [pi, pj](int k) { return (k == pi ? 1.0 : 0.0) - (k == pj ? 1.0 : 0.0); }, sA, sB);
+}
+__global__ __launch_bounds__(kTriThreads) void k_wb_big_mid(LobView L, WbView W, WbBig Bg) {
+    __shared__ double sA[16], sB[16];
+    tri_big_mid(L, wb_big_buf(L, W, Bg), sA, sB);
+}
+__global__ __launch_bounds__(kTriThreads) void k_wb_big_fin(LobView L, WbView W, WbBig Bg) {
+    __shared__ double sA[16], sB[16];
+    tri_big_fin(L, wb_big_buf(L, W, Bg), sA, sB);
+}
+
 // ---- C = D^-1 + U^T Z ----
 __global__ __launch_bounds__(kBlock) void k_wb_cap(LobView L, WbView W) {
     const long s = W.s;
