@@ -134,14 +134,33 @@ __device__ __forceinline__ void mob_carry_in(Mob M, Mob* sM, double* p_in, doubl
 // ---- T = tridiag(L) + sigma I = L U, pivots by the continued fraction u_e = b_e - a_e^2/u_{e-1}
 // (a_e = L[e, e-1]), parallelised as a scan of Moebius maps.  One workgroup of 1024 threads.
 // bad[0] <- 1 when a pivot is not positive (T not positive definite: caller falls back).
+// Tridiagonal band of L, row-parallel over the whole chip (the factorisation below is one workgroup: letting it
+// search the CSR rows itself cost 42 us per solve): sub-diagonal, diagonal, super-diagonal in the solver's layout.
+__global__ __launch_bounds__(kBlock) void k_tri_band(CsrView A, int c, int stride, double* __restrict__ ba,
+                                                     double* __restrict__ bd, double* __restrict__ bu) {
+    for (int e = blockIdx.x * kBlock + threadIdx.x; e < A.n; e += gridDim.x * kBlock) {
+        double a = 0.0, d = 0.0, u = 0.0;
+        for (int p = A.rowptr[e]; p < A.rowptr[e + 1]; ++p) {
+            const int col = A.col[p];
+            const double x = A.val[p];
+            if (col == e) d += x;
+            else if (col == e - 1) a += x;
+            else if (col == e + 1) u += x;
+        }
+        const int k = tri_perm(e, c, stride);
+        ba[k] = a; bd[k] = d; bu[k] = u;
+    }
+}
+
 // chain_only: T = (odometry-chain Laplacian) + sigma I, i.e. the diagonal counts the two band neighbours
 // only -- the closures are then added back exactly by the Woodbury correction (woodbury.h).
 template <int C>
-__global__ __launch_bounds__(kTriThreads) void k_tri_factor(CsrView A, double sigma, double* tl,
+__global__ __launch_bounds__(kTriThreads) void k_tri_factor(int n, const double* __restrict__ ba, const double* __restrict__ bd,
+                                                            const double* __restrict__ bu, double sigma, double* tl,
                                                             double* tdinv, double* tcu, int* bad, int chain_only) {
     __shared__ Mob sM[16];
     __shared__ double s_afirst[kTriThreads + 1];
-    const int t = threadIdx.x, n = A.n;   // thread t owns the unknowns e = t*C .. t*C + C-1 (zero padded past n)
+    const int t = threadIdx.x;   // thread t owns the unknowns e = t*C .. t*C + C-1 (zero padded past n)
     double av[C], bv[C];
     Mob M{1.0, 0.0, 0.0, 1.0};
 #pragma unroll
@@ -149,14 +168,9 @@ __global__ __launch_bounds__(kTriThreads) void k_tri_factor(CsrView A, double si
         av[i] = 0.0; bv[i] = 1.0;
         const int e = t * C + i;
         if (e < n) {
-            double a = 0.0, b = 0.0, up = 0.0;
-            for (int p = A.rowptr[e]; p < A.rowptr[e + 1]; ++p) {
-                const int col = A.col[p];
-                if (col == e) b += A.val[p];
-                else if (col == e - 1) a += A.val[p];
-                else if (col == e + 1) up += A.val[p];
-            }
-            if (chain_only) b = -(a + up);
+            const int k = i * kTriThreads + t;
+            const double a = ba[k];
+            const double b = chain_only ? -(a + bu[k]) : bd[k];
             av[i] = a; bv[i] = b + sigma;
             M = mob_mul(Mob{bv[i], -a * a, 1.0, 0.0}, M);
         }

@@ -223,6 +223,7 @@ struct Solver {
     double *lx_rT = nullptr, *lx_wT = nullptr, *lx_tl = nullptr, *lx_tdinv = nullptr, *lx_tcu = nullptr;
     double *lx_ys = nullptr, *lx_pas = nullptr, *lx_as = nullptr, *lx_bs = nullptr;   // big-n solver scratch
     double* lx_maps = nullptr;   // 4 x stride chunk maps of the multi-workgroup tridiagonal solve
+    double *lx_ba = nullptr, *lx_bd = nullptr, *lx_bu = nullptr;   // tridiagonal band of L in the solver's layout
     // exact chain + closures preconditioner (woodbury.h)
     int *wb_ui = nullptr, *wb_uj = nullptr, *wb_counts = nullptr;
     double *wb_uc = nullptr, *wb_g = nullptr, *wb_h = nullptr, *wb_Zt = nullptr, *wb_Cm = nullptr;
@@ -285,7 +286,7 @@ struct Solver {
         void* ptrs[] = {u, V, tri, part, Z0, Z1, st, st2, y_raw, w2, yvec, ypart, sdev,
                         part_c, part_a2, part_r, scratch3, rq_dev, start, wc, ctri, part_u, part_a, stc,
                         lx_x, lx_Lx, lx_p, lx_Lp, lx_Lw, lx_rT, lx_wT, lx_tl, lx_tdinv, lx_tcu, lx_part, lx_partR,
-                        lx_ys, lx_pas, lx_as, lx_bs, lx_maps, wb_ui, wb_uj, wb_counts, wb_uc, wb_g, wb_h, wb_Zt, wb_Cm, wb_pas, wb_maps,
+                        lx_ys, lx_pas, lx_as, lx_bs, lx_maps, lx_ba, lx_bd, lx_bu, wb_ui, wb_uj, wb_counts, wb_uc, wb_g, wb_h, wb_Zt, wb_Cm, wb_pas, wb_maps,
                         lx_colT, lx_bad, lx_st};
         if (h_lrec) (void)hipHostFree(h_lrec);
         if (wb_handle) (void)rocblas_destroy_handle(wb_handle);
@@ -449,7 +450,7 @@ struct Solver {
             ST_TRY(dev_alloc(&lx_x, n)); ST_TRY(dev_alloc(&lx_Lx, n)); ST_TRY(dev_alloc(&lx_p, n));
             ST_TRY(dev_alloc(&lx_Lp, n)); ST_TRY(dev_alloc(&lx_Lw, n));
             const size_t tcap = (size_t)lob_c() * (size_t)lob_stride();   // chunk-transposed, zero padded past n
-            double** tr[] = {&lx_rT, &lx_wT, &lx_tl, &lx_tdinv, &lx_tcu};
+            double** tr[] = {&lx_rT, &lx_wT, &lx_tl, &lx_tdinv, &lx_tcu, &lx_ba, &lx_bd, &lx_bu};
             for (double** q : tr) {
                 ST_TRY(dev_alloc(q, tcap));
                 HIP_TRY(hipMemsetAsync(*q, 0, sizeof(double) * tcap, stream));
@@ -642,13 +643,16 @@ struct Solver {
         const double sigma = (wb_s > 0 ? 1e-8 : 2.5e-7) * scale;
         HIP_TRY(hipMemsetAsync(lx_bad, 0, sizeof(int), stream));
         if (n > kTriMaxN) k_tri_factor_big<<<1, kTriThreads, 0, stream>>>(A, L.stride, sigma, lx_tl, lx_tdinv, lx_tcu, lx_as, lx_bs, lx_bad, chain_only);
-        else switch (L.c) {
-#define MACHIP_LOB_CASE(C) case C: k_tri_factor<C><<<1, kTriThreads, 0, stream>>>(A, sigma, lx_tl, lx_tdinv, lx_tcu, lx_bad, chain_only); break;
+        else {
+            k_tri_band<<<g2, kBlock, 0, stream>>>(A, L.c, L.stride, lx_ba, lx_bd, lx_bu);
+            switch (L.c) {
+#define MACHIP_LOB_CASE(C) case C: k_tri_factor<C><<<1, kTriThreads, 0, stream>>>(n, lx_ba, lx_bd, lx_bu, sigma, lx_tl, lx_tdinv, lx_tcu, lx_bad, chain_only); break;
             MACHIP_LOB_CASE(1) MACHIP_LOB_CASE(2) MACHIP_LOB_CASE(3) MACHIP_LOB_CASE(4) MACHIP_LOB_CASE(5) MACHIP_LOB_CASE(6)
             MACHIP_LOB_CASE(7) MACHIP_LOB_CASE(8) MACHIP_LOB_CASE(9) MACHIP_LOB_CASE(10) MACHIP_LOB_CASE(11) MACHIP_LOB_CASE(12)
             MACHIP_LOB_CASE(13) MACHIP_LOB_CASE(14) MACHIP_LOB_CASE(15)
 #undef MACHIP_LOB_CASE
-            default: k_tri_factor<16><<<1, kTriThreads, 0, stream>>>(A, sigma, lx_tl, lx_tdinv, lx_tcu, lx_bad, chain_only); break;
+            default: k_tri_factor<16><<<1, kTriThreads, 0, stream>>>(n, lx_ba, lx_bd, lx_bu, sigma, lx_tl, lx_tdinv, lx_tcu, lx_bad, chain_only); break;
+            }
         }
         k_lob_perm_cols<<<(int)std::min<long>(kMaxGrid, (nnz + kBlock - 1) / kBlock), kBlock, 0, stream>>>(A.col, nnz, L.c, L.stride, lx_colT);
         CsrView AT = A;
