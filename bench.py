@@ -1,29 +1,45 @@
 #!/usr/bin/env python3
 """bench.py -- Frank-Wolfe iterations/second (each including the full Fiedler solve) of the
-MAC hot path on MI355X, with the CPU reference-equivalent path timed beside it.
+MAC hot path on MI355X, with the CPU paths timed beside it.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5a|c5b]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c4|c2|c3|c5a|c5b|c5] [--mode shard|replicas]
 
 One "step" = one Frank-Wolfe iteration (mac/optimization/frankwolfe.py:53-76 with
 problem = MAC.problem): assemble L(x) -> Fiedler pair to the reference's stop rule at tol 1e-8 ->
 supergradient of all m candidates -> top-K LP -> dual bound / norms -> x update.  Inputs (edge
 lists, x0, start vector) are resident in HBM before the timed region starts.
 
-N = 1 workload: BASELINE.json configs[1] (ER N=10k, p=0.01, chain fixed, K=10%).  For N > 1 the same
-workload is run with the candidates sharded over the ranks: every rank evaluates
-the supergradient of its contiguous candidate range, one RCCL all-gather rebuilds the m-vector
-on every rank, the eigen-solve is replicated.  "scaling": "strong".
+Default workload (N = 1): BASELINE.json configs[3], the configuration the north star quotes its target on
+(ER N = 100 000, ~2M candidate edges, chain fixed, K = 10 %); it fits one GPU.  The timed region is a PASS of
+exactly K iterations from x0; passes are repeated until >= --min-seconds of wall time have been measured and
+the MEDIAN pass is reported (`repeats`, `pass_ms`), so the figure is reproducible and visible from outside.
 
-Prints ONE JSON line (rank 0).  No torch anywhere: ranks launched by torch.distributed.run find each
-other through mac_amd.dist.FileGroup (single node), the data path is libmachip.so (HIP + RCCL) via ctypes.
+--gpus N > 1:
+  * --mode shard (default; the north star's split): the same workload with the
+    candidates sharded over the ranks: every rank evaluates the supergradient of its contiguous candidate
+    range, one RCCL all-gather rebuilds the m-vector on every rank, everything else is replicated.
+    "scaling": "strong".  DESIGN section 6 states what this can and cannot scale.
+  * --mode replicas: every rank runs an independent problem of the same graph with its own budget K_r
+    (the reference's budget sweep, examples/g2o_experiment.py:306-336; --config c5: one pose graph per
+    rank), no collective; value = all ranks' iterations / max-over-ranks time.  "scaling": "weak".
+  Launched by `torch.distributed.run` (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in the environment) or, when those
+  are absent, by bench.py itself: it spawns N rank processes, one GPU each, and refuses to run when fewer
+  than N devices are visible.
+
+Prints ONE JSON line (rank 0).  No torch anywhere: ranks find each other through mac_amd.dist.FileGroup
+(single node), the data path is libmachip.so (HIP + RCCL) via ctypes.
 """
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
+import uuid
 
-os.environ.setdefault("OMP_NUM_THREADS", "1")          # the CPU baseline is a 1-core path (SuperLU)
+os.environ.setdefault("OMP_NUM_THREADS", "1")          # the CPU baselines are 1-core paths (SuperLU, ARPACK)
 os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
 os.environ.setdefault("MKL_NUM_THREADS", "1")
 
@@ -33,16 +49,33 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
+KERNEL = "k_pipe_vec (fused Lanczos step: CSR SpMV + all vector work of one step)"
 
 
 # ---------------------------------------------------------------------------------------------
 # workloads
 # ---------------------------------------------------------------------------------------------
 def er_workload(n, p, seed, name):
-    import networkx as nx
-    G = nx.fast_gnp_random_graph(n, p, seed=seed)
-    e = np.array([(min(a, b), max(a, b)) for a, b in G.edges() if abs(a - b) != 1], dtype=np.int32)
-    ci, cj = e[:, 0].copy(), e[:, 1].copy()
+    cache = os.path.join(tempfile.gettempdir(), f"machip_wl_{n}_{seed}_{os.getuid()}.npz")
+    if os.path.exists(cache):
+        try:
+            z = np.load(cache)
+            ci, cj = z["ci"], z["cj"]
+        except Exception:
+            ci = None
+    else:
+        ci = None
+    if ci is None:
+        import networkx as nx
+        G = nx.fast_gnp_random_graph(n, p, seed=seed)
+        e = np.array([(min(a, b), max(a, b)) for a, b in G.edges() if abs(a - b) != 1], dtype=np.int32)
+        ci, cj = e[:, 0].copy(), e[:, 1].copy()
+        try:        # generation takes ~20 s at N = 100k; the PMC / rank children of one run reuse it
+            tmp = cache + f".{os.getpid()}.tmp.npz"
+            np.savez(tmp, ci=ci, cj=cj)
+            os.replace(tmp, cache)
+        except OSError:
+            pass
     m = len(ci)
     k = m // 10
     x0 = np.zeros(m)
@@ -80,33 +113,39 @@ def make_workload(cfg):
     raise SystemExit(f"unknown --config {cfg}")
 
 
+def step_bytes(n, nnz):
+    """Algorithmic bytes of ONE fused Lanczos step (SURVEY 8(d) B_spmv + the fused vector work):
+    12 nnz (val f64 + col i32) + 4 (n+1) (rowptr) + 56 n (gather record counted once per row 16 B, own-row
+    record 16 B, next record written 16 B, basis column written 8 B).  In the mixed-precision mode the
+    records and values are 4-byte floats: 8 nnz + 4 (n+1) + 32 n."""
+    return 12.0 * nnz + 4.0 * (n + 1) + 56.0 * n
+
+
 # ---------------------------------------------------------------------------------------------
-def run_fw(P, k, iters, x0, profile=False, reps=40):
-    """iters Frank-Wolfe iterations from x0 with the stop tests disabled; returns per-iteration
-    records.  With profile=True the fused Lanczos SpMV kernel is additionally timed with
-    hipEvents on each iteration's L(x) (outside any timed region)."""
+def run_pass(P, k, iters, x0, tol=1e-8):
+    """iters Frank-Wolfe iterations from x0 with the stop tests disabled (device-resident loop)."""
     P.set_x(x0)
     rec = []
     for it in range(iters):
-        f, dual, gn = P.fw_step(k, it)
+        f, dual, gn = P.fw_step(k, it, tol=tol)
         st = P.stats
-        r = dict(f=f, dual=dual, gnorm=gn, steps=int(st.lanczos_steps), nnz=int(st.nnz), support=int(st.support),
-                 gpu_ms=float(st.gpu_ms), residual=float(st.residual))
-        if profile:
-            us, by = P.profile_spmv(reps)
-            r.update(spmv_us=us, spmv_bytes=by)
+        rec.append(dict(f=f, dual=dual, gnorm=gn, steps=int(st.lanczos_steps), nnz=int(st.nnz), support=int(st.support),
+                        gpu_ms=float(st.gpu_ms), step_ms=float(st.step_ms), steps_timed=int(st.steps_timed),
+                        residual=float(st.residual)))
         P.fw_commit()
-        rec.append(r)
     return rec
 
 
-def cpu_baseline(w, budget_s=12.0, max_iters=20, min_s=3.0):
-    """Reference-equivalent CPU path (the oracle: TraceMIN + SuperLU exactly as networkx runs it
-    for the reference, NumPy assembly/gradient/LP), timed on this host, 1 thread.  Bounded sample:
-    Frank-Wolfe iterations of the same workload from x0 until `budget_s` is spent (config 2: the
-    first iteration alone takes ~30 s) -- small workloads repeat the 20-iteration pass until `min_s`."""
+# ---------------------------------------------------------------------------------------------
+# CPU baselines (oracle/ is imported here and only here, as the thing timed BESIDE the product)
+# ---------------------------------------------------------------------------------------------
+def cpu_baseline(w, fiedler, budget_s, max_iters=20, min_s=3.0):
+    """Frank-Wolfe iterations of the same workload from x0 on the host CPU, 1 thread, until `budget_s` is spent.
+    fiedler = "tracemin": the reference-equivalent path (oracle/: TraceMIN + SuperLU exactly as networkx runs it
+    for the reference, NumPy assembly / gradient / LP).  fiedler = "eigsh": the same loop with SciPy's ARPACK
+    Lanczos -- NOT what the reference runs, the strong CPU baseline SURVEY section 8(d) asks for."""
     import oracle
-    mo = oracle.MacOracle(w["fi"], w["fj"], w["fw"], w["ci"], w["cj"], w["cw"], w["n"])
+    mo = oracle.MacOracle(w["fi"], w["fj"], w["fw"], w["ci"], w["cj"], w["cw"], w["n"], fiedler=fiedler)
     t0 = time.perf_counter()
     done, passes = 0, 0
     fs = []
@@ -127,23 +166,24 @@ def cpu_baseline(w, budget_s=12.0, max_iters=20, min_s=3.0):
             break
     el = time.perf_counter() - t0
     what = f"first {done} Frank-Wolfe iterations" if passes == 1 else f"{passes} passes of the first {max_iters} Frank-Wolfe iterations"
-    return dict(value=done / el, unit="iter/s", cores=1, kind="port",
-                sample=f"{what} of the same workload ({el:.1f} s), oracle/ "
-                       "(TraceMIN-Fiedler with SuperLU LU, tol 1e-8, RandomState(7) start) on the host CPU, 1 thread",
-                f_traj=fs)
+    how = ("oracle/ (TraceMIN-Fiedler with SuperLU LU, tol 1e-8, RandomState(7) start = the reference's arithmetic)"
+           if fiedler == "tracemin" else
+           "oracle/ loop with scipy.sparse.linalg.eigsh (ARPACK Lanczos, which='SA', tol 1e-10) instead of TraceMIN -- not the reference's solver")
+    return dict(value=done / el, unit="iter/s", cores=1, host_cores=os.cpu_count(), kind="port",
+                sample=f"{what} of the same workload ({el:.1f} s), {how} on the host CPU, 1 thread", f_traj=fs)
 
 
-def _cpu_child(cfg, q):
-    q.put(cpu_baseline(make_workload(cfg)))
+def _cpu_child(cfg, fiedler, budget_s, q):
+    q.put(cpu_baseline(make_workload(cfg), fiedler, budget_s))
 
 
-def cpu_baseline_bounded(cfg, hard_s=120.0):
+def cpu_baseline_bounded(cfg, fiedler, budget_s, hard_s):
     """cpu_baseline in a child process with a hard wall-clock limit: one SuperLU factorisation cannot be
-    interrupted from Python, and at config 4 (N = 100k) it does not finish (fill-in)."""
+    interrupted from Python, and at config 4 (N = 100k) it does not finish (fill-in, SURVEY 6.2: > 50 min)."""
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_cpu_child, args=(cfg, q))
+    p = ctx.Process(target=_cpu_child, args=(cfg, fiedler, budget_s, q))
     t0 = time.perf_counter()
     p.start()
     res = None
@@ -165,16 +205,57 @@ def cpu_baseline_bounded(cfg, hard_s=120.0):
         raise RuntimeError(f"cpu_baseline child exited with code {p.exitcode}")
     if res is None:
         el = time.perf_counter() - t0
-        return dict(value=1.0 / el, unit="iter/s", cores=1, kind="port", f_traj=[],
+        return dict(value=1.0 / el, unit="iter/s", cores=1, host_cores=os.cpu_count(), kind="port", f_traj=[],
+                    upper_bound=True,
                     sample=f"the first Frank-Wolfe iteration of the same workload did not finish within {el:.0f} s "
-                           "(workload generation included); value is that upper bound; oracle/ (TraceMIN-Fiedler with "
-                           "SuperLU LU) on the host CPU, 1 thread")
+                           "(workload load included; the reference's sparse LU needs > 50 min here, SURVEY 6.2); value is that "
+                           f"UPPER BOUND; oracle/ ({fiedler}) on the host CPU, 1 thread")
     return res
 
 
+# ---------------------------------------------------------------------------------------------
+# PMC traffic of the dominant kernel: two short rocprofv3 passes of this same script
+# ---------------------------------------------------------------------------------------------
+def pmc_traffic(cfg, steps=3, timeout_s=240):
+    """HBM bytes per launch of the fused step kernel = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes), each counter from
+    its own `rocprofv3 --pmc` pass (MI355X_MICROARCH.md: FETCH_SIZE on gfx950 tallies 128-byte requests at 64 B)
+    of `bench.py --config cfg --steps 3 --pmc-child`.  Returns (bytes or None, note)."""
+    import csv
+    import glob
+    rp = shutil.which("rocprofv3")
+    if rp is None:
+        return None, "rocprofv3 not on PATH"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="machip_pmc_")
+        env = dict(os.environ, TMPDIR=tempfile.gettempdir())
+        cmd = [rp, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
+               sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", str(steps), "--warmup", "0", "--pmc-child"]
+        try:
+            subprocess.run(cmd, cwd=tempfile.gettempdir(), env=env, timeout=timeout_s, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            tot, cnt = 0.0, 0
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if r["Counter_Name"] == counter and "k_pipe_" in r["Kernel_Name"] and "k_pipe_tail" not in r["Kernel_Name"] \
+                                and "k_pipe_init" not in r["Kernel_Name"]:
+                            tot += float(r["Counter_Value"]); cnt += 1
+            if cnt == 0:
+                return None, f"rocprofv3 --pmc {counter} produced no rows for the step kernel"
+            vals[counter] = (tot / cnt, cnt)
+        except subprocess.TimeoutExpired:
+            return None, f"rocprofv3 --pmc {counter} pass timed out"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    by = (2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024.0
+    return by, (f"traffic = (2*FETCH_SIZE + WRITE_SIZE) KiB per launch over {vals['FETCH_SIZE'][1]} launches, two separate "
+                f"rocprofv3 --pmc passes of this script ({steps} iterations each) run by this bench invocation")
+
+
+# ---------------------------------------------------------------------------------------------
 def bench_c5_batched(args):
-    """BASELINE.json configs[4]: city10000 + sphere2500 as a batch of independent problems (replicas, no
-    collective): one handle + stream + host thread per graph on the same GPU; ctypes releases the GIL, the
+    """BASELINE.json configs[4] on ONE GPU: city10000 + sphere2500 as a batch of independent problems (replicas,
+    no collective): one handle + stream + host thread per graph on the same GPU; ctypes releases the GIL, the
     tiny kernels of the two solves overlap on the chip.  value = total FW iterations of both / wall time."""
     import threading
     from mac_amd import _lib
@@ -183,14 +264,15 @@ def bench_c5_batched(args):
     Ps = []
     for w in ws:
         P = _lib.Problem(w["n"], w["fi"], w["fj"], w["fw"], w["ci"], w["cj"], w["cw"])
+        P.set_precision(args.precision)
         P.set_start(reference_start_block(w["n"])[:, 0].copy())
-        run_fw(P, w["k"], args.warmup, w["x0"])
+        run_pass(P, w["k"], args.warmup, w["x0"])
         P.set_x(w["x0"]); P.synchronize()
         Ps.append(P)
     fs = [None, None]
 
     def work(i):
-        fs[i] = [r["f"] for r in run_fw(Ps[i], ws[i]["k"], args.steps, ws[i]["x0"])]
+        fs[i] = [r["f"] for r in run_pass(Ps[i], ws[i]["k"], args.steps, ws[i]["x0"])]
     t0 = time.perf_counter()
     th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
     for t in th:
@@ -202,12 +284,13 @@ def bench_c5_batched(args):
     el = time.perf_counter() - t0
     t1 = time.perf_counter()
     for i in range(2):
-        run_fw(Ps[i], ws[i]["k"], args.steps, ws[i]["x0"])
+        run_pass(Ps[i], ws[i]["k"], args.steps, ws[i]["x0"])
         Ps[i].synchronize()
     seq = time.perf_counter() - t1
     print(json.dumps({"metric": "frank_wolfe_iters_per_sec", "value": 2 * args.steps / el, "unit": "iter/s", "n_gpus": 1,
                       "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / (2 * args.steps),
-                      "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                      "dtype": "f64" if args.precision == 0 else "f32 iterate + f64 Rayleigh/residual refinement",
                       "data": "dataset (tests/golden/data)",
                       "config": {"workload": "configs[4]: city10000.g2o + sphere2500.g2o batched (2 concurrent handles, 1 GPU), K=20%",
                                  "fw_iters_each": args.steps, "parallelism": "replicas: one stream + host thread per graph"},
@@ -216,28 +299,63 @@ def bench_c5_batched(args):
         P.close()
 
 
+# ---------------------------------------------------------------------------------------------
+def self_launch(args):
+    """--gpus N without a launcher: spawn N rank processes (one GPU each) of this script."""
+    from mac_amd import _lib
+    _lib.load()
+    have = _lib.device_count()
+    if have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible -- refusing to run a mislabelled {have}-GPU job")
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    key = uuid.uuid4().hex
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), MACHIP_RDZV_KEY=key, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    if any(codes):
+        raise SystemExit(f"rank exit codes {codes}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c2")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--config", default="c4")
+    ap.add_argument("--mode", default="shard", choices=["shard", "replicas"], help="N > 1: candidate shard + RCCL (strong) or independent problems (weak)")
+    ap.add_argument("--precision", type=int, default=0, help="0 = f64 throughout; 1 = f32 Krylov iterate + f64 Rayleigh/residual refinement (configs[4])")
+    ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the K-iteration pass until this much wall time is measured")
+    ap.add_argument("--max-repeats", type=int, default=50)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes (roofline.traffic = null)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     from mac_amd import _lib           # loads libmachip.so (HIP 7.2 runtime) before anything else
     _lib.load()
     _lib.require_device()
+    ndev = _lib.device_count()
+    if world > 1 and ndev < world:
+        raise SystemExit(f"--gpus {world} but only {ndev} GPU(s) visible")
     dist = None
-    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ     # under torch.distributed.run
-    if world > 1 or launched:
+    if world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ):
         from mac_amd.dist import FileGroup     # rendezvous / barrier / max only; data path is RCCL
         dist = FileGroup(rank, world)
 
@@ -245,90 +363,132 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    if args.config == "c5":
+    if args.config == "c5" and world == 1:
         return bench_c5_batched(args)
-    w = make_workload(args.config)
+    replicas = world > 1 and (args.mode == "replicas" or args.config == "c5")
+    cfg = args.config
+    if cfg == "c5":                      # one pose graph per rank (SURVEY 8(e) last row)
+        cfg = "c5b" if rank % 2 == 0 else "c5a"
+    w = make_workload(cfg)
     n, m, k = w["n"], len(w["cw"]), w["k"]
-    P = _lib.Problem(n, w["fi"], w["fj"], w["fw"], w["ci"], w["cj"], w["cw"], device=local_rank % max(1, _lib.device_count()))
+    if replicas and args.config != "c5":  # budget sweep: rank r solves the same graph with budget K_r
+        k = max(1, int(round(k * (0.5 + rank / max(1, world - 1)))))
+    P = _lib.Problem(n, w["fi"], w["fj"], w["fw"], w["ci"], w["cj"], w["cw"], device=local_rank % max(1, ndev))
+    P.set_precision(args.precision)
     from mac_amd.utils.fiedler import reference_start_block
     P.set_start(reference_start_block(n)[:, 0].copy())
-    if dist is not None:
+    if dist is not None and not replicas:
         from mac_amd.dist import attach
-        attach(P, dist, rank, world)      # ncclCommInitRank inside libmachip; gloo only carries the id
+        attach(P, dist, rank, world)      # ncclCommInitRank inside libmachip; the file group only carries the id
 
     # ---- warmup (untimed) ----
-    run_fw(P, k, args.warmup, w["x0"])
-    P.set_x(w["x0"])
-    P.synchronize()
-    barrier()
-    # ---- timed region: exactly K Frank-Wolfe iterations from x0 ----
-    t0 = time.perf_counter()
-    rec = []
-    for it in range(args.steps):
-        f, dual, gn = P.fw_step(k, it)
-        st = P.stats
-        rec.append((f, int(st.lanczos_steps), int(st.nnz), int(st.support), float(st.gpu_ms)))
-        P.fw_commit()
-    P.synchronize()
-    barrier()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        el = dist.max(el)
+    run_pass(P, k, args.warmup, w["x0"])
+    if args.pmc_child:                    # profiled child of pmc_traffic(): a few iterations, nothing printed
+        run_pass(P, k, args.steps, w["x0"])
+        P.close()
+        return
+    # ---- timed region: passes of exactly K Frank-Wolfe iterations from x0, median pass reported ----
+    passes, total = [], 0.0
+    while True:
+        P.set_x(w["x0"])
+        P.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        rec = []
+        for it in range(args.steps):
+            f, dual, gn = P.fw_step(k, it)
+            st = P.stats
+            rec.append((f, int(st.lanczos_steps), int(st.nnz), int(st.support), float(st.gpu_ms), float(st.step_ms), int(st.steps_timed)))
+            P.fw_commit()
+        P.synchronize()
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            el = dist.max(el)             # every rank sees the same number, so every rank stops after the same pass
+        passes.append((el, rec))
+        total += el
+        if total >= args.min_seconds or len(passes) >= args.max_repeats:
+            break
+    order = sorted(range(len(passes)), key=lambda i: passes[i][0])
+    el, rec = passes[order[(len(order) - 1) // 2]]       # the median pass (lower median)
+    units = args.steps
+    if replicas:
+        units = args.steps * world        # every rank ran K iterations of its own problem
 
     out = None
     if rank == 0:
         steps = np.array([r[1] for r in rec], dtype=float)
+        if world == 1:
+            par = "single GPU" + (" (RCCL communicator of 1 rank)" if dist is not None else "")
+        elif replicas:
+            par = (f"replicas x{world}: one independent problem per GPU (" +
+                   ("city10000 / sphere2500 alternating" if args.config == "c5" else "budget sweep K_r = K (0.5 + r/(R-1))") + "), no collective")
+        else:
+            par = f"candidate shard x{world} + RCCL all-gather of the gradient, eigen-solve replicated"
         out = {
             "metric": "frank_wolfe_iters_per_sec",
-            "value": args.steps / el,
+            "value": units / el,
             "unit": "iter/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * el / args.steps,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak" if replicas else "strong",
             "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic" if args.config in ("c2", "c4") else "dataset (tests/golden/data)",
-            "config": {"workload": w["name"], "N": n, "m_candidates": m, "K": k, "fixed_edges": int(len(w["fw"])),
-                       "fw_iters": args.steps, "fiedler_tol": 1e-8,
-                       "parallelism": ("single GPU" + (" (RCCL communicator of 1 rank)" if dist is not None else "")) if world == 1 else f"candidate shard x{world} + RCCL all-gather of the gradient, eigen-solve replicated"},
+            "dtype": "f64" if args.precision == 0 else "f32 iterate + f64 Rayleigh/residual refinement",
+            "data": "synthetic" if cfg in ("c2", "c4") else "dataset (tests/golden/data)",
+            "config": {"workload": w["name"] if args.config != "c5" else "configs[4]: city10000.g2o / sphere2500.g2o, one graph per GPU, K=20%",
+                       "N": n, "m_candidates": m, "K": k, "fixed_edges": int(len(w["fw"])),
+                       "fw_iters": args.steps, "fiedler_tol": 1e-8, "parallelism": par},
+            "repeats": len(passes),
+            "pass_ms": [round(1e3 * p[0], 3) for p in passes],
+            "timed_wall_s": total,
             "lanczos_steps_per_iter": float(steps.mean()),
             "lambda2_first_last": [rec[0][0], rec[-1][0]],
             "nnz_first_last": [rec[0][2], rec[-1][2]],
             "eig_ms_per_iter": float(np.mean([r[4] for r in rec])),
         }
-    # ---- roofline of the dominant kernel (fused Lanczos SpMV), replay of the timed iterations ----
-    if not args.no_roofline:
-        prof = run_fw(P, k, args.steps, w["x0"], profile=True)
-        if rank == 0:
-            wts = np.array([r["steps"] for r in prof], dtype=float)
-            us = float(np.sum(wts * np.array([r["spmv_us"] for r in prof])) / wts.sum())
-            by = float(np.sum(wts * np.array([r["spmv_bytes"] for r in prof])) / wts.sum())
+    # ---- roofline of the dominant kernel: in-solve duration from the hipEvents that bracket the Krylov chunks
+    #      on the handle's stream (machip_solve_stats.step_ms / steps_timed), summed over EVERY timed pass ----
+    if not args.no_roofline and rank == 0:
+        sm = sum(r[5] for p in passes for r in p[1])
+        sc = sum(r[6] for p in passes for r in p[1])
+        by_num = sum(r[6] * step_bytes(n, r[2]) for p in passes for r in p[1])
+        if args.precision == 1:
+            by_num = sum(r[6] * (8.0 * r[2] + 4.0 * (n + 1) + 32.0 * n) for p in passes for r in p[1])
+        if sc > 0 and sm > 0:
+            us = 1e3 * sm / sc
+            by = by_num / sc
             ach = by / (us * 1e-6) / 1e9
-            traffic, tnote = None, "PMC traffic not collected for this config (tools/profile_round.sh)"
-            pj = os.path.join(ROOT, "profiles", f"r1_{args.config}_summary.json")
-            if os.path.exists(pj):      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
-                dom = json.load(open(pj))["dominant"]
-                traffic = dom["hbm_bytes_per_launch"]
-                tnote = (f"traffic = 2*FETCH_SIZE + WRITE_SIZE per launch from profiles/r1_{args.config}_summary.json "
-                         f"(rocprofv3 --pmc passes of this command; rocprof avg launch {dom['avg_us']:.2f} us)")
-            out["roofline"] = {"bound": "hbm", "kernel": "k_pipe_vec (fused Lanczos step: CSR SpMV + all vector work of one step)",
-                               "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "traffic": traffic, "avg_launch_us": us, "algorithmic_bytes_per_launch": by,
-                               "note": "launch-latency bound: ~6-12 MB per launch, working set is Infinity-Cache resident; " + tnote}
+            traffic, tnote = None, "PMC passes skipped"
+            if world == 1 and not args.no_pmc:
+                traffic, tnote = pmc_traffic(args.config)
+            note = ("avg_launch_us = step_ms / steps_timed of machip_solve_stats: hipEvents on the handle's stream around the Krylov "
+                    "chunks of every solve in the timed passes (step kernels + one 1-wave tail kernel per chunk, so slightly above "
+                    "the pure kernel average rocprofv3 reports); algorithmic bytes = 12 nnz + 4 (n+1) + 56 n per launch, "
+                    "step-weighted over the iterations; the CSR and the gather operand are Infinity-Cache resident "
+                    "(<= 55 MB), peak is the 8 TB/s HBM figure all the same; " + tnote)
             if w["n"] <= 3072:   # small chain-like graphs run the single-workgroup solver, not this kernel
-                out["roofline"]["note"] = ("at this size the solve runs in the LDS/register-resident single-workgroup kernel k_lan_persist "
-                                           "(HBM traffic: one 8n-byte basis column per step); the figures here are the multi-workgroup "
-                                           "fused step replayed on the same matrices, for comparison only; " + tnote)
+                note = ("at this size the solve runs in the LDS/register-resident single-workgroup kernel k_lan_persist (HBM traffic: one "
+                        "8n-byte basis column per step); bytes are still counted with the multi-workgroup formula; " + note)
+            out["roofline"] = {"bound": "hbm", "kernel": KERNEL, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_us": us,
+                               "algorithmic_bytes_per_launch": by, "launches_timed": sc, "note": note}
     if rank == 0 and world == 1 and not args.no_cpu:
-        cb = cpu_baseline_bounded(args.config)
+        small = n <= 20000 and cfg != "c2"
+        cb = cpu_baseline_bounded(cfg, "tracemin", budget_s=12.0, hard_s=20.0 if small else 45.0)
         ft = cb.pop("f_traj")
         out["cpu_baseline"] = cb
         if ft:
             out["cpu_parity_lambda2_rel"] = float(max(abs(a - r[0]) / abs(a) for a, r in zip(ft, rec)))
         out["speedup_vs_cpu"] = out["value"] / cb["value"]
+        cs = cpu_baseline_bounded(cfg, "eigsh", budget_s=15.0, hard_s=60.0)
+        fts = cs.pop("f_traj")
+        out["cpu_baseline_strong"] = cs
+        if fts:
+            out["cpu_strong_parity_lambda2_rel"] = float(max(abs(a - r[0]) / abs(a) for a, r in zip(fts, rec)))
+        out["speedup_vs_cpu_strong"] = out["value"] / cs["value"]
     if rank == 0:
         print(json.dumps(out))
     P.close()

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MACHIP_ABI_VERSION 1
+#define MACHIP_ABI_VERSION 2
 
 typedef enum machip_status {
     MACHIP_OK = 0,
@@ -51,9 +51,14 @@ typedef struct machip_solve_stats {
                               nx:232,246)                                                  */
     double lnorm;          /* ||L||_inf                                                    */
     double gpu_ms;         /* device time of the solve (hipEvents on the handle's stream)  */
+    double step_ms;        /* ... of which the Krylov chunks alone (events bracketing the
+                              step kernels; explicit checks / Ritz vector excluded)        */
+    int64_t steps_timed;   /* steps covered by step_ms: step_ms / steps_timed = in-solve
+                              duration of one fused step launch                            */
 } machip_solve_stats;
 
 int machip_version(void);
+int machip_sizeof_stats(void);             /* sizeof(machip_solve_stats): binding layout check */
 int machip_device_count(void);            /* 0 when no GPU is visible                      */
 const char* machip_last_error(void);
 
@@ -156,6 +161,15 @@ int machip_comm_init(machip_problem* p, int rank, int nranks, const void* id128)
  * 'tracemin_pcg' here).  Mode 2 falls back to mode 1 when it does not apply (n <= 256) or
  * stagnates; results obey the same stop rule either way. */
 int machip_set_solver(machip_problem* p, int mode);
+
+/* Arithmetic of the Krylov iterate (BASELINE.json configs[4], SURVEY section 8(b) `precision`):
+ * 0 = fp64 throughout (default, what the reference computes in, mac/utils/fiedler.py:27-44);
+ * 1 = fp32 Lanczos iterate (fp32 matrix values, 8-byte {t, v} float2 gather records, fp64
+ *     accumulation of every inner product) followed by fp64 refinement: the Ritz vector is
+ *     re-orthogonalised, its Rayleigh quotient and the reference's residual test are evaluated in
+ *     fp64 on the fp64 L(x), and fp64 steps continue from it until the test passes.  The returned
+ *     pair therefore obeys the same stop rule and the same 1e-8 parity bound as mode 0. */
+int machip_set_precision(machip_problem* p, int precision);
 
 int machip_synchronize(machip_problem* p);
 

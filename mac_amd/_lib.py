@@ -30,7 +30,8 @@ class Disconnected(MachipError):
 class SolveStats(C.Structure):
     _fields_ = [("lanczos_steps", C.c_int64), ("spmv_total", C.c_int64), ("vec_passes", C.c_int64),
                 ("restarts", C.c_int64), ("nnz", C.c_int64), ("support", C.c_int64),
-                ("residual", C.c_double), ("lnorm", C.c_double), ("gpu_ms", C.c_double)]
+                ("residual", C.c_double), ("lnorm", C.c_double), ("gpu_ms", C.c_double),
+                ("step_ms", C.c_double), ("steps_timed", C.c_int64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -43,6 +44,7 @@ _lib = None
 # name -> (restype, argtypes); every symbol declared in include/machip.h
 SIGNATURES = {
     "machip_version": (C.c_int, []),
+    "machip_sizeof_stats": (C.c_int, []),
     "machip_device_count": (C.c_int, []),
     "machip_last_error": (C.c_char_p, []),
     "machip_create": (C.c_int, [C.c_int, C.c_int64, C.c_int64, _i32p, _i32p, _f64p, C.c_int64, _i32p, _i32p,
@@ -68,6 +70,7 @@ SIGNATURES = {
     "machip_comm_unique_id": (C.c_int, [C.c_void_p]),
     "machip_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "machip_set_solver": (C.c_int, [C.c_void_p, C.c_int]),
+    "machip_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "machip_synchronize": (C.c_int, [C.c_void_p]),
 }
 _EXTRA = {"machip_host_tridiag_smallest": (C.c_int, [_f64p, _f64p, C.c_int, _f64p, _f64p])}
@@ -250,6 +253,10 @@ class Problem:
     def set_solver(self, mode):
         """0 = automatic, 1 = Lanczos, 2 = preconditioned (LOBPCG + tridiagonal chain solve)."""
         check(self._lib.machip_set_solver(self._h, int(mode)))
+
+    def set_precision(self, precision):
+        """0 = fp64 throughout, 1 = fp32 Krylov iterate + fp64 Rayleigh/residual refinement."""
+        check(self._lib.machip_set_precision(self._h, int(precision)))
 
     def synchronize(self):
         check(self._lib.machip_synchronize(self._h))

@@ -249,6 +249,7 @@ int run_fiedler(machip_problem* p, double tol, int max_steps, const double* x0, 
 extern "C" {
 
 int machip_version(void) { return MACHIP_ABI_VERSION; }
+int machip_sizeof_stats(void) { return (int)sizeof(machip_solve_stats); }
 
 int machip_device_count(void) {
     int c = 0;
@@ -595,6 +596,12 @@ int machip_comm_init(machip_problem* p, int rank, int nranks, const void* id128)
 int machip_set_solver(machip_problem* p, int mode) {
     if (!p || mode < 0 || mode > 2) return fail(MACHIP_BAD_ARG, "machip_set_solver: mode must be 0 (auto), 1 (Lanczos) or 2 (preconditioned)");
     p->sol.solver_mode = mode;
+    return MACHIP_OK;
+}
+
+int machip_set_precision(machip_problem* p, int precision) {
+    if (!p || precision < 0 || precision > 1) return fail(MACHIP_BAD_ARG, "machip_set_precision: 0 (f64) or 1 (f32 iterate + f64 refinement)");
+    p->sol.precision = precision;
     return MACHIP_OK;
 }
 

@@ -204,7 +204,7 @@ struct Solver {
     unsigned long long* d_hflag = nullptr;
     unsigned int epoch = 0;
     double* h_pin = nullptr;    // misc
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evs0 = nullptr, evs1 = nullptr;   // evs*: bracket the Krylov chunks only
     std::vector<hipEvent_t> ev_pool;
     // cached chunk graphs: (variant, width, grid, steps) -> exec
     std::map<std::tuple<int, int, int, int, int>, std::array<hipGraphExec_t, 2>> graphs;
@@ -238,6 +238,7 @@ struct Solver {
     double *h_lrec = nullptr, *d_hlrec = nullptr;
     bool lob_ready = false, last_was_lob = false;
     int solver_mode = 0;        // 0 = auto, 1 = Lanczos, 2 = preconditioned (LOBPCG + tridiagonal solve)
+    int precision = 0;          // 0 = fp64; 1 = fp32 Krylov iterate + fp64 refinement (machip_set_precision)
     bool chain_like = false;    // the fixed edges contain (nearly) the whole chain (i, i+1)
     long chain_edges = 0;       // how many of them
     long support_hint = -1;     // active candidate edges of the matrix about to be solved (-1 = unknown)
@@ -278,6 +279,7 @@ struct Solver {
         *h_flag = 0;
         HIP_TRY(hipHostMalloc((void**)&h_pin, (4 * (vcap + 2) + 2 * kMaxGrid + 64) * sizeof(double), hipHostMallocDefault));
         HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
+        HIP_TRY(hipEventCreate(&evs0)); HIP_TRY(hipEventCreate(&evs1));
         return MACHIP_OK;
     }
     void destroy() {
@@ -296,6 +298,8 @@ struct Solver {
         if (h_pin) (void)hipHostFree(h_pin);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
+        if (evs0) (void)hipEventDestroy(evs0);
+        if (evs1) (void)hipEventDestroy(evs1);
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
     }
 
@@ -792,6 +796,7 @@ struct Solver {
                 if (stats) {
                     stats->lanczos_steps = iters; stats->spmv_total = spmvs; stats->vec_passes = iters * 16;
                     stats->restarts = rst; stats->nnz = nnz; stats->residual = res; stats->lnorm = lnorm; stats->gpu_ms = ms;
+                    stats->step_ms = ms; stats->steps_timed = iters;
                 }
                 if (lam < 1e-12 * (lnorm > 0 ? lnorm : 1.0))
                     return fail(MACHIP_DISCONNECTED, "lambda_2 ~ 0: the graph is not connected");
@@ -813,6 +818,8 @@ struct Solver {
         HIP_TRY(hipEventRecord(ev0, stream));
         if (max_steps <= 0) max_steps = 200000;
         long steps_total = 0, spmv_total = 0, restarts = 0;
+        double step_ms_acc = 0.0;   // stream time of the Krylov chunks alone (step kernels + one tail kernel per chunk)
+        long steps_timed_acc = 0;
         int status = MACHIP_NOT_CONVERGED;
         double lam = 0.0, res = 0.0;
         const double tiny_l = (lnorm > 0 ? lnorm : 1.0);
@@ -853,6 +860,8 @@ struct Solver {
                 k_pipe_init<<<pp.grid, kBlock, 0, stream>>>(L, u, (int)epoch);
             }
             int J_enq = 0;        // steps enqueued in this sequence
+            int J_timed = 0;      // ... of which already accounted in step_ms
+            HIP_TRY(hipEventRecord(evs0, stream));
             ha.clear(); hb.assign(1, 0.0); hl1.assign(1, 0.0);
             guess.clear();
             double theta_prev = 0.0, last_check_est = 1e300, est_latest = 1e300;
@@ -982,7 +991,15 @@ struct Solver {
                 if (debug) fprintf(stderr, "[machip] %s J=%d Jeff=%d theta=%.15g est=%.3e to_go=%.0f broke=%d pend=%zu passes=%d\n", pmode ? "persist" : (classic ? "classic" : "pipe"), J, Jeff, sm.theta, lnorm > 0 ? est / lnorm : est, std::min(to_go, 1e9), (int)broke, pend.size(), sm.passes);
                 if ((trig && est < 0.5 * last_check_est) || broke || at_cap) {
                     double rq = 0.0, r1 = 0.0;
+                    HIP_TRY(hipEventRecord(evs1, stream));   // everything enqueued so far = steps [J_timed, J_enq)
                     ST_TRY(explicit_check(A, pl, Jeff, sm.s.data(), &rq, &r1));   // syncs the stream
+                    {
+                        float sms = 0.f;
+                        HIP_TRY(hipEventElapsedTime(&sms, evs0, evs1));
+                        step_ms_acc += sms; steps_timed_acc += J_enq - J_timed;
+                        J_timed = J_enq;
+                        HIP_TRY(hipEventRecord(evs0, stream));
+                    }
                     spmv_total += 1;
                     J_last = Jeff;
                     last_check_est = std::max(est, 1e-300);
@@ -1023,6 +1040,8 @@ struct Solver {
             stats->residual = res;
             stats->lnorm = lnorm;
             stats->gpu_ms = ms;
+            stats->step_ms = step_ms_acc;
+            stats->steps_timed = steps_timed_acc;
         }
         if (status == MACHIP_OK && lam < 1e-12 * tiny_l)
             return fail(MACHIP_DISCONNECTED, "lambda_2 ~ 0: the graph is not connected");

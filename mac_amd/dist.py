@@ -39,19 +39,32 @@ def attach(problem, dist, rank: int, nranks: int):
     return shard_bounds(problem.m, rank, nranks)
 
 
+def default_key() -> str:
+    ppid = os.getppid()
+    start = "0"
+    try:
+        with open(f"/proc/{ppid}/stat") as fh:      # field 22 = start time of the launcher (clock ticks since boot)
+            start = fh.read().rsplit(")", 1)[1].split()[19]
+    except (OSError, IndexError):
+        pass
+    return f"{os.environ.get('MASTER_PORT', '0')}_{ppid}_{start}"
+
+
 class FileGroup:
     """Single-node process group over a shared temp directory: rendezvous / barrier / max only.
 
     bench.py uses it instead of torch.distributed so that no second HIP runtime (the one bundled
     with the PyTorch wheel) is ever loaded next to libmachip's -- the data path is RCCL inside
-    libmachip either way.  The directory key is MASTER_PORT + the launcher's PID (all ranks of one
-    ``torch.distributed.run`` share their parent), so concurrent or stale jobs cannot collide.
+    libmachip either way.  The directory key is ``MACHIP_RDZV_KEY`` when the launcher sets one (bench.py's own
+    launcher passes a fresh uuid), else MASTER_PORT + the launcher's PID + the launcher's start time from
+    /proc (all ranks of one ``torch.distributed.run`` share their parent; a crashed earlier job that happened to
+    share port and launcher PID has a different start time, so its leftovers are never read).
     Offers the subset of torch.distributed's interface that mac_amd.dist needs."""
 
     def __init__(self, rank: int, world: int, key: str = None, root: str = "/tmp", timeout: float = 600.0):
         self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
         if key is None:
-            key = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+            key = os.environ.get("MACHIP_RDZV_KEY") or default_key()
         self.dir = os.path.join(root, f"machip_rdzv_{key}")
         os.makedirs(self.dir, exist_ok=True)
         self._seq = 0

@@ -20,7 +20,7 @@ __all__ = [
     "laplacian_from_edges", "mac_laplacian", "tracemin_fiedler",
     "find_fiedler_pair", "supergradient", "solve_subset_box_lp",
     "naive_stepsize", "frank_wolfe", "round_nearest", "round_madow_base",
-    "naive_greedy_subset", "MacOracle", "dense_fiedler", "split_chain_edges",
+    "naive_greedy_subset", "MacOracle", "dense_fiedler", "eigsh_fiedler", "split_chain_edges",
     "parse_g2o_edges",
 ]
 
@@ -118,6 +118,16 @@ def find_fiedler_pair(L, X=None, tol=1e-8, seed=None):
     assert X.shape[0] == n and X.shape[1] == q
     sigma, X, _ = tracemin_fiedler(L, X, tol=tol)
     return sigma[0], X[:, 0], X
+
+
+def eigsh_fiedler(L, tol=1e-10):
+    """NOT the reference's solver: SciPy's ARPACK Lanczos for the two smallest eigenvalues of L
+    (0 and lambda_2), the "strong CPU baseline" of SURVEY section 8(d).  Returns (lambda_2, v_2)."""
+    n = L.shape[0]
+    v0 = np.random.RandomState(7).normal(size=n)
+    w, V = spla.eigsh(sp.csr_matrix(L, dtype=np.float64), k=2, which="SA", tol=tol, v0=v0, ncv=min(n - 1, 64))
+    o = np.argsort(w)
+    return float(w[o[1]]), V[:, o[1]]
 
 
 def dense_fiedler(L):
@@ -219,7 +229,9 @@ class MacOracle:
     arrays: fixed (fi,fj,fw), candidates (ci,cj,cw), n nodes."""
 
     def __init__(self, fi, fj, fw, ci, cj, cw, n, fiedler_tol=1e-8,
-                 min_selection_weight_tol=1e-10):
+                 min_selection_weight_tol=1e-10, fiedler="tracemin"):
+        assert fiedler in ("tracemin", "eigsh")
+        self.fiedler = fiedler
         self.n = int(n)
         self.ci = np.asarray(ci, dtype=np.int64)
         self.cj = np.asarray(cj, dtype=np.int64)
@@ -237,7 +249,10 @@ class MacOracle:
     def problem(self, x):
         """(lambda_2, supergradient); mac.py:104-128 (always tracemin_lu, tol
         1e-8, cold start: SURVEY section 0 items 1-2)."""
-        f, v, _ = find_fiedler_pair(self.laplacian(x))
+        if self.fiedler == "eigsh":     # bench.py's strong CPU baseline only
+            f, v = eigsh_fiedler(self.laplacian(x))
+        else:
+            f, v, _ = find_fiedler_pair(self.laplacian(x))
         return f, supergradient(v, self.ci, self.cj, self.cw)
 
     def solve(self, k, x_init, max_iters=5, relative_duality_gap_tol=1e-4,

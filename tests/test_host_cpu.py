@@ -1,6 +1,7 @@
 """CPU-side tests (no GPU): the C-ABI library loads and exports every symbol include/machip.h
 declares, host logic (tridiagonal analysis, rounding, FW driver, Laplacian builders), and the
 product refuses to run without a device (no silent fallback)."""
+import ctypes as C
 import os
 import re
 
@@ -28,7 +29,9 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), f"libmachip.so does not export {s}"
         assert s in _lib.SIGNATURES, f"ctypes binding lacks {s}"
     assert set(_lib.SIGNATURES) == set(syms)
-    assert lib.machip_version() == 1
+    hdr = open(os.path.join(ROOT, "include", "machip.h")).read()
+    assert lib.machip_version() == int(re.search(r"#define MACHIP_ABI_VERSION (\d+)", hdr).group(1))
+    assert C.sizeof(_lib.SolveStats) == lib.machip_sizeof_stats()
 
 
 def test_no_silent_cpu_fallback():
