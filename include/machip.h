@@ -153,6 +153,16 @@ int machip_profile_spmv(machip_problem* p, int reps, double* avg_us, double* byt
  * rank 0, distributed by the caller. */
 int machip_comm_unique_id(void* id128);
 int machip_comm_init(machip_problem* p, int rank, int nranks, const void* id128);
+/* The same split inside ONE process (the ncclCommInitAll style of SURVEY section 8(e)): `nranks` handles of the
+ * same problem -- one per GPU, or several on one GPU -- become ranks 0..nranks-1 of an in-process communicator;
+ * each handle is then driven by its own host thread and machip_fw_step / machip_gradient on every handle is
+ * collective (all handles must call it).  The all-gather is peer-to-peer device copies between the handles'
+ * gradient buffers bracketed by a host barrier; shard arithmetic and call site are those of the RCCL path.
+ * Destroying one handle releases peers blocked in the collective with MACHIP_RCCL_ERROR. */
+int machip_comm_init_local(machip_problem** handles, int nranks);
+/* The candidate range [lo, hi) of `rank` and the padded shard length (host arithmetic only, no GPU needed):
+ * shard = ceil(m / nranks), lo = min(m, rank shard), hi = min(m, lo + shard). */
+int machip_shard_plan(int64_t m, int nranks, int rank, int64_t* lo, int64_t* hi, int64_t* shard);
 
 /* Eigen-solver selection -- the reference's `fiedler_method` string (mac/solvers/mac.py:23,68;
  * mac/utils/fiedler.py:38-42 dispatches 'tracemin_pcg' | 'tracemin_lu' | 'tracemin_cholesky', all

@@ -69,6 +69,8 @@ SIGNATURES = {
     "machip_profile_spmv": (C.c_int, [C.c_void_p, C.c_int, _f64p, _f64p]),
     "machip_comm_unique_id": (C.c_int, [C.c_void_p]),
     "machip_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "machip_comm_init_local": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "machip_shard_plan": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "machip_set_solver": (C.c_int, [C.c_void_p, C.c_int]),
     "machip_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "machip_synchronize": (C.c_int, [C.c_void_p]),
@@ -282,6 +284,21 @@ def _single_node_bootstrap():
     bootstrap on the loopback interface unless the caller chose one.  (On the test boxes the only other
     interface is a container veth, over which ncclCommInitRank was once seen to hang.)"""
     os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+
+
+def comm_init_local(problems):
+    """Join the given Problems (same edge lists, one per GPU or several on one GPU) as ranks 0..R-1 of an
+    in-process communicator; afterwards each must be driven by its own host thread."""
+    lib = load()
+    arr = (C.c_void_p * len(problems))(*[p._h for p in problems])
+    check(lib.machip_comm_init_local(arr, len(problems)))
+
+
+def shard_plan(m, nranks, rank):
+    """(lo, hi, shard) exactly as libmachip computes them (host arithmetic, no GPU needed)."""
+    lo, hi, sh = C.c_int64(), C.c_int64(), C.c_int64()
+    check(load().machip_shard_plan(int(m), int(nranks), int(rank), C.byref(lo), C.byref(hi), C.byref(sh)))
+    return int(lo.value), int(hi.value), int(sh.value)
 
 
 def comm_unique_id() -> bytes:

@@ -3,6 +3,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <numeric>
 #include <vector>
 
@@ -19,6 +22,34 @@ using namespace machip;
         if (r__ != ncclSuccess)                                                              \
             return fail(MACHIP_RCCL_ERROR, std::string(#expr) + ": " + ncclGetErrorString(r__)); \
     } while (0)
+
+// In-process communicator (machip_comm_init_local): the ranks are handles of ONE process driven by one host
+// thread each (one GPU per handle, or several handles on one GPU); the all-gather is peer-to-peer device copies
+// between the handles' gradient buffers, bracketed by a host barrier.  Same shard arithmetic and the same call
+// site as the RCCL communicator.
+struct LocalGroup {
+    int nranks = 0;
+    std::vector<double*> g;     // every rank's gradient buffer (device)
+    std::mutex mu;
+    std::condition_variable cv;
+    int waiting = 0;
+    unsigned long generation = 0;
+    bool broken = false;
+    // returns false when the group was broken (a rank failed or was destroyed): never blocks forever
+    bool barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        if (broken) return false;
+        const unsigned long gen = generation;
+        if (++waiting == nranks) { waiting = 0; ++generation; cv.notify_all(); return true; }
+        cv.wait(lk, [&] { return generation != gen || broken; });
+        return !broken;
+    }
+    void abort() {
+        std::lock_guard<std::mutex> lk(mu);
+        broken = true;
+        cv.notify_all();
+    }
+};
 
 struct machip_problem {
     int device = 0;
@@ -52,6 +83,7 @@ struct machip_problem {
     Solver sol;
     // multi-GPU
     ncclComm_t comm = nullptr;
+    std::shared_ptr<LocalGroup> lgroup;
     int rank = 0, nranks = 1;
 
     CsrView csr() const { return CsrView{n, rowptr, col, val}; }
@@ -140,6 +172,9 @@ int build_pattern(machip_problem* p, int64_t nf, const int32_t* fi, const int32_
     p->asm_rpb = (int)rpb;
     p->asm_grid = (int)(((long)n + rpb - 1) / rpb);
     if (p->asm_grid < 1) p->asm_grid = 1;
+    // k_asm_fill scans its rows' counts in (rpb + 1) ints of dynamic LDS: stay inside the 64 KB every launch may use
+    if ((rpb + 1) * (long)sizeof(int) > 64 * 1024)
+        return fail(MACHIP_BAD_ARG, "num_nodes above the supported 16.7 million (row-offset scan of the assembly kernel)");
     return MACHIP_OK;
 }
 
@@ -161,6 +196,7 @@ int assemble(machip_problem* p) {
         case 32: launch_asm<32>(p); break;
         default: launch_asm<64>(p); break;
     }
+    HIP_TRY(hipGetLastError());       // a refused launch must not leave stale row offsets behind a MACHIP_OK
     const int gb = p->asm_grid;
     HIP_TRY(hipMemcpyAsync(p->h_int, p->blk_sum, sizeof(int) * 3 * kMaxGrid, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipMemcpyAsync(p->h_dbl, p->blk_lnorm, sizeof(double) * (size_t)gb, hipMemcpyDeviceToHost, p->stream));
@@ -198,27 +234,48 @@ int select_on(machip_problem* p, const double* keys, long k, SelState* st, int p
             k_sel_pass<<<std::max(grid, 1), kBlock, 0, p->stream>>>(keys, m, pass, p->hist, st);
     }
     k_sel_ties<<<1, 1024, 0, p->stream>>>(keys, m, st, prefer_high);
+    HIP_TRY(hipGetLastError());
     return MACHIP_OK;
 }
 
 int select_topk(machip_problem* p, long k) { return select_on(p, p->g, k, p->sel, 0); }
 
+// Contiguous candidate ranges: shard = ceil(m / R); rank r owns [r shard, (r+1) shard) clipped to m;
+// the gathered vector is padded to R shard entries.  The ONE place this arithmetic lives (machip_shard_plan exports it).
+void shard_plan(long m, int nranks, int rank, long* lo, long* hi, long* shard) {
+    const long sh = nranks > 0 ? (m + nranks - 1) / nranks : m;
+    *shard = sh;
+    *lo = std::min(m, sh * rank);
+    *hi = std::min(m, *lo + sh);
+}
+
+int local_allgather(machip_problem* p, long shard) {
+    LocalGroup& G = *p->lgroup;
+    HIP_TRY(hipStreamSynchronize(p->stream));                 // my shard is in my buffer
+    if (!G.barrier()) return fail(MACHIP_RCCL_ERROR, "in-process communicator was shut down by another rank");
+    for (int r = 0; r < G.nranks; ++r)
+        if (r != p->rank)
+            HIP_TRY(hipMemcpyAsync(p->g + shard * r, G.g[(size_t)r] + shard * r, sizeof(double) * (size_t)shard,
+                                   hipMemcpyDeviceToDevice, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (!G.barrier()) return fail(MACHIP_RCCL_ERROR, "in-process communicator was shut down by another rank");   // nobody overwrites a shard a peer is still reading
+    return MACHIP_OK;
+}
+
 int compute_gradient(machip_problem* p) {
     if (!p->have_vec) return fail(MACHIP_BAD_ARG, "no Fiedler vector on the device: call machip_fiedler first");
     const long m = p->m;
-    long lo = 0, hi = m;
-    if (p->nranks > 1) {
-        const long shard = p->m_pad / p->nranks;
-        lo = std::min(m, shard * p->rank);
-        hi = std::min(m, lo + shard);
-    }
+    long lo = 0, hi = m, shard = m;
+    if (p->nranks > 1) shard_plan(m, p->nranks, p->rank, &lo, &hi, &shard);
     if (hi > lo) {
         const int grid = (int)std::min<long>(kMaxGrid * 4, (hi - lo + kBlock - 1) / kBlock);
         k_grad<<<grid, kBlock, 0, p->stream>>>(p->ci, p->cj, p->cw, p->sol.yvec, lo, hi, p->g);
+        HIP_TRY(hipGetLastError());
     }
     if (p->nranks > 1) {
-        const long shard = p->m_pad / p->nranks;
-        NCCL_TRY(ncclAllGather(p->g + shard * p->rank, p->g, (size_t)shard, ncclDouble, p->comm, p->stream));
+        if (p->comm) NCCL_TRY(ncclAllGather(p->g + shard * p->rank, p->g, (size_t)shard, ncclDouble, p->comm, p->stream));
+        else if (p->lgroup) { const int st = local_allgather(p, shard); if (st != MACHIP_OK) { p->lgroup->abort(); return st; } }
+        else return fail(MACHIP_BAD_ARG, "nranks > 1 without a communicator");
     }
     return MACHIP_OK;
 }
@@ -324,6 +381,7 @@ void machip_destroy(machip_problem* p) {
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     if (p->comm) (void)ncclCommDestroy(p->comm);
+    if (p->lgroup) p->lgroup->abort();      // peers blocked in the group's barrier return an error instead of hanging
     p->sol.destroy();
     void* ptrs[] = {p->prow, p->pcol, p->pk, p->pw, p->ci, p->cj, p->cw, p->x, p->x_next, p->g, p->s, p->scratch_m, p->cnt,
                     p->blk_sum, p->rowptr, p->col, p->val, p->blk_lnorm, p->hist, p->sel, p->part_fw};
@@ -428,6 +486,7 @@ int machip_fw_step(machip_problem* p, int64_t k, int iter, double tol, int max_s
     const int grid = std::max(1, (int)std::min<long>(kMaxGrid, (p->m + kBlock - 1) / kBlock));
     const double gamma = 2.0 / ((double)iter + 2.0);   // frankwolfe.py:7-8
     k_fw_final<<<grid, kBlock, 0, p->stream>>>(p->g, p->x, p->m, p->sel, gamma, p->x_next, nullptr, p->part_fw);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(p->h_dbl, p->part_fw, sizeof(double) * 2 * kMaxGrid, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
     double d = 0.0, q2 = 0.0;
@@ -588,8 +647,37 @@ int machip_comm_init(machip_problem* p, int rank, int nranks, const void* id128)
     memcpy(&id, id128, sizeof(id));
     NCCL_TRY(ncclCommInitRank(&p->comm, nranks, id, rank));
     p->rank = rank; p->nranks = nranks;
-    const long shard = (p->m + nranks - 1) / nranks;
+    long lo, hi, shard;
+    shard_plan(p->m, nranks, rank, &lo, &hi, &shard);
     p->m_pad = shard * nranks;   // <= m + 63 < allocation slack
+    return MACHIP_OK;
+}
+
+int machip_comm_init_local(machip_problem** handles, int nranks) {
+    if (!handles || nranks < 1 || nranks > 64) return fail(MACHIP_BAD_ARG, "machip_comm_init_local: 1..64 handles");
+    for (int r = 0; r < nranks; ++r) {
+        machip_problem* p = handles[r];
+        if (!p || p->csr_only || p->comm || p->lgroup) return fail(MACHIP_BAD_ARG, "machip_comm_init_local: NULL, CSR-only or already attached handle");
+        if (p->m != handles[0]->m || p->n != handles[0]->n) return fail(MACHIP_BAD_ARG, "machip_comm_init_local: handles of different problems");
+    }
+    auto G = std::make_shared<LocalGroup>();
+    G->nranks = nranks;
+    for (int r = 0; r < nranks; ++r) G->g.push_back(handles[r]->g);
+    for (int r = 0; r < nranks; ++r) {
+        machip_problem* p = handles[r];
+        long lo, hi, shard;
+        shard_plan(p->m, nranks, r, &lo, &hi, &shard);
+        p->m_pad = shard * nranks;
+        p->rank = r; p->nranks = nranks; p->lgroup = G;
+    }
+    return MACHIP_OK;
+}
+
+int machip_shard_plan(int64_t m, int nranks, int rank, int64_t* lo, int64_t* hi, int64_t* shard) {
+    if (m < 0 || nranks < 1 || rank < 0 || rank >= nranks || !lo || !hi || !shard) return fail(MACHIP_BAD_ARG, "machip_shard_plan: bad argument");
+    long a, b, c;
+    shard_plan((long)m, nranks, rank, &a, &b, &c);
+    *lo = a; *hi = b; *shard = c;
     return MACHIP_OK;
 }
 

@@ -51,10 +51,7 @@ inline int env_int(const char* name, int dflt) {
 
 // Every workgroup of a step kernel re-reduces the previous step's per-workgroup partials, so
 // that traffic grows with grid^2: cap the grid (grid-stride loops cover the rest of the rows).
-inline int grid_cap() {
-    static const int cap = std::max(1, std::min(kMaxGrid, env_int("MACHIP_MAXGRID", 256)));
-    return cap;
-}
+inline int grid_cap() { return std::max(1, std::min(kMaxGrid, env_int("MACHIP_MAXGRID", 256))); }
 
 inline SpmvPlan plan_spmv(int n, long nnz, int forced_variant) {
     SpmvPlan pl;
@@ -361,7 +358,7 @@ struct Solver {
         k_pipe_tail<<<1, 64, 0, stream>>>(L, steps);
     }
     int enqueue_chunk(const CsrView& A, const SpmvPlan& pl, int steps) {
-        if (!use_graph) { launch_chunk(A, pl, steps); return MACHIP_OK; }
+        if (!use_graph) { launch_chunk(A, pl, steps); HIP_TRY(hipGetLastError()); return MACHIP_OK; }
         if (graph_csr_key != (const void*)A.val) {   // different matrix buffers: cached graphs are stale
             for (auto& kv : graphs) for (hipGraphExec_t ge : kv.second) if (ge) (void)hipGraphExecDestroy(ge);
             graphs.clear();
@@ -394,6 +391,7 @@ struct Solver {
         const int KS = std::max(1, std::min(ks_max, J / 8));
         k_ritz_partial<<<dim3(g2, KS), kBlock, 0, stream>>>(V, n, J, sdev, ypart);
         k_ritz_combine<<<g2, kBlock, 0, stream>>>(ypart, n, KS, y_raw, part_c);
+        HIP_TRY(hipGetLastError());
         return check_vector(A, pl, rq, res_l1);
     }
     // Same, for a vector already in y_raw with its sums in part_c.
@@ -905,6 +903,7 @@ struct Solver {
                         for (int j = J_enq ? J_enq + 1 : 0; j <= hi; ++j) h_tri[3 * (size_t)j + 1] = std::numeric_limits<double>::quiet_NaN();
                     if (pmode) {
                         launch_persist(A, chunk);
+                        HIP_TRY(hipGetLastError());   // (157 KB of static LDS: a refused launch must surface, not time out)
                     } else if (classic) {
                         enqueue_classic(A, pl, chunk);
                         double* hp = h_pin + (vcap + 2) + 2 * kMaxGrid + 32;   // staging: 3 x (chunk+1)

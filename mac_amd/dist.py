@@ -12,14 +12,12 @@ from typing import Tuple
 
 
 def shard_bounds(m: int, rank: int, nranks: int) -> Tuple[int, int, int]:
-    """(lo, hi, shard) of rank's candidate range; identical to compute_gradient() in
-    mac_amd/csrc/machip.hip: shard = ceil(m / R), ranges are [r*shard, (r+1)*shard) clipped to m,
-    the gathered vector is padded to R*shard entries."""
+    """(lo, hi, shard) of rank's candidate range, computed BY libmachip (machip_shard_plan: the very function
+    compute_gradient() and machip_comm_init use): shard = ceil(m / R), ranges are [r*shard, (r+1)*shard) clipped
+    to m, the gathered vector is padded to R*shard entries."""
     assert 0 <= rank < nranks
-    shard = (m + nranks - 1) // nranks
-    lo = min(m, shard * rank)
-    hi = min(m, lo + shard)
-    return lo, hi, shard
+    from mac_amd import _lib
+    return _lib.shard_plan(m, nranks, rank)
 
 
 def exchange_unique_id(dist, rank: int, make_id) -> bytes:

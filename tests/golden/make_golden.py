@@ -214,6 +214,29 @@ def city10000_vertices(meta):
     meta["city10000_vertices"] = {"exact_at": exact_at, "min_ref_gap_rel": float(np.min(gaps))}
 
 
+def er100k_x0(meta):
+    """BASELINE.json configs[3] at x0: lambda_2 and a strided sample of v_2 from SciPy's ARPACK Lanczos on the
+    REFERENCE's own MAC.laplacian(x0) (the reference's TraceMIN + SuperLU does not finish at this size,
+    SURVEY 6.2).  MAC.__init__ alone takes ~4 s here, the eigen-solve ~10 s."""
+    import scipy.sparse.linalg as spla
+    n = 100000
+    p = 2.0e6 / (n * (n - 1) / 2)
+    G = nx.fast_gnp_random_graph(n, p, seed=0)
+    fixed = [Edge(a, a + 1, 1.0) for a in range(n - 1)]
+    cand = [Edge(min(a, b), max(a, b), 1.0) for (a, b) in G.edges() if abs(a - b) != 1]
+    m_ = len(cand); k = m_ // 10
+    x0 = np.zeros(m_); x0[np.random.default_rng(0).choice(m_, k, replace=False)] = 1.0
+    mac = MAC(fixed, cand, n)
+    L = mac.laplacian(x0)
+    w, V = spla.eigsh(L, k=2, which="SA", tol=1e-13, ncv=96, v0=np.random.RandomState(7).normal(size=n))
+    o = np.argsort(w)
+    lam, v = float(w[o[1]]), V[:, o[1]]
+    res = np.abs(L @ v - lam * v).sum() / abs(L).sum(axis=1).max()
+    save("er100k_x0", n=n, m=m_, k=k, lam=lam, v_stride=v[::997], residual=res, nnz=L.nnz,
+         x0_idx_head=np.nonzero(x0)[0][:512].astype(np.int64))
+    meta["er100k_x0"] = {"lam": lam, "residual": float(res), "nnz": int(L.nnz)}
+
+
 def main(only=None):
     meta_path = os.path.join(OUT, "golden_meta.json")
     if only and os.path.exists(meta_path):
@@ -226,6 +249,8 @@ def main(only=None):
         return er10k_solve(meta), json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
     if only == "er10k_exact_topk":
         return er10k_exact_topk(meta), json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
+    if only == "er100k_x0":
+        return er100k_x0(meta), json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
     if only == "city10000_vertices":
         return city10000_vertices(meta), json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
     if only == "g2o_extra":

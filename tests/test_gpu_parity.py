@@ -380,12 +380,24 @@ def test_er_solve_trajectory(nm):
     assert abs(u - g["upper"]) <= 1e-6 * abs(g["upper"])
 
 
-@pytest.mark.parametrize("nm", ["intel", "sphere2500", "kitti_05"])
+@pytest.mark.parametrize("nm", ["intel", "sphere2500", "kitti_05", "city10000"])
 def test_pose_graph_solve_trajectory(nm):
     g = load_golden("g2o_" + nm)
     mac = MAC(edges_of(g, "f"), edges_of(g, "c"), int(g["n"]))
     rounded, w, u = mac.solve(int(g["k"]), g["x_init"], max_iters=20, use_cache=False)
     ft = np.array([t[0] for t in mac.trace])
+    if nm == "city10000":
+        # all 10 688 closure weights are 100: near-ties at the K-th gradient entry (relative gaps 1e-5..1e-3,
+        # golden ref_gap_rel) are decided differently by two 1e-8-accurate eigenvectors from some iteration on;
+        # test_city10000_vertices_until_the_fork pins WHERE and shows the HIP vertex is the exact one there.
+        # Up to the fork the trajectories are identical, afterwards they stay in the same regime.
+        fork = city_fork_iteration()
+        assert np.allclose(ft[:fork + 1], g["f_traj"][:fork + 1], rtol=1e-6)
+        assert np.array_equal([t[3] for t in mac.trace][:fork + 1], g["supp"][:fork + 1])
+        assert np.all(np.abs(ft - g["f_traj"][:len(ft)]) <= 0.05 * g["f_traj"][:len(ft)])
+        assert abs(u - g["upper"]) <= 2e-2 * abs(g["upper"])
+        assert int(rounded.sum()) == int(g["k"])
+        return
     assert np.allclose(ft, g["f_traj"][:len(ft)], rtol=1e-6)
     assert np.array_equal([t[3] for t in mac.trace], g["supp"][:len(ft)])
     assert abs(u - g["upper"]) <= 1e-5 * abs(g["upper"])
@@ -395,6 +407,72 @@ def test_pose_graph_solve_trajectory(nm):
     mac2 = MAC(edges_of(g, "f"), edges_of(g, "c"), int(g["n"]))
     r2, w2, u2 = mac2.solve(int(g["k"]), g["x_init"], max_iters=20, use_cache=True)
     assert np.allclose([t[0] for t in mac2.trace], ft, rtol=1e-6)
+
+
+def city_fork_iteration():
+    """First iteration whose LP vertex the golden lists as decided by an exact solve (20 = never)."""
+    ex = [int(t) for t in load_golden("city10000_vertices")["exact_at"]]
+    return min(ex) if ex else 20
+
+
+def test_city10000_vertices_until_the_fork():
+    """BASELINE.json configs[4], city10000: LP vertex by LP vertex against the reference's own run
+    (tests/golden/city10000_vertices.npz).  While the vertices agree both runs hold the same x and lambda_2
+    must agree to 1e-8.  At the first iteration where they differ the golden holds the EXACT vertex (dense
+    numpy eigh of the reference's own MAC.laplacian(x), stable sort) and the HIP vertex must equal it: the
+    reference's 1e-8-accurate eigenvector, not the HIP one, mis-ranks the near-tie.  After a fork the two
+    runs optimise from different points and are only compared in test_pose_graph_solve_trajectory."""
+    g = load_golden("g2o_city10000"); gv = load_golden("city10000_vertices")
+    k = int(g["k"])
+    P = problem_of(g)
+    P.set_start(reference_start_block(int(g["n"]))[:, 0].copy())
+    P.set_x(g["x_init"])
+    forked = False
+    for it in range(20):
+        f, dual, gn = P.fw_step(k, it)
+        assert abs(f - gv["f_traj"][it]) <= LAM_RTOL * abs(f), (it, f, gv["f_traj"][it])
+        s = np.nonzero(P.lp_topk(k))[0]
+        if not np.array_equal(s, gv["ref_s"][it]):
+            key = f"exact_s{it}"
+            assert key in gv.files, f"vertices differ at iteration {it} and the golden holds no exact vertex there"
+            assert abs(f - float(gv[f"exact_lam{it}"])) <= 1e-10 * abs(f)
+            assert np.array_equal(s, gv[key]), (it, len(np.setdiff1d(s, gv[key])))
+            assert not np.array_equal(gv["ref_s"][it], gv[key])        # it is the reference that missed
+            forked = True
+            break
+        P.fw_commit()
+    assert forked == (city_fork_iteration() < 20)
+    P.close()
+
+
+def test_batched_two_handles_match_sequential():
+    """BASELINE.json configs[4] batched mode (bench.py --config c5): city10000 and sphere2500 as two handles
+    driven by two host threads on one GPU give bit-identical trajectories to running them one after the other."""
+    import threading
+    gs = [load_golden("g2o_city10000"), load_golden("g2o_sphere2500")]
+
+    def run(g, out, i):
+        P = problem_of(g)
+        P.set_start(reference_start_block(int(g["n"]))[:, 0].copy())
+        P.set_x(g["x_init"])
+        fs = []
+        for it in range(6):
+            f, dual, gn = P.fw_step(int(g["k"]), it)
+            fs.append(f)
+            P.fw_commit()
+        out[i] = (np.array(fs), P.get_x())
+        P.close()
+    seq, par = [None, None], [None, None]
+    for i, g in enumerate(gs):
+        run(g, seq, i)
+    th = [threading.Thread(target=run, args=(g, par, i)) for i, g in enumerate(gs)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i, g in enumerate(gs):
+        assert np.array_equal(seq[i][0], par[i][0]) and np.array_equal(seq[i][1], par[i][1])
+        assert np.allclose(seq[i][0][:3], g["f_traj"][:3], rtol=1e-6)
 
 
 # --------------------------------------------------------------------------------------------
@@ -541,11 +619,90 @@ def test_rccl_path_single_rank():
     P0.close(); P1.close()
 
 
+@pytest.mark.parametrize("R", [2, 3, 8])
+def test_in_process_ranks_match_single_rank(R):
+    """Multi-GPU path as a PRODUCT test on one GPU: R handles of the same problem joined by
+    machip_comm_init_local (ranks 0..R-1, one host thread each; candidate shards + in-place all-gather through the
+    same compute_gradient call site and the same machip_shard_plan arithmetic as the RCCL path) must reproduce the
+    single-rank Frank-Wolfe run bit for bit -- m = 5 971 is not a multiple of 8, so the padded tail is exercised."""
+    import threading
+    g = load_golden("er2000_solve")
+    n, k, iters = int(g["n"]), int(g["k"]), 5
+    start = reference_start_block(n)[:, 0].copy()
+
+    def drive(P, out, i):
+        try:
+            P.set_start(start)
+            P.set_x(g["x_init"])
+            fs = []
+            for it in range(iters):
+                f, dual, gn = P.fw_step(k, it)
+                fs.append((f, dual, gn))
+                P.fw_commit()
+            gr = P.gradient()          # collective again: every rank ends with the full vector
+            out[i] = (np.array(fs), P.get_x(), gr)
+        except Exception as exc:       # a failing rank must not leave its peers in the barrier
+            out[i] = exc
+            P.close()
+    single = [None]
+    P0 = problem_of(g)
+    drive(P0, single, 0)
+    P0.close()
+    assert not isinstance(single[0], Exception), single[0]
+    Ps = [problem_of(g) for _ in range(R)]
+    _lib.comm_init_local(Ps)
+    m = len(g["cw"])
+    cover = []
+    for r in range(R):
+        lo, hi, shard = _lib.shard_plan(m, R, r)
+        cover.append((lo, hi))
+        assert shard * R >= m
+    assert cover[0][0] == 0 and cover[-1][1] == m and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+    out = [None] * R
+    th = [threading.Thread(target=drive, args=(Ps[r], out, r)) for r in range(R)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    for r in range(R):
+        assert not isinstance(out[r], Exception), out[r]
+        for a, b in zip(out[r], single[0]):
+            assert np.array_equal(a, b), f"rank {r} of {R} differs from the single-rank run"
+    assert np.allclose(single[0][0][:, 0], g["f_traj"][:iters], rtol=1e-6)
+    for P in Ps:
+        P.close()
+
+
+def test_in_process_group_releases_peers_when_a_rank_dies():
+    import threading
+    g = load_golden("er300_solve")
+    Ps = [problem_of(g) for _ in range(2)]
+    _lib.comm_init_local(Ps)
+    res = {}
+
+    def lone():
+        try:
+            Ps[0].set_x(g["x_init"])
+            Ps[0].fw_step(int(g["k"]), 0)
+            res["ok"] = True
+        except _lib.MachipError as exc:
+            res["err"] = str(exc)
+    t = threading.Thread(target=lone)
+    t.start()
+    import time
+    time.sleep(1.0)
+    Ps[1].close()                  # the peer never joins the collective
+    t.join(timeout=60)
+    assert not t.is_alive() and "err" in res, res
+    Ps[0].close()
+
+
 def test_full_size_config4_properties():
     """BASELINE.json configs[3] / north_star target size: ER N=100k, ~2M candidates, K=10%.  The
     reference cannot finish one solve here (SuperLU fill-in); lambda_2 is checked against
-    the value SURVEY 8(c) G8 records (0.281046460878, shift-free Lanczos on the same L(x)) and through
-    size-independent identities evaluated with an independent (SciPy) SpMV."""
+    the committed fixture tests/golden/er100k_x0.npz (scipy.sparse.linalg.eigsh on the reference's own
+    MAC.laplacian(x0), generator: make_golden.py er100k_x0) and through size-independent identities evaluated
+    with an independent (SciPy) SpMV."""
     import bench
     w = bench.make_workload("c4")
     n, m, k = w["n"], len(w["cw"]), w["k"]
@@ -553,7 +710,10 @@ def test_full_size_config4_properties():
     P = _lib.Problem(n, w["fi"], w["fj"], w["fw"], w["ci"], w["cj"], w["cw"])
     P.set_x(w["x0"])
     lam, v, _ = P.fiedler(tol=1e-8, x0=reference_start_block(n)[:, 0].copy())
-    assert abs(lam - 0.281046460878) <= 1e-8 * 0.281046460878
+    gx = load_golden("er100k_x0")
+    assert int(gx["m"]) == m and np.array_equal(np.nonzero(w["x0"])[0][:512], gx["x0_idx_head"])
+    assert abs(lam - float(gx["lam"])) <= 1e-8 * float(gx["lam"])
+    assert np.abs(sign_align(v[::997], gx["v_stride"]) - gx["v_stride"]).max() <= 2e-6
     assert P.stats.residual < 1e-8 and abs(np.linalg.norm(v) - 1) < 1e-12 and abs(v.sum()) < 1e-9
     Lf = oracle.laplacian_from_edges(w["fi"], w["fj"], w["fw"], n)
     L = oracle.mac_laplacian(Lf, w["ci"].astype(np.int64), w["cj"].astype(np.int64), w["cw"], w["x0"], n)

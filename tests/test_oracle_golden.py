@@ -87,7 +87,7 @@ def test_er_fw_trajectory(nm):
     assert np.array_equal(rounded, g["rounded"])
 
 
-@pytest.mark.parametrize("nm", ["intel", "sphere2500", "kitti_05"])
+@pytest.mark.parametrize("nm", ["intel", "sphere2500", "kitti_05", "city10000"])
 def test_pose_graph_goldens(nm):
     g = load_golden("g2o_" + nm)
     i, j, kap, n = oracle.parse_g2o_edges(os.path.join(GOLDEN, "data", nm + ".g2o"))
@@ -107,9 +107,10 @@ def test_pose_graph_goldens(nm):
     assert np.allclose(g0, g["grad_init"], rtol=1e-4, atol=1e-8 * np.abs(g["grad_init"]).max())
     assert abs(mo.evaluate_objective(np.ones(len(g["cw"]))) - g["lam_all"]) <= 1e-9 * g["lam_all"]
     tr = []
-    rounded, w, u = mo.solve(k, g["x_init"], max_iters=6, trace=tr)
-    assert np.allclose([t[0] for t in tr], g["f_traj"][:6], rtol=1e-7)
-    assert np.array_equal([t[3] for t in tr], g["supp"][:6])
+    iters = 3 if nm == "city10000" else 6        # (a city10000 iteration costs the oracle ~1.5 s)
+    rounded, w, u = mo.solve(k, g["x_init"], max_iters=iters, trace=tr)
+    assert np.allclose([t[0] for t in tr], g["f_traj"][:iters], rtol=1e-7)
+    assert np.array_equal([t[3] for t in tr], g["supp"][:iters])
     assert np.array_equal(oracle.round_madow_base(g["unrounded"], k, float(g["madow_u"])), g["madow"])
 
 
@@ -130,3 +131,19 @@ def test_rounding():
     assert np.array_equal(oracle.round_nearest(g["w"], int(g["k"]), g["weights"], 10), g["nearest_tb"])
     assert np.array_equal(oracle.round_madow_base(g["madow_in"], int(g["k"]), float(g["madow_u"])), g["madow"])
     assert oracle.round_nearest(np.arange(5.0), 0).sum() == 0
+
+
+def test_city10000_reference_vertices():
+    """The oracle reproduces the reference's LP vertices (top-K sets) on city10000 for the first iterations
+    (tests/golden/city10000_vertices.npz: every vertex of the reference's 20-iteration run)."""
+    g = load_golden("g2o_city10000"); gv = load_golden("city10000_vertices")
+    assert np.array_equal(gv["x_init"], g["x_init"]) and np.allclose(gv["f_traj"], g["f_traj"], rtol=0, atol=0)
+    mo = oracle.MacOracle(g["fi"], g["fj"], g["fw"], g["ci"], g["cj"], g["cw"], int(g["n"]))
+    k = int(g["k"])
+    x = g["x_init"].copy()
+    for it in range(3):
+        f, gr = mo.problem(x)
+        s = oracle.solve_subset_box_lp(gr, k)
+        assert abs(f - gv["f_traj"][it]) <= 1e-9 * abs(f)
+        assert np.array_equal(np.nonzero(s)[0], gv["ref_s"][it])
+        x = x + oracle.naive_stepsize(it) * (s - x)
