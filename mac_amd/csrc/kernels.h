@@ -408,6 +408,7 @@ struct PipeView {
                       // writes the other, so a late-starting workgroup never sees partials that a
                       // fast workgroup of the SAME launch has already replaced
     int P;            // valid partials per quantity (= grid of the step kernel, <= 256)
+    int pf;           // > 0: number of operand slices each XCD's workgroups prefetch (0 = off)
 };
 
 struct PipeCoef { double alpha, mu, beta, inv, l1prev; };
@@ -536,6 +537,20 @@ __global__ __launch_bounds__(BLOCK) void k_pipe_vec(CsrView A, PipeView L, int j
     Z2* __restrict__ Zn = (jrel & 1) ? L.Z0 : L.Z1;
     PipeRow pr;
     pr.clear();
+    // The gather operand was written by the previous launch from all eight XCDs and every launch starts with a
+    // cold L2: without help each XCD pulls its 16 n bytes in through scattered gather misses.  L.pf > 0: the
+    // workgroups of an XCD (blockIdx % 8 under round-robin dispatch; only speed depends on that) first sweep the
+    // operand once with coalesced loads, slice blockIdx / 8 of L.pf slices each, so the gathers find it in L2.
+    if (L.pf > 0 && wt >= 0) {
+        const int slice = (int)(blockIdx.x >> 3) % L.pf;
+        const int per = (A.n + L.pf - 1) / L.pf;
+        const int lo = slice * per, hi = min(A.n, lo + per);
+        double sink = 0.0;
+        for (int i = lo + wt * 8; i < hi; i += WORK * 8) {      // one 128-byte line (8 records) per lane
+            sink += Zc[i].t;
+        }
+        if (sink == 1.2345e300) pr.acc[5] = sink;                 // never true for finite data; keeps the loads alive
+    }
     bool have = false;
     double alpha = 0.0, beta = 0.0, mu = 0.0, inv = 0.0;
     double* vj = nullptr;

@@ -102,18 +102,26 @@ inline SpmvPlan plan_pipe(int n, long nnz, int maxlen) {
     // n <= 32k, where the gather operand is cache resident), 16 beyond; two independent load chains
     // per lane from 8 lanes up.  Hub rows (Frank-Wolfe vertices concentrate the selected edges on
     // few nodes) would serialise a narrow group: widen when the longest row is far above the mean.
-    int g = mean < 16.0 ? 4 : ((mean < 32.0 || n <= 32768) ? 8 : 16);
-    if (g == 4 && maxlen > 48) g = 16;
-    if (g == 8 && maxlen > 8 * mean && maxlen > 128) g = 16;
+    // Round 2, in-solve sweep (tools/sweep_pipe.py, step time from the events around the Krylov chunks):
+    //   n <= 32k (config 2): 8 lanes, 4 load chains, 512-thread workgroups (179 of them at n = 10k) are best or tied
+    //     on every iterate, hub rows included: 7.2 us against 7.6 us step-weighted, 5.6 against 6.9 us on the first;
+    //   n = 100k (config 4): 4 lanes up to 16 nnz/row -- also when a Frank-Wolfe vertex has produced hub rows, where
+    //     the 16-lane groups chosen in round 1 sat mostly idle (14.0 against 17.4 us) -- two load chains once hubs
+    //     exist; 8 lanes up to 24 nnz/row, 16 beyond.
+    int g, unr, blk;
+    if (n <= 32768) {
+        g = 8; unr = 4; blk = 512;
+    } else {
+        g = mean < 16.0 ? 4 : (mean < 24.0 ? 8 : 16);
+        if (g == 8 && maxlen > 8 * mean && maxlen > 128) g = 16;
+        unr = g == 4 ? (maxlen > 48 ? 2 : 1) : 2;
+        // at most grid_cap() workgroups (each re-reads every workgroup's partials): grow the workgroup instead of
+        // the grid (wave 0 of every workgroup only runs the prologue: BLOCK - 64 threads own rows)
+        blk = 256;
+        while (blk < 1024 && ((long)n + ((blk - 64) / g) - 1) / ((blk - 64) / g) > grid_cap()) blk <<= 1;
+    }
     pl.width = env_int("MACHIP_G", g);
-    // in a real solve the gather operand was written by the previous launch from all XCDs (cold lines): more
-    // loads in flight per lane pay off there even where the warm replay says otherwise (config 2: +4 %)
-    pl.unroll = env_int("MACHIP_UNROLL", pl.width == 8 && mean >= 32.0 ? 4 : (pl.width >= 8 ? 2 : 1));
-    // at most grid_cap() workgroups (each re-reads every workgroup's partials): grow the
-    // workgroup instead of the grid
-    // (wave 0 of every workgroup only runs the prologue: BLOCK - 64 threads own rows)
-    int blk = 256;
-    while (blk < 1024 && ((long)n + ((blk - 64) / pl.width) - 1) / ((blk - 64) / pl.width) > grid_cap()) blk <<= 1;
+    pl.unroll = env_int("MACHIP_UNROLL", unr);
     pl.block = env_int("MACHIP_BLOCK", blk);
     const int gpb = (pl.block - 64) / pl.width;
     pl.grid = (int)std::max<long>(1, std::min<long>(grid_cap(), ((long)n + gpb - 1) / gpb));
@@ -305,6 +313,9 @@ struct Solver {
     PipeView pview(const SpmvPlan& pl) const {
         PipeView L;
         L.n = n; L.st = st; L.Z0 = Z0; L.Z1 = Z1; L.V = V; L.tri = tri; L.htri = d_htri; L.hflag = d_hflag; L.part = part; L.P = pl.grid;
+        // operand prefetch: one slice per workgroup of an XCD (grid / 8 of them), only where the operand does not
+        // fit L1 anyway and the grid covers every XCD evenly
+        L.pf = (env_int("MACHIP_PREFETCH", 0) != 0 && pl.grid >= 64 && pl.grid % 8 == 0) ? pl.grid / 8 : 0;
         return L;
     }
     LanView check_view(const SpmvPlan& pl) const {   // "column 0" machinery for the explicit check

@@ -434,7 +434,7 @@ def test_city10000_vertices_until_the_fork():
         s = np.nonzero(P.lp_topk(k))[0]
         if not np.array_equal(s, gv["ref_s"][it]):
             key = f"exact_s{it}"
-            assert key in gv.files, f"vertices differ at iteration {it} and the golden holds no exact vertex there"
+            assert key in gv, f"vertices differ at iteration {it} and the golden holds no exact vertex there"
             assert abs(f - float(gv[f"exact_lam{it}"])) <= 1e-10 * abs(f)
             assert np.array_equal(s, gv[key]), (it, len(np.setdiff1d(s, gv[key])))
             assert not np.array_equal(gv["ref_s"][it], gv[key])        # it is the reference that missed
