@@ -130,7 +130,7 @@ def run_pass(P, k, iters, x0, tol=1e-8):
         f, dual, gn = P.fw_step(k, it, tol=tol)
         st = P.stats
         rec.append(dict(f=f, dual=dual, gnorm=gn, steps=int(st.lanczos_steps), nnz=int(st.nnz), support=int(st.support),
-                        gpu_ms=float(st.gpu_ms), step_ms=float(st.step_ms), steps_timed=int(st.steps_timed),
+                        gpu_ms=float(st.gpu_ms), step_ms=float(st.step_ms), steps_timed=int(st.steps_timed), steps_lowp=int(st.steps_lowp),
                         residual=float(st.residual)))
         P.fw_commit()
     return rec

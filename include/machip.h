@@ -55,6 +55,8 @@ typedef struct machip_solve_stats {
                               step kernels; explicit checks / Ritz vector excluded)        */
     int64_t steps_timed;   /* steps covered by step_ms: step_ms / steps_timed = in-solve
                               duration of one fused step launch                            */
+    int64_t steps_lowp;    /* of lanczos_steps, those run with fp32 storage
+                              (machip_set_precision(1)); the rest are fp64                 */
 } machip_solve_stats;
 
 int machip_version(void);

@@ -13,12 +13,14 @@ namespace machip {
 // ------------------------------------------------------------------------------------------
 // Views (passed by value as kernel arguments)
 // ------------------------------------------------------------------------------------------
-struct CsrView {
+template <typename T>
+struct CsrViewT {
     int n;
     const int* rowptr;   // n+1
     const int* col;      // nnz
-    const double* val;   // nnz
+    const T* val;        // nnz
 };
+using CsrView = CsrViewT<double>;    // float: the low-precision copy of the values used by the mixed-precision mode
 
 // Union sparsity pattern of fixed + candidate edges (built once, machip_create):
 // row r owns slots [prow[r], prow[r+1]); slot p is the off-diagonal (r, pcol[p]) fed by
@@ -389,17 +391,24 @@ __global__ __launch_bounds__(kBlock) void k_lan_tail(LanView L) {
 //   * no per-step host arguments: j = jA (chunk base, device memory) + jrel (baked into the graph
 //     node); chunks have an even number of steps so the Z / partial ping-pong parity is jrel & 1.
 // ------------------------------------------------------------------------------------------
-struct __attribute__((aligned(16))) Z2 { double t, v; };
+// Storage type T of the iterate: double, or float for the mixed-precision mode (machip_set_precision(1): fp32 matrix
+// values, 8-byte records, fp32 basis; every inner product is still accumulated in fp64 and taken of the STORED,
+// i.e. rounded, vectors, so the quadratic form below stays exact for what is in memory).
+template <typename T> struct ZRec;
+template <> struct __attribute__((aligned(16))) ZRec<double> { double t, v; };
+template <> struct __attribute__((aligned(8))) ZRec<float> { float t, v; };
+using Z2 = ZRec<double>;
 constexpr int kNP = 6;    // partial sums per workgroup: t.t  t.v  v.v  sum(t)  sum(v)  |v|_1
 constexpr int kMaxChunk = 64;
 constexpr int kMaxWaves = 16;
 
-struct PipeView {
+template <typename T>
+struct PipeViewT {
     int n;
     LanState* st;
-    Z2* Z0;
-    Z2* Z1;
-    double* V;
+    ZRec<T>* Z0;
+    ZRec<T>* Z1;
+    T* V;
     double* tri;      // interleaved (alpha_j, beta_j, ||v_j||_1) records
     double* htri;     // host-pinned mirror of tri, written by the tail kernel (zero-copy): the host
                       // polls hflag instead of issuing a stream-ordered copy between chunks
@@ -408,8 +417,8 @@ struct PipeView {
                       // writes the other, so a late-starting workgroup never sees partials that a
                       // fast workgroup of the SAME launch has already replaced
     int P;            // valid partials per quantity (= grid of the step kernel, <= 256)
-    int pf;           // > 0: number of operand slices each XCD's workgroups prefetch (0 = off)
 };
+using PipeView = PipeViewT<double>;
 
 struct PipeCoef { double alpha, mu, beta, inv, l1prev; };
 
@@ -455,7 +464,8 @@ __device__ __forceinline__ PipeCoef pipe_coefs(const double (&a)[kNP], int n) {
 // Prologue, run by wave 0 only: sum the P (<= 256) partials of each quantity, derive the
 // coefficients, publish them to the workgroup through LDS (scoef) and -- workgroup 0 -- to the
 // tridiagonal record.  The other waves go straight to their CSR loads.
-__device__ __forceinline__ PipeCoef pipe_prologue_wave0(const PipeView& L, int jrel, int adv_jA, double* scoef, int* j_out) {
+template <class PV>
+__device__ __forceinline__ PipeCoef pipe_prologue_wave0(const PV& L, int jrel, int adv_jA, double* scoef, int* j_out) {
     const int lane = threadIdx.x;   // caller guarantees threadIdx.x < 64
     const int jA = L.st->jA;
     const double* __restrict__ pin = L.part + (size_t)(jrel & 1) * (kNP * kMaxGrid);
@@ -489,20 +499,23 @@ struct PipeRow {   // per-thread accumulation of the next step's partial sums
         for (int q = 0; q < kNP; ++q) acc[q] = 0.0;
     }
     // raw sums (L t)[r], (L v)[r] -> w_j[r]; v_j[r] from Z[r]; store V, next Z = {t_j, v_j}.
-    __device__ __forceinline__ void finish(double alpha, double beta, double mu, double inv, const Z2& z,
-                                           double st, double sv, double* vj, Z2* Zn, int r) {
-        const double v = ((z.t - alpha * z.v) - mu) * inv;
+    template <typename T>
+    __device__ __forceinline__ void finish(double alpha, double beta, double mu, double inv, const ZRec<T>& z,
+                                           double st, double sv, T* vj, ZRec<T>* Zn, int r) {
+        const double zt = z.t, zv = z.v;
         const double w = (st - alpha * sv) * inv;
-        const double t = w - beta * z.v;            // Paige's intermediate for the next step
-        vj[r] = v;
-        Z2 o; o.t = t; o.v = v;
+        ZRec<T> o;
+        o.v = (T)(((zt - alpha * zv) - mu) * inv);
+        o.t = (T)(w - beta * zv);                   // Paige's intermediate for the next step
+        const double v = o.v, t = o.t;              // the sums below are those of the vectors as stored
+        vj[r] = o.v;
         Zn[r] = o;
         acc[0] += t * t; acc[1] += t * v; acc[2] += v * v;
         acc[3] += t; acc[4] += v; acc[5] += fabs(v);
     }
     // one partial per quantity per workgroup; smw: kMaxWaves*kNP doubles
-    template <int BLOCK>
-    __device__ __forceinline__ void store(const PipeView& L, int jrel, double* smw) {
+    template <int BLOCK, class PV>
+    __device__ __forceinline__ void store(const PV& L, int jrel, double* smw) {
         constexpr int NW = BLOCK / 64;
 #pragma unroll
         for (int q = 0; q < kNP; ++q) acc[q] = wave_total(acc[q]);
@@ -522,8 +535,9 @@ struct PipeRow {   // per-thread accumulation of the next step's partial sums
 };
 
 // ---- sub-wave vector form: G lanes per row, BLOCK threads per workgroup -------------------------
-template <int BLOCK, int G, int UNR = 1, bool DED = false>
-__global__ __launch_bounds__(BLOCK) void k_pipe_vec(CsrView A, PipeView L, int jrel) {
+template <int BLOCK, int G, int UNR = 1, bool DED = false, typename T = double>
+__global__ __launch_bounds__(BLOCK) void k_pipe_vec(CsrViewT<T> A, PipeViewT<T> L, int jrel) {
+    using Z2 = ZRec<T>;
     __shared__ double smw[kMaxWaves * kNP];
     __shared__ double scoef[8];
     // DED: wave 0 does nothing but the prologue (its reduction chain is then off the critical
@@ -537,35 +551,21 @@ __global__ __launch_bounds__(BLOCK) void k_pipe_vec(CsrView A, PipeView L, int j
     Z2* __restrict__ Zn = (jrel & 1) ? L.Z0 : L.Z1;
     PipeRow pr;
     pr.clear();
-    // The gather operand was written by the previous launch from all eight XCDs and every launch starts with a
-    // cold L2: without help each XCD pulls its 16 n bytes in through scattered gather misses.  L.pf > 0: the
-    // workgroups of an XCD (blockIdx % 8 under round-robin dispatch; only speed depends on that) first sweep the
-    // operand once with coalesced loads, slice blockIdx / 8 of L.pf slices each, so the gathers find it in L2.
-    if (L.pf > 0 && wt >= 0) {
-        const int slice = (int)(blockIdx.x >> 3) % L.pf;
-        const int per = (A.n + L.pf - 1) / L.pf;
-        const int lo = slice * per, hi = min(A.n, lo + per);
-        double sink = 0.0;
-        for (int i = lo + wt * 8; i < hi; i += WORK * 8) {      // one 128-byte line (8 records) per lane
-            sink += Zc[i].t;
-        }
-        if (sink == 1.2345e300) pr.acc[5] = sink;                 // never true for finite data; keeps the loads alive
-    }
     bool have = false;
     double alpha = 0.0, beta = 0.0, mu = 0.0, inv = 0.0;
-    double* vj = nullptr;
+    T* vj = nullptr;
     for (int r0 = blockIdx.x * GPB; r0 < A.n; r0 += gridDim.x * GPB) {   // workgroup-uniform trip count
         const int r = r0 + g;
         const bool mine = wt >= 0 && r < A.n;
         double st = 0.0, sv = 0.0;
-        Z2 zr; zr.t = 0.0; zr.v = 0.0;
+        Z2 zr; zr.t = 0; zr.v = 0;
         if (mine) {
             const int b = A.rowptr[r], e = A.rowptr[r + 1];
             if (lane == 0) zr = Zc[r];
             int p = b + lane;
             if (UNR > 1) {   // several independent (val, col, gather) chains in flight per lane
                 for (; p + (UNR - 1) * G < e; p += UNR * G) {
-                    double vv[UNR];
+                    T vv[UNR];
                     int cc[UNR];
                     Z2 zz[UNR];
 #pragma unroll
@@ -573,13 +573,13 @@ __global__ __launch_bounds__(BLOCK) void k_pipe_vec(CsrView A, PipeView L, int j
 #pragma unroll
                     for (int q = 0; q < UNR; ++q) zz[q] = Zc[cc[q]];
 #pragma unroll
-                    for (int q = 0; q < UNR; ++q) { st += vv[q] * zz[q].t; sv += vv[q] * zz[q].v; }
+                    for (int q = 0; q < UNR; ++q) { st += (double)vv[q] * (double)zz[q].t; sv += (double)vv[q] * (double)zz[q].v; }
                 }
             }
             for (; p < e; p += G) {
                 const double vv = A.val[p];
                 const Z2 z = Zc[A.col[p]];
-                st += vv * z.t; sv += vv * z.v;
+                st += vv * (double)z.t; sv += vv * (double)z.v;
             }
             st = group_sum<G>(st); sv = group_sum<G>(sv);
         }
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(BLOCK) void k_pipe_vec(CsrView A, PipeView L, int j
             vj = L.V + (size_t)scoef[4] * (size_t)L.n;
             have = true;
         }
-        if (mine && lane == 0) pr.finish(alpha, beta, mu, inv, zr, st, sv, vj, Zn, r);
+        if (mine && lane == 0) pr.template finish<T>(alpha, beta, mu, inv, zr, st, sv, vj, Zn, r);
     }
     pr.template store<BLOCK>(L, jrel, smw);
 }
@@ -641,18 +641,19 @@ __global__ __launch_bounds__(kBlock) void k_pipe_stream(CsrView A, PipeView L, i
             __syncthreads();
         }
         st = group_sum<TPR>(st); sv = group_sum<TPR>(sv);
-        if (row < nr && sub == 0) pr.finish(alpha, beta, mu, inv, zr, st, sv, vj, Zn, r0 + row);
+        if (row < nr && sub == 0) pr.finish<double>(alpha, beta, mu, inv, zr, st, sv, vj, Zn, r0 + row);
     }
     pr.template store<kBlock>(L, jrel, smw);
 }
 
 // Start a sequence from u0: Z0 = (u0, 0); partials such that step 0 normalises u0.
-__global__ __launch_bounds__(kBlock) void k_pipe_init(PipeView L, const double* __restrict__ u0, int epoch) {
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_pipe_init(PipeViewT<T> L, const double* __restrict__ u0, int epoch) {
     __shared__ double sm[4];
     double s1 = 0.0, s2 = 0.0;
     for (int r = blockIdx.x * kBlock + threadIdx.x; r < L.n; r += gridDim.x * kBlock) {
-        const double t = u0[r];
-        Z2 o; o.t = t; o.v = 0.0;
+        ZRec<T> o; o.t = (T)u0[r]; o.v = 0;
+        const double t = o.t;
         L.Z0[r] = o;
         s1 += t; s2 += t * t;
     }
@@ -668,7 +669,8 @@ __global__ __launch_bounds__(kBlock) void k_pipe_init(PipeView L, const double* 
 // so the host can test convergence, and advance the chunk base jA.  The step kernels only read
 // jA; this kernel is alone in its launch.  Zero-copy hand-off to the host: records [J-adv-1, J]
 // of tri -> pinned host memory, then the flag.
-__global__ __launch_bounds__(64) void k_pipe_tail(PipeView L, int adv) {
+template <typename T>
+__global__ __launch_bounds__(64) void k_pipe_tail(PipeViewT<T> L, int adv) {
     __shared__ double scoef[8];
     int j = 0;
     const PipeCoef c = pipe_prologue_wave0(L, adv, adv, scoef, &j);
@@ -704,6 +706,11 @@ __global__ __launch_bounds__(kBlock) void k_vec_sums(const double* __restrict__ 
     }
 }
 
+// fp64 -> fp32 copy of the assembled values (mixed-precision mode, once per solve).
+__global__ __launch_bounds__(kBlock) void k_to_f32(const double* __restrict__ src, float* __restrict__ dst, long cnt) {
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < cnt; i += (long)gridDim.x * kBlock) dst[i] = (float)src[i];
+}
+
 __global__ void k_set_state(LanState* st, int j) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { st->jA = j; st->jB = j; }
 }
@@ -721,7 +728,8 @@ __global__ __launch_bounds__(kBlock) void k_fill_start(double* __restrict__ u, i
 
 // Ritz vector y = V[:, 0:J) s, split over the Krylov dimension: grid (row tiles, KS); slice ks
 // accumulates columns ks, ks+KS, ... into ypart[ks*n + r].
-__global__ __launch_bounds__(kBlock) void k_ritz_partial(const double* __restrict__ V, int n, int J,
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_ritz_partial(const T* __restrict__ V, int n, int J,
                                                          const double* __restrict__ s,
                                                          double* __restrict__ ypart) {
     const int KS = gridDim.y, ks = blockIdx.y;
@@ -735,7 +743,7 @@ __global__ __launch_bounds__(kBlock) void k_ritz_partial(const double* __restric
             for (int q = 0; q < U; ++q) {
                 const int k = k0 + q * KS;
                 const bool ok = k < J;
-                v[q] = ok ? V[(size_t)k * n + r] : 0.0;
+                v[q] = ok ? (double)V[(size_t)k * n + r] : 0.0;
                 c[q] = ok ? s[k] : 0.0;
             }
 #pragma unroll

@@ -29,12 +29,13 @@ constexpr int kPersistMaxRows = 6;        // rows per thread held in registers (
                                            // beyond that the register file spills and one CU's FP64 issue rate loses
                                            // to the multi-workgroup path (n = 4 661: 4.0 us/step either way)
 
-struct PersistView {
+template <typename T>
+struct PersistViewT {
     int n;
     LanState* st;
     double* u;      // un-normalised next Lanczos vector (state between chunks)
     double* vprev;  // v_{J-1}
-    double* V;      // basis, column-major
+    T* V;           // basis, column-major (fp32 in the mixed-precision mode)
     double* tri;    // (alpha_j, beta_j, ||v_j||_1) triples
     double* htri;   // pinned mirror
     unsigned long long* hflag;
@@ -42,6 +43,7 @@ struct PersistView {
     long long* clk;   // tools/ubench_persist.hip: phase stamps of thread 0
 #endif
 };
+using PersistView = PersistViewT<double>;
 
 // nc_max: upper bound of the entries outside the tridiagonal band (the band itself lives in registers)
 inline bool persist_fits(int n, long nc_max) {
@@ -69,7 +71,8 @@ __device__ __forceinline__ void persist_sum2(double& a, double& b, double* red) 
     a = sa; b = sb;
 }
 
-__global__ void k_persist_begin(PersistView L, int epoch) {
+template <typename T>
+__global__ void k_persist_begin(PersistViewT<T> L, int epoch) {
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < L.n; r += gridDim.x * blockDim.x) L.vprev[r] = 0.0;
     if (blockIdx.x == 0 && threadIdx.x == 0) { L.st->jA = 0; L.st->epoch = epoch; }
 }
@@ -81,8 +84,10 @@ __global__ void k_persist_begin(PersistView L, int epoch) {
 // rows -- are kept as a CSR in LDS next to the gather operand.  (A plain
 // thread-per-row CSR in LDS was tried first: rows of ~4 entries put the 64 lanes of a load on 4 banks
 // and the step cost 4 us, LDS-bound.)
-template <int RPT>
-__global__ __launch_bounds__(kPersistThreads) void k_lan_persist(CsrView A, PersistView L, int steps) {
+// T = float (mixed-precision mode): the row data, the operand in LDS, the vectors in registers and the basis column
+// are fp32 and the matrix-vector product runs in fp32; the two reductions of a step accumulate in fp64.
+template <int RPT, typename T = double>
+__global__ __launch_bounds__(kPersistThreads) void k_lan_persist(CsrView A, PersistViewT<T> L, int steps) {
     __shared__ __align__(16) unsigned char pool[kPersistPool];
     __shared__ double red1[2 * kPersistThreads / 64], red2[2 * kPersistThreads / 64];
     __shared__ double srec[3 * (kPersistMaxSteps + 1)];   // (alpha, beta, l1) of this chunk
@@ -92,31 +97,33 @@ __global__ __launch_bounds__(kPersistThreads) void k_lan_persist(CsrView A, Pers
 #ifdef PERSIST_CLOCKS
     if (t == 0) L.clk[10] = wall_clock64();
 #endif
-    double* svec = reinterpret_cast<double*>(pool);
-    int* crow = reinterpret_cast<int*>(svec + n);          // n + 1 offsets of the out-of-band entries
+    T* svec = reinterpret_cast<T*>(pool);
+    int* crow = reinterpret_cast<int*>(pool + (size_t)n * 8);   // n + 1 offsets of the out-of-band entries (same layout for both T)
     // ---- band and the first two off-band entries -> registers; count the overflow of every row ----
-    double dg[RPT], lo[RPT], up[RPT], c0v[RPT], c1v[RPT];
+    T dg[RPT], lo[RPT], up[RPT], c0v[RPT], c1v[RPT];
     int c0c[RPT], c1c[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int r = t + k * kPersistThreads;
-        dg[k] = 0.0; lo[k] = 0.0; up[k] = 0.0; c0v[k] = 0.0; c1v[k] = 0.0; c0c[k] = 0; c1c[k] = 0;
+        double dgd = 0.0, lod = 0.0, upd = 0.0;
+        c0v[k] = 0; c1v[k] = 0; c0c[k] = 0; c1c[k] = 0;
         if (r < n) {
             int c = 0;
             for (int p = A.rowptr[r]; p < A.rowptr[r + 1]; ++p) {
                 const int col = A.col[p];
                 const double x = A.val[p];
-                if (col == r) dg[k] += x;
-                else if (col == r - 1) lo[k] += x;
-                else if (col == r + 1) up[k] += x;
+                if (col == r) dgd += x;
+                else if (col == r - 1) lod += x;
+                else if (col == r + 1) upd += x;
                 else {
-                    if (c == 0) { c0c[k] = col; c0v[k] = x; }
-                    else if (c == 1) { c1c[k] = col; c1v[k] = x; }
+                    if (c == 0) { c0c[k] = col; c0v[k] = (T)x; }
+                    else if (c == 1) { c1c[k] = col; c1v[k] = (T)x; }
                     ++c;
                 }
             }
             crow[r + 1] = max(0, c - 2);
         }
+        dg[k] = (T)dgd; lo[k] = (T)lod; up[k] = (T)upd;
     }
     if (t == 0) crow[0] = 0;
     __syncthreads();
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_lan_persist(CsrView A, Pers
     }
     const int nc = crow[n];
     int* ccol = crow + (n + 1);
-    double* cval = reinterpret_cast<double*>(pool + (((size_t)n * 8 + ((size_t)n + 1 + (size_t)nc) * 4 + 7) & ~(size_t)7));
+    T* cval = reinterpret_cast<T*>(pool + (((size_t)n * 8 + ((size_t)n + 1 + (size_t)nc) * 4 + 7) & ~(size_t)7));
     bool any_over = false;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
@@ -151,19 +158,19 @@ __global__ __launch_bounds__(kPersistThreads) void k_lan_persist(CsrView A, Pers
             for (int p = A.rowptr[r]; p < A.rowptr[r + 1]; ++p) {
                 const int col = A.col[p];
                 if (col < r - 1 || col > r + 1) {
-                    if (c >= 2) { ccol[q] = col; cval[q] = A.val[p]; ++q; }
+                    if (c >= 2) { ccol[q] = col; cval[q] = (T)A.val[p]; ++q; }
                     ++c;
                 }
             }
         }
     }
     const int J0 = L.st->jA;
-    double u[RPT], vp[RPT], v[RPT];
+    T u[RPT], vp[RPT], v[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int r = t + k * kPersistThreads;
-        u[k] = r < n ? L.u[r] : 0.0;
-        vp[k] = r < n ? L.vprev[r] : 0.0;
+        u[k] = r < n ? (T)L.u[r] : (T)0;
+        vp[k] = r < n ? (T)L.vprev[r] : (T)0;
     }
     const double dn = (double)n, rdn = 1.0 / dn;
     __syncthreads();
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_lan_persist(CsrView A, Pers
         // ---- beta_j = ||u - mean||, v_j = (u - mean) / beta_j  (nx:209-213 project()) ----
         double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-        for (int k = 0; k < RPT; ++k) { s1 += u[k]; s2 += u[k] * u[k]; }
+        for (int k = 0; k < RPT; ++k) { const double uk = u[k]; s1 += uk; s2 += uk * uk; }
         persist_sum2(s1, s2, red1);
         PCLK(s == 0, 2);
         const double mu = s1 * rdn;
@@ -187,12 +194,12 @@ __global__ __launch_bounds__(kPersistThreads) void k_lan_persist(CsrView A, Pers
         }
         const double inv = rs;
         double l1 = 0.0, al = 0.0;
-        double* vj = L.V + (size_t)j * (size_t)n;
+        T* vj = L.V + (size_t)j * (size_t)n;
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
             const int r = t + k * kPersistThreads;
-            v[k] = (u[k] - mu) * inv;
-            if (r < n) { svec[r] = v[k]; vj[r] = v[k]; l1 += fabs(v[k]); } else v[k] = 0.0;
+            v[k] = (T)(((double)u[k] - mu) * inv);
+            if (r < n) { svec[r] = v[k]; vj[r] = v[k]; l1 += fabs((double)v[k]); } else v[k] = 0;
         }
         PCLK(s == 0, 3);
         lds_barrier();
@@ -203,7 +210,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_lan_persist(CsrView A, Pers
         for (int k = 0; k < RPT; ++k) {
             const int r = t + k * kPersistThreads;
             const int rm = max(r - 1, 0), rp = min(r + 1, n - 1);     // lo/up are 0 where the neighbour does not exist
-            double w = dg[k] * v[k];
+            T w = dg[k] * v[k];
             if (r < n) w += lo[k] * svec[rm] + up[k] * svec[rp] + c0v[k] * svec[c0c[k]] + c1v[k] * svec[c1c[k]];
             u[k] = w;
         }
@@ -218,14 +225,14 @@ __global__ __launch_bounds__(kPersistThreads) void k_lan_persist(CsrView A, Pers
             }
         }
 #pragma unroll
-        for (int k = 0; k < RPT; ++k) al += v[k] * u[k];
+        for (int k = 0; k < RPT; ++k) al += (double)v[k] * (double)u[k];
         PCLK(s == 0, 5);
         persist_sum2(al, l1, red2);
         PCLK(s == 0, 6);
         // ---- u_{j+1} = w - alpha_j v_j - beta_j v_{j-1} ----
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
-            u[k] = (u[k] - al * v[k]) - beta * vp[k];
+            u[k] = (u[k] - (T)al * v[k]) - (T)beta * vp[k];
             vp[k] = v[k];
         }
         if (t == 0) { srec[3 * s] = al; srec[3 * s + 1] = beta; srec[3 * s + 2] = l1; }

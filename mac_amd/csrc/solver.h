@@ -150,6 +150,19 @@ inline void launch_spmv(const SpmvPlan& pl, hipStream_t s, const CsrView& A, con
     }
 }
 
+// fp32 storage (mixed-precision mode): the shapes plan_pipe actually chooses; anything else maps to the nearest
+template <int BLOCK>
+inline void launch_pipe_b(const SpmvPlan& pl, hipStream_t s, const CsrViewT<float>& A, const PipeViewT<float>& L, int jrel) {
+    const int key = pl.width * 10 + pl.unroll;
+    switch (key) {
+        case 41: k_pipe_vec<BLOCK, 4, 1, true, float><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 42: case 44: k_pipe_vec<BLOCK, 4, 2, true, float><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 81: case 82: k_pipe_vec<BLOCK, 8, 2, true, float><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 84: k_pipe_vec<BLOCK, 8, 4, true, float><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        default: k_pipe_vec<BLOCK, 16, 2, true, float><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+    }
+}
+
 template <int BLOCK>
 inline void launch_pipe_b(const SpmvPlan& pl, hipStream_t s, const CsrView& A, const PipeView& L, int jrel) {
     const int key = pl.width * 10 + pl.unroll;
@@ -183,6 +196,11 @@ inline void launch_pipe(const SpmvPlan& pl, hipStream_t s, const CsrView& A, con
     else if (pl.block == 512) launch_pipe_b<512>(pl, s, A, L, jrel);
     else launch_pipe_b<256>(pl, s, A, L, jrel);
 }
+inline void launch_pipe(const SpmvPlan& pl, hipStream_t s, const CsrViewT<float>& A, const PipeViewT<float>& L, int jrel) {
+    if (pl.block == 1024) launch_pipe_b<1024>(pl, s, A, L, jrel);      // (the LDS row-tile variant exists in fp64 only)
+    else if (pl.block == 512) launch_pipe_b<512>(pl, s, A, L, jrel);
+    else launch_pipe_b<256>(pl, s, A, L, jrel);
+}
 
 struct Solver {
     int n = 0;
@@ -199,6 +217,9 @@ struct Solver {
     // classic (two-kernel) Lanczos state: the accurate fallback for tiny / nearly exhausted Krylov spaces
     double *wc = nullptr, *ctri = nullptr, *part_u = nullptr, *part_a = nullptr;
     LanState* stc = nullptr;
+    float* valf = nullptr;      // fp32 copy of the matrix values (mixed-precision mode), grown on demand
+    size_t valf_cap = 0;
+    bool last_seq_f32 = false;  // the basis V of the last sequence holds floats (ritz_block must not read it as fp64)
     double* start = nullptr;    // persistent cold-start vector
     bool have_start = false, have_prev = false;
     int ks_max = 16;
@@ -256,6 +277,8 @@ struct Solver {
         size_t budget = (size_t)env_int("MACHIP_VBUDGET_MB", 4096) * (size_t)(1 << 20);
         vcap = budget / (sizeof(double) * (size_t)std::max(n, 1));
         vcap = std::max<size_t>(std::min<size_t>(vcap, 16384), 64);
+        vcap = std::min<size_t>(vcap, (size_t)n + 10);   // a Krylov sequence never exceeds n - 1 + 8 columns (jcap)
+        vcap = std::max<size_t>(vcap, 64);
         vcap = (size_t)env_int("MACHIP_VCAP", (int)vcap);
         // rocprofiler-sdk (ROCm 7.2) segfaults inside its HSA interception when short graphs are
         // launched in quick succession (reproduced under rocprofv3 --kernel-trace on the pose-graph
@@ -294,7 +317,7 @@ struct Solver {
                         part_c, part_a2, part_r, scratch3, rq_dev, start, wc, ctri, part_u, part_a, stc,
                         lx_x, lx_Lx, lx_p, lx_Lp, lx_Lw, lx_rT, lx_wT, lx_tl, lx_tdinv, lx_tcu, lx_part, lx_partR,
                         lx_ys, lx_pas, lx_as, lx_bs, lx_maps, lx_ba, lx_bd, lx_bu, wb_ui, wb_uj, wb_counts, wb_uc, wb_g, wb_h, wb_Zt, wb_Cm, wb_pas, wb_maps,
-                        lx_colT, lx_bad, lx_st};
+                        lx_colT, lx_bad, lx_st, valf};
         if (h_lrec) (void)hipHostFree(h_lrec);
         if (wb_handle) (void)rocblas_destroy_handle(wb_handle);
         for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -310,12 +333,10 @@ struct Solver {
 
     int vgrid() const { return (int)std::min<long>(kMaxGrid, ((long)n + kBlock - 1) / kBlock); }
 
-    PipeView pview(const SpmvPlan& pl) const {
-        PipeView L;
-        L.n = n; L.st = st; L.Z0 = Z0; L.Z1 = Z1; L.V = V; L.tri = tri; L.htri = d_htri; L.hflag = d_hflag; L.part = part; L.P = pl.grid;
-        // operand prefetch: one slice per workgroup of an XCD (grid / 8 of them), only where the operand does not
-        // fit L1 anyway and the grid covers every XCD evenly
-        L.pf = (env_int("MACHIP_PREFETCH", 0) != 0 && pl.grid >= 64 && pl.grid % 8 == 0) ? pl.grid / 8 : 0;
+    template <typename T = double>
+    PipeViewT<T> pview(const SpmvPlan& pl) const {
+        PipeViewT<T> L;     // T = float: records and basis live in the same buffers, read as fp32
+        L.n = n; L.st = st; L.Z0 = reinterpret_cast<ZRec<T>*>(Z0); L.Z1 = reinterpret_cast<ZRec<T>*>(Z1); L.V = reinterpret_cast<T*>(V); L.tri = tri; L.htri = d_htri; L.hflag = d_hflag; L.part = part; L.P = pl.grid;
         return L;
     }
     LanView check_view(const SpmvPlan& pl) const {   // "column 0" machinery for the explicit check
@@ -348,34 +369,46 @@ struct Solver {
     }
 
     // ---- small graphs: a whole chunk of Lanczos steps in one single-workgroup launch (persist.h) ----
-    PersistView persist_view() const {
-        PersistView L;
-        L.n = n; L.st = st; L.u = u; L.vprev = wc; L.V = V; L.tri = tri; L.htri = d_htri; L.hflag = d_hflag;
+    template <typename T = double>
+    PersistViewT<T> persist_view() const {
+        PersistViewT<T> L;
+        L.n = n; L.st = st; L.u = u; L.vprev = wc; L.V = reinterpret_cast<T*>(V); L.tri = tri; L.htri = d_htri; L.hflag = d_hflag;
         return L;
     }
-    void launch_persist(const CsrView& A, int steps) {
-        const PersistView L = persist_view();
+    template <typename T>
+    void launch_persist_t(const CsrView& A, int steps) {
+        const PersistViewT<T> L = persist_view<T>();
         switch ((n + 2 * kPersistThreads - 1) / (2 * kPersistThreads)) {   // rows per thread, rounded up to 2
-            case 1: k_lan_persist<2><<<1, kPersistThreads, 0, stream>>>(A, L, steps); break;
-            case 2: k_lan_persist<4><<<1, kPersistThreads, 0, stream>>>(A, L, steps); break;
-            default: k_lan_persist<6><<<1, kPersistThreads, 0, stream>>>(A, L, steps); break;
+            case 1: k_lan_persist<2, T><<<1, kPersistThreads, 0, stream>>>(A, L, steps); break;
+            case 2: k_lan_persist<4, T><<<1, kPersistThreads, 0, stream>>>(A, L, steps); break;
+            default: k_lan_persist<6, T><<<1, kPersistThreads, 0, stream>>>(A, L, steps); break;
         }
+    }
+    void launch_persist(const CsrView& A, int steps, bool f32 = false) {
+        if (f32) launch_persist_t<float>(A, steps); else launch_persist_t<double>(A, steps);
     }
 
     // ---- one chunk = `steps` step kernels + the tail kernel ------------------------------------
-    void launch_chunk(const CsrView& A, const SpmvPlan& pl, int steps) {
+    void launch_chunk(const CsrView& A, const SpmvPlan& pl, int steps, bool f32 = false) {
+        if (f32) {
+            const PipeViewT<float> L = pview<float>(pl);
+            const CsrViewT<float> Af{A.n, A.rowptr, A.col, valf};
+            for (int s = 0; s < steps; ++s) launch_pipe(pl, stream, Af, L, s);
+            k_pipe_tail<<<1, 64, 0, stream>>>(L, steps);
+            return;
+        }
         const PipeView L = pview(pl);
         for (int s = 0; s < steps; ++s) launch_pipe(pl, stream, A, L, s);
         k_pipe_tail<<<1, 64, 0, stream>>>(L, steps);
     }
-    int enqueue_chunk(const CsrView& A, const SpmvPlan& pl, int steps) {
-        if (!use_graph) { launch_chunk(A, pl, steps); HIP_TRY(hipGetLastError()); return MACHIP_OK; }
+    int enqueue_chunk(const CsrView& A, const SpmvPlan& pl, int steps, bool f32 = false) {
+        if (!use_graph) { launch_chunk(A, pl, steps, f32); HIP_TRY(hipGetLastError()); return MACHIP_OK; }
         if (graph_csr_key != (const void*)A.val) {   // different matrix buffers: cached graphs are stale
             for (auto& kv : graphs) for (hipGraphExec_t ge : kv.second) if (ge) (void)hipGraphExecDestroy(ge);
             graphs.clear();
             graph_csr_key = (const void*)A.val;
         }
-        const auto key = std::make_tuple(pl.variant, pl.width * 10 + pl.unroll, pl.grid, pl.block, steps);
+        const auto key = std::make_tuple(pl.variant + (f32 ? 100 : 0), pl.width * 10 + pl.unroll, pl.grid, pl.block, steps);
         auto it = graphs.find(key);
         if (it == graphs.end()) it = graphs.emplace(key, std::array<hipGraphExec_t, 2>{nullptr, nullptr}).first;
         // two executables per shape, used alternately: with one chunk running ahead, the same
@@ -384,7 +417,7 @@ struct Solver {
         if (!ge) {
             hipGraph_t g = nullptr;
             HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-            launch_chunk(A, pl, steps);
+            launch_chunk(A, pl, steps, f32);
             HIP_TRY(hipStreamEndCapture(stream, &g));
             HIP_TRY(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
             (void)hipGraphDestroy(g);
@@ -395,12 +428,15 @@ struct Solver {
 
     // y = V[:, :J] s  -> normalised into yvec; w2 = L yvec; returns (rq, ||w2 - rq yvec||_1).
     int explicit_check(const CsrView& A, const SpmvPlan& pl, int J, const double* s_host, double* rq,
-                       double* res_l1) {
+                       double* res_l1, bool f32 = false) {
         memcpy(h_pin, s_host, sizeof(double) * (size_t)J);
         HIP_TRY(hipMemcpyAsync(sdev, h_pin, sizeof(double) * (size_t)J, hipMemcpyHostToDevice, stream));
         const int g2 = vgrid();
         const int KS = std::max(1, std::min(ks_max, J / 8));
-        k_ritz_partial<<<dim3(g2, KS), kBlock, 0, stream>>>(V, n, J, sdev, ypart);
+        // (fp32 basis: the combination is accumulated in fp64; everything after it -- normalisation, L y, Rayleigh
+        // quotient, the reference's residual test -- is fp64 on the fp64 matrix)
+        if (f32) k_ritz_partial<float><<<dim3(g2, KS), kBlock, 0, stream>>>(reinterpret_cast<const float*>(V), n, J, sdev, ypart);
+        else k_ritz_partial<<<dim3(g2, KS), kBlock, 0, stream>>>(V, n, J, sdev, ypart);
         k_ritz_combine<<<g2, kBlock, 0, stream>>>(ypart, n, KS, y_raw, part_c);
         HIP_TRY(hipGetLastError());
         return check_vector(A, pl, rq, res_l1);
@@ -805,7 +841,7 @@ struct Solver {
                 if (stats) {
                     stats->lanczos_steps = iters; stats->spmv_total = spmvs; stats->vec_passes = iters * 16;
                     stats->restarts = rst; stats->nnz = nnz; stats->residual = res; stats->lnorm = lnorm; stats->gpu_ms = ms;
-                    stats->step_ms = ms; stats->steps_timed = iters;
+                    stats->step_ms = ms; stats->steps_timed = iters; stats->steps_lowp = 0;
                 }
                 if (lam < 1e-12 * (lnorm > 0 ? lnorm : 1.0))
                     return fail(MACHIP_DISCONNECTED, "lambda_2 ~ 0: the graph is not connected");
@@ -856,6 +892,24 @@ struct Solver {
         const bool pmode = env_int("MACHIP_PERSIST", 1) != 0 && chain_like && persist_fits(n, nnz - n - 2 * chain_edges);
         const int pchunk0 = std::min(kPersistMaxSteps, std::max(2, env_int("MACHIP_PCHUNK", 64)));
         const bool debug = env_int("MACHIP_DEBUG", 0) != 0;
+        // ---- mixed precision (machip_set_precision(1)): the FIRST Krylov sequence stores matrix values, records and
+        // basis in fp32 (inner products accumulated in fp64).  An fp32 recurrence cannot resolve lambda_2 beyond
+        // ~eps_32 ||L||, so it only runs until its residual estimate reaches f32_switch ||L||_inf (or stalls); its Ritz
+        // vector is then formed with fp64 accumulation, checked in fp64 (Rayleigh quotient + the reference's residual
+        // test on the fp64 matrix) and, when the test does not pass yet, fp64 sequences continue from it. ----
+        bool f32_seq = precision == 1 && !classic && pp.variant == kVec;
+        const double f32_switch = std::max(tol, 1e-9 * (double)env_int("MACHIP_F32_SWITCH_E9", 2000));   // default 2e-6
+        long steps_lowp = 0;
+        if (f32_seq && !pmode) {
+            if (valf_cap < (size_t)nnz) {
+                if (valf) (void)hipFree(valf);
+                valf = nullptr; valf_cap = 0;
+                const size_t want = (size_t)nnz + (size_t)nnz / 4 + 1024;
+                ST_TRY(dev_alloc(&valf, want));
+                valf_cap = want;
+            }
+            k_to_f32<<<(int)std::min<long>(kMaxGrid, (nnz + kBlock - 1) / kBlock), kBlock, 0, stream>>>(A.val, valf, nnz);
+        }
         while (!done && steps_total < max_steps) {
             // ---- (re)start a Krylov sequence from u ----
             if (pmode) {
@@ -864,10 +918,16 @@ struct Solver {
             } else if (classic) {
                 k_vec_sums<<<g2, kBlock, 0, stream>>>(u, n, part_u);
                 k_set_state<<<1, 64, 0, stream>>>(stc, 0);
+            } else if (f32_seq) {
+                ++epoch;
+                k_pipe_init<<<pp.grid, kBlock, 0, stream>>>(pview<float>(pp), u, (int)epoch);
             } else {
                 ++epoch;
                 k_pipe_init<<<pp.grid, kBlock, 0, stream>>>(L, u, (int)epoch);
             }
+            const double seq_tol = f32_seq ? f32_switch : tol;     // what this sequence's residual estimate aims for
+            double best_est = 1e300;
+            int chunks_since_best = 0;
             int J_enq = 0;        // steps enqueued in this sequence
             int J_timed = 0;      // ... of which already accounted in step_ms
             HIP_TRY(hipEventRecord(evs0, stream));
@@ -881,7 +941,7 @@ struct Solver {
             std::deque<std::pair<int, double>> hist;
             double to_go = 1e18;
             const bool sched = env_int("MACHIP_SCHED", 1) != 0;
-            const double ltarget = std::log(std::max(tol * tiny_l, 1e-300));
+            const double ltarget = std::log(std::max(seq_tol * tiny_l, 1e-300));
             const int jcap = (int)std::min<size_t>(vcap - 2, (size_t)std::max(2, n - 1) + 8) & ~1;
             const size_t cs = vcap + 2;   // stride of the classic alpha / beta / l1 arrays
 
@@ -890,8 +950,8 @@ struct Solver {
                 // one chunk runs ahead of the host -- except in the end game (same threshold as the
                 // short chunks), where the chunk in flight is likely the last one and a speculative
                 // successor would only delay the explicit residual check queued behind it
-                const bool near = sched ? (to_go < 2.0 * chunk0 || (to_go >= 1e17 && est_latest < 1e3 * tol * lnorm))
-                                        : est_latest < 1e3 * tol * lnorm;
+                const bool near = sched ? (to_go < 2.0 * chunk0 || (to_go >= 1e17 && est_latest < 1e3 * seq_tol * lnorm))
+                                        : est_latest < 1e3 * seq_tol * lnorm;
                 const bool use_classic = classic && !pmode;
                 const int depth = (use_classic || near) ? 1 : ((sched && to_go > 8.0 * chunk0) ? 3 : 2);
                 while ((int)pend.size() < depth && J_enq < jcap && steps_total < max_steps) {
@@ -913,7 +973,7 @@ struct Solver {
                     if (pmode || !classic)   // zero-copy records: poison the beta slots only this chunk writes
                         for (int j = J_enq ? J_enq + 1 : 0; j <= hi; ++j) h_tri[3 * (size_t)j + 1] = std::numeric_limits<double>::quiet_NaN();
                     if (pmode) {
-                        launch_persist(A, chunk);
+                        launch_persist(A, chunk, f32_seq);
                         HIP_TRY(hipGetLastError());   // (157 KB of static LDS: a refused launch must surface, not time out)
                     } else if (classic) {
                         enqueue_classic(A, pl, chunk);
@@ -922,7 +982,7 @@ struct Solver {
                             HIP_TRY(hipMemcpyAsync(hp + q * (size_t)(kMaxChunk + 2), ctri + q * cs + (size_t)J_enq,
                                                    sizeof(double) * (size_t)(chunk + 1), hipMemcpyDeviceToHost, stream));
                     } else {
-                        ST_TRY(enqueue_chunk(A, pp, chunk));
+                        ST_TRY(enqueue_chunk(A, pp, chunk, f32_seq));
                     }
                     (void)lo;
                     Pending p;
@@ -937,6 +997,7 @@ struct Solver {
                     pend.push_back(p);
                     J_enq = hi;
                     steps_total += chunk; spmv_total += chunk;
+                    if (f32_seq) steps_lowp += chunk;
                 }
                 if (pend.empty()) { need_restart = true; break; }
                 Pending p = pend.front();
@@ -997,12 +1058,16 @@ struct Solver {
                     }
                 }
                 const bool at_cap = (J >= jcap) || (steps_total >= max_steps && pend.empty());
-                const bool trig = broke || est < trigger_slack * tol * lnorm;
+                bool trig = broke || est < trigger_slack * seq_tol * lnorm;
+                if (f32_seq) {      // an fp32 recurrence that has stopped improving has reached its floor: hand over
+                    if (est < 0.7 * best_est) { best_est = est; chunks_since_best = 0; }
+                    else if (++chunks_since_best >= 4 && est < 1e-3 * lnorm) { trig = true; last_check_est = 1e300; }
+                }
                 if (debug) fprintf(stderr, "[machip] %s J=%d Jeff=%d theta=%.15g est=%.3e to_go=%.0f broke=%d pend=%zu passes=%d\n", pmode ? "persist" : (classic ? "classic" : "pipe"), J, Jeff, sm.theta, lnorm > 0 ? est / lnorm : est, std::min(to_go, 1e9), (int)broke, pend.size(), sm.passes);
                 if ((trig && est < 0.5 * last_check_est) || broke || at_cap) {
                     double rq = 0.0, r1 = 0.0;
                     HIP_TRY(hipEventRecord(evs1, stream));   // everything enqueued so far = steps [J_timed, J_enq)
-                    ST_TRY(explicit_check(A, pl, Jeff, sm.s.data(), &rq, &r1));   // syncs the stream
+                    ST_TRY(explicit_check(A, pl, Jeff, sm.s.data(), &rq, &r1, f32_seq));   // syncs the stream
                     {
                         float sms = 0.f;
                         HIP_TRY(hipEventElapsedTime(&sms, evs0, evs1));
@@ -1017,7 +1082,7 @@ struct Solver {
                     res = lnorm > 0 ? r1 / lnorm : r1;
                     if (debug) fprintf(stderr, "[machip]    check J=%d rq=%.15g res=%.3e (tol %.1e)\n", Jeff, rq, res, tol);
                     if (res < tol) { converged = true; status = MACHIP_OK; break; }
-                    if (broke || at_cap) { need_restart = true; break; }
+                    if (broke || at_cap || f32_seq) { need_restart = true; break; }   // fp32 sequence: one check, then fp64
                 }
             }
             // drain what is still in flight (its results are not needed)
@@ -1026,10 +1091,15 @@ struct Solver {
             }
             if (!pend.empty()) HIP_TRY(hipStreamSynchronize(stream));
             pend.clear();
+            last_seq_f32 = f32_seq;
             if (converged) { done = true; break; }
             if (steps_total >= max_steps) break;
             // restart from the best Ritz vector found so far (it sits normalised in yvec)
             HIP_TRY(hipMemcpyAsync(u, yvec, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream));
+            if (f32_seq) {
+                f32_seq = false;   // the planned hand-over to fp64: a fresh fused sequence, not counted as a restart
+                continue;
+            }
             ++restarts;
             classic = true;   // refine with the accurate form (see enqueue_classic)
             if (restarts > 64) break;
@@ -1052,6 +1122,7 @@ struct Solver {
             stats->gpu_ms = ms;
             stats->step_ms = step_ms_acc;
             stats->steps_timed = steps_timed_acc;
+            stats->steps_lowp = steps_lowp;
         }
         if (status == MACHIP_OK && lam < 1e-12 * tiny_l)
             return fail(MACHIP_DISCONNECTED, "lambda_2 ~ 0: the graph is not connected");
@@ -1067,7 +1138,7 @@ struct Solver {
         const int Jeff = std::max(1, std::min(J_last, (int)ha.size()));
         const int ncand = std::min(Jeff, q + 6);
         std::vector<double> th, S;
-        if (!last_was_lob) tri::smallest_block(ha.data(), hb.data(), Jeff, ncand, th, S, wk);   // (no Krylov basis after the preconditioned mode: X is completed with orthonormal filler)
+        if (!last_was_lob && !last_seq_f32) tri::smallest_block(ha.data(), hb.data(), Jeff, ncand, th, S, wk);   // (no Krylov basis after the preconditioned mode: X is completed with orthonormal filler)
         const int g2 = vgrid();
         HIP_TRY(hipMemcpyAsync(X_host, yvec, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));

@@ -31,7 +31,11 @@ class MAC:
         Q: Optional[np.ndarray] = None
 
     def __init__(self, fixed_edges, candidate_edges, num_nodes, fiedler_method="hip",
-                 fiedler_tol=1e-8, min_selection_weight_tol=1e-10, device=0, max_lanczos_steps=0):
+                 fiedler_tol=1e-8, min_selection_weight_tol=1e-10, device=0, max_lanczos_steps=0, precision=0):
+        """Arguments as mac/solvers/mac.py:22-24, plus (keyword-only in spirit, defaults keep the reference's call
+        sites unchanged): ``device`` (GPU ordinal), ``max_lanczos_steps`` (0 = library default) and ``precision``
+        (0 = fp64 throughout; 1 = fp32 Krylov iterate + fp64 Rayleigh / residual refinement, BASELINE.json configs[4];
+        the returned pairs obey the same stop rule either way)."""
         _fiedler.check_method(fiedler_method)
         num_edges = len(fixed_edges) + len(candidate_edges)
         assert (num_nodes - 1) <= num_edges                        # mac.py:47
@@ -53,6 +57,8 @@ class MAC:
         # every cold eigen-solve starts from column 0 of the reference's block (fiedler.py:27-32)
         self._dev.set_start(_fiedler.reference_start_block(num_nodes)[:, 0].copy())
         self._dev.set_solver(_fiedler.solver_mode(fiedler_method))
+        self.precision = int(precision)
+        self._dev.set_precision(self.precision)
         self.last_stats = None
 
     # -------------------------------------------------------------------------------
