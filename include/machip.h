@@ -166,6 +166,17 @@ int machip_comm_init_local(machip_problem** handles, int nranks);
  * shard = ceil(m / nranks), lo = min(m, rank shard), hi = min(m, lo + shard). */
 int machip_shard_plan(int64_t m, int nranks, int rank, int64_t* lo, int64_t* hi, int64_t* shard);
 
+/* MAC.evaluate_objective for B selection vectors at once (mac/solvers/mac.py:91-102 as called in a loop by
+ * round_madow(value_fn=evaluate_objective, max_iters > 1), mac/utils/rounding.py:63-75, and by the budget sweep of
+ * examples/g2o_experiment.py:347-376).  X: B x m row-major on the host; lambda2: B doubles; status (may be NULL): B
+ * machip_status values (OK / NOT_CONVERGED / DISCONNECTED per entry).  The handle keeps up to MACHIP_LANES (default 8)
+ * evaluation lanes -- own x, CSR buffers, eigen-solver state and stream, sharing the pattern and the candidate
+ * arrays -- driven by one host thread each, so the small latency-bound solves of a pose graph overlap on the GPU.
+ * Cold starts from the handle's start vector (machip_set_start), solver mode / precision of the handle; the
+ * handle's own x, gradient and Fiedler vector are not touched.  Returns the first hard error, else MACHIP_OK. */
+int machip_eval_batch(machip_problem* p, int B, const double* X, double tol, int max_steps, double* lambda2,
+                      int* status);
+
 /* Eigen-solver selection -- the reference's `fiedler_method` string (mac/solvers/mac.py:23,68;
  * mac/utils/fiedler.py:38-42 dispatches 'tracemin_pcg' | 'tracemin_lu' | 'tracemin_cholesky', all
  * computing the same pair).  mode 0 = automatic (default), 1 = Lanczos on L restricted to 1-perp,

@@ -71,6 +71,7 @@ SIGNATURES = {
     "machip_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "machip_comm_init_local": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "machip_shard_plan": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "machip_eval_batch": (C.c_int, [C.c_void_p, C.c_int, _f64p, C.c_double, C.c_int, _f64p, C.POINTER(C.c_int)]),
     "machip_set_solver": (C.c_int, [C.c_void_p, C.c_int]),
     "machip_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "machip_synchronize": (C.c_int, [C.c_void_p]),
@@ -255,6 +256,18 @@ class Problem:
     def set_solver(self, mode):
         """0 = automatic, 1 = Lanczos, 2 = preconditioned (LOBPCG + tridiagonal chain solve)."""
         check(self._lib.machip_set_solver(self._h, int(mode)))
+
+    def eval_batch(self, X, tol=1e-8, max_steps=0):
+        """lambda_2(L(x_b)) for every row of X (B x m), solved concurrently on the handle's evaluation lanes.
+        Returns (lambda2[B], status[B])."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        assert X.ndim == 2 and X.shape[1] == self.m
+        B = X.shape[0]
+        lam = np.zeros(B)
+        st = np.zeros(B, dtype=np.int32)
+        check(self._lib.machip_eval_batch(self._h, B, p_f64(X), float(tol), int(max_steps), p_f64(lam),
+                                          st.ctypes.data_as(C.POINTER(C.c_int))))
+        return lam, st
 
     def set_precision(self, precision):
         """0 = fp64 throughout, 1 = fp32 Krylov iterate + fp64 Rayleigh/residual refinement."""

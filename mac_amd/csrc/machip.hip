@@ -2,11 +2,13 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
 #include <numeric>
+#include <thread>
 #include <vector>
 
 #include "solver.h"
@@ -85,6 +87,10 @@ struct machip_problem {
     ncclComm_t comm = nullptr;
     std::shared_ptr<LocalGroup> lgroup;
     int rank = 0, nranks = 1;
+    // evaluation lanes (machip_eval_batch): lightweight copies that share the pattern and the candidate arrays
+    bool is_lane = false;
+    std::vector<machip_problem*> lanes;
+    unsigned long start_version = 0, lane_start_version = 0;
 
     CsrView csr() const { return CsrView{n, rowptr, col, val}; }
     PatternView pattern() const { return PatternView{n, prow, pcol, pk, pw}; }
@@ -378,8 +384,11 @@ int machip_create(int device, int64_t n, int64_t n_fixed, const int32_t* fi, con
 
 void machip_destroy(machip_problem* p) {
     if (!p) return;
+    for (machip_problem* q : p->lanes) machip_destroy(q);
+    p->lanes.clear();
     (void)hipSetDevice(p->device);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
+    if (p->is_lane) { p->prow = p->pcol = p->pk = nullptr; p->pw = nullptr; p->ci = p->cj = nullptr; p->cw = nullptr; }   // borrowed
     if (p->comm) (void)ncclCommDestroy(p->comm);
     if (p->lgroup) p->lgroup->abort();      // peers blocked in the group's barrier return an error instead of hanging
     p->sol.destroy();
@@ -451,6 +460,7 @@ int machip_set_start(machip_problem* p, const double* x0) {
     HIP_TRY(hipMemcpyAsync(p->sol.start, x0, sizeof(double) * (size_t)p->n, hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
     p->sol.have_start = true;
+    ++p->start_version;
     return MACHIP_OK;
 }
 
@@ -678,6 +688,87 @@ int machip_shard_plan(int64_t m, int nranks, int rank, int64_t* lo, int64_t* hi,
     long a, b, c;
     shard_plan((long)m, nranks, rank, &a, &b, &c);
     *lo = a; *hi = b; *shard = c;
+    return MACHIP_OK;
+}
+
+namespace {
+int make_lane(machip_problem* p, machip_problem** out) {
+    machip_problem* q = new machip_problem();
+    q->is_lane = true;
+    q->device = p->device; q->n = p->n; q->m = p->m; q->m_pad = p->m; q->tol_sel = p->tol_sel;
+    q->prow = p->prow; q->pcol = p->pcol; q->pk = p->pk; q->pw = p->pw; q->P = p->P;
+    q->asm_G = p->asm_G; q->asm_rpb = p->asm_rpb; q->asm_grid = p->asm_grid;
+    q->ci = p->ci; q->cj = p->cj; q->cw = p->cw;
+    auto body = [&]() -> int {
+        HIP_TRY(hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking));
+        ST_TRY(dev_alloc(&q->x, (size_t)q->m + 64));
+        const size_t cap = (size_t)q->P + (size_t)q->n + 8;
+        ST_TRY(dev_alloc(&q->cnt, (size_t)q->n + 1)); ST_TRY(dev_alloc(&q->blk_sum, 3 * kMaxGrid));
+        ST_TRY(dev_alloc(&q->rowptr, (size_t)q->n + 1)); ST_TRY(dev_alloc(&q->col, cap)); ST_TRY(dev_alloc(&q->val, cap));
+        ST_TRY(dev_alloc(&q->blk_lnorm, kMaxGrid));
+        ST_TRY(alloc_common(q));
+        q->sol.chain_like = p->sol.chain_like; q->sol.chain_edges = p->sol.chain_edges;
+        return MACHIP_OK;
+    };
+    const int st = body();
+    if (st != MACHIP_OK) { machip_destroy(q); return st; }
+    *out = q;
+    return MACHIP_OK;
+}
+}  // namespace
+
+int machip_eval_batch(machip_problem* p, int B, const double* X, double tol, int max_steps, double* lambda2, int* status) {
+    if (!p || p->csr_only || p->is_lane || B < 0 || (B && (!X || !lambda2))) return fail(MACHIP_BAD_ARG, "machip_eval_batch: bad argument");
+    if (B == 0) return MACHIP_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    const int nl = std::max(1, std::min(B, std::min(16, env_int("MACHIP_LANES", 8))));
+    while ((int)p->lanes.size() < nl) {
+        machip_problem* q = nullptr;
+        ST_TRY(make_lane(p, &q));
+        p->lanes.push_back(q);
+        p->lane_start_version = ~0ul;   // (re)send the start vector to every lane below
+    }
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    for (int l = 0; l < nl; ++l) {
+        machip_problem* q = p->lanes[(size_t)l];
+        q->sol.solver_mode = p->sol.solver_mode; q->sol.precision = p->sol.precision;
+        if (p->sol.have_start && p->lane_start_version != p->start_version) {
+            HIP_TRY(hipMemcpy(q->sol.start, p->sol.start, sizeof(double) * (size_t)p->n, hipMemcpyDeviceToDevice));
+            q->sol.have_start = true;
+        }
+    }
+    p->lane_start_version = p->start_version;
+    std::atomic<int> next{0};
+    std::vector<int> lane_status((size_t)nl, MACHIP_OK);
+    std::vector<std::string> lane_err((size_t)nl);
+    auto work = [&](int l) {
+        machip_problem* q = p->lanes[(size_t)l];
+        if (hipSetDevice(q->device) != hipSuccess) { lane_status[(size_t)l] = MACHIP_HIP_ERROR; lane_err[(size_t)l] = "hipSetDevice failed"; return; }
+        for (int b = next.fetch_add(1); b < B; b = next.fetch_add(1)) {
+            int st = MACHIP_OK;
+            double lam = 0.0;
+            if (hipMemcpyAsync(q->x, X + (size_t)b * (size_t)q->m, sizeof(double) * (size_t)q->m, hipMemcpyHostToDevice, q->stream) != hipSuccess ||
+                hipStreamSynchronize(q->stream) != hipSuccess) {
+                st = fail(MACHIP_HIP_ERROR, "machip_eval_batch: copy of x failed");
+            } else {
+                q->assembled = false;
+                st = assemble(q);
+                if (st == MACHIP_OK) st = run_fiedler(q, tol, max_steps, nullptr, 0, &lam, nullptr);
+            }
+            lambda2[b] = lam;
+            if (status) status[b] = st;
+            if (st != MACHIP_OK && st != MACHIP_NOT_CONVERGED && st != MACHIP_DISCONNECTED) {
+                lane_status[(size_t)l] = st; lane_err[(size_t)l] = g_err;     // hard failure: stop this lane
+                return;
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int l = 1; l < nl; ++l) th.emplace_back(work, l);
+    work(0);
+    for (auto& t : th) t.join();
+    for (int l = 0; l < nl; ++l)
+        if (lane_status[(size_t)l] != MACHIP_OK) return fail((machip_status)lane_status[(size_t)l], lane_err[(size_t)l]);
     return MACHIP_OK;
 }
 

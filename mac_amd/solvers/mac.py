@@ -79,6 +79,14 @@ class MAC:
         self.last_stats = self._dev.stats.asdict()
         return lam
 
+    def evaluate_objective_batch(self, X):
+        """evaluate_objective for every row of X (B x m) in one call: the solves run concurrently on the device
+        (machip_eval_batch).  What round_madow(max_iters > 1) and budget sweeps call in a loop in the reference."""
+        lam, st = self._dev.eval_batch(np.asarray(X, dtype=np.float64), tol=self.fiedler_tol, max_steps=self.max_lanczos_steps)
+        if np.any(st == _lib.NOT_CONVERGED):
+            raise _lib.NotConverged(_lib.NOT_CONVERGED, "an eigen-solve of the batch hit the step cap")
+        return lam
+
     def problem(self, x, cache=None):
         """(lambda_2(L(x)), supergradient) (mac.py:104-128).  The reference always solves
         with tol 1e-8 here (mac.py:115); so does this."""
@@ -128,7 +136,8 @@ class MAC:
 
         start = timer()
         if rounding == "madow":
-            rounded = round_madow(w, k, value_fn=self.evaluate_objective, max_iters=random_rounding_max_iters)
+            rounded = round_madow(w, k, value_fn=self.evaluate_objective, max_iters=random_rounding_max_iters,
+                                  batch_value_fn=self.evaluate_objective_batch)
         else:
             # rounding == "nearest" (mac.py:209), on the device-resident x (machip_round_nearest)
             rounded = dev.round_nearest(k, decimals=10)

@@ -61,10 +61,19 @@ def round_madow_base(w, k, seed=None):
     return x
 
 
-def round_madow(w, k, seed=None, value_fn=None, max_iters=1):
-    """mac/utils/rounding.py:63-75: best of ``max_iters`` Madow draws under ``value_fn``."""
-    if value_fn is None or max_iters == 1:
+def round_madow(w, k, seed=None, value_fn=None, max_iters=1, batch_value_fn=None):
+    """mac/utils/rounding.py:63-75: best of ``max_iters`` Madow draws under ``value_fn``.
+
+    ``batch_value_fn`` (extension): a function of a (B, m) array returning B values; the draws are then generated
+    first -- the random stream is consumed exactly as in the sequential loop, one uniform per draw, ``value_fn``
+    never touches it -- and evaluated in one batched call (MAC.evaluate_objective_batch); the first maximum wins,
+    like the strict ``>`` of the reference's loop.  The cumulative sums stay on the host: a parallel scan rounds
+    differently from ``np.cumsum`` and could move a pick across an interval boundary."""
+    if (value_fn is None and batch_value_fn is None) or max_iters == 1:
         return round_madow_base(w, k, seed)
+    if batch_value_fn is not None:
+        draws = np.stack([round_madow_base(w, k, seed) for _ in range(max_iters)])
+        return draws[int(np.argmax(batch_value_fn(draws)))]
     best_x, best_val = None, -np.inf
     for _ in range(max_iters):
         x = round_madow_base(w, k, seed)

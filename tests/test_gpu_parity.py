@@ -619,8 +619,7 @@ def test_rccl_path_single_rank():
     P0.close(); P1.close()
 
 
-@pytest.mark.parametrize("R", [2, 3, 8])
-def test_mixed_precision_matches_fp64_results(nm_unused=None):
+def test_mixed_precision_matches_fp64_results():
     """machip_set_precision(1) (BASELINE.json configs[4]: fp32 Krylov iterate + fp64 Rayleigh / residual refinement):
     the returned pair obeys the same stop rule and the same bounds as the fp64 mode -- lambda_2 1e-8 against the
     REFERENCE goldens, vector 2e-6, gradient 1e-5 of max|g| -- on the two graphs of configs[4], on intel and on a
@@ -878,6 +877,53 @@ def test_madow_rounding_with_objective_reruns():
     assert mac.evaluate_objective(rounded) <= u + 1e-9
     r2, w2, u2, rt = mac.solve(k, g["x_init"], max_iters=6, return_rounding_time=True, fallback=True)
     assert rt >= 0 and r2.sum() == k and np.allclose(w, w2, atol=1e-12)
+
+
+def test_eval_batch_matches_single_evaluations():
+    """machip_eval_batch (MAC.evaluate_objective_batch): B selection vectors solved concurrently on the handle's
+    evaluation lanes give, entry by entry, the value the one-at-a-time MAC.evaluate_objective gives (identical
+    kernels and start vector, so bit-identical), against the reference goldens where they exist; the handle's own
+    state (x, warm-start vector) is untouched."""
+    g = load_golden("g2o_intel")
+    mac = MAC(edges_of(g, "f"), edges_of(g, "c"), int(g["n"]))
+    m, k = len(g["cw"]), int(g["k"])
+    rs = np.random.RandomState(11)
+    X = np.zeros((13, m))
+    X[0] = g["x_init"]; X[1] = 1.0; X[2] = g["rounded"]; X[3] = g["unrounded"]
+    for b in range(4, 13):
+        X[b, rs.choice(m, k, replace=False)] = 1.0
+    mac._dev.set_x(g["x_init"])
+    lam = mac.evaluate_objective_batch(X)
+    assert abs(lam[0] - g["lam_init"]) <= LAM_RTOL * g["lam_init"]
+    assert abs(lam[1] - g["lam_all"]) <= LAM_RTOL * g["lam_all"]
+    assert abs(lam[2] - g["lam_rounded"]) <= LAM_RTOL * g["lam_rounded"]
+    assert np.array_equal(mac._dev.get_x(), g["x_init"])
+    single = np.array([mac.evaluate_objective(X[b]) for b in range(13)])
+    assert np.array_equal(lam, single)
+    lam2 = mac.evaluate_objective_batch(X[::-1])          # lanes are reusable; order of arrival does not matter
+    assert np.array_equal(lam2, lam[::-1])
+    # a disconnected selection is reported per entry, not as a failure of the call
+    gp = load_golden("petersen_solve_k3")
+    P = _lib.Problem(10, np.arange(8), np.arange(8) + 1, np.ones(8), np.array([0, 2]), np.array([9, 5]), np.ones(2))
+    lamp, st = P.eval_batch(np.array([[1.0, 0.0], [0.0, 1.0], [1.0, 1.0]]))
+    assert st[1] == _lib.DISCONNECTED and st[0] == _lib.OK and st[2] == _lib.OK and lamp[0] > 0
+    P.close()
+
+
+def test_madow_multi_try_is_batched_and_picks_like_the_sequential_loop():
+    """round_madow(max_iters > 1) (mac/utils/rounding.py:63-75): the draws consume the random stream exactly as the
+    reference's loop does and the winner of the batched evaluation is the winner of the one-by-one loop."""
+    from mac_amd.utils.rounding import round_madow
+    g = load_golden("g2o_sphere2500")
+    mac = MAC(edges_of(g, "f"), edges_of(g, "c"), int(g["n"]))
+    k = int(g["k"])
+    w = g["unrounded"]
+    a = round_madow(w, k, seed=np.random.RandomState(42), value_fn=mac.evaluate_objective, max_iters=6)
+    b = round_madow(w, k, seed=np.random.RandomState(42), max_iters=6, batch_value_fn=mac.evaluate_objective_batch)
+    assert np.array_equal(a, b) and a.sum() == k
+    one = round_madow(w, k, seed=np.random.RandomState(42))
+    assert np.array_equal(one, g["madow"])                 # first draw == the reference's single draw (golden)
+    assert mac.evaluate_objective(b) >= mac.evaluate_objective(one) - 1e-12
 
 
 def test_device_round_nearest_matches_oracle():
