@@ -676,10 +676,16 @@ __global__ __launch_bounds__(64) void k_pipe_tail(PipeViewT<T> L, int adv) {
     const PipeCoef c = pipe_prologue_wave0(L, adv, adv, scoef, &j);
     const int lo = max(0, j - adv - 1);
     const int cnt = 3 * (j - lo + 1);
-    for (int i = threadIdx.x; i < cnt; i += 64) L.htri[3 * lo + i] = L.tri[3 * lo + i];
-    if (threadIdx.x == 0) {   // the three values this kernel has just produced go from registers
-        if (j > 0) { L.htri[3 * (j - 1)] = c.alpha; L.htri[3 * (j - 1) + 2] = c.l1prev; }
-        L.htri[3 * j + 1] = c.beta;
+    // every host address is written exactly once: the three values this kernel has just produced (alpha_{j-1},
+    // l1_{j-1}, beta_j) go from registers, the bulk copy skips their slots (L.tri may still hold the old ones)
+    const int sa = j > 0 ? 3 * (j - 1) : -1, sl = j > 0 ? 3 * (j - 1) + 2 : -1, sb = 3 * j + 1;
+    for (int i = threadIdx.x; i < cnt; i += 64) {
+        const int q = 3 * lo + i;
+        if (q != sa && q != sl && q != sb && q < 3 * j) L.htri[q] = L.tri[q];   // (alpha_j, l1_j belong to the next chunk)
+    }
+    if (threadIdx.x == 0) {
+        if (j > 0) { L.htri[sa] = c.alpha; L.htri[sl] = c.l1prev; }
+        L.htri[sb] = c.beta;
     }
     __threadfence_system();
     if (threadIdx.x == 0) {

@@ -361,6 +361,7 @@ int machip_create(int device, int64_t n, int64_t n_fixed, const int32_t* fi, con
         ST_TRY(dev_alloc(&p->blk_lnorm, kMaxGrid));
         ST_TRY(dev_alloc(&p->hist, 6 * kBins)); ST_TRY(dev_alloc(&p->sel, 2)); ST_TRY(dev_alloc(&p->part_fw, 2 * kMaxGrid));
         ST_TRY(alloc_common(p));
+        p->sol.csr_cap = cap;
         // pose-graph shape: do the fixed edges contain (nearly) the whole chain (i, i+1)?  Decides
         // whether the preconditioned eigen-solver mode is considered (solver.h, precond.h).
         {
@@ -707,6 +708,7 @@ int make_lane(machip_problem* p, machip_problem** out) {
         ST_TRY(dev_alloc(&q->rowptr, (size_t)q->n + 1)); ST_TRY(dev_alloc(&q->col, cap)); ST_TRY(dev_alloc(&q->val, cap));
         ST_TRY(dev_alloc(&q->blk_lnorm, kMaxGrid));
         ST_TRY(alloc_common(q));
+        q->sol.csr_cap = cap;
         q->sol.chain_like = p->sol.chain_like; q->sol.chain_edges = p->sol.chain_edges;
         return MACHIP_OK;
     };

@@ -248,6 +248,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_lan_persist(CsrView A, Pers
     const int J = J0 + steps;
     const int cnt = 3 * steps + 2;
     for (int i = t; i < cnt; i += kPersistThreads) {
+        if (i == 3 * steps) continue;      // the alpha_J slot belongs to the next chunk (the host poisons and awaits it)
         const double x = srec[i];
         L.tri[3 * (size_t)J0 + i] = x;
         L.htri[3 * (size_t)J0 + i] = x;

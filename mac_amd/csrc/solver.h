@@ -217,8 +217,8 @@ struct Solver {
     // classic (two-kernel) Lanczos state: the accurate fallback for tiny / nearly exhausted Krylov spaces
     double *wc = nullptr, *ctri = nullptr, *part_u = nullptr, *part_a = nullptr;
     LanState* stc = nullptr;
-    float* valf = nullptr;      // fp32 copy of the matrix values (mixed-precision mode), grown on demand
-    size_t valf_cap = 0;
+    float* valf = nullptr;      // fp32 copy of the matrix values (mixed-precision mode)
+    size_t valf_cap = 0, csr_cap = 0;   // csr_cap: capacity of the caller's CSR buffers (0 = unknown: grow on demand)
     bool last_seq_f32 = false;  // the basis V of the last sequence holds floats (ritz_block must not read it as fp64)
     long last_steps_lowp = 0;   // fp32 steps of the last Lanczos solve
     double* start = nullptr;    // persistent cold-start vector
@@ -917,9 +917,13 @@ struct Solver {
         long steps_lowp = 0;
         if (f32_seq && !pmode) {
             if (valf_cap < (size_t)nnz) {
+                // cached chunk graphs carry the old pointer: drop them together with the buffer
+                HIP_TRY(hipStreamSynchronize(stream));
+                for (auto& kv : graphs) for (hipGraphExec_t ge : kv.second) if (ge) (void)hipGraphExecDestroy(ge);
+                graphs.clear();
                 if (valf) (void)hipFree(valf);
                 valf = nullptr; valf_cap = 0;
-                const size_t want = (size_t)nnz + (size_t)nnz / 4 + 1024;
+                const size_t want = std::max<size_t>((size_t)nnz + (size_t)nnz / 2 + 1024, csr_cap);   // csr_cap: the most L(x) can ever hold
                 ST_TRY(dev_alloc(&valf, want));
                 valf_cap = want;
             }
@@ -983,8 +987,11 @@ struct Solver {
                     if (chunk <= 0) break;
                     const int lo = std::max(0, J_enq - 1);
                     const int hi = J_enq + chunk;           // records lo..hi inclusive
-                    if (pmode || !classic)   // zero-copy records: poison the beta slots only this chunk writes
-                        for (int j = J_enq ? J_enq + 1 : 0; j <= hi; ++j) h_tri[3 * (size_t)j + 1] = std::numeric_limits<double>::quiet_NaN();
+                    if (pmode || !classic) {   // zero-copy records: poison every slot this chunk delivers for the first time
+                        const double qnan = std::numeric_limits<double>::quiet_NaN();
+                        for (int j = J_enq ? J_enq + 1 : 0; j <= hi; ++j) h_tri[3 * (size_t)j + 1] = qnan;        // beta_j
+                        for (int j = J_enq; j < hi; ++j) { h_tri[3 * (size_t)j] = qnan; h_tri[3 * (size_t)j + 2] = qnan; }   // alpha_j, l1_j
+                    }
                     if (pmode) {
                         launch_persist(A, chunk, f32_seq);
                         HIP_TRY(hipGetLastError());   // (157 KB of static LDS: a refused launch must surface, not time out)
@@ -1023,10 +1030,12 @@ struct Solver {
                     // the flag can overtake the records on their way to host memory: the beta slots of this chunk
                     // were poisoned before it was enqueued, wait until every one has landed
                     unsigned long budget = 5000000ul;   // ~20 ms in total: a genuine NaN (non-finite input) must not stall the solve
-                    for (int j = p.jstart ? p.jstart + 1 : 0; j <= p.jend && budget; ++j) {
-                        volatile double* slot = h_tri + 3 * (size_t)j + 1;
+                    auto wait_slot = [&](size_t idx) {
+                        volatile double* slot = h_tri + idx;
                         while (*slot != *slot && budget) { --budget; __builtin_ia32_pause(); }
-                    }
+                    };
+                    for (int j = p.jstart ? p.jstart + 1 : 0; j <= p.jend && budget; ++j) wait_slot(3 * (size_t)j + 1);
+                    for (int j = p.jstart; j < p.jend && budget; ++j) { wait_slot(3 * (size_t)j); wait_slot(3 * (size_t)j + 2); }
                 }
                 if (p.classic) {   // scatter the staged (alpha, beta, l1) into the interleaved mirror
                     const double* hp = h_pin + (vcap + 2) + 2 * kMaxGrid + 32;

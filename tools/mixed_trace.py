@@ -9,6 +9,8 @@ from mac_amd.utils.fiedler import reference_start_block
 w = bench.make_workload(cfg)
 P = _lib.Problem(w["n"], w["fi"], w["fj"], w["fw"], w["ci"], w["cj"], w["cw"])
 P.set_start(reference_start_block(w["n"])[:, 0].copy())
+if len(sys.argv) > 4:      # pre-iterations already in the requested precision
+    P.set_precision(prec)
 bench.run_pass(P, w["k"], pre, w["x0"]) if pre else P.set_x(w["x0"])
 P.set_precision(prec)
 os.environ["MACHIP_DEBUG"] = "1"

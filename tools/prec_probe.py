@@ -10,6 +10,7 @@ for cfg in (sys.argv[1:] or ["c3", "c5a", "c5b", "c2"]):
     w = bench.make_workload(cfg)
     res = {}
     for prec in (0, 1):
+        print(f"-- {cfg} precision {prec}", flush=True)
         P = _lib.Problem(w["n"], w["fi"], w["fj"], w["fw"], w["ci"], w["cj"], w["cw"])
         P.set_precision(prec)
         P.set_start(reference_start_block(w["n"])[:, 0].copy())
