@@ -822,12 +822,13 @@ struct Solver {
         const bool small = n <= kPersistThreads * kPersistMaxRows;
         const long ratio = small ? 9 : 6;
         const bool sparse = (double)support_hint <= env_int("MACHIP_LOB_DENSITY_PCT", small ? 3 : 12) * 0.01 * (double)n;
-        // The preconditioned mode is a block-size-1 LOBPCG: on graphs whose low eigenvectors are localised (random
-        // graphs: Anderson-type modes on low-degree nodes, eigenvalues a few per cent apart) it can settle on lambda_3
-        // and pass the reference's residual test there (seen at config 2 when a mis-learnt step count selected it:
-        // +7 % on lambda_2).  It is therefore confined to chain-DOMINATED graphs -- at most two active closures per
-        // node, the regime of every pose graph and of the fuzz runs -- also when a caller forces it; denser graphs
-        // always take the Lanczos path, which sees the whole Krylov space.
+        // The preconditioned mode is a block-size-1 LOBPCG preconditioned by the odometry chain: it is built for, and
+        // has only been validated on (fuzz runs, every pose graph), chain-DOMINATED graphs.  On a dense random graph
+        // the chain is no preconditioner at all (config 2, selected there by a mis-learnt step count: 44 us x 60-220
+        // iterations against 1.1 ms of Lanczos), and a single-vector iteration has no guard against settling on a
+        // higher eigenpair of a clustered spectrum, which the reference's residual test cannot tell apart.  So it is
+        // confined to at most two active closures per node -- also when a caller forces it; denser graphs always take
+        // the Lanczos path, which sees the whole Krylov space.
         const bool chain_dominated = support_hint < 0 || support_hint <= 2 * (long)n;
         const bool stiff = hist_lan_steps > 2500 && (hist_lob_iters < 0 || hist_lob_iters * ratio < hist_lan_steps);
         const bool slow_lob = hist_lan_steps > 0 && hist_lob_iters > 0 && hist_lob_iters * ratio > 2 * hist_lan_steps;

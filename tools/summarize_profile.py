@@ -13,14 +13,18 @@ def short(n):
     n = n.replace("machip::", "").replace("void ", "")
     return n.split("(")[0]
 
+import glob
 stats = []
-with open(os.path.join(src, "trace", "t_kernel_stats.csv")) as fh:
+cands = glob.glob(os.path.join(src, "trace", "**", "t_kernel_stats.csv"), recursive=True)
+with open(cands[0]) as fh:
     for r in csv.DictReader(fh):
         stats.append((short(r["Name"]), int(r["Calls"]), float(r["TotalDurationNs"]), float(r["AverageNs"]),
                       float(r["Percentage"]), float(r["MinNs"]), float(r["MaxNs"])))
 
 def pmc(path, counter):
     acc = collections.defaultdict(lambda: [0, 0.0])
+    if not os.path.exists(path):
+        path = (glob.glob(os.path.join(os.path.dirname(path), "**", os.path.basename(path)), recursive=True) or [path])[0]
     with open(path) as fh:
         for r in csv.DictReader(fh):
             if r["Counter_Name"] != counter:
