@@ -216,10 +216,11 @@ def cpu_baseline_bounded(cfg, fiedler, budget_s, hard_s):
 # ---------------------------------------------------------------------------------------------
 # PMC traffic of the dominant kernel: two short rocprofv3 passes of this same script
 # ---------------------------------------------------------------------------------------------
-def pmc_traffic(cfg, steps=3, timeout_s=240):
+def pmc_traffic(cfg, steps, precision=0, timeout_s=300):
     """HBM bytes per launch of the fused step kernel = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes), each counter from
     its own `rocprofv3 --pmc` pass (MI355X_MICROARCH.md: FETCH_SIZE on gfx950 tallies 128-byte requests at 64 B)
-    of `bench.py --config cfg --steps 3 --pmc-child`.  Returns (bytes or None, note)."""
+    of `bench.py --config cfg --steps K --warmup 0 --pmc-child`: the SAME K iterations from x0 as a timed pass, so the
+    launches counted are the launches timed.  Returns (bytes or None, note)."""
     import csv
     import glob
     rp = shutil.which("rocprofv3")
@@ -230,7 +231,8 @@ def pmc_traffic(cfg, steps=3, timeout_s=240):
         d = tempfile.mkdtemp(prefix="machip_pmc_")
         env = dict(os.environ, TMPDIR=tempfile.gettempdir())
         cmd = [rp, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
-               sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", str(steps), "--warmup", "0", "--pmc-child"]
+               sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", str(steps), "--warmup", "0",
+               "--precision", str(precision), "--pmc-child"]
         try:
             subprocess.run(cmd, cwd=tempfile.gettempdir(), env=env, timeout=timeout_s, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             tot, cnt = 0.0, 0
@@ -249,7 +251,7 @@ def pmc_traffic(cfg, steps=3, timeout_s=240):
             shutil.rmtree(d, ignore_errors=True)
     by = (2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024.0
     return by, (f"traffic = (2*FETCH_SIZE + WRITE_SIZE) KiB per launch over {vals['FETCH_SIZE'][1]} launches, two separate "
-                f"rocprofv3 --pmc passes of this script ({steps} iterations each) run by this bench invocation")
+                f"rocprofv3 --pmc passes of this script (the same {steps} iterations from x0 as a timed pass) run by this bench invocation")
 
 
 # ---------------------------------------------------------------------------------------------
@@ -463,7 +465,7 @@ def main():
             ach = by / (us * 1e-6) / 1e9
             traffic, tnote = None, "PMC passes skipped"
             if world == 1 and not args.no_pmc:
-                traffic, tnote = pmc_traffic(args.config)
+                traffic, tnote = pmc_traffic(args.config, args.steps, args.precision)
             note = ("avg_launch_us = step_ms / steps_timed of machip_solve_stats: hipEvents on the handle's stream around the Krylov "
                     "chunks of every solve in the timed passes (step kernels + one 1-wave tail kernel per chunk, so slightly above "
                     "the pure kernel average rocprofv3 reports); algorithmic bytes = 12 nnz + 4 (n+1) + 56 n per launch, "

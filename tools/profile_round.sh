@@ -1,6 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (through gpurun): kernel-trace stats + PMC HBM-traffic passes of bench.py.
 # usage: tools/profile_round.sh <tag> [bench args...]   -> gpurun_out/<tag>/   (then tools/summarize_profile.py <tag>)
+# Pass --warmup 0 so that the launches in the trace are exactly the launches of the one timed pass.
 set -u
 tag=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag

@@ -58,6 +58,13 @@ with open(out_md, "w") as fh:
         fh.write("bench line of the traced run (profiler attached, so slower than the un-profiled number):\n\n```\n" + json.dumps(bench_line) + "\n```\n\n")
     fh.write(f"Dominant kernel: **{dom['kernel']}**, {dom['calls']} launches, average {dom['avg_us']:.2f} us, "
              f"HBM traffic/launch (2*FETCH+WRITE) {dom['hbm_bytes_per_launch']/1e6:.2f} MB.\n\n")
+    if bench_line and bench_line.get("roofline"):
+        r = bench_line["roofline"]
+        frac_trace = r["algorithmic_bytes_per_launch"] / (dom["avg_us"] * 1e-6) / 1e9 / r["peak"]
+        fh.write(f"Cross-check of the bench line's roofline object: in-solve step time (hipEvents around the Krylov chunks, "
+                 f"tail kernels and inter-kernel gaps included) {r['avg_launch_us']:.2f} us over {r['launches_timed']} launches -> frac "
+                 f"{r['frac']:.4f}; rocprofv3 kernel average {dom['avg_us']:.2f} us over {dom['calls']} launches -> frac {frac_trace:.4f} "
+                 f"(ratio {r['avg_launch_us'] / dom['avg_us']:.3f}).\n\n")
     fh.write("| kernel | calls | total ms | avg us | min us | max us | % | FETCH KiB/launch | WRITE KiB/launch |\n|---|---|---|---|---|---|---|---|---|\n")
     for r in rows:
         fh.write(f"| `{r['kernel'][:60]}` | {r['calls']} | {r['total_ms']:.2f} | {r['avg_us']:.2f} | {r['min_us']:.2f} | {r['max_us']:.2f} | "
