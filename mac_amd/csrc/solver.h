@@ -609,11 +609,25 @@ struct Solver {
         HIP_TRY(hipGraphLaunch(ge, stream));
         return MACHIP_OK;
     }
+    // Most closures the exact (Woodbury) preconditioner takes: the dense s x s factorisation grows as s^3 (rocSOLVER:
+    // 7 ms at 2 048), its memory as s^2 + n s; MACHIP_WB_MAX raises the default for graphs that converge no other way.
+    int wb_max_s() const { return std::max(64, std::min(16384, env_int("MACHIP_WB_MAX", kWbMaxS))); }
+    int wb_cap_s = 0;      // what the buffers below were sized for
     int wb_alloc() {
-        if (wb_ui) return MACHIP_OK;
-        ST_TRY(dev_alloc(&wb_ui, kWbMaxS)); ST_TRY(dev_alloc(&wb_uj, kWbMaxS)); ST_TRY(dev_alloc(&wb_counts, 2));
-        ST_TRY(dev_alloc(&wb_uc, kWbMaxS)); ST_TRY(dev_alloc(&wb_g, kWbMaxS)); ST_TRY(dev_alloc(&wb_h, kWbMaxS));
-        ST_TRY(dev_alloc(&wb_Cm, (size_t)kWbMaxS * kWbMaxS));
+        const int want = wb_max_s();
+        if (wb_ui && wb_cap_s >= want) return MACHIP_OK;
+        if (wb_ui) {
+            HIP_TRY(hipStreamSynchronize(stream));
+            drop_graphs();          // cached chunk graphs carry the old addresses
+            void* old[] = {wb_ui, wb_uj, wb_counts, wb_uc, wb_g, wb_h, wb_Cm, wb_maps};
+            for (void* q : old) if (q) (void)hipFree(q);
+            wb_ui = wb_uj = wb_counts = nullptr; wb_uc = wb_g = wb_h = wb_Cm = wb_maps = nullptr;
+        }
+        wb_cap_s = want;
+        ST_TRY(dev_alloc(&wb_ui, (size_t)want)); ST_TRY(dev_alloc(&wb_uj, (size_t)want)); ST_TRY(dev_alloc(&wb_counts, 2));
+        ST_TRY(dev_alloc(&wb_uc, (size_t)want)); ST_TRY(dev_alloc(&wb_g, (size_t)want)); ST_TRY(dev_alloc(&wb_h, (size_t)want));
+        ST_TRY(dev_alloc(&wb_Cm, (size_t)want * (size_t)want));
+        if (wb_handle) return MACHIP_OK;
         if (rocblas_create_handle(&wb_handle) != rocblas_status_success) return fail(MACHIP_HIP_ERROR, "rocblas_create_handle failed");
         if (rocblas_set_stream(wb_handle, stream) != rocblas_status_success) return fail(MACHIP_HIP_ERROR, "rocblas_set_stream failed");
         return MACHIP_OK;
@@ -623,7 +637,7 @@ struct Solver {
         const size_t cap = (size_t)L.c * (size_t)L.stride;
         if (cap * (size_t)s > wb_Zt_cap) {
             if (wb_Zt) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(wb_Zt); wb_Zt = nullptr; }
-            wb_Zt_cap = cap * (size_t)std::min(kWbMaxS, std::max(s + s / 2, 64));
+            wb_Zt_cap = cap * (size_t)std::min(wb_cap_s, std::max(s + s / 2, 64));
             ST_TRY(dev_alloc(&wb_Zt, wb_Zt_cap));
         }
         WbView W;
@@ -635,7 +649,7 @@ struct Solver {
                 wb_pas_cap = wb_Zt_cap;
                 ST_TRY(dev_alloc(&wb_pas, wb_pas_cap));
             }
-            if (!wb_maps) ST_TRY(dev_alloc(&wb_maps, (size_t)4 * kMaxGrid * kWbMaxS));
+            if (!wb_maps) ST_TRY(dev_alloc(&wb_maps, (size_t)4 * kMaxGrid * (size_t)wb_cap_s));
             WbBig Bg{wb_pas, wb_maps};
             k_wb_big_fwd<<<dim3(gw, s), kTriThreads, 0, stream>>>(L, W, Bg);
             k_wb_big_mid<<<dim3(gw, s), kTriThreads, 0, stream>>>(L, W, Bg);
@@ -677,15 +691,15 @@ struct Solver {
         // ---- exact preconditioner (woodbury.h) when the graph is chain + at most kWbMaxS closures ----
         wb_active.s = 0;
         int wb_s = 0;
-        if (env_int("MACHIP_WOODBURY", 1) != 0 && chain_like && support_hint >= 0 && support_hint <= kWbMaxS) {
+        if (env_int("MACHIP_WOODBURY", 1) != 0 && chain_like && support_hint >= 0 && support_hint <= wb_max_s()) {
             ST_TRY(wb_alloc());
             HIP_TRY(hipMemsetAsync(lx_bad, 0, sizeof(int), stream));
-            k_wb_extract<<<1, kTriThreads, 0, stream>>>(A, (n + kTriThreads - 1) / kTriThreads, kWbMaxS, wb_ui, wb_uj, wb_uc, wb_counts, lx_bad);
+            k_wb_extract<<<1, kTriThreads, 0, stream>>>(A, (n + kTriThreads - 1) / kTriThreads, wb_cap_s, wb_ui, wb_uj, wb_uc, wb_counts, lx_bad);
             int hc[2] = {0, 0};
             HIP_TRY(hipMemcpyAsync(&hc[0], wb_counts, sizeof(int), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipMemcpyAsync(&hc[1], lx_bad, sizeof(int), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
-            if (hc[0] > 0 && hc[0] <= kWbMaxS && !hc[1]) wb_s = hc[0];
+            if (hc[0] > 0 && hc[0] <= wb_cap_s && !hc[1]) wb_s = hc[0];
         }
         const int chain_only = wb_s > 0 ? 1 : 0;
         // ---- T = tridiag(L) + sigma I (chain Laplacian + sigma I under the exact preconditioner), factored on

@@ -64,7 +64,9 @@ with open(out_md, "w") as fh:
         fh.write(f"Cross-check of the bench line's roofline object: in-solve step time (hipEvents around the Krylov chunks, "
                  f"tail kernels and inter-kernel gaps included) {r['avg_launch_us']:.2f} us over {r['launches_timed']} launches -> frac "
                  f"{r['frac']:.4f}; rocprofv3 kernel average {dom['avg_us']:.2f} us over {dom['calls']} launches -> frac {frac_trace:.4f} "
-                 f"(ratio {r['avg_launch_us'] / dom['avg_us']:.3f}).\n\n")
+                 f"(ratio {r['avg_launch_us'] / dom['avg_us']:.3f}).  With a profiler attached libmachip launches eagerly instead of "
+                 f"through hipGraphs (rocprofiler-sdk crashes on short graphs, DESIGN section 5), so on small matrices the in-solve figure "
+                 f"of THIS traced run contains launch gaps the un-profiled bench line does not have.\n\n")
     fh.write("| kernel | calls | total ms | avg us | min us | max us | % | FETCH KiB/launch | WRITE KiB/launch |\n|---|---|---|---|---|---|---|---|---|\n")
     for r in rows:
         fh.write(f"| `{r['kernel'][:60]}` | {r['calls']} | {r['total_ms']:.2f} | {r['avg_us']:.2f} | {r['min_us']:.2f} | {r['max_us']:.2f} | "
