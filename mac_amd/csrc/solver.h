@@ -611,10 +611,17 @@ struct Solver {
     }
     // Most closures the exact (Woodbury) preconditioner takes: the dense s x s factorisation grows as s^3 (rocSOLVER:
     // 7 ms at 2 048), its memory as s^2 + n s; MACHIP_WB_MAX raises the default for graphs that converge no other way.
-    int wb_max_s() const { return std::max(64, std::min(16384, env_int("MACHIP_WB_MAX", kWbMaxS))); }
+    // Two tiers: up to wb_soft() closures the exact preconditioner is built at once; between wb_soft() and wb_hard() the
+    // tridiagonal one runs first and the solve ESCALATES to the exact one only when it turns out to crawl (the dense
+    // factorisation then costs tens of ms -- against seconds, or no convergence at all: fuzz seed 129, n = 36 874,
+    // 3 900 active closures, lambda_2 / ||L|| = 1e-10: 200 000 iterations without converging -> 27 iterations, 36 ms).
+    int wb_soft() const { return std::max(64, std::min(16384, env_int("MACHIP_WB_MAX", kWbMaxS))); }
+    int wb_hard() const { return std::max(wb_soft(), std::min(16384, env_int("MACHIP_WB_HARD", 8192))); }
+    int wb_limit_now = kWbMaxS;   // the tier this solve_lob call may use
+    bool lob_escalate = false;    // set by solve_lob when it gives up early in favour of the exact preconditioner
     int wb_cap_s = 0;      // what the buffers below were sized for
     int wb_alloc() {
-        const int want = wb_max_s();
+        const int want = wb_limit_now;
         if (wb_ui && wb_cap_s >= want) return MACHIP_OK;
         if (wb_ui) {
             HIP_TRY(hipStreamSynchronize(stream));
@@ -691,7 +698,10 @@ struct Solver {
         // ---- exact preconditioner (woodbury.h) when the graph is chain + at most kWbMaxS closures ----
         wb_active.s = 0;
         int wb_s = 0;
-        if (env_int("MACHIP_WOODBURY", 1) != 0 && chain_like && support_hint >= 0 && support_hint <= wb_max_s()) {
+        lob_escalate = false;
+        const bool wb_enabled = env_int("MACHIP_WOODBURY", 1) != 0 && chain_like && support_hint >= 0;
+        const bool may_escalate = wb_enabled && support_hint > wb_limit_now && support_hint <= wb_hard();
+        if (wb_enabled && support_hint <= wb_limit_now) {
             ST_TRY(wb_alloc());
             HIP_TRY(hipMemsetAsync(lx_bad, 0, sizeof(int), stream));
             k_wb_extract<<<1, kTriThreads, 0, stream>>>(A, (n + kTriThreads - 1) / kTriThreads, wb_cap_s, wb_ui, wb_uj, wb_uc, wb_counts, lx_bad);
@@ -797,6 +807,14 @@ struct Solver {
                     }
                 }
                 if (bad || !(est == est) || est < tol * scale || jend >= cap || jend - best_it > patience) check = true;
+                // the tridiagonal preconditioner crawls and an exact one is affordable: hand back for the second tier
+                if (!wb && may_escalate && !check && ((jend >= 1500 && to_go > 3000.0) || jend >= 6000)) {
+                    HIP_TRY(hipStreamSynchronize(stream));
+                    *iters = it_enq; *restarts_out = restarts;
+                    lob_escalate = true;
+                    if (debug) fprintf(stderr, "[machip] lobpcg it=%d: escalating to the exact preconditioner (to_go %.0f)\n", jend, std::min(to_go, 1e9));
+                    return MACHIP_NOT_CONVERGED;
+                }
             }
             // ---- explicit check of the current x (fresh SpMV), also the refresh point of a restart ----
             HIP_TRY(hipStreamSynchronize(stream));
@@ -853,7 +871,14 @@ struct Solver {
             HIP_TRY(hipEventRecord(ev0, stream));
             double lam = 0.0, res = 0.0;
             long iters = 0, spmvs = 0, rst = 0;
-            const int st = solve_lob(A, nnz, lnorm, tol, max_steps, start_mode, &lam, &res, &iters, &spmvs, &rst);
+            wb_limit_now = wb_soft();
+            int st = solve_lob(A, nnz, lnorm, tol, max_steps, start_mode, &lam, &res, &iters, &spmvs, &rst);
+            if (st == MACHIP_NOT_CONVERGED && lob_escalate) {
+                long it1 = iters, sp1 = spmvs;
+                wb_limit_now = wb_hard();
+                st = solve_lob(A, nnz, lnorm, tol, max_steps, start_mode, &lam, &res, &iters, &spmvs, &rst);
+                iters += it1; spmvs += sp1;
+            }
             if (st == MACHIP_OK) {
                 HIP_TRY(hipEventRecord(ev1, stream));
                 HIP_TRY(hipEventSynchronize(ev1));

@@ -1208,3 +1208,57 @@ def test_exact_preconditioner_on_a_large_chain_with_weak_links():
     lam_ref = np.sort(w)[1] - shift
     assert abs(lam - lam_ref) <= 1e-4 * lam_ref          # the stop rule itself resolves a lambda_2 this small no better
     P.close()
+
+
+def test_stiff_chain_with_thousands_of_closures_escalates_to_the_exact_preconditioner():
+    """Fuzz seed 129 of tools/fuzz_modes.py (round 1's non-converging class: > 2 048 active closures AND
+    lambda_2 / ||L||_inf ~ 1e-10; n = 36 874, 5 568 closures of which ~3 900 active): the tridiagonal preconditioner
+    crawls, the solve escalates to the exact (Woodbury) one -- second tier, up to 8 192 closures -- and converges in
+    a few dozen iterations, in the automatic mode; residual checked with SciPy's SpMV, lambda_2 against SciPy's
+    shift-invert Lanczos."""
+    import scipy.sparse.linalg as spla
+    rng = np.random.default_rng(1000 + 129)
+    n = int(rng.choice([rng.integers(260, 3072), rng.integers(3072, 16384), rng.integers(16384, 60000)]))
+    ncl = int(rng.integers(1, max(2, int(n * rng.choice([0.005, 0.05, 0.3])))))
+    fi = np.arange(n - 1, dtype=np.int32)
+    fw = 10.0 ** rng.uniform(0, rng.choice([0.5, 2, 3]), n - 1)
+    a = rng.integers(0, n, ncl); span = int(rng.choice([50, 3000, n]))
+    b = np.clip(a + rng.integers(-span, span + 1, ncl), 0, n - 1)
+    keep = np.abs(a - b) > 1
+    ci = np.minimum(a, b)[keep].astype(np.int32); cj = np.maximum(a, b)[keep].astype(np.int32)
+    cw = 10.0 ** rng.uniform(0, 2.5, len(ci))
+    x = rng.random(len(ci)); x[rng.random(len(ci)) < 0.3] = 0.0
+    assert n == 36874 and len(ci) == 5568
+    P = _lib.Problem(n, fi, fi + 1, fw, ci, cj, cw)
+    P.set_x(x)
+    lam, vec, _ = P.fiedler()
+    st = P.stats.asdict()
+    assert st["support"] > 2048 and st["residual"] < 1e-8
+    assert st["lanczos_steps"] < 20000          # (200 000 iterations without converging before the second tier existed)
+    L = oracle.mac_laplacian(oracle.laplacian_from_edges(fi, fi + 1, fw, n), ci.astype(np.int64), cj.astype(np.int64), cw, x, n)
+    assert np.abs(L @ vec - lam * vec).sum() / abs(L).sum(axis=1).max() < 1e-8
+    shift = 1e-9
+    w = spla.eigsh(L + shift * sp.identity(n, format="csr"), k=2, sigma=0, which="LM", return_eigenvectors=False)
+    lam_ref = np.sort(w)[1] - shift
+    assert abs(lam - lam_ref) <= 1e-2 * lam_ref     # lambda_2 = 1.07e-7 = 1.2e-10 ||L||: the residual rule resolves it no better
+    P.close()
+
+
+def test_budget_sweep_driver_reproduces_the_reference_budget():
+    """tools/g2o_sweep.py (the loop of examples/g2o_experiment.py:306-336: one device-resident problem, one MAC.solve per
+    budget, nearest + Madow rounding, batched evaluation of the four selections): its 20 % row on intel equals the
+    reference's golden for that budget (warm starts allowed: same optimum), and lambda_2 grows with the budget."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import g2o_sweep
+    g = load_golden("g2o_intel")
+    rows = g2o_sweep.sweep(os.path.join(ROOT, "tests", "golden", "data", "intel.g2o"), pcts=(0.1, 0.2, 0.4), verbose=False)
+    r = rows[1]
+    assert r["k"] == int(g["k"])
+    assert abs(r["naive"] - g["lam_init"]) <= 1e-8 * g["lam_init"]
+    assert abs(r["upper"] - g["upper"]) <= 1e-5 * g["upper"]
+    assert abs(r["nearest"] - g["lam_rounded"]) <= 1e-6 * g["lam_rounded"] or np.array_equal(r["result"], g["rounded"])
+    assert np.array_equal(r["madow_x"], g["madow"])
+    assert abs(r["madow"] - oracle_of(g).evaluate_objective(g["madow"])) <= 1e-7 * r["madow"]
+    assert rows[0]["nearest"] <= rows[1]["nearest"] <= rows[2]["nearest"]
+    for r in rows:
+        assert r["naive"] <= r["nearest"] * (1 + 1e-9) and r["unrounded"] <= r["upper"] * (1 + 1e-9)

@@ -17,14 +17,17 @@ from mac_amd.utils.g2o import read_g2o_file, split_edges  # noqa: E402
 from mac_amd.utils.rounding import round_madow        # noqa: E402
 
 
-def main(path):
+def sweep(path, pcts=(0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 1.0), verbose=True):
     edges, n = read_g2o_file(path)
     odom, lc = split_edges(edges)
-    print(f"{path}: {n} poses, {len(odom)} odometry edges, {len(lc)} loop closures")
+    if verbose:
+        print(f"{path}: {n} poses, {len(odom)} odometry edges, {len(lc)} loop closures")
     mac = MAC(odom, lc, n, fiedler_method="tracemin_cholesky")      # reference string, runs on HIP
     naive = NaiveGreedy(lc)
-    print(f"{'pct':>5} {'k':>6} {'naive':>12} {'unrounded':>12} {'nearest':>12} {'madow':>12} {'upper':>12} {'solve_s':>8}")
-    for pct in [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 1.0]:
+    if verbose:
+        print(f"{'pct':>5} {'k':>6} {'naive':>12} {'unrounded':>12} {'nearest':>12} {'madow':>12} {'upper':>12} {'solve_s':>8}")
+    rows = []
+    for pct in pcts:
         k = int(pct * len(lc))
         w_init = naive.subset(k)
         t0 = time.perf_counter()
@@ -32,9 +35,14 @@ def main(path):
                                                     return_rounding_time=True, use_cache=True)
         dt = time.perf_counter() - t0
         madow = round_madow(unrounded, k, seed=np.random.RandomState(42)) if k < len(lc) else result
-        ev = mac.evaluate_objective
-        print(f"{pct:5.1f} {k:6d} {ev(w_init):12.8f} {ev(unrounded):12.8f} {ev(result):12.8f} {ev(madow):12.8f} {upper:12.8f} {dt:8.3f}")
+        # the four evaluations of a budget in one batched call (machip_eval_batch: concurrent evaluation lanes)
+        lam = mac.evaluate_objective_batch(np.stack([w_init, unrounded, result, madow]))
+        rows.append(dict(pct=pct, k=k, naive=lam[0], unrounded=lam[1], nearest=lam[2], madow=lam[3], upper=upper,
+                         solve_s=dt, result=result, madow_x=madow))
+        if verbose:
+            print(f"{pct:5.1f} {k:6d} {lam[0]:12.8f} {lam[1]:12.8f} {lam[2]:12.8f} {lam[3]:12.8f} {upper:12.8f} {dt:8.3f}")
+    return rows
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "tests/golden/data/intel.g2o")
+    sweep(sys.argv[1] if len(sys.argv) > 1 else "tests/golden/data/intel.g2o")
