@@ -417,8 +417,17 @@ struct PipeViewT {
                       // writes the other, so a late-starting workgroup never sees partials that a
                       // fast workgroup of the SAME launch has already replaced
     int P;            // valid partials per quantity (= grid of the step kernel, <= 256)
+#ifdef PIPE_CLOCKS
+    long long* clk;   // tools/ubench5.hip: 8 wall-clock stamps (100 MHz) per workgroup
+#endif
 };
 using PipeView = PipeViewT<double>;
+
+#ifdef PIPE_CLOCKS   // tools/ubench5.hip: phase stamps of one worker lane and of the prologue wave per workgroup
+#define PIPE_CLK(cond, i) do { if (cond) L.clk[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define PIPE_CLK(cond, i) do { } while (0)
+#endif
 
 struct PipeCoef { double alpha, mu, beta, inv, l1prev; };
 
@@ -470,9 +479,24 @@ __device__ __forceinline__ PipeCoef pipe_prologue_wave0(const PV& L, int jrel, i
     const int jA = L.st->jA;
     const double* __restrict__ pin = L.part + (size_t)(jrel & 1) * (kNP * kMaxGrid);
     double a[kNP];
+    {   // all loads of the first 256 partials per quantity in flight at once (they are cold: written by the previous
+        // launch from every XCD); a loop with a run-time trip count made up to four dependent round trips of ~0.5 us
+        double v[kNP][4];
 #pragma unroll
-    for (int q = 0; q < kNP; ++q) a[q] = 0.0;
-    for (int i = lane; i < L.P; i += 64) {
+        for (int c = 0; c < 4; ++c) {
+            const int i = lane + 64 * c;
+            const bool ok = i < L.P;
+#pragma unroll
+            for (int q = 0; q < kNP; ++q) v[q][c] = ok ? pin[q * kMaxGrid + i] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < kNP; ++q) {   // same order of additions as the plain loop
+            a[q] = 0.0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[q] += v[q][c];
+        }
+    }
+    for (int i = lane + 256; i < L.P; i += 64) {   // grids beyond 256 workgroups (MACHIP_MAXGRID)
 #pragma unroll
         for (int q = 0; q < kNP; ++q) a[q] += pin[q * kMaxGrid + i];
     }
@@ -535,7 +559,45 @@ struct PipeRow {   // per-thread accumulation of the next step's partial sums
 };
 
 // ---- sub-wave vector form: G lanes per row, BLOCK threads per workgroup -------------------------
-template <int BLOCK, int G, int UNR = 1, bool DED = false, typename T = double>
+// Raw sums (L t)[r], (L v)[r] of one row by its G-lane group, and the row's own record (lane 0).
+template <int G, int UNR, typename T>
+__device__ __forceinline__ void pipe_row_sums(const CsrViewT<T>& A, const ZRec<T>* __restrict__ Zc, int r, int lane, bool mine,
+                                              double& st, double& sv, ZRec<T>& zr) {
+    using Z2 = ZRec<T>;
+    st = 0.0; sv = 0.0;
+    zr.t = 0; zr.v = 0;
+    if (mine) {
+        const int b = A.rowptr[r], e = A.rowptr[r + 1];
+        if (lane == 0) zr = Zc[r];
+        int p = b + lane;
+        if (UNR > 1) {   // several independent (val, col, gather) chains in flight per lane
+            for (; p + (UNR - 1) * G < e; p += UNR * G) {
+                T vv[UNR];
+                int cc[UNR];
+                Z2 zz[UNR];
+#pragma unroll
+                for (int q = 0; q < UNR; ++q) { vv[q] = A.val[p + q * G]; cc[q] = A.col[p + q * G]; }
+#pragma unroll
+                for (int q = 0; q < UNR; ++q) zz[q] = Zc[cc[q]];
+#pragma unroll
+                for (int q = 0; q < UNR; ++q) { st += (double)vv[q] * (double)zz[q].t; sv += (double)vv[q] * (double)zz[q].v; }
+            }
+        }
+        for (; p < e; p += G) {
+            const double vv = A.val[p];
+            const Z2 z = Zc[A.col[p]];
+            st += vv * (double)z.t; sv += vv * (double)z.v;
+        }
+        st = group_sum<G>(st); sv = group_sum<G>(sv);
+    }
+}
+
+// Round 2 (tools/ubench5.hip, wall-clock stamps per workgroup): the prologue of wave 0 -- 1 536 partials that the
+// previous launch wrote from all XCDs, i.e. cold in this XCD's L2 -- is done 3.5-5.5 us after kernel entry, the first
+// row tile after 1.9-4.4 us: with the barrier behind the first tile the row waves sat idle for up to 2 us per step.
+// The coefficients are only needed by finish(), so the first DEFER tiles keep their raw sums in registers and the
+// barrier comes after them; finish() then runs in the same row order as before (bit-identical partial sums).
+template <int BLOCK, int G, int UNR = 1, bool DED = false, typename T = double, int DEFER = 3>
 __global__ __launch_bounds__(BLOCK) void k_pipe_vec(CsrViewT<T> A, PipeViewT<T> L, int jrel) {
     using Z2 = ZRec<T>;
     __shared__ double smw[kMaxWaves * kNP];
@@ -546,52 +608,44 @@ __global__ __launch_bounds__(BLOCK) void k_pipe_vec(CsrViewT<T> A, PipeViewT<T> 
     constexpr int GPB = WORK / G;
     const int wt = DED ? (int)threadIdx.x - 64 : (int)threadIdx.x;
     const int lane = wt >= 0 ? wt % G : 0, g = wt >= 0 ? wt / G : 0;
+    PIPE_CLK(threadIdx.x == 0, 0);
+    PIPE_CLK(wt == 0, 2);
     if (threadIdx.x < 64) { int jdummy; (void)pipe_prologue_wave0(L, jrel, -1, scoef, &jdummy); }
+    PIPE_CLK(threadIdx.x == 0, 1);
     const Z2* __restrict__ Zc = (jrel & 1) ? L.Z1 : L.Z0;
     Z2* __restrict__ Zn = (jrel & 1) ? L.Z0 : L.Z1;
     PipeRow pr;
     pr.clear();
-    bool have = false;
-    double alpha = 0.0, beta = 0.0, mu = 0.0, inv = 0.0;
-    T* vj = nullptr;
-    for (int r0 = blockIdx.x * GPB; r0 < A.n; r0 += gridDim.x * GPB) {   // workgroup-uniform trip count
+    // ---- the first DEFER tiles: raw sums only ----
+    double dst[DEFER], dsv[DEFER];
+    Z2 dzr[DEFER];
+#pragma unroll
+    for (int i = 0; i < DEFER; ++i) {
+        const int r = (blockIdx.x + i * gridDim.x) * GPB + g;
+        pipe_row_sums<G, UNR, T>(A, Zc, r, lane, wt >= 0 && r < A.n, dst[i], dsv[i], dzr[i]);
+    }
+    PIPE_CLK(wt == 0, 3);
+    __syncthreads();     // the coefficients of wave 0 are in scoef
+    PIPE_CLK(wt == 0, 4);
+    const double alpha = scoef[0], beta = scoef[1], mu = scoef[2], inv = scoef[3];
+    T* vj = L.V + (size_t)scoef[4] * (size_t)L.n;
+#pragma unroll
+    for (int i = 0; i < DEFER; ++i) {
+        const int r = (blockIdx.x + i * gridDim.x) * GPB + g;
+        if (wt >= 0 && r < A.n && lane == 0) pr.template finish<T>(alpha, beta, mu, inv, dzr[i], dst[i], dsv[i], vj, Zn, r);
+    }
+    // ---- remaining tiles ----
+    for (int r0 = (blockIdx.x + DEFER * gridDim.x) * GPB; r0 < A.n; r0 += gridDim.x * GPB) {
         const int r = r0 + g;
         const bool mine = wt >= 0 && r < A.n;
-        double st = 0.0, sv = 0.0;
-        Z2 zr; zr.t = 0; zr.v = 0;
-        if (mine) {
-            const int b = A.rowptr[r], e = A.rowptr[r + 1];
-            if (lane == 0) zr = Zc[r];
-            int p = b + lane;
-            if (UNR > 1) {   // several independent (val, col, gather) chains in flight per lane
-                for (; p + (UNR - 1) * G < e; p += UNR * G) {
-                    T vv[UNR];
-                    int cc[UNR];
-                    Z2 zz[UNR];
-#pragma unroll
-                    for (int q = 0; q < UNR; ++q) { vv[q] = A.val[p + q * G]; cc[q] = A.col[p + q * G]; }
-#pragma unroll
-                    for (int q = 0; q < UNR; ++q) zz[q] = Zc[cc[q]];
-#pragma unroll
-                    for (int q = 0; q < UNR; ++q) { st += (double)vv[q] * (double)zz[q].t; sv += (double)vv[q] * (double)zz[q].v; }
-                }
-            }
-            for (; p < e; p += G) {
-                const double vv = A.val[p];
-                const Z2 z = Zc[A.col[p]];
-                st += vv * (double)z.t; sv += vv * (double)z.v;
-            }
-            st = group_sum<G>(st); sv = group_sum<G>(sv);
-        }
-        if (!have) {   // first tile: the prologue of wave 0 overlapped with the loads above
-            __syncthreads();
-            alpha = scoef[0]; beta = scoef[1]; mu = scoef[2]; inv = scoef[3];
-            vj = L.V + (size_t)scoef[4] * (size_t)L.n;
-            have = true;
-        }
+        double st, sv;
+        Z2 zr;
+        pipe_row_sums<G, UNR, T>(A, Zc, r, lane, mine, st, sv, zr);
         if (mine && lane == 0) pr.template finish<T>(alpha, beta, mu, inv, zr, st, sv, vj, Zn, r);
     }
+    PIPE_CLK(wt == 0, 5);
     pr.template store<BLOCK>(L, jrel, smw);
+    PIPE_CLK(wt == 0, 6);
 }
 
 // ---- LDS row-tile ("CSR-stream") form ------------------------------------------------------------
