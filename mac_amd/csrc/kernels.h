@@ -476,33 +476,49 @@ __device__ __forceinline__ PipeCoef pipe_coefs(const double (&a)[kNP], int n) {
 template <class PV>
 __device__ __forceinline__ PipeCoef pipe_prologue_wave0(const PV& L, int jrel, int adv_jA, double* scoef, int* j_out) {
     const int lane = threadIdx.x;   // caller guarantees threadIdx.x < 64
-    const int jA = L.st->jA;
     const double* __restrict__ pin = L.part + (size_t)(jrel & 1) * (kNP * kMaxGrid);
     double a[kNP];
-    {   // all loads of the first 256 partials per quantity in flight at once (they are cold: written by the previous
-        // launch from every XCD); a loop with a run-time trip count made up to four dependent round trips of ~0.5 us
+    {   // The first 256 partials per quantity: 24 UNCONDITIONAL loads per lane (always in bounds: the arrays hold kMaxGrid
+        // entries), masked afterwards.  Round 2, tools/ubench5.hip + the ISA: written as `i < P ? pin[..] : 0` (or as a loop
+        // with a run-time trip count) the compiler emitted one predicated load + s_waitcnt per value -- 25 dependent cold
+        // round trips, 3.2 us before the first partial was even requested: THE long pole of every step on matrices that
+        // fit one row tile per workgroup (config 2, city10000).
         double v[kNP][4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int i = lane + 64 * c;
-            const bool ok = i < L.P;
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int q = 0; q < kNP; ++q) v[q][c] = ok ? pin[q * kMaxGrid + i] : 0.0;
-        }
+            for (int q = 0; q < kNP; ++q) v[q][c] = pin[q * kMaxGrid + lane + 64 * c];
+#ifdef PIPE_CLOCKS
+        asm volatile("" ::: "memory");
+        if (lane == 0) L.clk[blockIdx.x * 8 + 3] = wall_clock64();     // (slot 3: partial loads ISSUED)
+        asm volatile("" ::: "memory");
+#endif
 #pragma unroll
-        for (int q = 0; q < kNP; ++q) {   // same order of additions as the plain loop
+        for (int q = 0; q < kNP; ++q) {   // same order of additions as a plain loop over the workgroups
             a[q] = 0.0;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) a[q] += v[q][c];
+            for (int c = 0; c < 4; ++c) a[q] += (lane + 64 * c < L.P) ? v[q][c] : 0.0;
         }
     }
-    for (int i = lane + 256; i < L.P; i += 64) {   // grids beyond 256 workgroups (MACHIP_MAXGRID)
+    for (int base = 256; base < L.P; base += 256) {   // grids beyond 256 workgroups (MACHIP_MAXGRID): same batching per 256
+        double v[kNP][4];
 #pragma unroll
-        for (int q = 0; q < kNP; ++q) a[q] += pin[q * kMaxGrid + i];
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int q = 0; q < kNP; ++q) v[q][c] = pin[q * kMaxGrid + base + lane + 64 * c];    // base + 255 < kMaxGrid
+#pragma unroll
+        for (int q = 0; q < kNP; ++q)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[q] += (base + lane + 64 * c < L.P) ? v[q][c] : 0.0;
     }
+#ifdef PIPE_CLOCKS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) L.clk[blockIdx.x * 8 + 7] = wall_clock64();
+#endif
 #pragma unroll
     for (int q = 0; q < kNP; ++q) a[q] = wave_total(a[q]);
     const PipeCoef c = pipe_coefs(a, L.n);
+    const int jA = L.st->jA;
     const int j = jA + jrel;
     if (lane == 0) {
         scoef[0] = c.alpha; scoef[1] = c.beta; scoef[2] = c.mu; scoef[3] = c.inv; scoef[4] = (double)j;
@@ -553,7 +569,11 @@ struct PipeRow {   // per-thread accumulation of the next step's partial sums
             double s = 0.0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) s += smw[w * kNP + threadIdx.x];
-            L.part[(size_t)((jrel + 1) & 1) * (kNP * kMaxGrid) + threadIdx.x * kMaxGrid + blockIdx.x] = s;
+            // write-through store: the next launch reads these 48 bytes first thing, and a plain store only leaves
+            // this XCD's L2 with the end-of-kernel write-back (tools/ubench5.hip: the partials used to arrive 3.3-5.3 us
+            // after the next kernel's entry)
+            __hip_atomic_store(&L.part[(size_t)((jrel + 1) & 1) * (kNP * kMaxGrid) + threadIdx.x * kMaxGrid + blockIdx.x], s,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 };
@@ -624,7 +644,6 @@ __global__ __launch_bounds__(BLOCK) void k_pipe_vec(CsrViewT<T> A, PipeViewT<T> 
         const int r = (blockIdx.x + i * gridDim.x) * GPB + g;
         pipe_row_sums<G, UNR, T>(A, Zc, r, lane, wt >= 0 && r < A.n, dst[i], dsv[i], dzr[i]);
     }
-    PIPE_CLK(wt == 0, 3);
     __syncthreads();     // the coefficients of wave 0 are in scoef
     PIPE_CLK(wt == 0, 4);
     const double alpha = scoef[0], beta = scoef[1], mu = scoef[2], inv = scoef[3];

@@ -10,7 +10,10 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "c4"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 shapes = [None, (4, 1, 1024, 256), (4, 2, 1024, 256), (8, 2, 1024, 256), (8, 4, 1024, 256), (16, 2, 1024, 256), (16, 4, 1024, 256),
           (8, 4, 512, 512), (8, 4, 512, 1024), (16, 2, 512, 512), (16, 2, 512, 1024), (4, 2, 512, 1024), (8, 2, 256, 1024),
-          (16, 2, 1024, 512), (8, 2, 1024, 512), (8, 4, 1024, 512), (4, 4, 512, 1024)]
+          (16, 2, 1024, 512), (8, 2, 1024, 512), (8, 4, 1024, 512), (4, 4, 512, 1024), (8, 4, 256, 512), (8, 4, 256, 1024),
+          (4, 2, 256, 512), (4, 2, 256, 1024), (16, 2, 256, 1024), (4, 1, 256, 1024)]
+if len(sys.argv) > 3:      # restrict to a few shapes: indices
+    shapes = [shapes[int(t)] for t in sys.argv[3].split(",")]
 w = bench.make_workload(cfg)
 P = _lib.Problem(w["n"], w["fi"], w["fj"], w["fw"], w["ci"], w["cj"], w["cw"])
 P.set_start(reference_start_block(w["n"])[:, 0].copy())

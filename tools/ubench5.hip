@@ -37,7 +37,7 @@ void run(const char* nm, CsrView A, PipeView L, hipStream_t s, long nnz, std::ve
         printf("      %-46s min %6.2f  mean %6.2f  max %6.2f us after the first workgroup's entry\n", what, mn, av / grid, mx);
     };
     printf("   %s blk=%d G=%d unr=%d grid=%d: %.2f us per step back-to-back (nnz %ld)\n", nm, BLOCK, G, UNR, grid, 1e3 * ms / steps, nnz);
-    stat(0, "workgroup entry (wave 0)"); stat(2, "worker wave entry"); stat(1, "prologue done (wave 0)"); stat(3, "first tile loaded + reduced (worker)");
+    stat(0, "workgroup entry (wave 0)"); stat(2, "worker wave entry"); stat(7, "prologue: partials loaded (wave 0)"); stat(1, "prologue done (wave 0)"); stat(3, "prologue: partial loads issued (wave 0)");
     stat(4, "barrier passed"); stat(5, "last tile finished"); stat(6, "epilogue (partials stored)");
     CK(hipFree(u0));
 }
