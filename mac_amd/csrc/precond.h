@@ -606,11 +606,23 @@ __global__ __launch_bounds__(kBlock) void k_lob_update(LobView L, int jrel) {
     }
     if (threadIdx.x < 64) {
         double s[kLobNS];
+        {   // all partial loads in flight at once, masked afterwards (a loop with a run-time trip count compiles into one
+            // dependent cold round trip per value -- see pipe_prologue_wave0 in kernels.h); same order of additions
 #pragma unroll
-        for (int q = 0; q < kLobNS; ++q) {
-            double a = 0.0;
-            for (int i = threadIdx.x; i < L.P_c; i += 64) a += L.part[(size_t)q * kMaxGrid + i];
-            s[q] = wave_total(a);
+            for (int q = 0; q < kLobNS; ++q) s[q] = 0.0;
+            for (int base = 0; base < L.P_c; base += 256) {
+                double v[kLobNS][4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int q = 0; q < kLobNS; ++q) v[q][c] = L.part[(size_t)q * kMaxGrid + base + threadIdx.x + 64 * c];   // < kMaxGrid
+#pragma unroll
+                for (int q = 0; q < kLobNS; ++q)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) s[q] += (base + (int)threadIdx.x + 64 * c < L.P_c) ? v[q][c] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < kLobNS; ++q) s[q] = wave_total(s[q]);
         }
         if (threadIdx.x == 0) {
             const LobCoef co = lob_rayleigh_ritz(s, L.n, L.st->havep0 != 0 || jrel > 0);
