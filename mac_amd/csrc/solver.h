@@ -42,6 +42,7 @@ struct SpmvPlan {
     int grid = 1;
     int block = kBlock;   // threads per workgroup of the fused step kernel (256, 512 or 1024)
     int unroll = 1;       // independent (val, col, gather) chains per lane
+    int defer = 1;        // row tiles whose finish() waits behind the barrier (k_pipe_vec DEFER): 3 where a workgroup owns several
 };
 
 inline int env_int(const char* name, int dflt) {
@@ -125,7 +126,11 @@ inline SpmvPlan plan_pipe(int n, long nnz, int maxlen) {
     pl.unroll = env_int("MACHIP_UNROLL", unr);
     pl.block = env_int("MACHIP_BLOCK", blk);
     const int gpb = (pl.block - 64) / pl.width;
-    pl.grid = (int)std::max<long>(1, std::min<long>(grid_cap(), ((long)n + gpb - 1) / gpb));
+    const long tiles = ((long)n + gpb - 1) / gpb;
+    pl.grid = (int)std::max<long>(1, std::min<long>(grid_cap(), tiles));
+    // a workgroup with several row tiles keeps the first three un-finished behind the barrier (the prologue's latency
+    // is then hidden); with one tile per workgroup that only costs registers
+    pl.defer = env_int("MACHIP_DEFER", tiles > 2L * pl.grid ? 3 : 1);
     return pl;
 }
 
@@ -156,31 +161,41 @@ template <int BLOCK>
 inline void launch_pipe_b(const SpmvPlan& pl, hipStream_t s, const CsrViewT<float>& A, const PipeViewT<float>& L, int jrel) {
     const int key = pl.width * 10 + pl.unroll;
     switch (key) {
-        case 41: k_pipe_vec<BLOCK, 4, 1, true, float><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 42: case 44: k_pipe_vec<BLOCK, 4, 2, true, float><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 81: case 82: k_pipe_vec<BLOCK, 8, 2, true, float><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 84: k_pipe_vec<BLOCK, 8, 4, true, float><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        default: k_pipe_vec<BLOCK, 16, 2, true, float><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 41: k_pipe_vec<BLOCK, 4, 1, true, float, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 42: case 44: k_pipe_vec<BLOCK, 4, 2, true, float, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 81: case 82: k_pipe_vec<BLOCK, 8, 2, true, float, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 84: k_pipe_vec<BLOCK, 8, 4, true, float, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        default: k_pipe_vec<BLOCK, 16, 2, true, float, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
     }
 }
 
 template <int BLOCK>
 inline void launch_pipe_b(const SpmvPlan& pl, hipStream_t s, const CsrView& A, const PipeView& L, int jrel) {
     const int key = pl.width * 10 + pl.unroll;
+    if (pl.defer >= 3) {   // several row tiles per workgroup: the shapes plan_pipe picks there (others: DEFER = 1 below)
+        switch (key) {
+            case 41: k_pipe_vec<BLOCK, 4, 1, true, double, 3><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); return;
+            case 42: k_pipe_vec<BLOCK, 4, 2, true, double, 3><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); return;
+            case 82: k_pipe_vec<BLOCK, 8, 2, true, double, 3><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); return;
+            case 84: k_pipe_vec<BLOCK, 8, 4, true, double, 3><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); return;
+            case 162: k_pipe_vec<BLOCK, 16, 2, true, double, 3><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); return;
+            default: break;
+        }
+    }
     switch (key) {
-        case 41: k_pipe_vec<BLOCK, 4, 1, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 42: k_pipe_vec<BLOCK, 4, 2, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 44: k_pipe_vec<BLOCK, 4, 4, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 84: k_pipe_vec<BLOCK, 8, 4, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 164: k_pipe_vec<BLOCK, 16, 4, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 81: k_pipe_vec<BLOCK, 8, 1, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 82: k_pipe_vec<BLOCK, 8, 2, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 161: k_pipe_vec<BLOCK, 16, 1, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 162: k_pipe_vec<BLOCK, 16, 2, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 321: k_pipe_vec<BLOCK, 32, 1, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 322: k_pipe_vec<BLOCK, 32, 2, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 641: k_pipe_vec<BLOCK, 64, 1, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        default: k_pipe_vec<BLOCK, 64, 2, true><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 41: k_pipe_vec<BLOCK, 4, 1, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 42: k_pipe_vec<BLOCK, 4, 2, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 44: k_pipe_vec<BLOCK, 4, 4, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 84: k_pipe_vec<BLOCK, 8, 4, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 164: k_pipe_vec<BLOCK, 16, 4, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 81: k_pipe_vec<BLOCK, 8, 1, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 82: k_pipe_vec<BLOCK, 8, 2, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 161: k_pipe_vec<BLOCK, 16, 1, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 162: k_pipe_vec<BLOCK, 16, 2, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 321: k_pipe_vec<BLOCK, 32, 1, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 322: k_pipe_vec<BLOCK, 32, 2, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 641: k_pipe_vec<BLOCK, 64, 1, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        default: k_pipe_vec<BLOCK, 64, 2, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
     }
 }
 
@@ -410,7 +425,7 @@ struct Solver {
             graphs.clear();
             graph_csr_key = (const void*)A.val;
         }
-        const auto key = std::make_tuple(pl.variant + (f32 ? 100 : 0), pl.width * 10 + pl.unroll, pl.grid, pl.block, steps);
+        const auto key = std::make_tuple(pl.variant + (f32 ? 100 : 0) + 1000 * pl.defer, pl.width * 10 + pl.unroll, pl.grid, pl.block, steps);
         auto it = graphs.find(key);
         if (it == graphs.end()) it = graphs.emplace(key, std::array<hipGraphExec_t, 2>{nullptr, nullptr}).first;
         // two executables per shape, used alternately: with one chunk running ahead, the same
