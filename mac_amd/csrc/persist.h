@@ -71,6 +71,31 @@ __device__ __forceinline__ void persist_sum2(double& a, double& b, double* red) 
     a = sa; b = sb;
 }
 
+// One value (the alpha reduction of a step).
+__device__ __forceinline__ void persist_sum1(double& a, double* red) {
+    a = wave_total(a);
+    const int w = threadIdx.x >> 6;
+    constexpr int W = kPersistThreads / 64;
+    if ((threadIdx.x & 63) == 0) red[w] = a;
+    lds_barrier();
+    double sa = 0.0;
+#pragma unroll
+    for (int k = 0; k < W; ++k) sa += red[k];
+    a = sa;
+}
+// Three values (chunk end).
+__device__ __forceinline__ void persist_sum3(double& a, double& b, double& c, double* red) {
+    a = wave_total(a); b = wave_total(b); c = wave_total(c);
+    const int w = threadIdx.x >> 6;
+    constexpr int W = kPersistThreads / 64;
+    if ((threadIdx.x & 63) == 0) { red[w] = a; red[W + w] = b; red[2 * W + w] = c; }
+    lds_barrier();
+    double sa = 0.0, sb = 0.0, sc = 0.0;
+#pragma unroll
+    for (int k = 0; k < W; ++k) { sa += red[k]; sb += red[W + k]; sc += red[2 * W + k]; }
+    a = sa; b = sb; c = sc;
+}
+
 template <typename T>
 __global__ void k_persist_begin(PersistViewT<T> L, int epoch) {
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < L.n; r += gridDim.x * blockDim.x) L.vprev[r] = 0.0;
@@ -89,7 +114,7 @@ __global__ void k_persist_begin(PersistViewT<T> L, int epoch) {
 template <int RPT, typename T = double>
 __global__ __launch_bounds__(kPersistThreads) void k_lan_persist(CsrView A, PersistViewT<T> L, int steps) {
     __shared__ __align__(16) unsigned char pool[kPersistPool];
-    __shared__ double red1[2 * kPersistThreads / 64], red2[2 * kPersistThreads / 64];
+    __shared__ double red1[3 * kPersistThreads / 64], red2[2 * kPersistThreads / 64];
     __shared__ double srec[3 * (kPersistMaxSteps + 1)];   // (alpha, beta, l1) of this chunk
     __shared__ int s_scan[kPersistThreads];
     const int t = threadIdx.x, n = A.n;
@@ -179,27 +204,38 @@ __global__ __launch_bounds__(kPersistThreads) void k_lan_persist(CsrView A, Pers
         const int j = J0 + s;
         PCLK(s == 1, 8);
         // ---- beta_j = ||u - mean||, v_j = (u - mean) / beta_j  (nx:209-213 project()) ----
+        // (round 2, tools/ubench_persist.hip: a wave-wide fp64 DPP total costs ~400 shader cycles per VALUE on the step's
+        // critical path, the barrier around it ~250: merging the two reductions of a step into one four-value reduction
+        // made the step slower (2.34 against 1.61 us), dropping a value makes it faster -- ||v_j||_1 is only used by the
+        // host for the LAST vector of a chunk, so it moved into the chunk's closing reduction)
         double s1 = 0.0, s2 = 0.0;
 #pragma unroll
         for (int k = 0; k < RPT; ++k) { const double uk = u[k]; s1 += uk; s2 += uk * uk; }
-        persist_sum2(s1, s2, red1);
+        double l1_last = 0.0;
+        if (s == steps) {
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) l1_last += fabs((double)vp[k]);      // ||v_{J-1}||_1
+            persist_sum3(s1, s2, l1_last, red1);
+        } else {
+            persist_sum2(s1, s2, red1);
+        }
         PCLK(s == 0, 2);
         const double mu = s1 * rdn;
         const double nrm2 = s2 - dn * mu * mu;
         const double rs = nrm2 > 1e-290 ? rsqrt(nrm2) : 0.0;
         const double beta = nrm2 * rs;
-        if (s == steps) {              // chunk end: only beta_J is needed (the host's residual estimate)
-            if (t == 0) { srec[3 * s] = 0.0; srec[3 * s + 1] = beta; }
+        if (s == steps) {              // chunk end: beta_J (the host's residual estimate) and ||v_{J-1}||_1
+            if (t == 0) { srec[3 * s] = 0.0; srec[3 * s + 1] = beta; if (s > 0) srec[3 * (s - 1) + 2] = l1_last; }
             break;
         }
         const double inv = rs;
-        double l1 = 0.0, al = 0.0;
+        double al = 0.0;
         T* vj = L.V + (size_t)j * (size_t)n;
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
             const int r = t + k * kPersistThreads;
             v[k] = (T)(((double)u[k] - mu) * inv);
-            if (r < n) { svec[r] = v[k]; vj[r] = v[k]; l1 += fabs((double)v[k]); } else v[k] = 0;
+            if (r < n) { svec[r] = v[k]; vj[r] = v[k]; } else v[k] = 0;
         }
         PCLK(s == 0, 3);
         lds_barrier();
@@ -227,7 +263,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_lan_persist(CsrView A, Pers
 #pragma unroll
         for (int k = 0; k < RPT; ++k) al += (double)v[k] * (double)u[k];
         PCLK(s == 0, 5);
-        persist_sum2(al, l1, red2);
+        persist_sum1(al, red2);
         PCLK(s == 0, 6);
         // ---- u_{j+1} = w - alpha_j v_j - beta_j v_{j-1} ----
 #pragma unroll
@@ -235,7 +271,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_lan_persist(CsrView A, Pers
             u[k] = (u[k] - (T)al * v[k]) - (T)beta * vp[k];
             vp[k] = v[k];
         }
-        if (t == 0) { srec[3 * s] = al; srec[3 * s + 1] = beta; srec[3 * s + 2] = l1; }
+        if (t == 0) { srec[3 * s] = al; srec[3 * s + 1] = beta; srec[3 * s + 2] = 0.0; }
         PCLK(s == 0, 7);
     }
 #pragma unroll

@@ -1262,3 +1262,43 @@ def test_budget_sweep_driver_reproduces_the_reference_budget():
     assert rows[0]["nearest"] <= rows[1]["nearest"] <= rows[2]["nearest"]
     for r in rows:
         assert r["naive"] <= r["nearest"] * (1 + 1e-9) and r["unrounded"] <= r["upper"] * (1 + 1e-9)
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """bench.py --gpus N without a launcher spawns N ranks itself and must refuse -- loudly, non-zero -- when fewer than
+    N devices are visible (round 1: `--gpus 8` silently ran and reported a 1-GPU job)."""
+    ndev = _lib.device_count()
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ndev + 1), "--config", "c3", "--steps", "2",
+                        "--warmup", "0", "--no-cpu", "--no-pmc"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
+    assert '"metric"' not in r.stdout
+    # and a launcher environment that disagrees with --gpus is an error too
+    env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29555")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "c3", "--steps", "2", "--warmup", "0",
+                         "--no-cpu", "--no-pmc"], env=env2, capture_output=True, text=True, timeout=300)
+    assert r2.returncode != 0 and "WORLD_SIZE" in (r2.stderr + r2.stdout)
+
+
+def test_bench_line_contract_on_a_small_config():
+    """One JSON line with the contract's fields, `roofline` from the in-solve step timer and both CPU baselines."""
+    import json
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c5a", "--steps", "6", "--warmup", "1", "--min-seconds", "0.2",
+                        "--no-pmc"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "cpu_baseline_strong", "repeats"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["vs_baseline"] is None and "workload" in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["launches_timed"] > 0
+    assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["host_cores"] >= 1 and d["cpu_baseline"]["kind"] == "port"
+    assert d["cpu_parity_lambda2_rel"] < 1e-8
