@@ -452,6 +452,30 @@ __device__ __forceinline__ double wave_total(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// N wave totals at once, stage by stage: the N chains are independent, so the DPP moves and adds of one stage issue
+// back to back instead of each chain waiting out its own dependent latencies (results identical to wave_total).
+template <int N>
+__device__ __forceinline__ void wave_total_n(double (&v)[N]) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] = dpp_add<0x111, 0xf>(v[q]);
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] = dpp_add<0x112, 0xf>(v[q]);
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] = dpp_add<0x114, 0xf>(v[q]);
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] = dpp_add<0x118, 0xf>(v[q]);
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] = dpp_add<0x142, 0xa>(v[q]);
+#pragma unroll
+    for (int q = 0; q < N; ++q) v[q] = dpp_add<0x143, 0xc>(v[q]);
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v[q]), 63);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(v[q]), 63);
+        v[q] = __hiloint2double(hi, lo);
+    }
+}
+
 // Finish step j-1's reductions from the summed partials.  Identical on every workgroup.
 __device__ __forceinline__ PipeCoef pipe_coefs(const double (&a)[kNP], int n) {
     PipeCoef c;
@@ -459,13 +483,18 @@ __device__ __forceinline__ PipeCoef pipe_coefs(const double (&a)[kNP], int n) {
     c.alpha = tv;                             // Paige: v.(L v - beta v_prev); 0 at j = 0 (v = 0)
     const double al = c.alpha;
     const double uu = tt - 2.0 * al * tv + al * al * vv;
-    c.mu = (a[3] - al * a[4]) / (double)n;
-    const double nrm2 = uu - (double)n * c.mu * c.mu;
+    const double dn = (double)n;
+    c.mu = (a[3] - al * a[4]) * __builtin_amdgcn_rcp(dn) * (2.0 - dn * __builtin_amdgcn_rcp(dn));   // one Newton step on the hardware reciprocal: the mean to 1e-15 relative without a division
+    const double nrm2 = uu - dn * c.mu * c.mu;
     // ||u||^2 is a difference of O(||t||^2) terms: below ~1e-10 of their size it is rounding
     // noise, i.e. the Krylov space is (numerically) invariant -> report an exact breakdown.
     const double scale = tt + al * al * vv;
-    c.beta = (nrm2 > 1e-10 * scale) ? sqrt(nrm2) : 0.0;
-    c.inv = c.beta > 1e-290 ? 1.0 / c.beta : 0.0;
+    // beta = ||u||, 1/beta through rsqrt (this chain -- it used to be a sqrt and a division, ~100 dependent fp64
+    // instructions -- sits on the critical path of every step: the row waves wait for it at the barrier)
+    const bool ok = nrm2 > 1e-10 * scale && nrm2 > 1e-290;
+    const double rs = ok ? rsqrt(nrm2) : 0.0;
+    c.beta = ok ? nrm2 * rs : 0.0;
+    c.inv = c.beta > 1e-290 ? rs : 0.0;
     c.l1prev = a[5];
     return c;
 }
@@ -476,6 +505,7 @@ __device__ __forceinline__ PipeCoef pipe_coefs(const double (&a)[kNP], int n) {
 template <class PV>
 __device__ __forceinline__ PipeCoef pipe_prologue_wave0(const PV& L, int jrel, int adv_jA, double* scoef, int* j_out) {
     const int lane = threadIdx.x;   // caller guarantees threadIdx.x < 64
+    const int jA = L.st->jA;        // (requested first, consumed last: in flight together with the partial loads below)
     const double* __restrict__ pin = L.part + (size_t)(jrel & 1) * (kNP * kMaxGrid);
     double a[kNP];
     {   // The first 256 partials per quantity: 24 UNCONDITIONAL loads per lane (always in bounds: the arrays hold kMaxGrid
@@ -515,10 +545,8 @@ __device__ __forceinline__ PipeCoef pipe_prologue_wave0(const PV& L, int jrel, i
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) L.clk[blockIdx.x * 8 + 7] = wall_clock64();
 #endif
-#pragma unroll
-    for (int q = 0; q < kNP; ++q) a[q] = wave_total(a[q]);
+    wave_total_n<kNP>(a);
     const PipeCoef c = pipe_coefs(a, L.n);
-    const int jA = L.st->jA;
     const int j = jA + jrel;
     if (lane == 0) {
         scoef[0] = c.alpha; scoef[1] = c.beta; scoef[2] = c.mu; scoef[3] = c.inv; scoef[4] = (double)j;
@@ -553,27 +581,23 @@ struct PipeRow {   // per-thread accumulation of the next step's partial sums
         acc[0] += t * t; acc[1] += t * v; acc[2] += v * v;
         acc[3] += t; acc[4] += v; acc[5] += fabs(v);
     }
-    // one partial per quantity per workgroup; smw: kMaxWaves*kNP doubles
+    // One partial per quantity per workgroup.  sred: kNP x (BLOCK/64) x 64 doubles of LDS.  Round 2 (tools/ubench5.hip: "last
+    // tile finished" -> "partials stored" took 1.7-2.3 us): a wave-wide fp64 total is 12 DPP moves + 6 adds, and with every
+    // wave of the workgroup reducing all six quantities the SIMDs issued 6 x NW of them.  Now every lane parks its six
+    // sums in LDS, and after the barrier wave q adds the NW values of its lane for quantity q and runs ONE wave total.
     template <int BLOCK, class PV>
-    __device__ __forceinline__ void store(const PV& L, int jrel, double* smw) {
+    __device__ __forceinline__ void store(const PV& L, int jrel, double* sred) {
         constexpr int NW = BLOCK / 64;
+        const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-        for (int q = 0; q < kNP; ++q) acc[q] = wave_total(acc[q]);
-        const int wv = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-            for (int q = 0; q < kNP; ++q) smw[wv * kNP + q] = acc[q];
-        }
+        for (int q = 0; q < kNP; ++q) sred[(q * NW + wv) * 64 + lane] = acc[q];
         __syncthreads();
-        if (threadIdx.x < kNP) {
+        for (int q = wv; q < kNP; q += NW) {     // workgroup-uniform per wave
             double s = 0.0;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) s += smw[w * kNP + threadIdx.x];
-            // write-through store: the next launch reads these 48 bytes first thing, and a plain store only leaves
-            // this XCD's L2 with the end-of-kernel write-back (tools/ubench5.hip: the partials used to arrive 3.3-5.3 us
-            // after the next kernel's entry)
-            __hip_atomic_store(&L.part[(size_t)((jrel + 1) & 1) * (kNP * kMaxGrid) + threadIdx.x * kMaxGrid + blockIdx.x], s,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            for (int w = 0; w < NW; ++w) s += sred[(q * NW + w) * 64 + lane];
+            s = wave_total(s);
+            if (lane == 0) L.part[(size_t)((jrel + 1) & 1) * (kNP * kMaxGrid) + q * kMaxGrid + blockIdx.x] = s;
         }
     }
 };
@@ -620,7 +644,7 @@ __device__ __forceinline__ void pipe_row_sums(const CsrViewT<T>& A, const ZRec<T
 template <int BLOCK, int G, int UNR = 1, bool DED = false, typename T = double, int DEFER = 3>
 __global__ __launch_bounds__(BLOCK) void k_pipe_vec(CsrViewT<T> A, PipeViewT<T> L, int jrel) {
     using Z2 = ZRec<T>;
-    __shared__ double smw[kMaxWaves * kNP];
+    __shared__ double smw[kNP * BLOCK];     // epilogue scratch: six sums per lane
     __shared__ double scoef[8];
     // DED: wave 0 does nothing but the prologue (its reduction chain is then off the critical
     // path of the row work); the other waves own the rows.
@@ -672,7 +696,7 @@ constexpr int kPipeTile = 1024;   // staged products per LDS tile, x2 arrays (16
 
 template <int TPR>
 __global__ __launch_bounds__(kBlock) void k_pipe_stream(CsrView A, PipeView L, int jrel) {
-    __shared__ double smw[kMaxWaves * kNP];
+    __shared__ double smw[kNP * kBlock];
     __shared__ double scoef[8];
     __shared__ double pt[kPipeTile], pv[kPipeTile];
     __shared__ int sptr[kBlock / TPR + 1];

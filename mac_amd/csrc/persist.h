@@ -60,7 +60,7 @@ __device__ __forceinline__ void lds_barrier() {
 
 // Sum two values over the workgroup; `red` = 2 x kPersistThreads/64 doubles, two of them used alternately.
 __device__ __forceinline__ void persist_sum2(double& a, double& b, double* red) {
-    a = wave_total(a); b = wave_total(b);
+    { double v[2] = {a, b}; wave_total_n<2>(v); a = v[0]; b = v[1]; }
     const int w = threadIdx.x >> 6;
     constexpr int W = kPersistThreads / 64;
     if ((threadIdx.x & 63) == 0) { red[w] = a; red[W + w] = b; }
@@ -85,7 +85,7 @@ __device__ __forceinline__ void persist_sum1(double& a, double* red) {
 }
 // Three values (chunk end).
 __device__ __forceinline__ void persist_sum3(double& a, double& b, double& c, double* red) {
-    a = wave_total(a); b = wave_total(b); c = wave_total(c);
+    { double v[3] = {a, b, c}; wave_total_n<3>(v); a = v[0]; b = v[1]; c = v[2]; }
     const int w = threadIdx.x >> 6;
     constexpr int W = kPersistThreads / 64;
     if ((threadIdx.x & 63) == 0) { red[w] = a; red[W + w] = b; red[2 * W + w] = c; }

@@ -621,8 +621,7 @@ __global__ __launch_bounds__(kBlock) void k_lob_update(LobView L, int jrel) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) s[q] += (base + (int)threadIdx.x + 64 * c < L.P_c) ? v[q][c] : 0.0;
             }
-#pragma unroll
-            for (int q = 0; q < kLobNS; ++q) s[q] = wave_total(s[q]);
+            wave_total_n<kLobNS>(s);
         }
         if (threadIdx.x == 0) {
             const LobCoef co = lob_rayleigh_ritz(s, L.n, L.st->havep0 != 0 || jrel > 0);
