@@ -1302,3 +1302,8 @@ def test_bench_line_contract_on_a_small_config():
     assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["launches_timed"] > 0
     assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["host_cores"] >= 1 and d["cpu_baseline"]["kind"] == "port"
     assert d["cpu_parity_lambda2_rel"] < 1e-8
+
+
+def test_graft_entry_smoke():
+    import importlib
+    importlib.import_module("__graft_entry__").smoke()
