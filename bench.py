@@ -307,7 +307,7 @@ def self_launch(args):
     from mac_amd import _lib
     _lib.load()
     have = _lib.device_count()
-    if have < args.gpus:
+    if have < args.gpus and os.environ.get("MACHIP_SHARE_GPU") != "1":      # (MACHIP_SHARE_GPU=1: protocol test, several ranks on one GPU)
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible -- refusing to run a mislabelled {have}-GPU job")
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
@@ -318,11 +318,26 @@ def self_launch(args):
                    MASTER_PORT=str(port), MACHIP_RDZV_KEY=key, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode())
-    sys.stdout.flush()
-    if any(codes):
+    # a rank that dies (no GPU, RCCL refusing the communicator ...) must not leave its peers waiting in a collective
+    import threading
+    buf = []
+    rd = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    rd.start()
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            failed = True
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.2)
+    codes = [p.wait() for p in procs]
+    rd.join(timeout=5)
+    if not failed and not any(codes):
+        sys.stdout.write((buf[0] if buf else b"").decode())
+        sys.stdout.flush()
+    else:
         raise SystemExit(f"rank exit codes {codes}")
 
 
@@ -354,7 +369,7 @@ def main():
     _lib.load()
     _lib.require_device()
     ndev = _lib.device_count()
-    if world > 1 and ndev < world:
+    if world > 1 and ndev < world and os.environ.get("MACHIP_SHARE_GPU") != "1":
         raise SystemExit(f"--gpus {world} but only {ndev} GPU(s) visible")
     dist = None
     if world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ):
