@@ -1307,3 +1307,24 @@ def test_bench_line_contract_on_a_small_config():
 def test_graft_entry_smoke():
     import importlib
     importlib.import_module("__graft_entry__").smoke()
+
+
+def test_trajectory_is_bit_reproducible_run_to_run():
+    """Two runs of the same Frank-Wolfe trajectory (fresh handles, fused multi-workgroup path and single-workgroup path)
+    give bit-identical lambda_2, step counts and iterates: no floating-point atomics, fixed reduction orders, a
+    chunk scheduler that decides on step counts only."""
+    for nm in ["er2000_solve", "g2o_intel", "g2o_city10000"]:
+        g = load_golden(nm)
+        runs = []
+        for rep in range(2):
+            P = problem_of(g)
+            P.set_start(reference_start_block(int(g["n"]))[:, 0].copy())
+            P.set_x(g["x_init"])
+            fs, st = [], []
+            for it in range(4):
+                f, dual, gn = P.fw_step(int(g["k"]), it)
+                fs.append((f, dual, gn)); st.append(int(P.stats.lanczos_steps))
+                P.fw_commit()
+            runs.append((np.array(fs), st, P.get_x()))
+            P.close()
+        assert np.array_equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1] and np.array_equal(runs[0][2], runs[1][2]), nm

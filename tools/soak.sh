@@ -9,7 +9,7 @@ for i in $(seq 1 $n); do
 done
 prev=""
 for i in $(seq 1 $n); do
-  h=$(python bench.py --no-cpu --no-roofline --steps 20 --warmup 1 2>/dev/null | python -c "import sys,json,hashlib; d=json.loads(sys.stdin.read()); print(d['lambda2_first_last'], d['lanczos_steps_per_iter'])")
+  h=$(python bench.py --no-cpu --no-roofline --no-pmc --min-seconds 0 --steps 20 --warmup 1 2>/dev/null | python -c "import sys,json,hashlib; d=json.loads(sys.stdin.read()); print(d['lambda2_first_last'], d['lanczos_steps_per_iter'])")
   echo "bench $i: $h"
   if [ -n "$prev" ] && [ "$h" != "$prev" ]; then echo "NONDETERMINISTIC"; fail=1; fi
   prev="$h"
