@@ -163,16 +163,22 @@ __global__ __launch_bounds__(kTriThreads) void k_tri_factor(int n, const double*
     const int t = threadIdx.x;   // thread t owns the unknowns e = t*C .. t*C + C-1 (zero padded past n)
     double av[C], bv[C];
     Mob M{1.0, 0.0, 0.0, 1.0};
+    {   // all 2 C loads in flight at once (always in bounds: the band arrays hold C x 1024 entries), masked afterwards --
+        // inside `if (e < n)` the compiler had emitted one predicated load + wait per value, 2 C dependent round trips
+        const double* __restrict__ bsel = chain_only ? bu : bd;
+        double la[C], lb[C];
 #pragma unroll
-    for (int i = 0; i < C; ++i) {
-        av[i] = 0.0; bv[i] = 1.0;
-        const int e = t * C + i;
-        if (e < n) {
-            const int k = i * kTriThreads + t;
-            const double a = ba[k];
-            const double b = chain_only ? -(a + bu[k]) : bd[k];
-            av[i] = a; bv[i] = b + sigma;
-            M = mob_mul(Mob{bv[i], -a * a, 1.0, 0.0}, M);
+        for (int i = 0; i < C; ++i) { const int k = i * kTriThreads + t; la[i] = ba[k]; lb[i] = bsel[k]; }
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            av[i] = 0.0; bv[i] = 1.0;
+            const int e = t * C + i;
+            if (e < n) {
+                const double a = la[i];
+                const double b = chain_only ? -(a + lb[i]) : lb[i];
+                av[i] = a; bv[i] = b + sigma;
+                M = mob_mul(Mob{bv[i], -a * a, 1.0, 0.0}, M);
+            }
         }
     }
     s_afirst[t] = av[0];

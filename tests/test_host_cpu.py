@@ -166,3 +166,15 @@ def test_graft_entry_build_runs():
     import importlib
     ge = importlib.import_module("__graft_entry__")
     ge.build()
+
+
+def test_bench_refuses_to_launch_ranks_without_devices():
+    """bench.py --gpus 2 on a box with fewer than two GPUs (here: none) must refuse loudly instead of printing a line."""
+    import subprocess
+    import sys
+    if _lib.device_count() >= 2:
+        pytest.skip("two GPUs present")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "MACHIP_SHARE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "c3"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout) and '"metric"' not in r.stdout
