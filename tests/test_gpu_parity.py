@@ -1328,3 +1328,41 @@ def test_trajectory_is_bit_reproducible_run_to_run():
             runs.append((np.array(fs), st, P.get_x()))
             P.close()
         assert np.array_equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1] and np.array_equal(runs[0][2], runs[1][2]), nm
+
+
+def test_new_entry_points_reject_bad_arguments():
+    """BAD_ARG (-> AssertionError, like the reference's asserts) instead of undefined behaviour on the round-2 entry points."""
+    g = load_golden("er300_solve")
+    P = problem_of(g)
+    m = len(g["cw"])
+    with pytest.raises(AssertionError):
+        P.set_precision(2)
+    with pytest.raises(AssertionError):
+        _lib.shard_plan(10, 0, 0)
+    with pytest.raises(AssertionError):
+        _lib.shard_plan(10, 4, 4)
+    lam, st = P.eval_batch(np.zeros((0, m)))                      # empty batch is fine
+    assert lam.shape == (0,)
+    with pytest.raises(AssertionError):
+        P.eval_batch(np.zeros((2, m + 1)))                         # wrong width (caught by the binding)
+    Q = problem_of(load_golden("er2000_solve"))
+    with pytest.raises(AssertionError):
+        _lib.comm_init_local([P, Q])                               # handles of different problems
+    _lib.comm_init_local([P])                                      # a group of one is legal ...
+    with pytest.raises(AssertionError):
+        _lib.comm_init_local([P])                                  # ... joining twice is not
+    P.set_x(g["x_init"])
+    f, d, gn = P.fw_step(int(g["k"]), 0)                           # and a one-rank group behaves like no group
+    assert abs(f - g["f_traj"][0]) <= LAM_RTOL * g["f_traj"][0]
+    # more vectors than lanes, mixed precision lanes, order independence
+    P2 = problem_of(load_golden("g2o_sphere2500")); g2 = load_golden("g2o_sphere2500")
+    P2.set_start(reference_start_block(int(g2["n"]))[:, 0].copy())
+    X = np.stack([g2["x_init"], g2["rounded"], g2["unrounded"]] * 7)           # 21 > 8 lanes
+    lam64, st64 = P2.eval_batch(X)
+    assert np.all(st64 == 0) and np.array_equal(lam64[:3], lam64[3:6]) and np.array_equal(lam64[:3], lam64[18:21])
+    P2.set_precision(1)
+    lam32, st32 = P2.eval_batch(X)
+    assert np.all(st32 == 0) and np.allclose(lam32, lam64, rtol=1e-8)
+    assert abs(lam64[0] - g2["lam_init"]) <= LAM_RTOL * g2["lam_init"]
+    for h in (P, Q, P2):
+        h.close()
