@@ -48,7 +48,7 @@ using PersistView = PersistViewT<double>;
 // nc_max: upper bound of the entries outside the tridiagonal band (the band itself lives in registers)
 inline bool persist_fits(int n, long nc_max) {
     return n <= kPersistThreads * kPersistMaxRows && nc_max >= 0 &&
-           (size_t)nc_max * 12 + (size_t)n * 8 + ((size_t)n + 2) * 4 + 64 <= (size_t)kPersistPool;
+           (size_t)nc_max * 20 + (size_t)n * 8 + ((size_t)n + 2) * 4 + 64 <= (size_t)kPersistPool;   // col 4 + val 8 + product 8 per overflow entry
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
@@ -173,6 +173,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_lan_persist(CsrView A, Pers
     const int nc = crow[n];
     int* ccol = crow + (n + 1);
     T* cval = reinterpret_cast<T*>(pool + (((size_t)n * 8 + ((size_t)n + 1 + (size_t)nc) * 4 + 7) & ~(size_t)7));
+    T* cprod = reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(cval) + (size_t)nc * 8);   // products of the overflow entries (per step)
     bool any_over = false;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
@@ -250,13 +251,22 @@ __global__ __launch_bounds__(kPersistThreads) void k_lan_persist(CsrView A, Pers
             if (r < n) w += lo[k] * svec[rm] + up[k] * svec[rp] + c0v[k] * svec[c0c[k]] + c1v[k] * svec[c1c[k]];
             u[k] = w;
         }
-        if (any_over) {
+        if (nc > 0) {   // workgroup-uniform
+            // Round 2: the entries beyond a row's two register slots used to be walked by the row's thread -- three
+            // dependent LDS reads per entry (column -> operand, value), a hub row of 10 entries holding up its wave and,
+            // at the next barrier, the workgroup (tools/ubench_persist.hip, 600 closures on 1 728 nodes: 2 360 of a step's
+            // 5 400 cycles).  Now all threads form the products of the flat entry list (gathers in parallel, perfectly
+            // balanced), and after one more LDS barrier the row's thread only adds its segment, in the same order as before.
+            for (int e = t; e < nc; e += kPersistThreads) cprod[e] = cval[e] * svec[ccol[e]];
+            lds_barrier();
+            if (any_over) {
 #pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                const int r = t + k * kPersistThreads;
-                if (r < n) {
-                    const int b = crow[r], e = crow[r + 1];
-                    for (int p = b; p < e; ++p) u[k] += cval[p] * svec[ccol[p]];
+                for (int k = 0; k < RPT; ++k) {
+                    const int r = t + k * kPersistThreads;
+                    if (r < n) {
+                        const int b = crow[r], e = crow[r + 1];
+                        for (int p = b; p < e; ++p) u[k] += cprod[p];
+                    }
                 }
             }
         }
