@@ -632,7 +632,7 @@ struct Solver {
     // factorisation then costs tens of ms -- against seconds, or no convergence at all: fuzz seed 129, n = 36 874,
     // 3 900 active closures, lambda_2 / ||L|| = 1e-10: 200 000 iterations without converging -> 27 iterations, 36 ms).
     int wb_soft() const { return std::max(64, std::min(16384, env_int("MACHIP_WB_MAX", kWbMaxS))); }
-    int wb_hard() const { return std::max(wb_soft(), std::min(16384, env_int("MACHIP_WB_HARD", 8192))); }
+    int wb_hard() const { return std::max(wb_soft(), std::min(16384, env_int("MACHIP_WB_HARD", 16384))); }   // (11 600 closures on 30 000 nodes at lambda_2/||L|| = 3e-9: 0.30 s escalated against 0.75-0.9 s)
     int wb_limit_now = kWbMaxS;   // the tier this solve_lob call may use
     bool lob_escalate = false;    // set by solve_lob when it gives up early in favour of the exact preconditioner
     int wb_cap_s = 0;      // what the buffers below were sized for

@@ -1213,7 +1213,7 @@ def test_exact_preconditioner_on_a_large_chain_with_weak_links():
 def test_stiff_chain_with_thousands_of_closures_escalates_to_the_exact_preconditioner():
     """Fuzz seed 129 of tools/fuzz_modes.py (round 1's non-converging class: > 2 048 active closures AND
     lambda_2 / ||L||_inf ~ 1e-10; n = 36 874, 5 568 closures of which ~3 900 active): the tridiagonal preconditioner
-    crawls, the solve escalates to the exact (Woodbury) one -- second tier, up to 8 192 closures -- and converges in
+    crawls, the solve escalates to the exact (Woodbury) one -- second tier, up to 16 384 closures -- and converges in
     a few dozen iterations, in the automatic mode; residual checked with SciPy's SpMV, lambda_2 against SciPy's
     shift-invert Lanczos."""
     import scipy.sparse.linalg as spla
