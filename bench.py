@@ -216,7 +216,7 @@ def cpu_baseline_bounded(cfg, fiedler, budget_s, hard_s):
 # ---------------------------------------------------------------------------------------------
 # PMC traffic of the dominant kernel: two short rocprofv3 passes of this same script
 # ---------------------------------------------------------------------------------------------
-def pmc_traffic(cfg, steps, precision=0, timeout_s=300):
+def pmc_traffic(cfg, steps, precision=0, timeout_s=150):
     """HBM bytes per launch of the fused step kernel = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes), each counter from
     its own `rocprofv3 --pmc` pass (MI355X_MICROARCH.md: FETCH_SIZE on gfx950 tallies 128-byte requests at 64 B)
     of `bench.py --config cfg --steps K --warmup 0 --pmc-child`: the SAME K iterations from x0 as a timed pass, so the
