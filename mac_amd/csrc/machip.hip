@@ -297,6 +297,7 @@ int run_fiedler(machip_problem* p, double tol, int max_steps, const double* x0, 
     machip_solve_stats local;
     memset(&local, 0, sizeof(local));
     p->sol.maxlen_hint = p->maxlen;
+    p->sol.pan_allowed = !p->csr_only;     // panel.h walks rows as this library assembles them (diagonal first)
     p->sol.support_hint = (p->csr_only && !p->sol.chain_like) ? -1 : p->support;
     const int st = p->sol.solve(p->csr(), p->nnz, p->lnorm, tol, max_steps, (x0 == nullptr && warm_start) ? 1 : 0,
                                 kAuto, lambda2, &local);

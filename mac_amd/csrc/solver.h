@@ -22,6 +22,7 @@
 #include "persist.h"
 #include "precond.h"
 #include "woodbury.h"
+#include "panel.h"
 #include "tridiag.h"
 
 namespace machip {
@@ -34,7 +35,7 @@ inline int dev_alloc(T** p, size_t count) {
     return MACHIP_OK;
 }
 
-enum SpmvVariant { kAuto = 0, kStream = 1, kVec = 2 };
+enum SpmvVariant { kAuto = 0, kStream = 1, kVec = 2, kPanel = 3 };
 
 struct SpmvPlan {
     int variant = kVec;   // kStream or kVec
@@ -132,6 +133,41 @@ inline SpmvPlan plan_pipe(int n, long nnz, int maxlen) {
     // is then hidden); with one tile per workgroup that only costs registers
     pl.defer = env_int("MACHIP_DEFER", tiles > 2L * pl.grid ? 3 : 1);
     return pl;
+}
+
+// Column-panel step (panel.h): shape of the panel form for a matrix of n rows.  NP panels of C <= 16 384 columns (8 bytes
+// per column in LDS), NB row blocks of TPB 64-row tiles, NB * NP <= 256 workgroups (one per CU: the panel takes most of
+// the CU's LDS).  Panel loads cost NB x 16 n bytes of coalesced L2 traffic per step, the partials 2 x NP x 8 n bytes: the
+// defaults balance the two (MACHIP_PANEL_NP / MACHIP_PANEL_NB override; swept on MI355X, profiles/r3_c4_panel.md).
+struct PanPlan {
+    bool on = false;
+    int NP = 1, C = 1, NB = 1, TPB = 1, RPT = 1;
+    int grid2 = 1, block2 = 256;     // launch shape of k_pan_fin
+};
+inline PanPlan plan_panel(int n, long nnz, int maxlen, bool allowed) {
+    PanPlan pp;
+    const int mode = env_int("MACHIP_PANEL", -1);     // -1 auto, 0 off, 1 forced (tests: small graphs with several panels)
+    if (!allowed || mode == 0 || n < 128) return pp;
+    const double mean = (double)nnz / (double)std::max(n, 1);
+    // automatic: the operand must be too large for the gather path's caches to serve cheaply (measured cross-over) and
+    // the rows must not be dominated by hubs (a lane walks its row's entries of a panel one by one)
+    if (mode < 0 && !(n >= env_int("MACHIP_PANEL_MIN_N", 65536) && n <= 400000 && mean >= 6.0 && (double)maxlen <= 16.0 * mean + 64.0)) return pp;
+    int np = env_int("MACHIP_PANEL_NP", (n + 8447) / 8448);
+    np = std::max(1, std::min(np, 64));
+    int C = (n + np - 1) / np;
+    if (C > 16 * 1024) { np = (n + 16 * 1024 - 1) / (16 * 1024); C = (n + np - 1) / np; }
+    if (np > 64) return pp;
+    np = (n + C - 1) / C;                              // panels that actually hold columns
+    const int groups = (n + 63) / 64;
+    int nb = env_int("MACHIP_PANEL_NB", std::max(1, grid_cap() / np));
+    nb = std::max(1, std::min(nb, groups));
+    const int tpb = (groups + nb - 1) / nb;
+    nb = (groups + tpb - 1) / tpb;
+    pp.on = true; pp.NP = np; pp.C = C; pp.NB = nb; pp.TPB = tpb; pp.RPT = (C + 1023) / 1024;
+    pp.block2 = env_int("MACHIP_PANEL_B2", 256);
+    if (pp.block2 != 256 && pp.block2 != 512 && pp.block2 != 1024) pp.block2 = 256;
+    pp.grid2 = (int)std::max<long>(1, std::min<long>(env_int("MACHIP_PANEL_G2", grid_cap()), ((long)n + pp.block2 - 1) / pp.block2));
+    return pp;
 }
 
 template <class Op>
@@ -287,6 +323,11 @@ struct Solver {
     long support_hint = -1;     // active candidate edges of the matrix about to be solved (-1 = unknown)
     long hist_lan_steps = -1, hist_lob_iters = -1;   // steps / iterations of the last solve in each mode
     static constexpr int kLobCap = 100000;
+    // column-panel step (panel.h): the panel form of the matrix being solved, rebuilt per solve from its CSR
+    bool pan_allowed = false;   // the CSR is one this library assembled (diagonal first, other columns ascending)
+    PanPlan pan;
+    PanView panv{};
+    size_t pan_cap = 0, pan_nt_cap = 0, pan_y_cap = 0;
 
     int init(int n_, hipStream_t s) {
         n = n_;
@@ -335,6 +376,10 @@ struct Solver {
                         lx_x, lx_Lx, lx_p, lx_Lp, lx_Lw, lx_rT, lx_wT, lx_tl, lx_tdinv, lx_tcu, lx_part, lx_partR,
                         lx_ys, lx_pas, lx_as, lx_bs, lx_maps, lx_ba, lx_bd, lx_bu, wb_ui, wb_uj, wb_counts, wb_uc, wb_g, wb_h, wb_Zt, wb_Cm, wb_pas, wb_maps,
                         lx_colT, lx_bad, lx_st, valf};
+        {
+            void* pb[] = {panv.tptr, panv.tlen, panv.bval, panv.bcol, panv.ypart, panv.coef, panv.tcount};
+            for (void* q : pb) if (q) (void)hipFree(q);
+        }
         if (h_lrec) (void)hipHostFree(h_lrec);
         if (wb_handle) (void)rocblas_destroy_handle(wb_handle);
         for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -405,8 +450,61 @@ struct Solver {
         if (f32) launch_persist_t<float>(A, steps); else launch_persist_t<double>(A, steps);
     }
 
+    // ---- column-panel step (panel.h) ---------------------------------------------------------------
+    // (Re)build the panel form of A on the stream: buffers grow on demand (cached chunk graphs carry their addresses).
+    int ensure_panel(const CsrView& A, long nnz, const PanPlan& pn) {
+        const size_t NT = (size_t)pn.NB * pn.NP * pn.TPB;
+        bool dropped = false;
+        auto regrow = [&](auto** ptr, size_t count) -> int {
+            if (*ptr) { if (!dropped) { HIP_TRY(hipStreamSynchronize(stream)); drop_graphs(); dropped = true; } (void)hipFree(*ptr); *ptr = nullptr; }
+            return dev_alloc(ptr, count);
+        };
+        if (NT > pan_nt_cap) {
+            ST_TRY(regrow(&panv.tptr, NT + 1)); ST_TRY(regrow(&panv.tcount, NT)); ST_TRY(regrow(&panv.tlen, NT * 64));
+            pan_nt_cap = NT;
+        }
+        if ((size_t)nnz > pan_cap) {
+            const size_t want = std::max<size_t>((size_t)nnz + (size_t)nnz / 2 + 1024, csr_cap);
+            ST_TRY(regrow(&panv.bval, want)); ST_TRY(regrow(&panv.bcol, want));
+            pan_cap = want;
+        }
+        if ((size_t)pn.NP * (size_t)n > pan_y_cap) {
+            ST_TRY(regrow(&panv.ypart, (size_t)pn.NP * (size_t)n));
+            pan_y_cap = (size_t)pn.NP * (size_t)n;
+        }
+        if (!panv.coef) ST_TRY(dev_alloc(&panv.coef, 8));
+        panv.n = n; panv.NP = pn.NP; panv.C = pn.C; panv.NB = pn.NB; panv.TPB = pn.TPB;
+        const int groups = pn.NB * pn.TPB;
+        const int gg = (groups + (kBlock / 64) - 1) / (kBlock / 64);
+        k_pan_count<<<gg, kBlock, 0, stream>>>(A, panv);
+        k_pan_scan<<<1, 1024, 0, stream>>>(panv);
+        k_pan_fill<<<gg, kBlock, 0, stream>>>(A, panv);
+        HIP_TRY(hipGetLastError());
+        return MACHIP_OK;
+    }
+    void launch_pan_step(const PipeView& L, int s) {
+        const int g1 = pan.NB * pan.NP;
+        switch (pan.RPT) {
+#define MACHIP_PAN_CASE(R) case R: k_pan_mul<R><<<g1, kPanThreads, 0, stream>>>(panv, L, s); break;
+            MACHIP_PAN_CASE(1) MACHIP_PAN_CASE(2) MACHIP_PAN_CASE(3) MACHIP_PAN_CASE(4) MACHIP_PAN_CASE(5) MACHIP_PAN_CASE(6)
+            MACHIP_PAN_CASE(7) MACHIP_PAN_CASE(8) MACHIP_PAN_CASE(9) MACHIP_PAN_CASE(10) MACHIP_PAN_CASE(11) MACHIP_PAN_CASE(12)
+            MACHIP_PAN_CASE(13) MACHIP_PAN_CASE(14) MACHIP_PAN_CASE(15)
+#undef MACHIP_PAN_CASE
+            default: k_pan_mul<16><<<g1, kPanThreads, 0, stream>>>(panv, L, s); break;
+        }
+        if (pan.block2 == 1024) k_pan_fin<1024><<<pan.grid2, 1024, 0, stream>>>(panv, L, s);
+        else if (pan.block2 == 512) k_pan_fin<512><<<pan.grid2, 512, 0, stream>>>(panv, L, s);
+        else k_pan_fin<256><<<pan.grid2, 256, 0, stream>>>(panv, L, s);
+    }
+
     // ---- one chunk = `steps` step kernels + the tail kernel ------------------------------------
     void launch_chunk(const CsrView& A, const SpmvPlan& pl, int steps, bool f32 = false) {
+        if (pl.variant == kPanel) {
+            const PipeView L = pview(pl);
+            for (int s = 0; s < steps; ++s) launch_pan_step(L, s);
+            k_pipe_tail<<<1, 64, 0, stream>>>(L, steps);
+            return;
+        }
         if (f32) {
             const PipeViewT<float> L = pview<float>(pl);
             const CsrViewT<float> Af{A.n, A.rowptr, A.col, valf};
@@ -925,7 +1023,7 @@ struct Solver {
     int solve_lanczos(const CsrView& A, long nnz, double lnorm, double tol, int max_steps, int start_mode,
                       int forced_variant, double* lambda2, machip_solve_stats* stats) {
         const SpmvPlan pl = plan_spmv(n, nnz, forced_variant);   // explicit-check kernels
-        const SpmvPlan pp = plan_pipe(n, nnz, maxlen_hint);      // fused Lanczos-step kernel
+        SpmvPlan pp = plan_pipe(n, nnz, maxlen_hint);            // fused Lanczos-step kernel
         const int g2 = vgrid();
         HIP_TRY(hipEventRecord(ev0, stream));
         if (max_steps <= 0) max_steps = 200000;
@@ -950,13 +1048,20 @@ struct Solver {
         const int chunk_near = std::min(chunk0, std::max(2, env_int("MACHIP_CHUNK_NEAR", 8) & ~1));   // once the residual estimate is within 1e3 of the target
         if (max_steps & 1) ++max_steps;
         const double trigger_slack = 1.5;   // run the explicit check a little early rather than late
-        const PipeView L = pview(pp);
         std::deque<Pending> pend;
         bool done = false;
 
         bool classic = n <= env_int("MACHIP_CLASSIC_N", 256);
         // LDS-resident single-workgroup form when the matrix fits (classic recurrence: also fine after restarts)
         const bool pmode = env_int("MACHIP_PERSIST", 1) != 0 && chain_like && persist_fits(n, nnz - n - 2 * chain_edges);
+        // column-panel step (panel.h) where the gather operand is too large for the caches (fp64 sequences only)
+        pan = plan_panel(n, nnz, maxlen_hint, pan_allowed && precision == 0 && !pmode && !classic && pp.variant == kVec);
+        if (pan.on) {
+            ST_TRY(ensure_panel(A, nnz, pan));
+            pp.variant = kPanel; pp.grid = pan.grid2; pp.block = pan.block2;
+            pp.width = pan.NP * 100 + pan.RPT; pp.unroll = 0; pp.defer = pan.NB;
+        }
+        const PipeView L = pview(pp);
         const int pchunk0 = std::min(kPersistMaxSteps, std::max(2, env_int("MACHIP_PCHUNK", 64)));
         const bool debug = env_int("MACHIP_DEBUG", 0) != 0;
         // ---- mixed precision (machip_set_precision(1)): the FIRST Krylov sequence stores matrix values, records and

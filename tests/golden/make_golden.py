@@ -237,6 +237,70 @@ def er100k_x0(meta):
     meta["er100k_x0"] = {"lam": lam, "residual": float(res), "nnz": int(L.nnz)}
 
 
+def _er_problem(n, p, seed=0):
+    G = nx.fast_gnp_random_graph(n, p, seed=seed)
+    fixed = [Edge(a, a + 1, 1.0) for a in range(n - 1)]
+    cand = [Edge(min(a, b), max(a, b), 1.0) for (a, b) in G.edges() if abs(a - b) != 1]
+    m_ = len(cand); k = m_ // 10
+    x0 = np.zeros(m_); x0[np.random.default_rng(0).choice(m_, k, replace=False)] = 1.0
+    return fixed, cand, m_, k, x0
+
+
+def er10k_vertices(meta):
+    """BASELINE.json configs[1], teacher forcing: the reference's own 20 Frank-Wolfe iterations from the bench's
+    x0 with EVERY LP vertex stored (bit-packed 0/1 rows), lambda_2 per iterate and the relative gap between the
+    K-th and K+1-th gradient entries.  x_i is reconstructible: x_{i+1} = x_i + 2/(i+2) (s_i - x_i).  About two
+    hours of SuperLU here."""
+    from mac.optimization.constraints import solve_subset_box_lp
+    n = 10000
+    fixed, cand, m_, k, x = _er_problem(n, 0.01)
+    mac = MAC(fixed, cand, n)
+    iters = int(os.environ.get("ER10K_ITERS", "20"))
+    fs, ss, gaps, gsum = [], [], [], []
+    for it in range(iters):
+        f, g = mac.problem(x)
+        s = solve_subset_box_lp(g, k)
+        order = np.argsort(-g, kind="stable")
+        gaps.append((g[order[k - 1]] - g[order[k]]) / g[order[k - 1]])
+        fs.append(f); ss.append(np.packbits(s > 0.5)); gsum.append(g.sum())
+        print("er10k_vertices", it, f, gaps[-1], flush=True)
+        x = x + 2.0 / (it + 2) * (s - x)
+    save("er10k_vertices", n=n, m=m_, k=k, f_traj=np.array(fs), ref_s_bits=np.array(ss), ref_gap_rel=np.array(gaps),
+         grad_sum=np.array(gsum))
+    meta["er10k_vertices"] = {"iters": iters, "min_ref_gap_rel": float(np.min(gaps))}
+
+
+def er100k_arpack(meta):
+    """BASELINE.json configs[3], teacher forcing: the reference's TraceMIN + SuperLU does not finish at this size
+    (SURVEY 6.2), so the eigen-solve is SciPy's ARPACK Lanczos (tol 1e-13) on the REFERENCE's own
+    MAC.laplacian(x_i); gradient formula of mac.py:117-124 (vectorised), the reference's solve_subset_box_lp and
+    the reference's update.  Stores lambda_2, the ARPACK residual and the bit-packed LP vertex of the first
+    ER100K_ITERS (default 6) iterates."""
+    import scipy.sparse.linalg as spla
+    from mac.optimization.constraints import solve_subset_box_lp
+    n = 100000
+    fixed, cand, m_, k, x = _er_problem(n, 2.0e6 / (n * (n - 1) / 2))
+    mac = MAC(fixed, cand, n)
+    iters = int(os.environ.get("ER100K_ITERS", "6"))
+    lams, ress, ss, gaps, nnzs = [], [], [], [], []
+    for it in range(iters):
+        L = mac.laplacian(x)
+        w, V = spla.eigsh(L, k=2, which="SA", tol=1e-13, ncv=128, v0=np.random.RandomState(7).normal(size=n))
+        o = np.argsort(w)
+        lam, v = float(w[o[1]]), V[:, o[1]]
+        res = np.abs(L @ v - lam * v).sum() / abs(L).sum(axis=1).max()
+        g = mac.weights * (v[mac.edge_list[:, 0]] - v[mac.edge_list[:, 1]]) ** 2
+        s = solve_subset_box_lp(g, k)
+        order = np.argsort(-g, kind="stable")
+        gaps.append((g[order[k - 1]] - g[order[k]]) / g[order[k - 1]])
+        lams.append(lam); ress.append(res); ss.append(np.packbits(s > 0.5)); nnzs.append(L.nnz)
+        print("er100k_arpack", it, lam, res, gaps[-1], L.nnz, flush=True)
+        x = x + 2.0 / (it + 2) * (s - x)
+    save("er100k_arpack", n=n, m=m_, k=k, lam_traj=np.array(lams), residual=np.array(ress), ref_s_bits=np.array(ss),
+         ref_gap_rel=np.array(gaps), nnz=np.array(nnzs))
+    meta["er100k_arpack"] = {"iters": iters, "lam": [float(t) for t in lams], "max_residual": float(np.max(ress))}
+
+
 def main(only=None):
     meta_path = os.path.join(OUT, "golden_meta.json")
     if only and os.path.exists(meta_path):
@@ -253,6 +317,10 @@ def main(only=None):
         return er100k_x0(meta), json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
     if only == "city10000_vertices":
         return city10000_vertices(meta), json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
+    if only == "er10k_vertices":
+        return er10k_vertices(meta), json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
+    if only == "er100k_arpack":
+        return er100k_arpack(meta), json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
     if only == "g2o_extra":
         return g2o_cases(meta, [("kitti_05", 20)]), json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
 

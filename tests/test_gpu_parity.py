@@ -787,6 +787,10 @@ def test_full_size_config4_properties():
     {"MACHIP_G": "64", "MACHIP_BLOCK": "512"}, {"MACHIP_G": "32", "MACHIP_MAXGRID": "64"},
     {"MACHIP_GRAPH": "0", "MACHIP_CHUNK": "6", "MACHIP_CHUNK_NEAR": "2"}, {"MACHIP_CLASSIC_N": "100000"},
     {"MACHIP_VCAP": "80"}, {"MACHIP_ASM_G": "8"}, {"MACHIP_ASM_G": "32", "MACHIP_G": "8", "MACHIP_UNROLL": "1"},
+    # column-panel step (panel.h) forced onto small graphs: several panels / row blocks, ragged last panel and tile
+    {"MACHIP_PANEL": "1", "MACHIP_PANEL_NP": "3"}, {"MACHIP_PANEL": "1", "MACHIP_PANEL_NP": "1", "MACHIP_PANEL_NB": "2"},
+    {"MACHIP_PANEL": "1", "MACHIP_PANEL_NP": "5", "MACHIP_PANEL_NB": "7", "MACHIP_PANEL_B2": "512", "MACHIP_PANEL_G2": "3"},
+    {"MACHIP_PANEL": "1", "MACHIP_PANEL_NP": "7", "MACHIP_GRAPH": "0", "MACHIP_CHUNK": "6", "MACHIP_PANEL_B2": "1024"},
 ])
 def test_solver_variants_agree(env):
     """Every launch shape / row mapping of the fused step kernel, eager vs graph launches, odd chunk

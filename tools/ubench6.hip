@@ -1,0 +1,103 @@
+// tools/ubench6.hip -- where does the column-panel Lanczos step (panel.h) spend its time?  k_pan_mul compiled with
+// PAN_CLOCKS (100 MHz wall-clock stamps per workgroup), run as REAL consecutive steps (k_pan_mul + k_pan_fin) on
+// config-4-like matrices; the panel form is built by the library's own k_pan_count/scan/fill.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench6.hip -o /tmp/ubench6 && /tmp/ubench6 [NP NB]
+#define PIPE_CLOCKS 1
+#define PAN_CLOCKS 1
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+#include "../mac_amd/csrc/panel.h"
+namespace machip { thread_local std::string g_err; }
+using namespace machip;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+template <int RPT>
+void run(PanView P, PipeView L, hipStream_t s, long nnz, std::vector<double>& u0h) {
+    const int g1 = P.NB * P.NP, g2 = 256;
+    L.P = g2;
+    double* u0; CK(hipMalloc(&u0, P.n * 8)); CK(hipMemcpy(u0, u0h.data(), P.n * 8, hipMemcpyHostToDevice));
+    k_pipe_init<<<g2, kBlock, 0, s>>>(L, u0, 1);
+    hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
+    const int steps = 40;
+    for (int j = 0; j < 8; ++j) { k_pan_mul<RPT><<<g1, kPanThreads, 0, s>>>(P, L, j); k_pan_fin<256><<<g2, 256, 0, s>>>(P, L, j); }
+    CK(hipEventRecord(e0, s));
+    for (int j = 8; j < 8 + steps; ++j) { k_pan_mul<RPT><<<g1, kPanThreads, 0, s>>>(P, L, j); k_pan_fin<256><<<g2, 256, 0, s>>>(P, L, j); }
+    CK(hipEventRecord(e1, s));
+    for (int j = 0; j < steps; ++j) k_pan_mul<RPT><<<g1, kPanThreads, 0, s>>>(P, L, 1);     // K1 alone, back to back (same operand)
+    CK(hipEventRecord(e2, s)); CK(hipEventSynchronize(e2));
+    float ms, ms2; CK(hipEventElapsedTime(&ms, e0, e1)); CK(hipEventElapsedTime(&ms2, e1, e2));
+    CK(hipGetLastError());
+    std::vector<long long> c((size_t)g1 * 16);
+    CK(hipMemcpy(c.data(), P.clk, c.size() * 8, hipMemcpyDeviceToHost));
+    long long t0 = c[0];
+    for (int b = 0; b < g1; ++b) t0 = std::min(t0, c[(size_t)b * 16]);
+    auto stat = [&](int i, const char* what) {
+        double mn = 1e30, mx = 0, av = 0;
+        for (int b = 0; b < g1; ++b) { const double v = (c[(size_t)b * 16 + i] - t0) * 0.01; mn = std::min(mn, v); mx = std::max(mx, v); av += v; }
+        printf("      %-52s min %6.2f  mean %6.2f  max %6.2f us\n", what, mn, av / g1, mx);
+    };
+    printf("   NP=%d C=%d NB=%d TPB=%d RPT=%d grid=%d: %.2f us per step (mul+fin), mul alone %.2f us (nnz %ld)\n", P.NP, P.C, P.NB, P.TPB, RPT, g1, 1e3 * ms / steps, 1e3 * ms2 / steps, nnz);
+    stat(0, "workgroup entry (wave 0)"); stat(1, "wave 1 entry"); stat(2, "records + tile heads arrived (wave 1)"); stat(3, "prologue done (wave 0)");
+    stat(4, "barrier 1 passed"); stat(5, "panel in LDS, barrier 2 passed"); stat(6, "first entry batch consumed (wave 1)");
+    stat(7, "first tile group done (wave 1)"); stat(8, "wave 1 done"); stat(9, "wave 15 done");
+    CK(hipFree(u0));
+}
+
+int main(int argc, char** argv) {
+    hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    const int NPa = argc > 1 ? atoi(argv[1]) : 12, NBa = argc > 2 ? atoi(argv[2]) : 21;
+    for (double deg : {6.0, 26.0, 40.0}) {
+        const int n = 100000;
+        std::mt19937_64 rng(7);
+        std::vector<std::vector<int>> adj((size_t)n);
+        for (int i = 0; i + 1 < n; ++i) { adj[i].push_back(i + 1); adj[i + 1].push_back(i); }
+        for (long k = 0; k < (long)(deg * n / 2); ++k) { int a = (int)(rng() % n), b = (int)(rng() % n); if (a != b) { adj[a].push_back(b); adj[b].push_back(a); } }
+        std::vector<int> rp(n + 1, 0), col; std::vector<double> val;
+        for (int r = 0; r < n; ++r) {
+            auto& v = adj[r]; std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end());
+            col.push_back(r); val.push_back((double)v.size());
+            for (int c : v) { col.push_back(c); val.push_back(-1.0); }
+            rp[r + 1] = (int)col.size();
+        }
+        const long nnz = (long)col.size();
+        int *drp, *dcol; double* dval;
+        CK(hipMalloc(&drp, (n + 1) * 4)); CK(hipMalloc(&dcol, nnz * 4)); CK(hipMalloc(&dval, nnz * 8));
+        CK(hipMemcpy(drp, rp.data(), (n + 1) * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dcol, col.data(), nnz * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dval, val.data(), nnz * 8, hipMemcpyHostToDevice));
+        CsrView A{n, drp, dcol, dval};
+        PipeView L; L.n = n;
+        CK(hipMalloc(&L.st, sizeof(LanState))); CK(hipMemset(L.st, 0, sizeof(LanState)));
+        CK(hipMalloc(&L.Z0, n * sizeof(Z2))); CK(hipMalloc(&L.Z1, n * sizeof(Z2)));
+        CK(hipMalloc(&L.V, (size_t)n * 8 * 64)); CK(hipMalloc(&L.tri, 8 * 3 * 80));
+        CK(hipMalloc(&L.part, 16 * kNP * kMaxGrid)); CK(hipMemset(L.part, 0, 16 * kNP * kMaxGrid));
+        CK(hipMalloc(&L.clk, 8 * 8 * kMaxGrid)); CK(hipMemset(L.clk, 0, 8 * 8 * kMaxGrid));
+        L.htri = nullptr; L.hflag = nullptr; L.P = 256;
+        PanView P; P.n = n; P.NP = NPa; P.C = (n + P.NP - 1) / P.NP; P.NP = (n + P.C - 1) / P.C;
+        const int groups = (n + 63) / 64;
+        P.TPB = (groups + NBa - 1) / NBa; P.NB = (groups + P.TPB - 1) / P.TPB;
+        const size_t NT = (size_t)P.NB * P.NP * P.TPB;
+        CK(hipMalloc(&P.tptr, (NT + 1) * 4)); CK(hipMalloc(&P.tcount, NT * 4)); CK(hipMalloc(&P.tlen, NT * 64 * 2));
+        CK(hipMalloc(&P.bval, (nnz + 1024) * 8)); CK(hipMalloc(&P.bcol, (nnz + 1024) * 2)); CK(hipMalloc(&P.ypart, (size_t)P.NP * n * 8));
+        CK(hipMalloc(&P.coef, 64)); CK(hipMalloc(&P.clk, 16 * 8 * kMaxGrid)); CK(hipMemset(P.clk, 0, 16 * 8 * kMaxGrid));
+        const int gg = (P.NB * P.TPB + 3) / 4;
+        hipEvent_t a0, a1; CK(hipEventCreate(&a0)); CK(hipEventCreate(&a1));
+        CK(hipEventRecord(a0, s));
+        k_pan_count<<<gg, kBlock, 0, s>>>(A, P); k_pan_scan<<<1, 1024, 0, s>>>(P); k_pan_fill<<<gg, kBlock, 0, s>>>(A, P);
+        CK(hipEventRecord(a1, s)); CK(hipEventSynchronize(a1));
+        float bms; CK(hipEventElapsedTime(&bms, a0, a1));
+        std::vector<double> u0((size_t)n); for (int i = 0; i < n; ++i) u0[i] = (double)((i * 2654435761u) % 1000) / 500.0 - 1.0;
+        printf("== n=%d mean row %.1f nnz=%ld   panel form built in %.1f us\n", n, (double)nnz / n, nnz, 1e3 * bms);
+        const int RPT = (P.C + 1023) / 1024;
+        switch (RPT) {
+            case 5: run<5>(P, L, s, nnz, u0); break; case 6: run<6>(P, L, s, nnz, u0); break; case 7: run<7>(P, L, s, nnz, u0); break;
+            case 8: run<8>(P, L, s, nnz, u0); break; case 9: run<9>(P, L, s, nnz, u0); break; case 10: run<10>(P, L, s, nnz, u0); break;
+            case 12: run<12>(P, L, s, nnz, u0); break; case 13: run<13>(P, L, s, nnz, u0); break; case 14: run<14>(P, L, s, nnz, u0); break;
+            default: printf("RPT %d not instantiated\n", RPT); break;
+        }
+        CK(hipFree(drp)); CK(hipFree(dcol)); CK(hipFree(dval));
+    }
+    return 0;
+}
