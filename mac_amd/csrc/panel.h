@@ -6,39 +6,62 @@
 // outstanding-miss capacity times the L2 latency bounds the step at ~22 us -- 0.22 of the HBM roofline.  Here the gather
 // target is LDS instead:
 //   * L(x) is kept a second time in PANEL FORM: NB row blocks x NP column panels; workgroup (b, p) owns the entries of
-//     row block b whose column lies in panel p (~nnz / 256 of them), stored per 64-row tile in a jagged, lane-major
-//     order (entry i of lane l at  tile base + #{(l', i') : i' < i or (i' = i and l' < l), len(l') > i'}), so that a
-//     wave streams them with perfectly coalesced loads and every lane accumulates ITS OWN row: no shuffles, no
-//     staging, no atomics, a fixed summation order.
-//   * k_pan_mul (workgroup (b, p), 1024 threads): bulk-loads the panel's records {t_{j-1}, v_{j-1}} with coalesced
-//     16-byte loads while wave 0 finishes step j-1's reductions, turns them into v_j with the coefficients (8 bytes per
-//     column in LDS: a panel of up to 16 384 columns), then streams its tiles: y_p[r] = sum_{c in panel p} L[r,c] v_j[c]
-//     with the gathers served by LDS.  One 8-byte partial per (row, panel) goes to HBM.
+//     row block b whose column lies in panel p (~nnz / 256 of them).  Inside (b, p) the block's rows are SORTED by their
+//     number of entries in the panel (longest first) and cut into tiles of 64 consecutive sorted rows; a tile is stored
+//     as a dense  (longest row of the tile) x 64  array, entry i of lane l at  tile base + 64 i + l,  zero-padded
+//     (sliced ELLPACK with a block-wide sorting scope: rows of one tile differ by at most one entry almost everywhere,
+//     a few per cent of padding).  Sorted tile ts goes to worker wave ts mod 15, and a wave's tiles are adjacent in
+//     memory: a wave streams ONE contiguous range in 64-entry chunks with static addresses, every lane accumulates its
+//     own row (no shuffles, no staging of products, no atomics, a fixed summation order), every lane of every
+//     instruction does useful work, and all of a wave's loads are in flight at once.
+//   * k_pan_mul (workgroup (b, p), 1024 threads): wave 0 finishes step j-1's reductions; waves 1..15 bulk-load the
+//     panel's records {t_{j-1}, v_{j-1}} with coalesced 16-byte loads and request their chunk range, then turn the
+//     records into v_j with the coefficients (8 bytes per column in LDS) and accumulate
+//     y_p[r] = sum_{c in panel p} L[r,c] v_j[c] with the gathers served by LDS; the sums are un-sorted through an LDS
+//     image of the row block and written as one 8-byte partial per (row, panel), coalesced.
 //   * k_pan_fin (row-parallel): w = sum_p y_p[r] in panel order, Paige's t_j = w - beta_j v_{j-1}, the next record
 //     {t_j, v_j}, the basis column, and the six measured inner products of kernels.h (PipeRow): everything the
 //     one-kernel step does after its SpMV.  The recurrence, the records, the tridiagonal hand-off and the tail kernel
 //     are those of kernels.h; only the product L v_j is computed differently.
-// Two launches per step instead of one; per step 21 x 1.6 MB of coalesced panel loads + 2 x 9.6 MB of partials replace
-// 2.7 M scattered line requests.  Reference behaviour preserved: nx:209-213 (mean projection), stop rule nx:232/246
-// (evaluated by solver.h exactly as for the other step kernels).
+// Two launches per step instead of one; per step NB x 1.6 MB of coalesced panel loads + 2 x NP x 0.8 MB of partials
+// replace 2.7 M scattered line requests.  Reference behaviour preserved: nx:209-213 (mean projection), stop rule
+// nx:232/246 (evaluated by solver.h exactly as for the other step kernels).
+//
+// How the walk got here (tools/ubench6.hip, phase clocks on MI355X, n = 1e5): (1) rows in natural order, jagged tiles,
+// a ballot + rank per entry: 30 % of the lanes busy, VALU-issue bound, 9-14 us; (2) rows sorted per 320-row window,
+// loads per (tile, iteration): a chain of ~10 HBM round trips per wave -- once the number of outstanding loads depends
+// on wave-uniform branches the compiler can only wait for all of them -- 5-9 us; (3) dense chunk loads up front,
+// products parked in LDS, jagged sums out of LDS: the rank/mask bookkeeping alone kept the VALU busy for 3-6 us.
+// Padded tiles with a block-wide sort need none of it: one LDS gather and one FMA per 64 entries.
 #pragma once
 #include "kernels.h"
 
 namespace machip {
+
+constexpr int kPanThreads = 1024;
+constexpr int kPanWaves = kPanThreads / 64;
+constexpr int kPanWork = kPanWaves - 1;            // worker waves: wave 0 of k_pan_mul only runs the reduction prologue
+constexpr int kPanWorkThreads = 64 * kPanWork;
+constexpr int kPanTW = 8;          // most tiles per worker wave
+constexpr int kPanRows = 64 * kPanWork * kPanTW;   // most rows per row block (7 680)
+constexpr int kPanCH = 20;         // 64-entry chunks a wave holds in registers per round
+constexpr int kPanMaxLen = 127;    // longest row the build kernels' histograms describe (plan_panel checks)
+constexpr int kPanSlack = 64 * kPanCH + 64;        // entries the value / column arrays carry past the last tile
 
 struct PanView {
     int n;
     int NP;      // column panels
     int C;       // columns per panel (the last one may be shorter)
     int NB;      // row blocks
-    int TPB;     // 64-row tiles per row block
-    int* tptr;              // [NB*NP*TPB + 1] first entry of tile (b, p, t); tiles ordered ((b*NP + p)*TPB + t)
-    unsigned short* tlen;   // [NB*NP*TPB*64]  entries of row (b*TPB + t)*64 + lane inside panel p
-    double* bval;           // panel-form values
+    int NTB;     // 64-row tiles per row block (rows per block R = 64 NTB <= kPanRows)
+    int TWW;     // tiles per worker wave = ceil(NTB / 15); a (block, panel) has 15 TWW physical tiles
+    int* tptr;              // [tiles + 1] first entry of physical tile ((b*NP + p)*15 + w)*TWW + q  (sorted tile w + 15 q)
+    unsigned short* thead;  // [tiles*64] row (relative to the block) held by each slot
+    double* bval;           // panel-form values, zero-padded tiles
     unsigned short* bcol;   // column minus the panel's first column
     double* ypart;          // [NP][n] per-panel partial products
     double* coef;           // 8 doubles: (alpha, beta, mu, inv, j) of the running step, published by k_pan_mul for k_pan_fin
-    int* tcount;            // [NB*NP*TPB] entries per tile (assembly scratch)
+    int* tcount;            // [tiles] entries (with padding) per tile (assembly scratch)
 #ifdef PAN_CLOCKS
     long long* clk;         // tools/ubench6.hip: 16 wall-clock stamps (100 MHz) per workgroup
 #endif
@@ -61,32 +84,78 @@ __device__ __forceinline__ double pan_vj(double alpha, double mu, double inv, do
 
 // ------------------------------------------------------------------------------------------
 // Panel form of an assembled CSR (diagonal first, other columns ascending): three launches, integers only.
+// One workgroup per row block; thread t owns rows  block base + t + 1024 j.
 // ------------------------------------------------------------------------------------------
-// Pass 1: one wave per 64-row group, lane = row: entries per (row, panel) and per tile.
-__global__ __launch_bounds__(kBlock) void k_pan_count(CsrView A, PanView P) {
-    const int lane = threadIdx.x & 63;
-    const int gt = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);   // 64-row group
-    if (gt >= P.NB * P.TPB) return;
-    const int b = gt / P.TPB, t = gt - b * P.TPB;
-    const int r = gt * 64 + lane;
-    const bool valid = r < A.n;
-    int e = 0, end = 0, pd = -1;
-    if (valid) { e = A.rowptr[r] + 1; end = A.rowptr[r + 1]; pd = r / P.C; }   // (the diagonal sits first and is counted with its panel)
+constexpr int kPanRT = (kPanRows + kPanThreads - 1) / kPanThreads;   // rows per thread (8)
+
+struct PanRowWalk {    // a thread's cursor through its rows, panel by panel
+    int e[kPanRT], end[kPanRT], pd[kPanRT];
+    __device__ __forceinline__ void begin(const CsrView& A, const PanView& P, int row0, int R, int tid) {
+#pragma unroll
+        for (int j = 0; j < kPanRT; ++j) {
+            const int rl = tid + kPanThreads * j, r = row0 + rl;
+            const bool valid = rl < R && r < A.n;
+            const int d = valid ? A.rowptr[r] : 0;
+            end[j] = valid ? A.rowptr[r + 1] : 0;
+            e[j] = valid ? d + 1 : 0;             // (the diagonal sits first and is counted with its own panel)
+            pd[j] = valid ? r / P.C : -1;
+        }
+    }
+    // entries of row j inside panel p; *start = first off-diagonal one; the cursor moves past them
+    __device__ __forceinline__ int count(const CsrView& A, int j, int p, int hi, int* start) {
+        int c = (p == pd[j]) ? 1 : 0;
+        *start = e[j];
+        while (e[j] < end[j] && A.col[e[j]] < hi) { ++e[j]; ++c; }
+        return c;
+    }
+};
+
+// Pass 1: per panel, sort the block's rows by length (counting sort; ties in arrival order -- a row's sum does not
+// depend on the slot it lands in, so the tie order never shows in a result) and record slot -> row and the tile sizes.
+__global__ __launch_bounds__(kPanThreads) void k_pan_count(CsrView A, PanView P) {
+    __shared__ int hist[kPanMaxLen + 1], start[kPanMaxLen + 1], fill[kPanMaxLen + 1];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int R = 64 * P.NTB, NTP = kPanWork * P.TWW;
+    PanRowWalk W;
+    W.begin(A, P, b * R, R, tid);
     for (int p = 0; p < P.NP; ++p) {
+        if (tid <= kPanMaxLen) { hist[tid] = 0; fill[tid] = 0; }
+        __syncthreads();
         const int hi = (p + 1) * P.C;
-        int c = (p == pd) ? 1 : 0;
-        while (e < end && A.col[e] < hi) { ++e; ++c; }
-        const int vt = (b * P.NP + p) * P.TPB + t;
-        P.tlen[(size_t)vt * 64 + lane] = (unsigned short)c;
-        const int tot = wave_sum_i(c);
-        if (lane == 0) P.tcount[vt] = tot;
+        int c[kPanRT];
+#pragma unroll
+        for (int j = 0; j < kPanRT; ++j) {
+            int st;
+            c[j] = min(W.count(A, j, p, hi, &st), kPanMaxLen);
+            if (tid + kPanThreads * j < R) atomicAdd(&hist[c[j]], 1);
+        }
+        __syncthreads();
+        if (tid == 0) { int run = 0; for (int Lc = kPanMaxLen; Lc >= 0; --Lc) { start[Lc] = run; run += hist[Lc]; } }
+        __syncthreads();
+        const size_t vtb = (size_t)(b * P.NP + p) * NTP;
+#pragma unroll
+        for (int j = 0; j < kPanRT; ++j) {
+            const int rl = tid + kPanThreads * j;
+            if (rl < R) {
+                const int slot = start[c[j]] + atomicAdd(&fill[c[j]], 1);
+                const int ts = slot >> 6, w = ts % kPanWork, q = ts / kPanWork;
+                P.thead[(vtb + (size_t)(w * P.TWW + q)) * 64 + (slot & 63)] = (unsigned short)rl;
+            }
+        }
+        if (tid < NTP) {          // physical tile tid = (w, q) holds sorted tile ts = w + 15 q: its longest row comes first
+            const int w = tid / P.TWW, q = tid - w * P.TWW, ts = w + kPanWork * q;
+            int tm = 0;
+            if (ts < P.NTB) { const int s0 = ts * 64; for (int Lc = kPanMaxLen; Lc > 0; --Lc) if (s0 >= start[Lc] && s0 < start[Lc] + hist[Lc]) tm = Lc; }
+            P.tcount[vtb + tid] = 64 * tm;
+        }
+        __syncthreads();
     }
 }
 
-// Pass 2: exclusive scan of the tile counts (one workgroup; a few ten thousand values).
+// Pass 2: exclusive scan of the tile sizes (one workgroup; a few ten thousand values).
 __global__ __launch_bounds__(1024) void k_pan_scan(PanView P) {
     __shared__ int s_part[1024];
-    const int NT = P.NB * P.NP * P.TPB;
+    const int NT = P.NB * P.NP * kPanWork * P.TWW;
     const int per = (NT + 1023) / 1024;
     const int tid = threadIdx.x;
     const int lo = tid * per, hi = min(NT, lo + per);
@@ -105,144 +174,165 @@ __global__ __launch_bounds__(1024) void k_pan_scan(PanView P) {
     if (tid == 1023) P.tptr[NT] = s_part[1023];
 }
 
-// Pass 3: same walk; entry i of a lane goes behind the entries i' < i of its tile and the lower lanes' entries i.
-__global__ __launch_bounds__(kBlock) void k_pan_fill(CsrView A, PanView P) {
-    const int lane = threadIdx.x & 63;
-    const int gt = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    if (gt >= P.NB * P.TPB) return;
-    const int b = gt / P.TPB, t = gt - b * P.TPB;
-    const int r = gt * 64 + lane;
-    const bool valid = r < A.n;
-    int cur = 0, pd = -1, diag = 0;
-    if (valid) { diag = A.rowptr[r]; cur = diag + 1; pd = r / P.C; }
-    const unsigned long long below = (1ull << lane) - 1ull;
+// Pass 3: the same walk publishes where every row's entries of the panel start; the slots copy their row, zero-padded
+// to the tile's height (writes coalesced along the lanes).
+__global__ __launch_bounds__(kPanThreads) void k_pan_fill(CsrView A, PanView P) {
+    __shared__ int r_st[kPanRows];
+    __shared__ unsigned char r_c[kPanRows];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int R = 64 * P.NTB, NTP = kPanWork * P.TWW;
+    PanRowWalk W;
+    W.begin(A, P, b * R, R, tid);
     for (int p = 0; p < P.NP; ++p) {
-        const int vt = (b * P.NP + p) * P.TPB + t;
-        const int len = P.tlen[(size_t)vt * 64 + lane];
-        const int c0 = p * P.C;
-        int off = P.tptr[vt];
-        const int shift = (p == pd) ? 1 : 0;     // this lane's entry 0 is the diagonal
-        for (int i = 0;; ++i) {
-            const bool act = i < len;
-            const unsigned long long m = __ballot(act);
-            if (!m) break;
-            if (act) {
-                const int src = (shift && i == 0) ? diag : cur + i - shift;
-                const int dst = off + __popcll(m & below);
-                P.bval[dst] = A.val[src];
-                P.bcol[dst] = (unsigned short)(A.col[src] - c0);
-            }
-            off += __popcll(m);
+        const int hi = (p + 1) * P.C, c0 = p * P.C;
+#pragma unroll
+        for (int j = 0; j < kPanRT; ++j) {
+            int st;
+            const int c = min(W.count(A, j, p, hi, &st), kPanMaxLen);
+            const int rl = tid + kPanThreads * j;
+            if (rl < R) { r_st[rl] = (p == W.pd[j]) ? (st | (1 << 30)) : st; r_c[rl] = (unsigned char)c; }   // bit 30: entry 0 is the diagonal
         }
-        cur += len - shift;
+        __syncthreads();
+        const size_t vtb = (size_t)(b * P.NP + p) * NTP;
+        for (int s = tid; s < NTP * 64; s += kPanThreads) {
+            const size_t vt = vtb + (size_t)(s >> 6);
+            const int base = P.tptr[vt], tm = (P.tptr[vt + 1] - base) >> 6;
+            if (tm == 0) continue;
+            const int rl = P.thead[vt * 64 + (s & 63)];
+            const int stv = r_st[rl], c = r_c[rl];
+            const int shift = (stv >> 30) & 1, st = stv & ((1 << 30) - 1);
+            const int r = b * R + rl;
+            const int dg = (shift && r < A.n) ? A.rowptr[r] : 0;
+            for (int i = 0; i < tm; ++i) {
+                const int dst = base + 64 * i + (s & 63);
+                if (i < c) {
+                    const int src = (shift && i == 0) ? dg : st + i - shift;
+                    P.bval[dst] = A.val[src];
+                    P.bcol[dst] = (unsigned short)(A.col[src] - c0);
+                } else { P.bval[dst] = 0.0; P.bcol[dst] = 0; }
+            }
+        }
+        __syncthreads();
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // Step kernel 1: y_p = L[block b, panel p] v_j
 // ------------------------------------------------------------------------------------------
-constexpr int kPanThreads = 1024;
-constexpr int kPanWaves = kPanThreads / 64;
-constexpr int kPanTG = 6;     // tiles a wave walks together
-
-template <int RPT>   // records per thread: the panel holds at most RPT * 1024 columns
+template <int RPT>   // records per worker thread: the panel holds at most RPT * 960 columns
 __global__ __launch_bounds__(kPanThreads) void k_pan_mul(PanView A, PipeView L, int jrel) {
-    __shared__ double sv[RPT * kPanThreads];
+    __shared__ double sv[RPT * kPanWorkThreads];
+    __shared__ double yblk[kPanRows];
     __shared__ double scoef[8];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    static_assert((RPT * kPanWorkThreads + kPanRows + 8) * 8 <= 163840, "panel + row-block image exceed the LDS");
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x / A.NP, p = blockIdx.x - b * A.NP;
     const int c0 = p * A.C;
     const int Cp = min(A.C, A.n - c0);           // >= 1 by construction of the plan
-    const Z2* __restrict__ Zc = ((jrel & 1) ? L.Z1 : L.Z0) + c0;
+    const int R = 64 * A.NTB;
     PAN_CLK(tid == 0, 0); PAN_CLK(tid == 64, 1);
-    // the panel's records, all requested at once (clamped index: unconditional loads stay batched, cf. the prologue)
-    Z2 z[RPT];
-#pragma unroll
-    for (int i = 0; i < RPT; ++i) z[i] = Zc[min(tid + kPanThreads * i, Cp - 1)];
-    // this wave's tiles: t = wv + 16 q.  The entry stream of a tile is a chain of dependent round trips (lengths ->
-    // entries -> LDS), so kPanTG tiles are walked TOGETHER: their loads are issued back to back (first build: one tile
-    // after the other, ~12 serial round trips per wave, 24 us per step whatever the matrix held).
-    const int vt0 = (b * A.NP + p) * A.TPB;
-    int len[kPanTG], off[kPanTG];
-#pragma unroll
-    for (int q = 0; q < kPanTG; ++q) {
-        const int t = wv + kPanWaves * q;
-        const bool ok = t < A.TPB;
-        const int vt = vt0 + (ok ? t : 0);
-        const int l = A.tlen[(size_t)vt * 64 + lane], o = A.tptr[vt];
-        len[q] = ok ? l : 0; off[q] = o;
-    }
-#ifdef PAN_CLOCKS
-    if (tid >= 64 && tid < 128) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PAN_CLK(tid == 64, 2); }   // records + tile heads arrived (wave 1)
-#endif
-    if (tid < 64) {
+    // Wave 0 does nothing but finish step j-1's reductions (the coefficients everyone waits for); waves 1..15 own the
+    // panel's records and their tiles.  (One role per wave also keeps the two register-hungry phases -- 48 partial
+    // loads in flight there, records + a wave's chunks here -- out of each other's allocation.)
+    if (wv == 0) {
         int jd;
         const PipeCoef c = pipe_prologue_wave0(L, jrel, -1, scoef, &jd);
         if (blockIdx.x == 0 && lane == 0) {
             A.coef[0] = c.alpha; A.coef[1] = c.beta; A.coef[2] = c.mu; A.coef[3] = c.inv; A.coef[4] = (double)jd;
         }
         PAN_CLK(tid == 0, 3);
+        __syncthreads();
+        __syncthreads();
+        __syncthreads();
+        return;
     }
+    const int wt = tid - 64, ww = wv - 1;        // worker thread / worker wave
+#ifdef PAN_HEADSTART
+    __builtin_amdgcn_s_sleep(PAN_HEADSTART);     // (experiment: let wave 0's partial loads into the memory pipeline first)
+#endif
+    const Z2* __restrict__ Zc = ((jrel & 1) ? L.Z1 : L.Z0) + c0;
+    // the panel's records, all requested at once (clamped index: unconditional loads stay batched, cf. the prologue)
+    Z2 z[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) z[i] = Zc[min(wt + kPanWorkThreads * i, Cp - 1)];
+    // this wave's tiles: slot -> row, and the chunk (64 entries) at which each tile ends
+    const int vt0 = ((b * A.NP + p) * kPanWork + ww) * A.TWW;
+    int ro[kPanTW], cend[kPanTW];
+    int E0;
+    {
+        int tp[kPanTW + 1];
+#pragma unroll
+        for (int q = 0; q <= kPanTW; ++q) tp[q] = __builtin_amdgcn_readfirstlane(A.tptr[vt0 + min(q, A.TWW)]);
+#pragma unroll
+        for (int q = 0; q < kPanTW; ++q) ro[q] = A.thead[(size_t)(vt0 + min(q, A.TWW - 1)) * 64 + lane];
+        E0 = tp[0];
+#pragma unroll
+        for (int q = 0; q < kPanTW; ++q) cend[q] = (tp[q + 1] - E0) >> 6;      // (tiles q >= TWW: same as the last real one)
+    }
+    const int nch = cend[kPanTW - 1];
+    const double* __restrict__ bv = A.bval + E0 + lane;
+    const unsigned short* __restrict__ bc = A.bcol + E0 + lane;
+    double pv[kPanCH];
+    int pk[kPanCH];
+#pragma unroll
+    for (int c = 0; c < kPanCH; ++c) { pv[c] = 0.0; pk[c] = 0; }
+#pragma unroll
+    for (int c = 0; c < kPanCH; ++c)
+        if (c < nch) { pv[c] = bv[c * 64]; pk[c] = bc[c * 64]; }
+#ifdef PAN_CLOCKS
+    if (wv == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PAN_CLK(tid == 64, 2); }   // records, tile table, the wave's chunks arrived (wave 1)
+#endif
     __syncthreads();
     PAN_CLK(tid == 64, 4);
     {
         const double alpha = scoef[0], mu = scoef[2], inv = scoef[3];
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
-            const int c = tid + kPanThreads * i;
+            const int c = wt + kPanWorkThreads * i;
             if (c < Cp) sv[c] = pan_vj(alpha, mu, inv, z[i].t, z[i].v);
         }
+        for (int rl = wt; rl < R; rl += kPanWorkThreads) yblk[rl] = 0.0;      // rows of empty tiles
     }
     __syncthreads();
     PAN_CLK(tid == 64, 5);
-    const unsigned long long below = (1ull << lane) - 1ull;
-    for (int tq = 0; wv + kPanWaves * tq < A.TPB; tq += kPanTG) {
-        if (tq) {     // more than kPanTG tiles per wave: next group
+    double acc = 0.0;
+    for (int cb = 0; cb < nch; cb += kPanCH) {
+        if (cb) {     // more chunks than the registers hold: next round (one more round trip)
 #pragma unroll
-            for (int q = 0; q < kPanTG; ++q) {
-                const int t = wv + kPanWaves * (tq + q);
-                const bool ok = t < A.TPB;
-                const int vt = vt0 + (ok ? t : 0);
-                const int l = A.tlen[(size_t)vt * 64 + lane], o = A.tptr[vt];
-                len[q] = ok ? l : 0; off[q] = o;
+            for (int c = 0; c < kPanCH; ++c)
+                if (cb + c < nch) { pv[c] = bv[(cb + c) * 64]; pk[c] = bc[(cb + c) * 64]; }
+        }
+        // gathers of the whole round back to back (padding entries multiply v_j[first column of the panel] by zero)
+#pragma unroll
+        for (int c = 0; c < kPanCH; ++c) pv[c] *= sv[min(pk[c], Cp - 1)];
+        PAN_CLK(tid == 64 && cb == 0, 6);
+        // chunks of this round that close a (non-empty) tile, as a bit mask: one scalar test per chunk instead of a
+        // comparison with every tile end (the scalar unit was the bottleneck of this loop)
+        unsigned endmask = 0;
+#pragma unroll
+        for (int q = 0; q < kPanTW; ++q) {
+            const int prev = q ? cend[q - 1] : 0, last = cend[q] - 1 - cb;
+            if (q < A.TWW && cend[q] > prev && last >= 0 && last < kPanCH) endmask |= 1u << last;
+        }
+#pragma unroll
+        for (int c = 0; c < kPanCH; ++c) {
+            if (cb + c < nch) {
+                acc += pv[c];
+                if (endmask & (1u << c)) {       // its lanes' rows are complete
+#pragma unroll
+                    for (int q = 0; q < kPanTW; ++q)
+                        if (cb + c + 1 == cend[q] && (q == 0 ? cend[0] > 0 : cend[q] > cend[q - 1])) yblk[ro[q]] = acc;
+                    acc = 0.0;
+                }
             }
         }
-        double acc[kPanTG];
-#pragma unroll
-        for (int q = 0; q < kPanTG; ++q) acc[q] = 0.0;
-        for (int i0 = 0;; i0 += 2) {
-            unsigned long long m0[kPanTG], m1[kPanTG];
-            unsigned long long any = 0;
-#pragma unroll
-            for (int q = 0; q < kPanTG; ++q) { m0[q] = __ballot(len[q] > i0); m1[q] = __ballot(len[q] > i0 + 1); any |= m0[q]; }
-            if (!any) break;
-            double v0[kPanTG], v1[kPanTG];
-            int k0[kPanTG], k1[kPanTG];
-#pragma unroll
-            for (int q = 0; q < kPanTG; ++q) {     // inactive lanes read the tile's entry `off` (in bounds) and are not added
-                const int o1 = off[q] + __popcll(m0[q]);
-                const int e0 = (len[q] > i0) ? off[q] + __popcll(m0[q] & below) : off[q];
-                const int e1 = (len[q] > i0 + 1) ? o1 + __popcll(m1[q] & below) : off[q];
-                v0[q] = A.bval[e0]; v1[q] = A.bval[e1];
-                k0[q] = A.bcol[e0]; k1[q] = A.bcol[e1];
-                off[q] = o1 + __popcll(m1[q]);
-            }
-#pragma unroll
-            for (int q = 0; q < kPanTG; ++q) {
-                const bool a0 = len[q] > i0, a1 = len[q] > i0 + 1;
-                const double x0 = sv[a0 ? k0[q] : 0], x1 = sv[a1 ? k1[q] : 0];
-                if (a0) acc[q] += v0[q] * x0;
-                if (a1) acc[q] += v1[q] * x1;
-            }
-            PAN_CLK(tid == 64 && i0 == 0 && tq == 0, 6);
-        }
-        PAN_CLK(tid == 64 && tq == 0, 7);
-#pragma unroll
-        for (int q = 0; q < kPanTG; ++q) {
-            const int t = wv + kPanWaves * (tq + q);
-            const int row = (b * A.TPB + t) * 64 + lane;
-            if (t < A.TPB && row < A.n) A.ypart[(size_t)p * A.n + row] = acc[q];
-        }
+    }
+    PAN_CLK(tid == 64, 7);
+    __syncthreads();
+    // the row block's sums, un-sorted by the LDS image: coalesced stores
+    for (int rl = wt; rl < R; rl += kPanWorkThreads) {
+        const int row = b * R + rl;
+        if (row < A.n) A.ypart[(size_t)p * A.n + row] = yblk[rl];
     }
     PAN_CLK(tid == 64, 8); PAN_CLK(tid == 1023, 9);
 }

@@ -136,12 +136,12 @@ inline SpmvPlan plan_pipe(int n, long nnz, int maxlen) {
 }
 
 // Column-panel step (panel.h): shape of the panel form for a matrix of n rows.  NP panels of C <= 16 384 columns (8 bytes
-// per column in LDS), NB row blocks of TPB 64-row tiles, NB * NP <= 256 workgroups (one per CU: the panel takes most of
+// per column in LDS), NB row blocks of NTB 64-row tiles (TWW per worker wave), NB * NP <= 256 workgroups (one per CU: the panel takes most of
 // the CU's LDS).  Panel loads cost NB x 16 n bytes of coalesced L2 traffic per step, the partials 2 x NP x 8 n bytes: the
 // defaults balance the two (MACHIP_PANEL_NP / MACHIP_PANEL_NB override; swept on MI355X, profiles/r3_c4_panel.md).
 struct PanPlan {
     bool on = false;
-    int NP = 1, C = 1, NB = 1, TPB = 1, RPT = 1;
+    int NP = 1, C = 1, NB = 1, NTB = 1, TWW = 1, RPT = 1;
     int grid2 = 1, block2 = 256;     // launch shape of k_pan_fin
 };
 inline PanPlan plan_panel(int n, long nnz, int maxlen, bool allowed) {
@@ -149,22 +149,27 @@ inline PanPlan plan_panel(int n, long nnz, int maxlen, bool allowed) {
     const int mode = env_int("MACHIP_PANEL", -1);     // -1 auto, 0 off, 1 forced (tests: small graphs with several panels)
     if (!allowed || mode == 0 || n < 128) return pp;
     const double mean = (double)nnz / (double)std::max(n, 1);
-    // automatic: the operand must be too large for the gather path's caches to serve cheaply (measured cross-over) and
-    // the rows must not be dominated by hubs (a lane walks its row's entries of a panel one by one)
-    if (mode < 0 && !(n >= env_int("MACHIP_PANEL_MIN_N", 65536) && n <= 400000 && mean >= 6.0 && (double)maxlen <= 16.0 * mean + 64.0)) return pp;
+    // automatic: the operand must be too large for the gather path's caches to serve cheaply, and the matrix dense enough
+    // for the panel step's fixed costs (two launches, NB x 16 n bytes of panel loads, 2 x NP x 8 n bytes of partials) to
+    // pay: measured cross-over on MI355X at n = 1e5 (tools/sweep_panel.py, profiles/r3_c4_panel.md): ~17 entries per row
+    // (gather step 18.7 us and rising 4 us per million entries, panel step 18.3 us and rising 0.9 us per million)
+    if (maxlen > kPanMaxLen) return pp;               // the build kernels' length histograms stop at 127
+    if (mode < 0 && !(n >= env_int("MACHIP_PANEL_MIN_N", 65536) && n <= 400000 && mean >= 0.1 * env_int("MACHIP_PANEL_MIN_MEAN10", 170))) return pp;
     int np = env_int("MACHIP_PANEL_NP", (n + 8447) / 8448);
     np = std::max(1, std::min(np, 64));
     int C = (n + np - 1) / np;
-    if (C > 16 * 1024) { np = (n + 16 * 1024 - 1) / (16 * 1024); C = (n + np - 1) / np; }
+    if (C > 13 * kPanWorkThreads) { np = (n + 13 * kPanWorkThreads - 1) / (13 * kPanWorkThreads); C = (n + np - 1) / np; }   // 13 records per thread: LDS (panel + un-sort stage) and registers
     if (np > 64) return pp;
     np = (n + C - 1) / C;                              // panels that actually hold columns
     const int groups = (n + 63) / 64;
     int nb = env_int("MACHIP_PANEL_NB", std::max(1, grid_cap() / np));
     nb = std::max(1, std::min(nb, groups));
-    const int tpb = (groups + nb - 1) / nb;
-    nb = (groups + tpb - 1) / tpb;
-    pp.on = true; pp.NP = np; pp.C = C; pp.NB = nb; pp.TPB = tpb; pp.RPT = (C + 1023) / 1024;
-    pp.block2 = env_int("MACHIP_PANEL_B2", 256);
+    int ntb = (groups + nb - 1) / nb;                            // tiles per row block
+    ntb = std::min(ntb, kPanWork * kPanTW);                      // (the row block's LDS image holds 7 680 rows)
+    nb = (groups + ntb - 1) / ntb;
+    pp.on = true; pp.NP = np; pp.C = C; pp.NB = nb; pp.NTB = ntb; pp.TWW = (ntb + kPanWork - 1) / kPanWork;
+    pp.RPT = (C + kPanWorkThreads - 1) / kPanWorkThreads;
+    pp.block2 = env_int("MACHIP_PANEL_B2", 512);
     if (pp.block2 != 256 && pp.block2 != 512 && pp.block2 != 1024) pp.block2 = 256;
     pp.grid2 = (int)std::max<long>(1, std::min<long>(env_int("MACHIP_PANEL_G2", grid_cap()), ((long)n + pp.block2 - 1) / pp.block2));
     return pp;
@@ -377,7 +382,7 @@ struct Solver {
                         lx_ys, lx_pas, lx_as, lx_bs, lx_maps, lx_ba, lx_bd, lx_bu, wb_ui, wb_uj, wb_counts, wb_uc, wb_g, wb_h, wb_Zt, wb_Cm, wb_pas, wb_maps,
                         lx_colT, lx_bad, lx_st, valf};
         {
-            void* pb[] = {panv.tptr, panv.tlen, panv.bval, panv.bcol, panv.ypart, panv.coef, panv.tcount};
+            void* pb[] = {panv.tptr, panv.thead, panv.bval, panv.bcol, panv.ypart, panv.coef, panv.tcount};
             for (void* q : pb) if (q) (void)hipFree(q);
         }
         if (h_lrec) (void)hipHostFree(h_lrec);
@@ -453,18 +458,21 @@ struct Solver {
     // ---- column-panel step (panel.h) ---------------------------------------------------------------
     // (Re)build the panel form of A on the stream: buffers grow on demand (cached chunk graphs carry their addresses).
     int ensure_panel(const CsrView& A, long nnz, const PanPlan& pn) {
-        const size_t NT = (size_t)pn.NB * pn.NP * pn.TPB;
+        const size_t NT = (size_t)pn.NB * pn.NP * kPanWork * pn.TWW;
         bool dropped = false;
         auto regrow = [&](auto** ptr, size_t count) -> int {
             if (*ptr) { if (!dropped) { HIP_TRY(hipStreamSynchronize(stream)); drop_graphs(); dropped = true; } (void)hipFree(*ptr); *ptr = nullptr; }
             return dev_alloc(ptr, count);
         };
         if (NT > pan_nt_cap) {
-            ST_TRY(regrow(&panv.tptr, NT + 1)); ST_TRY(regrow(&panv.tcount, NT)); ST_TRY(regrow(&panv.tlen, NT * 64));
+            ST_TRY(regrow(&panv.tptr, NT + 1)); ST_TRY(regrow(&panv.tcount, NT)); ST_TRY(regrow(&panv.thead, NT * 64));
             pan_nt_cap = NT;
         }
-        if ((size_t)nnz > pan_cap) {
-            const size_t want = std::max<size_t>((size_t)nnz + (size_t)nnz / 2 + 1024, csr_cap);
+        // zero padding of the sorted tiles: at most 64 x (longest row) entries per (row block, panel) (the tile heights
+        // telescope), plus the slack the chunk loads may run into
+        const size_t need = (size_t)nnz + (size_t)pn.NB * pn.NP * 64 * (kPanMaxLen + 1) + kPanSlack;
+        if (need > pan_cap) {
+            const size_t want = need + (size_t)nnz / 2;
             ST_TRY(regrow(&panv.bval, want)); ST_TRY(regrow(&panv.bcol, want));
             pan_cap = want;
         }
@@ -473,12 +481,10 @@ struct Solver {
             pan_y_cap = (size_t)pn.NP * (size_t)n;
         }
         if (!panv.coef) ST_TRY(dev_alloc(&panv.coef, 8));
-        panv.n = n; panv.NP = pn.NP; panv.C = pn.C; panv.NB = pn.NB; panv.TPB = pn.TPB;
-        const int groups = pn.NB * pn.TPB;
-        const int gg = (groups + (kBlock / 64) - 1) / (kBlock / 64);
-        k_pan_count<<<gg, kBlock, 0, stream>>>(A, panv);
+        panv.n = n; panv.NP = pn.NP; panv.C = pn.C; panv.NB = pn.NB; panv.NTB = pn.NTB; panv.TWW = pn.TWW;
+        k_pan_count<<<pn.NB, kPanThreads, 0, stream>>>(A, panv);
         k_pan_scan<<<1, 1024, 0, stream>>>(panv);
-        k_pan_fill<<<gg, kBlock, 0, stream>>>(A, panv);
+        k_pan_fill<<<pn.NB, kPanThreads, 0, stream>>>(A, panv);
         HIP_TRY(hipGetLastError());
         return MACHIP_OK;
     }
@@ -488,9 +494,8 @@ struct Solver {
 #define MACHIP_PAN_CASE(R) case R: k_pan_mul<R><<<g1, kPanThreads, 0, stream>>>(panv, L, s); break;
             MACHIP_PAN_CASE(1) MACHIP_PAN_CASE(2) MACHIP_PAN_CASE(3) MACHIP_PAN_CASE(4) MACHIP_PAN_CASE(5) MACHIP_PAN_CASE(6)
             MACHIP_PAN_CASE(7) MACHIP_PAN_CASE(8) MACHIP_PAN_CASE(9) MACHIP_PAN_CASE(10) MACHIP_PAN_CASE(11) MACHIP_PAN_CASE(12)
-            MACHIP_PAN_CASE(13) MACHIP_PAN_CASE(14) MACHIP_PAN_CASE(15)
 #undef MACHIP_PAN_CASE
-            default: k_pan_mul<16><<<g1, kPanThreads, 0, stream>>>(panv, L, s); break;
+            default: k_pan_mul<13><<<g1, kPanThreads, 0, stream>>>(panv, L, s); break;
         }
         if (pan.block2 == 1024) k_pan_fin<1024><<<pan.grid2, 1024, 0, stream>>>(panv, L, s);
         else if (pan.block2 == 512) k_pan_fin<512><<<pan.grid2, 512, 0, stream>>>(panv, L, s);
@@ -1059,7 +1064,7 @@ struct Solver {
         if (pan.on) {
             ST_TRY(ensure_panel(A, nnz, pan));
             pp.variant = kPanel; pp.grid = pan.grid2; pp.block = pan.block2;
-            pp.width = pan.NP * 100 + pan.RPT; pp.unroll = 0; pp.defer = pan.NB;
+            pp.width = pan.NP * 100 + pan.RPT; pp.unroll = pan.TWW; pp.defer = pan.NB;
         }
         const PipeView L = pview(pp);
         const int pchunk0 = std::min(kPersistMaxSteps, std::max(2, env_int("MACHIP_PCHUNK", 64)));

@@ -39,10 +39,17 @@ void run(PanView P, PipeView L, hipStream_t s, long nnz, std::vector<double>& u0
         for (int b = 0; b < g1; ++b) { const double v = (c[(size_t)b * 16 + i] - t0) * 0.01; mn = std::min(mn, v); mx = std::max(mx, v); av += v; }
         printf("      %-52s min %6.2f  mean %6.2f  max %6.2f us\n", what, mn, av / g1, mx);
     };
-    printf("   NP=%d C=%d NB=%d TPB=%d RPT=%d grid=%d: %.2f us per step (mul+fin), mul alone %.2f us (nnz %ld)\n", P.NP, P.C, P.NB, P.TPB, RPT, g1, 1e3 * ms / steps, 1e3 * ms2 / steps, nnz);
+    printf("   NP=%d C=%d NB=%d NTB=%d RPT=%d grid=%d: %.2f us per step (mul+fin), mul alone %.2f us (nnz %ld)\n", P.NP, P.C, P.NB, P.NTB, RPT, g1, 1e3 * ms / steps, 1e3 * ms2 / steps, nnz);
     stat(0, "workgroup entry (wave 0)"); stat(1, "wave 1 entry"); stat(2, "records + tile heads arrived (wave 1)"); stat(3, "prologue done (wave 0)");
-    stat(4, "barrier 1 passed"); stat(5, "panel in LDS, barrier 2 passed"); stat(6, "first entry batch consumed (wave 1)");
-    stat(7, "first tile group done (wave 1)"); stat(8, "wave 1 done"); stat(9, "wave 15 done");
+    stat(4, "barrier 1 passed"); stat(5, "panel in LDS, barrier 2 passed"); stat(6, "first round multiplied (wave 1)");
+    stat(7, "tiles accumulated (wave 1)"); stat(8, "wave 1 done"); stat(9, "wave 15 done");
+    {   // who is late?  completion (slot 9) by XCD (blockIdx mod 8), by panel and by row block
+        double bx[8] = {0}, bp[64] = {0}, bb[256] = {0}; int nx[8] = {0}, np_[64] = {0}, nb_[256] = {0};
+        for (int b = 0; b < g1; ++b) { const double v = (c[(size_t)b * 16 + 9] - t0) * 0.01; bx[b % 8] += v; nx[b % 8]++; bp[b % P.NP] += v; np_[b % P.NP]++; bb[b / P.NP] += v; nb_[b / P.NP]++; }
+        printf("      done by XCD:  "); for (int i = 0; i < 8; ++i) printf(" %5.2f", bx[i] / std::max(1, nx[i])); printf("\n");
+        printf("      done by panel:"); for (int i = 0; i < P.NP; ++i) printf(" %5.2f", bp[i] / std::max(1, np_[i])); printf("\n");
+        printf("      done by block:"); for (int i = 0; i < P.NB; ++i) printf(" %5.2f", bb[i] / std::max(1, nb_[i])); printf("\n");
+    }
     CK(hipFree(u0));
 }
 
@@ -77,24 +84,25 @@ int main(int argc, char** argv) {
         L.htri = nullptr; L.hflag = nullptr; L.P = 256;
         PanView P; P.n = n; P.NP = NPa; P.C = (n + P.NP - 1) / P.NP; P.NP = (n + P.C - 1) / P.C;
         const int groups = (n + 63) / 64;
-        P.TPB = (groups + NBa - 1) / NBa; P.NB = (groups + P.TPB - 1) / P.TPB;
-        const size_t NT = (size_t)P.NB * P.NP * P.TPB;
-        CK(hipMalloc(&P.tptr, (NT + 1) * 4)); CK(hipMalloc(&P.tcount, NT * 4)); CK(hipMalloc(&P.tlen, NT * 64 * 2));
-        CK(hipMalloc(&P.bval, (nnz + 1024) * 8)); CK(hipMalloc(&P.bcol, (nnz + 1024) * 2)); CK(hipMalloc(&P.ypart, (size_t)P.NP * n * 8));
+        P.NTB = std::min((groups + NBa - 1) / NBa, kPanWork * kPanTW); P.NB = (groups + P.NTB - 1) / P.NTB; P.TWW = (P.NTB + kPanWork - 1) / kPanWork;
+        const size_t NT = (size_t)P.NB * P.NP * kPanWork * P.TWW;
+        const size_t ecap = (size_t)nnz + (size_t)P.NB * P.NP * 64 * 128 + kPanSlack;
+        CK(hipMalloc(&P.tptr, (NT + 1) * 4)); CK(hipMalloc(&P.tcount, NT * 4)); CK(hipMalloc(&P.thead, NT * 64 * 2));
+        CK(hipMalloc(&P.bval, ecap * 8)); CK(hipMalloc(&P.bcol, ecap * 2)); CK(hipMalloc(&P.ypart, (size_t)P.NP * n * 8));
         CK(hipMalloc(&P.coef, 64)); CK(hipMalloc(&P.clk, 16 * 8 * kMaxGrid)); CK(hipMemset(P.clk, 0, 16 * 8 * kMaxGrid));
-        const int gg = (P.NB * P.TPB + 3) / 4;
         hipEvent_t a0, a1; CK(hipEventCreate(&a0)); CK(hipEventCreate(&a1));
         CK(hipEventRecord(a0, s));
-        k_pan_count<<<gg, kBlock, 0, s>>>(A, P); k_pan_scan<<<1, 1024, 0, s>>>(P); k_pan_fill<<<gg, kBlock, 0, s>>>(A, P);
+        k_pan_count<<<P.NB, kPanThreads, 0, s>>>(A, P); k_pan_scan<<<1, 1024, 0, s>>>(P); k_pan_fill<<<P.NB, kPanThreads, 0, s>>>(A, P);
         CK(hipEventRecord(a1, s)); CK(hipEventSynchronize(a1));
         float bms; CK(hipEventElapsedTime(&bms, a0, a1));
         std::vector<double> u0((size_t)n); for (int i = 0; i < n; ++i) u0[i] = (double)((i * 2654435761u) % 1000) / 500.0 - 1.0;
-        printf("== n=%d mean row %.1f nnz=%ld   panel form built in %.1f us\n", n, (double)nnz / n, nnz, 1e3 * bms);
-        const int RPT = (P.C + 1023) / 1024;
+        int tot = 0; CK(hipMemcpy(&tot, P.tptr + NT, 4, hipMemcpyDeviceToHost));
+        printf("== n=%d mean row %.1f nnz=%ld   panel form built in %.1f us, %d entries with padding (+%.1f %%)\n", n, (double)nnz / n, nnz, 1e3 * bms, tot, 100.0 * (tot - nnz) / nnz);
+        const int RPT = (P.C + kPanWorkThreads - 1) / kPanWorkThreads;
         switch (RPT) {
             case 5: run<5>(P, L, s, nnz, u0); break; case 6: run<6>(P, L, s, nnz, u0); break; case 7: run<7>(P, L, s, nnz, u0); break;
             case 8: run<8>(P, L, s, nnz, u0); break; case 9: run<9>(P, L, s, nnz, u0); break; case 10: run<10>(P, L, s, nnz, u0); break;
-            case 12: run<12>(P, L, s, nnz, u0); break; case 13: run<13>(P, L, s, nnz, u0); break; case 14: run<14>(P, L, s, nnz, u0); break;
+            case 11: run<11>(P, L, s, nnz, u0); break; case 12: run<12>(P, L, s, nnz, u0); break; case 13: run<13>(P, L, s, nnz, u0); break;
             default: printf("RPT %d not instantiated\n", RPT); break;
         }
         CK(hipFree(drp)); CK(hipFree(dcol)); CK(hipFree(dval));
