@@ -49,7 +49,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
-KERNEL = "k_pipe_vec (fused Lanczos step: CSR SpMV + all vector work of one step)"
+KERNEL = ("one Lanczos step = k_pipe_vec (one kernel: CSR SpMV with gathered operand + all vector work) on sparse iterates, "
+          "k_pan_mul + k_pan_fin (column-panel form, operand in LDS; mac_amd/csrc/panel.h) from ~17 entries per row at N >= 65536")
+STEP_KERNELS = ("k_pipe_vec", "k_pipe_stream", "k_pan_mul", "k_pan_fin")     # launches that make up Lanczos steps
+STEP_HEADS = ("k_pipe_vec", "k_pipe_stream", "k_pan_mul")                    # one of these per step
+# reference-equivalent CPU path at sizes where it does finish (measured in the build
+# container, 1 core): seconds per Fiedler solve of the same ER family -- the extrapolation points for configs[3]
+REF_EXTRAPOLATION = {"N=20000 (m=200k cands)": 88.0, "N=40000 (m=800k cands)": 448.0, "N=100000": "> 3000 (did not finish in 50 min)"}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -239,18 +245,21 @@ def pmc_traffic(cfg, steps, precision=0, timeout_s=150):
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
                     for r in csv.DictReader(fh):
-                        if r["Counter_Name"] == counter and "k_pipe_" in r["Kernel_Name"] and "k_pipe_tail" not in r["Kernel_Name"] \
-                                and "k_pipe_init" not in r["Kernel_Name"]:
-                            tot += float(r["Counter_Value"]); cnt += 1
+                        if r["Counter_Name"] != counter:
+                            continue
+                        if any(kn in r["Kernel_Name"] for kn in STEP_KERNELS):
+                            tot += float(r["Counter_Value"])
+                        if any(kn in r["Kernel_Name"] for kn in STEP_HEADS):
+                            cnt += 1
             if cnt == 0:
-                return None, f"rocprofv3 --pmc {counter} produced no rows for the step kernel"
+                return None, f"rocprofv3 --pmc {counter} produced no rows for the step kernels"
             vals[counter] = (tot / cnt, cnt)
         except subprocess.TimeoutExpired:
             return None, f"rocprofv3 --pmc {counter} pass timed out"
         finally:
             shutil.rmtree(d, ignore_errors=True)
     by = (2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024.0
-    return by, (f"traffic = (2*FETCH_SIZE + WRITE_SIZE) KiB per launch over {vals['FETCH_SIZE'][1]} launches, two separate "
+    return by, (f"traffic = (2*FETCH_SIZE + WRITE_SIZE) KiB per Lanczos step (all launches of a step) over {vals['FETCH_SIZE'][1]} steps, two separate "
                 f"rocprofv3 --pmc passes of this script (the same {steps} iterations from x0 as a timed pass) run by this bench invocation")
 
 
@@ -294,7 +303,10 @@ def bench_c5_batched(args):
                       "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                       "dtype": "f64" if args.precision == 0 else "f32 iterate + f64 Rayleigh/residual refinement",
                       "data": "dataset (tests/golden/data)",
-                      "config": {"workload": "configs[4]: city10000.g2o + sphere2500.g2o batched (2 concurrent handles, 1 GPU), K=20%",
+                      "config": {"workload": "configs[4]: city10000.g2o + sphere2500.g2o batched (2 concurrent handles, 1 GPU), K=20%"
+                                             + ("" if args.precision == 0 else " -- precision 1 (fp32 iterate + fp64 refinement) as BASELINE.json words it; "
+                                                "measured SLOWER than the fp64 default on this hardware (DESIGN 4.2d)"),
+                                 "precision_note": "default --precision 0 (fp64) is the faster mode; --precision 1 is the fp32 + fp64-refinement arithmetic configs[4] names",
                                  "fw_iters_each": args.steps, "parallelism": "replicas: one stream + host thread per graph"},
                       "sequential_value": 2 * args.steps / seq, "lambda2_last": [fs[0][-1], fs[1][-1]]}))
     for P in Ps:
@@ -481,21 +493,43 @@ def main():
             traffic, tnote = None, "PMC passes skipped"
             if world == 1 and not args.no_pmc:
                 traffic, tnote = pmc_traffic(args.config, args.steps, args.precision)
-            note = ("avg_launch_us = step_ms / steps_timed of machip_solve_stats: hipEvents on the handle's stream around the Krylov "
+            note = ("unit = one Lanczos step (one launch of k_pipe_vec, or k_pan_mul + k_pan_fin where the column-panel form runs); "
+                    "avg_launch_us = step_ms / steps_timed of machip_solve_stats: hipEvents on the handle's stream around the Krylov "
                     "chunks of every solve in the timed passes (step kernels + one 1-wave tail kernel per chunk, so slightly above "
-                    "the pure kernel average rocprofv3 reports); algorithmic bytes = 12 nnz + 4 (n+1) + 56 n per launch, "
-                    "step-weighted over the iterations; the CSR and the gather operand are Infinity-Cache resident "
-                    "(<= 55 MB), peak is the 8 TB/s HBM figure all the same; " + tnote)
+                    "the pure kernel sums rocprofv3 reports); algorithmic bytes = 12 nnz + 4 (n+1) + 56 n per step whichever "
+                    "kernels run it, step-weighted over the iterations; the CSR and the operand are Infinity-Cache resident "
+                    "(<= 60 MB), peak is the 8 TB/s HBM figure all the same; " + tnote)
+            peak_meas = None
+            try:                          # the achievable peak measured on this box, reported next to the nominal one
+                rd, tr = _lib.membench(1 << 30, 8, local_rank % max(1, ndev))
+                peak_meas = {"read_GBps": rd, "triad_GBps": tr, "frac_of_read": ach / rd,
+                             "how": "machip_membench: read-only sum / STREAM triad over 1 GiB arrays (4x the Infinity Cache), 8 launches each"}
+            except Exception as e:        # noqa: BLE001
+                peak_meas = {"error": str(e)}
+            # secondary bound of the gather step (profiles/r2_c4_counters.md): one L1->L2 request per matrix
+            # entry + one per 128 contiguous bytes; the L2 takes 128 channels x ~2.1 GHz requests per second
+            nnz_mean = sum(r[6] * r[2] for p in passes for r in p[1]) / sc
+            req = nnz_mean * 1.1 + (12.0 * nnz_mean + 60.0 * n) / 128.0
+            l2_frac = (req / (us * 1e-6)) / (128 * 2.1e9)
             if w["n"] <= 3072:   # small chain-like graphs run the single-workgroup solver, not this kernel
                 note = ("at this size the solve runs in the LDS/register-resident single-workgroup kernel k_lan_persist (HBM traffic: one "
                         "8n-byte basis column per step); bytes are still counted with the multi-workgroup formula; " + note)
             out["roofline"] = {"bound": "hbm", "kernel": KERNEL, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_us": us,
-                               "algorithmic_bytes_per_launch": by, "launches_timed": sc, "note": note}
+                               "algorithmic_bytes_per_launch": by, "launches_timed": sc, "peak_measured": peak_meas,
+                               "l2_request_frac": l2_frac,
+                               "l2_request_note": "requests per step if every entry were gathered from L2 (1.1 nnz + streamed bytes / 128) "
+                                                  "/ step time / (128 channels x 2.1 GHz): the bound the one-kernel step runs into; the "
+                                                  "panel form serves the gathers from LDS and issues ~6x fewer",
+                               "note": note}
     if rank == 0 and world == 1 and not args.no_cpu:
         small = n <= 20000 and cfg != "c2"
         cb = cpu_baseline_bounded(cfg, "tracemin", budget_s=12.0, hard_s=20.0 if small else 45.0)
         ft = cb.pop("f_traj")
+        if cfg == "c4":
+            cb["sample"] += ("; reference itself (networkx TraceMIN + SuperLU) measured in the build container, seconds per Fiedler solve of "
+                             "the same ER family: " + json.dumps(REF_EXTRAPOLATION) + " (SURVEY 6.2 / 8(d))")
+            cb["reference_extrapolation_s_per_solve"] = REF_EXTRAPOLATION
         out["cpu_baseline"] = cb
         if ft:
             out["cpu_parity_lambda2_rel"] = float(max(abs(a - r[0]) / abs(a) for a, r in zip(ft, rec)))

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MACHIP_ABI_VERSION 2
+#define MACHIP_ABI_VERSION 3
 
 typedef enum machip_status {
     MACHIP_OK = 0,
@@ -195,6 +195,17 @@ int machip_set_solver(machip_problem* p, int mode);
 int machip_set_precision(machip_problem* p, int precision);
 
 int machip_synchronize(machip_problem* p);
+
+/* Measurement helpers (no counterpart in the reference; bench.py and the CPU tests use them).
+ * machip_membench: achieved HBM bandwidth on `device` in GB/s -- a read-only pass and the STREAM triad
+ * a = b + s c (two reads + one write per element) over arrays of `bytes` bytes each, `reps` back-to-back
+ * launches timed with HIP events.  SURVEY section 8(d): the roofline object of bench.py reports this measured
+ * peak next to the nominal 8 TB/s.
+ * machip_host_tridiag_smallest: host only, no GPU -- smallest eigenpair (theta, s[J]) of the J x J symmetric
+ * tridiagonal with diagonal a[0..J) and off-diagonal b[1..J) (b[0] unused): the O(J) analysis the Lanczos driver
+ * runs on every chunk of steps; exported so that `-m "not gpu"` tests can check it against LAPACK. */
+int machip_membench(int device, int64_t bytes, int reps, double* read_gbs, double* triad_gbs);
+int machip_host_tridiag_smallest(const double* a, const double* b, int J, double* theta, double* s);
 
 #ifdef __cplusplus
 }

@@ -75,8 +75,9 @@ SIGNATURES = {
     "machip_set_solver": (C.c_int, [C.c_void_p, C.c_int]),
     "machip_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "machip_synchronize": (C.c_int, [C.c_void_p]),
+    "machip_membench": (C.c_int, [C.c_int, C.c_int64, C.c_int, _f64p, _f64p]),
+    "machip_host_tridiag_smallest": (C.c_int, [_f64p, _f64p, C.c_int, _f64p, _f64p]),
 }
-_EXTRA = {"machip_host_tridiag_smallest": (C.c_int, [_f64p, _f64p, C.c_int, _f64p, _f64p])}
 
 
 def load():
@@ -88,12 +89,19 @@ def load():
         raise ImportError(f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
                           "(hipcc --offload-arch=gfx950); mac_amd has no CPU fallback")
     lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
-    for name, (res, args) in {**SIGNATURES, **_EXTRA}.items():
+    for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def membench(nbytes=1 << 30, reps=10, device=0):
+    """(read GB/s, STREAM-triad GB/s) measured on the device (machip_membench)."""
+    r, t = C.c_double(0.0), C.c_double(0.0)
+    check(load().machip_membench(int(device), int(nbytes), int(reps), C.byref(r), C.byref(t)))
+    return r.value, t.value
 
 
 def device_count():

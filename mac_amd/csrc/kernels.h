@@ -1141,6 +1141,30 @@ __global__ __launch_bounds__(kBlock) void k_round_mark(const double* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Stream microbenchmarks (machip_membench; SURVEY section 8(d): "confirm the peak on the box and report both"):
+// a read-only sum and the STREAM triad a = b + s c over arrays far larger than the 256 MB Infinity Cache.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_mb_read(const double2* __restrict__ a, long cnt2, double* __restrict__ out) {
+    double s0 = 0.0, s1 = 0.0;
+    const long stride = (long)gridDim.x * kBlock;
+    long i = (long)blockIdx.x * kBlock + threadIdx.x;
+    for (; i + 3 * stride < cnt2; i += 4 * stride) {      // four 16-byte loads in flight per lane
+        const double2 x0 = a[i], x1 = a[i + stride], x2 = a[i + 2 * stride], x3 = a[i + 3 * stride];
+        s0 += (x0.x + x1.x) + (x2.x + x3.x); s1 += (x0.y + x1.y) + (x2.y + x3.y);
+    }
+    for (; i < cnt2; i += stride) { const double2 x = a[i]; s0 += x.x; s1 += x.y; }
+    if (s0 + s1 == 1.2345e301) out[0] = s0;               // (never true: keeps the loads alive)
+}
+__global__ __launch_bounds__(kBlock) void k_mb_triad(double2* __restrict__ a, const double2* __restrict__ b,
+                                                      const double2* __restrict__ c, double s, long cnt2) {
+    const long stride = (long)gridDim.x * kBlock;
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < cnt2; i += stride) {
+        const double2 x = b[i], y = c[i];
+        a[i] = make_double2(x.x + s * y.x, x.y + s * y.y);
+    }
+}
+
 __global__ void k_sel_init(SelState* st, long long k) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         st->prefix = 0; st->kk = k; st->cnt_eq = 0; st->T = 0; st->tie_limit = -1; st->k = k;

@@ -794,6 +794,44 @@ int machip_synchronize(machip_problem* p) {
     return MACHIP_OK;
 }
 
+int machip_membench(int device, int64_t bytes, int reps, double* read_gbs, double* triad_gbs) {
+    if (bytes < (1 << 20) || reps < 1 || !read_gbs || !triad_gbs) return fail(MACHIP_BAD_ARG, "machip_membench: bytes >= 1 MiB, reps >= 1, non-NULL outputs");
+    if (machip_device_count() <= 0) return fail(MACHIP_NO_DEVICE, "no HIP device visible");
+    HIP_TRY(hipSetDevice(device));
+    const long cnt2 = (long)(bytes / 16);
+    double2 *a = nullptr, *b = nullptr, *c = nullptr;
+    double* out = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto body = [&]() -> int {
+        ST_TRY(dev_alloc(&a, (size_t)cnt2)); ST_TRY(dev_alloc(&b, (size_t)cnt2)); ST_TRY(dev_alloc(&c, (size_t)cnt2)); ST_TRY(dev_alloc(&out, 8));
+        HIP_TRY(hipMemset(a, 0, (size_t)cnt2 * 16)); HIP_TRY(hipMemset(b, 0, (size_t)cnt2 * 16)); HIP_TRY(hipMemset(c, 0, (size_t)cnt2 * 16));
+        HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+        const int grid = 256 * 16;           // 16 workgroups of 256 threads per CU
+        float ms = 0.f;
+        k_mb_read<<<grid, kBlock>>>(a, cnt2, out);
+        HIP_TRY(hipEventRecord(e0, nullptr));
+        for (int r = 0; r < reps; ++r) k_mb_read<<<grid, kBlock>>>(r & 1 ? b : a, cnt2, out);
+        HIP_TRY(hipEventRecord(e1, nullptr)); HIP_TRY(hipEventSynchronize(e1));
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        *read_gbs = (double)cnt2 * 16.0 * reps / (ms * 1e-3) / 1e9;
+        k_mb_triad<<<grid, kBlock>>>(a, b, c, 3.0, cnt2);
+        HIP_TRY(hipEventRecord(e0, nullptr));
+        for (int r = 0; r < reps; ++r) k_mb_triad<<<grid, kBlock>>>(a, b, c, 3.0, cnt2);
+        HIP_TRY(hipEventRecord(e1, nullptr)); HIP_TRY(hipEventSynchronize(e1));
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        *triad_gbs = (double)cnt2 * 48.0 * reps / (ms * 1e-3) / 1e9;      // two reads + one write per element
+        HIP_TRY(hipGetLastError());
+        return MACHIP_OK;
+    };
+    const int st = body();
+    const std::string keep = g_err;
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    for (void* q : {(void*)a, (void*)b, (void*)c, (void*)out}) if (q) (void)hipFree(q);
+    g_err = keep;
+    return st;
+}
+
 // Host-only helper exported for CPU tests of the tridiagonal analysis (not part of the
 // reference surface): smallest eigenpair of the J x J symmetric tridiagonal (a, b[1..J)).
 int machip_host_tridiag_smallest(const double* a, const double* b, int J, double* theta, double* s) {

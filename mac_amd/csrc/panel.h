@@ -62,6 +62,7 @@ struct PanView {
     double* ypart;          // [NP][n] per-panel partial products
     double* coef;           // 8 doubles: (alpha, beta, mu, inv, j) of the running step, published by k_pan_mul for k_pan_fin
     int* tcount;            // [tiles] entries (with padding) per tile (assembly scratch)
+    int* ps;                // [(NP+1)][n] first off-diagonal entry of row r at or behind panel p (assembly scratch)
 #ifdef PAN_CLOCKS
     long long* clk;         // tools/ubench6.hip: 16 wall-clock stamps (100 MHz) per workgroup
 #endif
@@ -83,72 +84,69 @@ __device__ __forceinline__ double pan_vj(double alpha, double mu, double inv, do
 }
 
 // ------------------------------------------------------------------------------------------
-// Panel form of an assembled CSR (diagonal first, other columns ascending): three launches, integers only.
-// One workgroup per row block; thread t owns rows  block base + t + 1024 j.
+// Panel form of an assembled CSR (diagonal first, other columns ascending): four launches, integers only.
 // ------------------------------------------------------------------------------------------
+// Pass 0: where every row's off-diagonal entries of panel p start, ps[p n + r] (p = 0 .. NP; one walk per row).
+// (First build of the panel form walked the rows inside the count / fill kernels, one workgroup per row block: 21
+// workgroups for the whole matrix, 0.9-1.3 ms per Frank-Wolfe iteration.  With this table count and fill run one
+// workgroup per (row block, panel).)
+__global__ __launch_bounds__(kBlock) void k_pan_rows(CsrView A, PanView P) {
+    const int r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= A.n) return;
+    int e = A.rowptr[r] + 1;               // (the diagonal sits first and is counted with its own panel)
+    const int end = A.rowptr[r + 1];
+    for (int p = 0; p < P.NP; ++p) {
+        P.ps[(size_t)p * A.n + r] = e;
+        const int hi = (p + 1) * P.C;
+        while (e < end && A.col[e] < hi) ++e;
+    }
+    P.ps[(size_t)P.NP * A.n + r] = end;
+}
+
 constexpr int kPanRT = (kPanRows + kPanThreads - 1) / kPanThreads;   // rows per thread (8)
 
-struct PanRowWalk {    // a thread's cursor through its rows, panel by panel
-    int e[kPanRT], end[kPanRT], pd[kPanRT];
-    __device__ __forceinline__ void begin(const CsrView& A, const PanView& P, int row0, int R, int tid) {
-#pragma unroll
-        for (int j = 0; j < kPanRT; ++j) {
-            const int rl = tid + kPanThreads * j, r = row0 + rl;
-            const bool valid = rl < R && r < A.n;
-            const int d = valid ? A.rowptr[r] : 0;
-            end[j] = valid ? A.rowptr[r + 1] : 0;
-            e[j] = valid ? d + 1 : 0;             // (the diagonal sits first and is counted with its own panel)
-            pd[j] = valid ? r / P.C : -1;
-        }
-    }
-    // entries of row j inside panel p; *start = first off-diagonal one; the cursor moves past them
-    __device__ __forceinline__ int count(const CsrView& A, int j, int p, int hi, int* start) {
-        int c = (p == pd[j]) ? 1 : 0;
-        *start = e[j];
-        while (e[j] < end[j] && A.col[e[j]] < hi) { ++e[j]; ++c; }
-        return c;
-    }
-};
+// entries of row r inside panel p (diagonal included when r lies in the panel); *start = first off-diagonal one
+__device__ __forceinline__ int pan_row_count(const PanView& P, int n, int r, int p, int* start) {
+    const int st = P.ps[(size_t)p * n + r];
+    *start = st;
+    return min(P.ps[(size_t)(p + 1) * n + r] - st + (r / P.C == p ? 1 : 0), kPanMaxLen);
+}
 
-// Pass 1: per panel, sort the block's rows by length (counting sort; ties in arrival order -- a row's sum does not
-// depend on the slot it lands in, so the tie order never shows in a result) and record slot -> row and the tile sizes.
+// Pass 1, one workgroup per (row block, panel): sort the block's rows by length (counting sort; ties in arrival order
+// -- a row's sum does not depend on the slot it lands in, so the tie order never shows in a result) and record
+// slot -> row and the tile sizes.
 __global__ __launch_bounds__(kPanThreads) void k_pan_count(CsrView A, PanView P) {
     __shared__ int hist[kPanMaxLen + 1], start[kPanMaxLen + 1], fill[kPanMaxLen + 1];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x / P.NP, p = blockIdx.x - b * P.NP, tid = threadIdx.x;
     const int R = 64 * P.NTB, NTP = kPanWork * P.TWW;
-    PanRowWalk W;
-    W.begin(A, P, b * R, R, tid);
-    for (int p = 0; p < P.NP; ++p) {
-        if (tid <= kPanMaxLen) { hist[tid] = 0; fill[tid] = 0; }
-        __syncthreads();
-        const int hi = (p + 1) * P.C;
-        int c[kPanRT];
+    if (tid <= kPanMaxLen) { hist[tid] = 0; fill[tid] = 0; }
+    __syncthreads();
+    int c[kPanRT];
 #pragma unroll
-        for (int j = 0; j < kPanRT; ++j) {
-            int st;
-            c[j] = min(W.count(A, j, p, hi, &st), kPanMaxLen);
-            if (tid + kPanThreads * j < R) atomicAdd(&hist[c[j]], 1);
-        }
-        __syncthreads();
-        if (tid == 0) { int run = 0; for (int Lc = kPanMaxLen; Lc >= 0; --Lc) { start[Lc] = run; run += hist[Lc]; } }
-        __syncthreads();
-        const size_t vtb = (size_t)(b * P.NP + p) * NTP;
+    for (int j = 0; j < kPanRT; ++j) {
+        const int rl = tid + kPanThreads * j, r = b * R + rl;
+        int st;
+        c[j] = (rl < R && r < A.n) ? pan_row_count(P, A.n, r, p, &st) : 0;
+        if (rl < R) atomicAdd(&hist[c[j]], 1);
+    }
+    __syncthreads();
+    if (tid == 0) { int run = 0; for (int Lc = kPanMaxLen; Lc >= 0; --Lc) { start[Lc] = run; run += hist[Lc]; } }
+    __syncthreads();
+    const size_t vtb = (size_t)(b * P.NP + p) * NTP;
 #pragma unroll
-        for (int j = 0; j < kPanRT; ++j) {
-            const int rl = tid + kPanThreads * j;
-            if (rl < R) {
-                const int slot = start[c[j]] + atomicAdd(&fill[c[j]], 1);
-                const int ts = slot >> 6, w = ts % kPanWork, q = ts / kPanWork;
-                P.thead[(vtb + (size_t)(w * P.TWW + q)) * 64 + (slot & 63)] = (unsigned short)rl;
-            }
+    for (int j = 0; j < kPanRT; ++j) {
+        const int rl = tid + kPanThreads * j;
+        if (rl < R) {
+            const int slot = start[c[j]] + atomicAdd(&fill[c[j]], 1);
+            const int ts = slot >> 6, w = ts % kPanWork, q = ts / kPanWork;
+            P.thead[(vtb + (size_t)(w * P.TWW + q)) * 64 + (slot & 63)] = (unsigned short)rl;
         }
-        if (tid < NTP) {          // physical tile tid = (w, q) holds sorted tile ts = w + 15 q: its longest row comes first
-            const int w = tid / P.TWW, q = tid - w * P.TWW, ts = w + kPanWork * q;
-            int tm = 0;
-            if (ts < P.NTB) { const int s0 = ts * 64; for (int Lc = kPanMaxLen; Lc > 0; --Lc) if (s0 >= start[Lc] && s0 < start[Lc] + hist[Lc]) tm = Lc; }
-            P.tcount[vtb + tid] = 64 * tm;
-        }
-        __syncthreads();
+    }
+    if (tid < NTP) {          // physical tile tid = (w, q) holds sorted tile ts = w + 15 q: its longest row comes first
+        const int w = tid / P.TWW, q = tid - w * P.TWW, ts = w + kPanWork * q;
+        int tm = 0;
+        if (ts < P.NTB) { const int s0 = ts * 64; for (int Lc = kPanMaxLen; Lc > 0; --Lc) if (s0 >= start[Lc] && s0 < start[Lc] + hist[Lc]) tm = Lc; }
+        P.tcount[vtb + tid] = 64 * tm;
     }
 }
 
@@ -174,45 +172,30 @@ __global__ __launch_bounds__(1024) void k_pan_scan(PanView P) {
     if (tid == 1023) P.tptr[NT] = s_part[1023];
 }
 
-// Pass 3: the same walk publishes where every row's entries of the panel start; the slots copy their row, zero-padded
-// to the tile's height (writes coalesced along the lanes).
+// Pass 3, one workgroup per (row block, panel): every slot copies its row's entries of the panel, zero-padded to the
+// tile's height (writes coalesced along the lanes).
 __global__ __launch_bounds__(kPanThreads) void k_pan_fill(CsrView A, PanView P) {
-    __shared__ int r_st[kPanRows];
-    __shared__ unsigned char r_c[kPanRows];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x / P.NP, p = blockIdx.x - b * P.NP, tid = threadIdx.x;
     const int R = 64 * P.NTB, NTP = kPanWork * P.TWW;
-    PanRowWalk W;
-    W.begin(A, P, b * R, R, tid);
-    for (int p = 0; p < P.NP; ++p) {
-        const int hi = (p + 1) * P.C, c0 = p * P.C;
-#pragma unroll
-        for (int j = 0; j < kPanRT; ++j) {
-            int st;
-            const int c = min(W.count(A, j, p, hi, &st), kPanMaxLen);
-            const int rl = tid + kPanThreads * j;
-            if (rl < R) { r_st[rl] = (p == W.pd[j]) ? (st | (1 << 30)) : st; r_c[rl] = (unsigned char)c; }   // bit 30: entry 0 is the diagonal
+    const int c0 = p * P.C;
+    const size_t vtb = (size_t)(b * P.NP + p) * NTP;
+    for (int s = tid; s < NTP * 64; s += kPanThreads) {
+        const size_t vt = vtb + (size_t)(s >> 6);
+        const int base = P.tptr[vt], tm = (P.tptr[vt + 1] - base) >> 6;
+        if (tm == 0) continue;
+        const int r = b * R + P.thead[vt * 64 + (s & 63)];
+        int st = 0, c = 0;
+        if (r < A.n) c = pan_row_count(P, A.n, r, p, &st);
+        const int shift = (r < A.n && r / P.C == p) ? 1 : 0;      // entry 0 is the diagonal
+        const int dg = shift ? A.rowptr[r] : 0;
+        for (int i = 0; i < tm; ++i) {
+            const int dst = base + 64 * i + (s & 63);
+            if (i < c) {
+                const int src = (shift && i == 0) ? dg : st + i - shift;
+                P.bval[dst] = A.val[src];
+                P.bcol[dst] = (unsigned short)(A.col[src] - c0);
+            } else { P.bval[dst] = 0.0; P.bcol[dst] = 0; }
         }
-        __syncthreads();
-        const size_t vtb = (size_t)(b * P.NP + p) * NTP;
-        for (int s = tid; s < NTP * 64; s += kPanThreads) {
-            const size_t vt = vtb + (size_t)(s >> 6);
-            const int base = P.tptr[vt], tm = (P.tptr[vt + 1] - base) >> 6;
-            if (tm == 0) continue;
-            const int rl = P.thead[vt * 64 + (s & 63)];
-            const int stv = r_st[rl], c = r_c[rl];
-            const int shift = (stv >> 30) & 1, st = stv & ((1 << 30) - 1);
-            const int r = b * R + rl;
-            const int dg = (shift && r < A.n) ? A.rowptr[r] : 0;
-            for (int i = 0; i < tm; ++i) {
-                const int dst = base + 64 * i + (s & 63);
-                if (i < c) {
-                    const int src = (shift && i == 0) ? dg : st + i - shift;
-                    P.bval[dst] = A.val[src];
-                    P.bcol[dst] = (unsigned short)(A.col[src] - c0);
-                } else { P.bval[dst] = 0.0; P.bcol[dst] = 0; }
-            }
-        }
-        __syncthreads();
     }
 }
 

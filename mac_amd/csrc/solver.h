@@ -382,7 +382,7 @@ struct Solver {
                         lx_ys, lx_pas, lx_as, lx_bs, lx_maps, lx_ba, lx_bd, lx_bu, wb_ui, wb_uj, wb_counts, wb_uc, wb_g, wb_h, wb_Zt, wb_Cm, wb_pas, wb_maps,
                         lx_colT, lx_bad, lx_st, valf};
         {
-            void* pb[] = {panv.tptr, panv.thead, panv.bval, panv.bcol, panv.ypart, panv.coef, panv.tcount};
+            void* pb[] = {panv.tptr, panv.thead, panv.bval, panv.bcol, panv.ypart, panv.coef, panv.tcount, panv.ps};
             for (void* q : pb) if (q) (void)hipFree(q);
         }
         if (h_lrec) (void)hipHostFree(h_lrec);
@@ -478,13 +478,15 @@ struct Solver {
         }
         if ((size_t)pn.NP * (size_t)n > pan_y_cap) {
             ST_TRY(regrow(&panv.ypart, (size_t)pn.NP * (size_t)n));
+            ST_TRY(regrow(&panv.ps, ((size_t)pn.NP + 1) * (size_t)n));
             pan_y_cap = (size_t)pn.NP * (size_t)n;
         }
         if (!panv.coef) ST_TRY(dev_alloc(&panv.coef, 8));
         panv.n = n; panv.NP = pn.NP; panv.C = pn.C; panv.NB = pn.NB; panv.NTB = pn.NTB; panv.TWW = pn.TWW;
-        k_pan_count<<<pn.NB, kPanThreads, 0, stream>>>(A, panv);
+        k_pan_rows<<<(n + kBlock - 1) / kBlock, kBlock, 0, stream>>>(A, panv);
+        k_pan_count<<<pn.NB * pn.NP, kPanThreads, 0, stream>>>(A, panv);
         k_pan_scan<<<1, 1024, 0, stream>>>(panv);
-        k_pan_fill<<<pn.NB, kPanThreads, 0, stream>>>(A, panv);
+        k_pan_fill<<<pn.NB * pn.NP, kPanThreads, 0, stream>>>(A, panv);
         HIP_TRY(hipGetLastError());
         return MACHIP_OK;
     }

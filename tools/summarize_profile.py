@@ -44,11 +44,17 @@ for (n, calls, tot, avg, pct, mn, mx) in stats:
     f = fetch.get(n, (0, 0.0))[1]; w = write.get(n, (0, 0.0))[1]
     rows.append(dict(kernel=n, calls=calls, total_ms=tot / 1e6, avg_us=avg / 1e3, pct=pct, min_us=mn / 1e3, max_us=mx / 1e3,
                      fetch_kib=f, write_kib=w, hbm_bytes_per_launch=(2.0 * f + w) * 1024.0))
-pipe = [r for r in rows if r["kernel"].startswith("k_pipe_vec") or r["kernel"].startswith("k_pipe_stream")]
-calls = sum(r["calls"] for r in pipe)
-dom = dict(kernel="k_pipe_{vec,stream} (fused Lanczos step)", calls=calls,
-           avg_us=sum(r["avg_us"] * r["calls"] for r in pipe) / max(1, calls),
-           hbm_bytes_per_launch=sum(r["hbm_bytes_per_launch"] * r["calls"] for r in pipe) / max(1, calls))
+# A Lanczos step = one launch of k_pipe_vec / k_pipe_stream (gather form), or k_pan_mul + k_pan_fin (column-panel form).
+heads = [r for r in rows if r["kernel"].startswith(("k_pipe_vec", "k_pipe_stream", "k_pan_mul"))]
+parts = [r for r in rows if r["kernel"].startswith(("k_pipe_vec", "k_pipe_stream", "k_pan_mul", "k_pan_fin"))]
+calls = sum(r["calls"] for r in heads)
+dom = dict(kernel="one Lanczos step: k_pipe_vec (gather form) or k_pan_mul + k_pan_fin (column-panel form)", calls=calls,
+           avg_us=sum(r["avg_us"] * r["calls"] for r in parts) / max(1, calls),
+           hbm_bytes_per_launch=sum(r["hbm_bytes_per_launch"] * r["calls"] for r in parts) / max(1, calls),
+           gather_steps=sum(r["calls"] for r in heads if not r["kernel"].startswith("k_pan")),
+           panel_steps=sum(r["calls"] for r in heads if r["kernel"].startswith("k_pan")),
+           gather_avg_us=sum(r["avg_us"] * r["calls"] for r in parts if not r["kernel"].startswith("k_pan")) / max(1, sum(r["calls"] for r in heads if not r["kernel"].startswith("k_pan"))),
+           panel_avg_us=sum(r["avg_us"] * r["calls"] for r in parts if r["kernel"].startswith("k_pan")) / max(1, sum(r["calls"] for r in heads if r["kernel"].startswith("k_pan"))))
 js = dict(tag=tag, bench=bench_line, dominant=dom, kernels=rows)
 json.dump(js, open(out_js, "w"), indent=1)
 with open(out_md, "w") as fh:
@@ -56,8 +62,9 @@ with open(out_md, "w") as fh:
              "(FETCH_SIZE, WRITE_SIZE); raw CSVs were in `gpurun_out/" + tag + "/` (scratch).\n\n")
     if bench_line:
         fh.write("bench line of the traced run (profiler attached, so slower than the un-profiled number):\n\n```\n" + json.dumps(bench_line) + "\n```\n\n")
-    fh.write(f"Dominant kernel: **{dom['kernel']}**, {dom['calls']} launches, average {dom['avg_us']:.2f} us, "
-             f"HBM traffic/launch (2*FETCH+WRITE) {dom['hbm_bytes_per_launch']/1e6:.2f} MB.\n\n")
+    fh.write(f"Dominant work: **{dom['kernel']}**, {dom['calls']} steps ({dom['gather_steps']} gather-form at {dom['gather_avg_us']:.2f} us, "
+             f"{dom['panel_steps']} panel-form at {dom['panel_avg_us']:.2f} us = k_pan_mul + k_pan_fin), kernel time per step {dom['avg_us']:.2f} us, "
+             f"HBM traffic per step (2*FETCH+WRITE) {dom['hbm_bytes_per_launch']/1e6:.2f} MB.\n\n")
     if bench_line and bench_line.get("roofline"):
         r = bench_line["roofline"]
         frac_trace = r["algorithmic_bytes_per_launch"] / (dom["avg_us"] * 1e-6) / 1e9 / r["peak"]
