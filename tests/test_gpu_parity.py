@@ -445,6 +445,102 @@ def test_city10000_vertices_until_the_fork():
     P.close()
 
 
+# --------------------------------------------------------------------------------------------
+# Teacher forcing: the HIP path evaluated ON THE REFERENCE'S OWN ITERATES.  x_i is rebuilt from the LP vertices the
+# reference run stored (x_{i+1} = x_i + 2/(i+2) (s_i - x_i), NumPy arithmetic exactly as frankwolfe.py:76 does it), so
+# every one of the late, stiff iterates is checked by value -- lambda_2 to 1e-8 -- and not through bounded drift of a
+# free-running trajectory.  The LP vertex is compared as a set: entries may only differ where the gradient lies within
+# the band a 1e-8-accurate eigenvector cannot resolve around the K-th value T: g = w d^2 with d = v_i - v_j known to
+# dv = 2e-6 (the Fiedler-vector tolerance of this file) gives |dg| <= 2 sqrt(w T) dv + w dv^2 (the golden stores the
+# reference's own relative gap at the K-th place: 1e-7 .. 1e-4, near-ties are the rule with equal weights).
+# --------------------------------------------------------------------------------------------
+def _teacher_forced(P, k, x0, ref_vertices, lam_ref, wmax=1.0, dv=2e-6):
+    x = np.array(x0, dtype=np.float64)
+    worst = 0.0
+    for i, lam_gold in enumerate(lam_ref):
+        P.set_x(x)
+        lam, _, _ = P.fiedler(tol=1e-8, want_vec=False)
+        rel = abs(lam - lam_gold) / abs(lam_gold)
+        worst = max(worst, rel)
+        assert rel <= LAM_RTOL, (i, lam, lam_gold, rel)
+        assert P.stats.residual < 1e-8
+        g = P.gradient()
+        s = P.lp_topk(k)
+        s_ref = ref_vertices(i)
+        assert int(s.sum()) == k == int(s_ref.sum())
+        diff = np.nonzero(s != s_ref)[0]
+        if len(diff):
+            thr = np.partition(g, len(g) - k)[len(g) - k]          # K-th largest gradient entry
+            band = 2.0 * np.sqrt(wmax * thr) * dv + wmax * dv * dv
+            assert np.all(np.abs(g[diff] - thr) <= band), (i, len(diff), float(np.abs(g[diff] - thr).max()), band)
+        x = x + 2.0 / (i + 2) * (s_ref - x)                          # the reference's iterate, not ours
+    return worst
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_teacher_forced_city10000_all_twenty_reference_iterates(precision):
+    """BASELINE.json configs[4] (city10000): lambda_2 on x_0 .. x_19 of the reference's own run (stiff from x_1 on:
+    lambda_2 = 0.0012, thousands of Lanczos steps or the preconditioned mode), fp64 and mixed precision."""
+    g = load_golden("g2o_city10000"); gv = load_golden("city10000_vertices")
+    m, k = len(g["cw"]), int(g["k"])
+    P = problem_of(g)
+    P.set_precision(precision)
+    P.set_start(reference_start_block(int(g["n"]))[:, 0].copy())
+
+    def vert(i):
+        s = np.zeros(m); s[gv["ref_s"][i]] = 1.0
+        return s
+    _teacher_forced(P, k, gv["x_init"], vert, gv["f_traj"], wmax=float(np.max(g["cw"])))
+    P.close()
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_teacher_forced_config2_all_twenty_reference_iterates(precision):
+    """BASELINE.json configs[1] (ER N = 10k): the reference's 20 iterates (tests/golden/er10k_vertices.npz, two CPU
+    hours of TraceMIN + SuperLU), lambda_2 to 1e-8 on each."""
+    import bench
+    w = bench.make_workload("c2")
+    gv = load_golden("er10k_vertices")
+    m, k = len(w["cw"]), w["k"]
+    assert int(gv["m"]) == m and int(gv["k"]) == k
+    assert np.array_equal(np.nonzero(w["x0"])[0], load_golden("er10k_x0")["x0_idx"])
+    P = _lib.Problem(w["n"], w["fi"], w["fj"], w["fw"], w["ci"], w["cj"], w["cw"])
+    P.set_precision(precision)
+    P.set_start(reference_start_block(w["n"])[:, 0].copy())
+    bits = gv["ref_s_bits"]
+    _teacher_forced(P, k, w["x0"], lambda i: np.unpackbits(bits[i])[:m].astype(np.float64), gv["f_traj"])
+    P.close()
+
+
+def test_teacher_forced_config4_first_six_iterates():
+    """BASELINE.json configs[3] (ER N = 100k, 2M candidates): lambda_2 on the first six iterates of the reference's
+    loop with ARPACK (tol 1e-13, residual <= 8e-14) standing in for the sparse LU that does not finish at this size
+    (tests/golden/er100k_arpack.npz: the reference's MAC.laplacian / solve_subset_box_lp / update, SciPy eigsh).  The
+    one-kernel gather step serves the sparse iterates, the column-panel step the dense ones; both must hit 1e-8, and the
+    panel step is also forced onto every iterate."""
+    import bench
+    w = bench.make_workload("c4")
+    gv = load_golden("er100k_arpack")
+    m, k = len(w["cw"]), w["k"]
+    assert int(gv["m"]) == m and int(gv["k"]) == k
+    P = _lib.Problem(w["n"], w["fi"], w["fj"], w["fw"], w["ci"], w["cj"], w["cw"])
+    P.set_start(reference_start_block(w["n"])[:, 0].copy())
+    bits = gv["ref_s_bits"]
+    vert = lambda i: np.unpackbits(bits[i])[:m].astype(np.float64)    # noqa: E731
+    _teacher_forced(P, k, w["x0"], vert, gv["lam_traj"])
+    old = os.environ.get("MACHIP_PANEL")
+    try:
+        for mode in ("1", "0"):
+            os.environ["MACHIP_PANEL"] = mode
+            _teacher_forced(P, k, w["x0"], vert, gv["lam_traj"])
+    finally:
+        if old is None:
+            os.environ.pop("MACHIP_PANEL", None)
+        else:
+            os.environ["MACHIP_PANEL"] = old
+    P.close()
+
+
 def test_batched_two_handles_match_sequential():
     """BASELINE.json configs[4] batched mode (bench.py --config c5): city10000 and sphere2500 as two handles
     driven by two host threads on one GPU give bit-identical trajectories to running them one after the other."""
