@@ -205,6 +205,10 @@ int machip_synchronize(machip_problem* p);
  * tridiagonal with diagonal a[0..J) and off-diagonal b[1..J) (b[0] unused): the O(J) analysis the Lanczos driver
  * runs on every chunk of steps; exported so that `-m "not gpu"` tests can check it against LAPACK. */
 int machip_membench(int device, int64_t bytes, int reps, double* read_gbs, double* triad_gbs);
+/* machip_fiedler_csr keeps one CSR-only handle (stream, device buffers, chunk graphs) between calls and reuses it when
+ * device and n match and the matrix fits -- every solve still starts from a clean solver state.  This frees it (the
+ * Python layer calls it at interpreter exit). */
+void machip_release_cache(void);
 int machip_host_tridiag_smallest(const double* a, const double* b, int J, double* theta, double* s);
 
 #ifdef __cplusplus

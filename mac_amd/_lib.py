@@ -77,6 +77,7 @@ SIGNATURES = {
     "machip_synchronize": (C.c_int, [C.c_void_p]),
     "machip_membench": (C.c_int, [C.c_int, C.c_int64, C.c_int, _f64p, _f64p]),
     "machip_host_tridiag_smallest": (C.c_int, [_f64p, _f64p, C.c_int, _f64p, _f64p]),
+    "machip_release_cache": (None, []),
 }
 
 
@@ -94,6 +95,8 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    import atexit
+    atexit.register(lib.machip_release_cache)     # the handle machip_fiedler_csr keeps between calls
     return lib
 
 

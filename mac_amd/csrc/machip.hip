@@ -90,13 +90,17 @@ struct machip_problem {
     // evaluation lanes (machip_eval_batch): lightweight copies that share the pattern and the candidate arrays
     bool is_lane = false;
     std::vector<machip_problem*> lanes;
-    unsigned long start_version = 0, lane_start_version = 0;
+    unsigned long start_version = 0;          // bumped whenever sol.start changes
+    unsigned long seen_start_version = ~0ul;  // (lane) the owner's start_version this lane last copied
 
     CsrView csr() const { return CsrView{n, rowptr, col, val}; }
     PatternView pattern() const { return PatternView{n, prow, pcol, pk, pw}; }
 };
 
 namespace {
+
+std::mutex g_csr_mu;                        // machip_fiedler_csr's cached handle
+machip_problem* g_csr_cache = nullptr;
 
 struct Slot {
     int col;
@@ -219,8 +223,8 @@ int assemble(machip_problem* p) {
     return MACHIP_OK;
 }
 
-int alloc_common(machip_problem* p) {
-    ST_TRY(p->sol.init(p->n, p->stream));
+int alloc_common(machip_problem* p, int vbudget_mb = 0) {
+    ST_TRY(p->sol.init(p->n, p->stream, vbudget_mb));
     HIP_TRY(hipHostMalloc((void**)&p->h_int, sizeof(int) * 3 * kMaxGrid, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void**)&p->h_dbl, sizeof(double) * 4 * kMaxGrid, hipHostMallocDefault));
     return MACHIP_OK;
@@ -293,6 +297,7 @@ int run_fiedler(machip_problem* p, double tol, int max_steps, const double* x0, 
         HIP_TRY(hipMemcpyAsync(p->sol.start, x0, sizeof(double) * (size_t)p->n, hipMemcpyHostToDevice, p->stream));
         HIP_TRY(hipStreamSynchronize(p->stream));
         p->sol.have_start = true;
+        ++p->start_version;          // evaluation lanes must pick the new vector up (machip_eval_batch)
     }
     machip_solve_stats local;
     memset(&local, 0, sizeof(local));
@@ -466,12 +471,24 @@ int machip_set_start(machip_problem* p, const double* x0) {
     return MACHIP_OK;
 }
 
+namespace {
+// Collective entry points of an in-process communicator: whatever makes a rank leave early (assembly, eigen-solve,
+// a HIP error) must release the peers waiting in the group's barrier instead of leaving them blocked.
+struct GroupGuard {
+    machip_problem* p;
+    bool ok = false;
+    ~GroupGuard() { if (!ok && p && p->lgroup) p->lgroup->abort(); }
+};
+}  // namespace
+
 int machip_gradient(machip_problem* p, double* g_out) {
     if (!p || p->csr_only) return fail(MACHIP_BAD_ARG, "bad handle");
+    GroupGuard guard{p};
     HIP_TRY(hipSetDevice(p->device));
     ST_TRY(compute_gradient(p));
     if (g_out) HIP_TRY(hipMemcpyAsync(g_out, p->g, sizeof(double) * (size_t)p->m, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
+    guard.ok = true;
     return MACHIP_OK;
 }
 
@@ -489,6 +506,7 @@ int machip_lp_topk(machip_problem* p, int64_t k, double* s_out) {
 int machip_fw_step(machip_problem* p, int64_t k, int iter, double tol, int max_steps, int warm_start,
                    double* f, double* dual, double* gnorm, machip_solve_stats* stats) {
     if (!p || p->csr_only || !f || !dual || !gnorm) return fail(MACHIP_BAD_ARG, "bad argument");
+    GroupGuard guard{p};
     HIP_TRY(hipSetDevice(p->device));
     ST_TRY(assemble(p));
     double lam = 0.0;
@@ -506,6 +524,7 @@ int machip_fw_step(machip_problem* p, int64_t k, int iter, double tol, int max_s
     *f = lam;
     *dual = lam + d;
     *gnorm = std::sqrt(q2);
+    guard.ok = true;
     return MACHIP_OK;
 }
 
@@ -570,18 +589,39 @@ int machip_fiedler_csr(int device, int64_t n, const int32_t* indptr, const int32
         lnorm = std::max(lnorm, s);   // nx:232
         maxlen_csr = std::max(maxlen_csr, (int)(indptr[r + 1] - indptr[r]));
     }
-    machip_problem* p = new machip_problem();
-    p->device = device; p->n = (int)n; p->csr_only = true;
+    // One CSR-only handle is kept between calls (stream, ~25 device buffers, pinned mirrors, chunk graphs: creating them
+    // costs more than a small solve -- a Madow loop or a sweep through find_fiedler_pair paid it per call).  It is reused
+    // when device and n match and the matrix fits; every solve starts from a clean solver state, so a cached handle
+    // computes exactly what a fresh one does.  A second thread calling concurrently gets a fresh handle of its own.
+    std::unique_lock<std::mutex> lk(g_csr_mu, std::try_to_lock);
+    machip_problem* p = nullptr;
+    bool cached = false;
+    if (lk.owns_lock() && g_csr_cache && g_csr_cache->device == device && g_csr_cache->n == (int)n && (long)g_csr_cache->sol.csr_cap >= nnz) {
+        p = g_csr_cache;
+        cached = true;
+    } else {
+        if (lk.owns_lock() && g_csr_cache) { machip_destroy(g_csr_cache); g_csr_cache = nullptr; }
+        p = new machip_problem();
+        p->device = device; p->n = (int)n; p->csr_only = true;
+    }
     auto body = [&]() -> int {
-        HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
-        ST_TRY(dev_alloc(&p->rowptr, (size_t)n + 1)); ST_TRY(dev_alloc(&p->col, (size_t)nnz)); ST_TRY(dev_alloc(&p->val, (size_t)nnz));
+        if (!cached) {
+            const size_t cap = (size_t)nnz + (size_t)nnz / 4 + 64;
+            HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+            ST_TRY(dev_alloc(&p->rowptr, (size_t)n + 1)); ST_TRY(dev_alloc(&p->col, cap)); ST_TRY(dev_alloc(&p->val, cap));
+            ST_TRY(alloc_common(p));
+            p->sol.csr_cap = cap;
+        }
         HIP_TRY(hipMemcpy(p->rowptr, indptr, sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice));
         if (nnz) {
             HIP_TRY(hipMemcpy(p->col, indices, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(p->val, data, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
         }
-        ST_TRY(alloc_common(p));
-        p->nnz = nnz; p->lnorm = lnorm; p->maxlen = maxlen_csr; p->assembled = true;
+        p->nnz = nnz; p->lnorm = lnorm; p->maxlen = maxlen_csr; p->assembled = true; p->have_vec = false;
+        // clean solver state: nothing learnt from, or left over by, an earlier matrix
+        Solver& S = p->sol;
+        S.have_prev = false; S.have_start = false; S.hist_lan_steps = -1; S.hist_lob_iters = -1; S.last_steps = 0;
+        S.last_steps_lowp = 0; S.J_last = 0; S.last_was_lob = false; S.last_seq_f32 = false; S.solver_mode = 0; S.precision = 0;
         // same solver selection as a MAC handle gets (solver.h): chain-like matrices may run the
         // single-workgroup / preconditioned modes; "support" = off-chain edges
         p->sol.chain_like = chain_cnt >= (long)(0.98 * (double)(n - 1));
@@ -592,9 +632,19 @@ int machip_fiedler_csr(int device, int64_t n, const int32_t* indptr, const int32
     int st = body();
     if (st == MACHIP_OK) st = machip_fiedler(p, tol, max_steps, x0, 0, lambda2, v_out, X_out, q, stats);
     const std::string keep = g_err;
-    machip_destroy(p);
+    const bool hard = st != MACHIP_OK && st != MACHIP_NOT_CONVERGED && st != MACHIP_DISCONNECTED;
+    if (lk.owns_lock() && !hard) g_csr_cache = p;          // keep it for the next call
+    else {
+        if (cached) g_csr_cache = nullptr;
+        machip_destroy(p);
+    }
     g_err = keep;
     return st;
+}
+
+void machip_release_cache(void) {
+    std::lock_guard<std::mutex> lk(g_csr_mu);
+    if (g_csr_cache) { machip_destroy(g_csr_cache); g_csr_cache = nullptr; }
 }
 
 int machip_spmv(machip_problem* p, const double* v, double* y, int variant) {
@@ -654,6 +704,7 @@ int machip_comm_unique_id(void* id128) {
 int machip_comm_init(machip_problem* p, int rank, int nranks, const void* id128) {
     if (!p || p->csr_only || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(MACHIP_BAD_ARG, "bad argument");
     if (nranks > 64) return fail(MACHIP_BAD_ARG, "at most 64 ranks");
+    if (p->comm || p->lgroup) return fail(MACHIP_BAD_ARG, "machip_comm_init: handle already belongs to a communicator");
     HIP_TRY(hipSetDevice(p->device));
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
@@ -708,7 +759,9 @@ int make_lane(machip_problem* p, machip_problem** out) {
         ST_TRY(dev_alloc(&q->cnt, (size_t)q->n + 1)); ST_TRY(dev_alloc(&q->blk_sum, 3 * kMaxGrid));
         ST_TRY(dev_alloc(&q->rowptr, (size_t)q->n + 1)); ST_TRY(dev_alloc(&q->col, cap)); ST_TRY(dev_alloc(&q->val, cap));
         ST_TRY(dev_alloc(&q->blk_lnorm, kMaxGrid));
-        ST_TRY(alloc_common(q));
+        // every lane keeps its own Krylov basis: a share of the handle's budget each (MACHIP_LANE_VBUDGET_MB, default
+        // MACHIP_VBUDGET_MB / 8 = 512 MB: 8 lanes together hold what the handle itself holds)
+        ST_TRY(alloc_common(q, std::max(16, env_int("MACHIP_LANE_VBUDGET_MB", std::max(16, env_int("MACHIP_VBUDGET_MB", 4096) / 8)))));
         q->sol.csr_cap = cap;
         q->sol.chain_like = p->sol.chain_like; q->sol.chain_edges = p->sol.chain_edges;
         return MACHIP_OK;
@@ -724,23 +777,30 @@ int machip_eval_batch(machip_problem* p, int B, const double* X, double tol, int
     if (!p || p->csr_only || p->is_lane || B < 0 || (B && (!X || !lambda2))) return fail(MACHIP_BAD_ARG, "machip_eval_batch: bad argument");
     if (B == 0) return MACHIP_OK;
     HIP_TRY(hipSetDevice(p->device));
-    const int nl = std::max(1, std::min(B, std::min(16, env_int("MACHIP_LANES", 8))));
+    int nl = std::max(1, std::min(B, std::min(16, env_int("MACHIP_LANES", 8))));
     while ((int)p->lanes.size() < nl) {
         machip_problem* q = nullptr;
-        ST_TRY(make_lane(p, &q));
+        const int st = make_lane(p, &q);
+        if (st != MACHIP_OK) {
+            // out of device memory for another lane: carry on with the lanes there are (the batch then takes longer, it
+            // does not fail); without any lane the error stands
+            if (p->lanes.empty()) return st;
+            (void)hipGetLastError();
+            nl = (int)p->lanes.size();
+            break;
+        }
         p->lanes.push_back(q);
-        p->lane_start_version = ~0ul;   // (re)send the start vector to every lane below
     }
     HIP_TRY(hipStreamSynchronize(p->stream));
     for (int l = 0; l < nl; ++l) {
         machip_problem* q = p->lanes[(size_t)l];
         q->sol.solver_mode = p->sol.solver_mode; q->sol.precision = p->sol.precision;
-        if (p->sol.have_start && p->lane_start_version != p->start_version) {
+        if (p->sol.have_start && q->seen_start_version != p->start_version) {     // per lane: a batch may use fewer lanes than exist
             HIP_TRY(hipMemcpy(q->sol.start, p->sol.start, sizeof(double) * (size_t)p->n, hipMemcpyDeviceToDevice));
             q->sol.have_start = true;
+            q->seen_start_version = p->start_version;
         }
     }
-    p->lane_start_version = p->start_version;
     std::atomic<int> next{0};
     std::vector<int> lane_status((size_t)nl, MACHIP_OK);
     std::vector<std::string> lane_err((size_t)nl);

@@ -334,10 +334,11 @@ struct Solver {
     PanView panv{};
     size_t pan_cap = 0, pan_nt_cap = 0, pan_y_cap = 0;
 
-    int init(int n_, hipStream_t s) {
+    // budget_mb > 0: HBM budget of the Krylov basis V for this instance (evaluation lanes take a share each)
+    int init(int n_, hipStream_t s, int budget_mb = 0) {
         n = n_;
         stream = s;
-        size_t budget = (size_t)env_int("MACHIP_VBUDGET_MB", 4096) * (size_t)(1 << 20);
+        size_t budget = (size_t)(budget_mb > 0 ? budget_mb : env_int("MACHIP_VBUDGET_MB", 4096)) * (size_t)(1 << 20);
         vcap = budget / (sizeof(double) * (size_t)std::max(n, 1));
         vcap = std::max<size_t>(std::min<size_t>(vcap, 16384), 64);
         vcap = std::min<size_t>(vcap, (size_t)n + 10);   // a Krylov sequence never exceeds n - 1 + 8 columns (jcap)
@@ -742,7 +743,11 @@ struct Solver {
     bool lob_escalate = false;    // set by solve_lob when it gives up early in favour of the exact preconditioner
     int wb_cap_s = 0;      // what the buffers below were sized for
     int wb_alloc() {
-        const int want = wb_limit_now;
+        // sized for the closures this solve actually has (+25 %, whole 256s), not for the tier's limit: 16 384 would mean
+        // a 2 GiB capacitance matrix held for the life of the handle (and of every evaluation lane)
+        long need = support_hint > 0 ? support_hint + support_hint / 4 : 256;
+        need = std::min<long>(wb_limit_now, std::max<long>(256, (need + 255) / 256 * 256));
+        const int want = (int)need;
         if (wb_ui && wb_cap_s >= want) return MACHIP_OK;
         if (wb_ui) {
             HIP_TRY(hipStreamSynchronize(stream));

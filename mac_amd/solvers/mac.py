@@ -83,8 +83,14 @@ class MAC:
         """evaluate_objective for every row of X (B x m) in one call: the solves run concurrently on the device
         (machip_eval_batch).  What round_madow(max_iters > 1) and budget sweeps call in a loop in the reference."""
         lam, st = self._dev.eval_batch(np.asarray(X, dtype=np.float64), tol=self.fiedler_tol, max_steps=self.max_lanczos_steps)
+        self.last_stats = None           # (statistics belong to single solves)
         if np.any(st == _lib.NOT_CONVERGED):
             raise _lib.NotConverged(_lib.NOT_CONVERGED, "an eigen-solve of the batch hit the step cap")
+        if np.any(st == _lib.DISCONNECTED):
+            # same behaviour as evaluate_objective on the same x (and as the reference, whose sparse LU raises "Factor is
+            # exactly singular" on a disconnected selection): the loop the batch replaces would have raised here
+            b = int(np.nonzero(st == _lib.DISCONNECTED)[0][0])
+            raise _lib.Disconnected(_lib.DISCONNECTED, f"entry {b} of the batch: lambda_2 ~ 0, the graph is not connected")
         return lam
 
     def problem(self, x, cache=None):
@@ -92,12 +98,14 @@ class MAC:
         with tol 1e-8 here (mac.py:115); so does this."""
         self._dev.set_x(np.asarray(x, dtype=np.float64))
         warm = cache is not None and cache.Q is not None
-        f, _, _ = self._dev.fiedler(tol=1e-8, max_steps=self.max_lanczos_steps,
-                                    warm_start=warm, want_vec=False)
+        f, v, _ = self._dev.fiedler(tol=1e-8, max_steps=self.max_lanczos_steps,
+                                    warm_start=warm, want_vec=cache is not None)
         self.last_stats = self._dev.stats.asdict()
         gradf = self._dev.gradient()
         if cache is not None:
-            cache.Q = True      # marker: the warm-start vector lives on the device
+            # the reference's slot holds an n x q ndarray (mac/solvers/mac.py:17-20); here: the converged Fiedler vector
+            # as an n x 1 block.  The copy the next solve warm-starts from stays on the device.
+            cache.Q = v.reshape(-1, 1)
         return f, gradf
 
     def solve(self, k, x_init=None, rounding="nearest", fallback=False, max_iters=5,

@@ -8,6 +8,7 @@ Tolerances (BASELINE.json north_star: fp64, lambda_2 within 1e-8 relative):
   BIT-EXACT given the same vector;  assembly: structure exact, values exact off-diagonal,
   diagonal to 1e-14 relative;  top-k / x update: bit-exact.
 """
+import ctypes as C
 import os
 
 import numpy as np
@@ -1008,6 +1009,69 @@ def test_eval_batch_matches_single_evaluations():
     lamp, st = P.eval_batch(np.array([[1.0, 0.0], [0.0, 1.0], [1.0, 1.0]]))
     assert st[1] == _lib.DISCONNECTED and st[0] == _lib.OK and st[2] == _lib.OK and lamp[0] > 0
     P.close()
+
+
+def test_round2_advice_regressions():
+    """Fixes of the round-2 advisor findings, each pinned:
+    (a) evaluation lanes track the handle's start vector PER LANE (a small batch after machip_set_start used to leave
+        the lanes it did not touch on the old vector) and the x0 argument of machip_fiedler counts as a change;
+    (b) MAC.evaluate_objective_batch raises on a disconnected entry like evaluate_objective does;
+    (c) find_fiedler_pair reuses one cached handle and computes exactly what a fresh handle computes;
+    (d) MAC.Cache.Q holds an ndarray (the reference's slot type), and the warm start still works;
+    (e) a handle cannot join two communicators."""
+    g = load_golden("g2o_intel")
+    mac = MAC(edges_of(g, "f"), edges_of(g, "c"), int(g["n"]))
+    n, m, k = int(g["n"]), len(g["cw"]), int(g["k"])
+    rng = np.random.default_rng(5)
+    X = np.zeros((8, m))
+    for b in range(8):
+        X[b, rng.choice(m, k, replace=False)] = 1.0
+    dev = mac._dev
+    lam_a = mac.evaluate_objective_batch(X)                    # creates 8 lanes on start vector A (the reference's)
+    startB = rng.normal(size=n)
+    dev.set_start(startB)
+    _ = mac.evaluate_objective_batch(X[:2])                    # refreshes lanes 0-1 only
+    lam_b = mac.evaluate_objective_batch(X)                    # lanes 2..7 must not be on A any more
+    single_b = np.array([mac.evaluate_objective(X[b]) for b in range(8)])
+    assert np.array_equal(lam_b, single_b)
+    startC = rng.normal(size=n)
+    dev.set_x(X[0]); lamC, _, _ = dev.fiedler(x0=startC, want_vec=False)      # x0 path replaces the start vector too
+    lam_c = mac.evaluate_objective_batch(X)
+    assert lam_c[0] == lamC and np.array_equal(lam_c, [mac.evaluate_objective(X[b]) for b in range(8)])
+    assert np.allclose(lam_a, lam_c, rtol=1e-7)
+    # (b)
+    macp = MAC([Edge(i, i + 1, 1.0) for i in range(8)], [Edge(0, 9, 1.0), Edge(2, 5, 1.0)], 10)
+    with pytest.raises(_lib.Disconnected):
+        macp.evaluate_objective(np.array([0.0, 1.0]))
+    with pytest.raises(_lib.Disconnected):
+        macp.evaluate_objective_batch(np.array([[1.0, 0.0], [0.0, 1.0], [1.0, 1.0]]))
+    # (c)
+    L = mac.laplacian(g["x_init"])
+    first = find_fiedler_pair(L)
+    _lib.load().machip_release_cache()
+    fresh = find_fiedler_pair(L)                                # fresh handle
+    again = find_fiedler_pair(L)                                # cached handle
+    gs = load_golden("g2o_sphere2500")
+    other = find_fiedler_pair(MAC(edges_of(gs, "f"), edges_of(gs, "c"), int(gs["n"])).laplacian(gs["x_init"]))   # other n: cache replaced
+    back = find_fiedler_pair(L)
+    for r in (fresh, again, back):
+        assert r[0] == first[0] and np.array_equal(r[1], first[1]) and np.array_equal(r[2], first[2])
+    assert abs(other[0] - gs["lam_init"]) <= LAM_RTOL * gs["lam_init"]
+    assert abs(first[0] - g["lam_init"]) <= LAM_RTOL * g["lam_init"]
+    # (d)
+    cache = MAC.Cache()
+    f0, g0 = mac.problem(g["x_init"], cache=cache)
+    assert isinstance(cache.Q, np.ndarray) and cache.Q.shape == (n, 1) and abs(np.linalg.norm(cache.Q) - 1) < 1e-12
+    f1, g1 = mac.problem(g["x_init"], cache=cache)             # warm start from the previous vector
+    assert abs(f1 - f0) <= LAM_RTOL * f0
+    # (e)
+    P1, P2 = problem_of(g), problem_of(g)
+    hs = (C.c_void_p * 2)(P1._h, P2._h)
+    lib = _lib.load()
+    assert lib.machip_comm_init_local(hs, 2) == _lib.OK
+    assert lib.machip_comm_init_local(hs, 2) == _lib.BAD_ARG
+    assert lib.machip_comm_init(P1._h, 0, 1, C.create_string_buffer(128)) == _lib.BAD_ARG
+    P1.close(); P2.close()
 
 
 def test_madow_multi_try_is_batched_and_picks_like_the_sequential_loop():
