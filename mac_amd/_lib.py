@@ -72,6 +72,8 @@ SIGNATURES = {
     "machip_comm_init_local": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "machip_shard_plan": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "machip_eval_batch": (C.c_int, [C.c_void_p, C.c_int, _f64p, C.c_double, C.c_int, _f64p, C.POINTER(C.c_int)]),
+    "machip_fw_sweep": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), _f64p, C.c_int, C.c_double, C.c_double, C.c_double,
+                                  C.c_int, C.c_int, C.c_int, _f64p, _f64p, _f64p, _f64p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "machip_set_solver": (C.c_int, [C.c_void_p, C.c_int]),
     "machip_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "machip_synchronize": (C.c_int, [C.c_void_p]),
@@ -279,6 +281,23 @@ class Problem:
         check(self._lib.machip_eval_batch(self._h, B, p_f64(X), float(tol), int(max_steps), p_f64(lam),
                                           st.ctypes.data_as(C.POINTER(C.c_int))))
         return lam, st
+
+    def fw_sweep(self, ks, X0, max_iters=5, gap_tol=1e-4, grad_tol=1e-8, tol=1e-8, max_steps=0, warm_start=False,
+                 round_decimals=10, want_rounded=True):
+        """Frank-Wolfe on B budgets of this graph at once (machip_fw_sweep).  Returns a dict of arrays: x (B x m),
+        rounded (B x m or None), upper, f_traj (B x max_iters, NaN where a problem stopped early), iters, status."""
+        X0 = np.ascontiguousarray(X0, dtype=np.float64)
+        ks = np.ascontiguousarray(ks, dtype=np.int64)
+        assert X0.ndim == 2 and X0.shape == (len(ks), self.m)
+        B = len(ks)
+        X = np.empty((B, self.m)); R = np.empty((B, self.m)) if want_rounded else None
+        up = np.zeros(B); ft = np.full((B, max(1, max_iters)), np.nan)
+        it = np.zeros(B, dtype=np.int32); st = np.zeros(B, dtype=np.int32)
+        check(self._lib.machip_fw_sweep(self._h, B, ks.ctypes.data_as(C.POINTER(C.c_int64)), p_f64(X0), int(max_iters),
+                                        float(gap_tol), float(grad_tol), float(tol), int(max_steps), int(bool(warm_start)),
+                                        int(round_decimals), p_f64(X), p_f64(R), p_f64(up), p_f64(ft),
+                                        it.ctypes.data_as(C.POINTER(C.c_int)), st.ctypes.data_as(C.POINTER(C.c_int))))
+        return dict(x=X, rounded=R, upper=up, f_traj=ft[:, :max_iters], iters=it, status=st)
 
     def set_precision(self, precision):
         """0 = fp64 throughout, 1 = fp32 Krylov iterate + fp64 Rayleigh/residual refinement."""

@@ -771,13 +771,20 @@ int make_lane(machip_problem* p, machip_problem** out) {
     *out = q;
     return MACHIP_OK;
 }
-}  // namespace
 
-int machip_eval_batch(machip_problem* p, int B, const double* X, double tol, int max_steps, double* lambda2, int* status) {
-    if (!p || p->csr_only || p->is_lane || B < 0 || (B && (!X || !lambda2))) return fail(MACHIP_BAD_ARG, "machip_eval_batch: bad argument");
-    if (B == 0) return MACHIP_OK;
-    HIP_TRY(hipSetDevice(p->device));
-    int nl = std::max(1, std::min(B, std::min(16, env_int("MACHIP_LANES", 8))));
+// FW state of a lane (gradient, LP vertex, next iterate, select scratch): only the sweep needs it
+int ensure_lane_fw(machip_problem* q) {
+    if (q->g) return MACHIP_OK;
+    const size_t mp = (size_t)q->m + 64 * 8;
+    ST_TRY(dev_alloc(&q->x_next, mp)); ST_TRY(dev_alloc(&q->g, mp)); ST_TRY(dev_alloc(&q->s, mp));
+    HIP_TRY(hipMemset(q->g, 0, sizeof(double) * mp));
+    ST_TRY(dev_alloc(&q->hist, 6 * kBins)); ST_TRY(dev_alloc(&q->sel, 2)); ST_TRY(dev_alloc(&q->part_fw, 2 * kMaxGrid));
+    return MACHIP_OK;
+}
+
+// Lanes [0, *nl_out) of the handle, created on demand, on the handle's solver mode / precision / start vector.
+int prepare_lanes(machip_problem* p, int B, bool fw, int* nl_out) {
+    int nl = std::max(1, std::min(B, std::min(16, env_int("MACHIP_LANES", 12))));
     while ((int)p->lanes.size() < nl) {
         machip_problem* q = nullptr;
         const int st = make_lane(p, &q);
@@ -801,6 +808,18 @@ int machip_eval_batch(machip_problem* p, int B, const double* X, double tol, int
             q->seen_start_version = p->start_version;
         }
     }
+    if (fw) for (int l = 0; l < nl; ++l) ST_TRY(ensure_lane_fw(p->lanes[(size_t)l]));
+    *nl_out = nl;
+    return MACHIP_OK;
+}
+}  // namespace
+
+int machip_eval_batch(machip_problem* p, int B, const double* X, double tol, int max_steps, double* lambda2, int* status) {
+    if (!p || p->csr_only || p->is_lane || B < 0 || (B && (!X || !lambda2))) return fail(MACHIP_BAD_ARG, "machip_eval_batch: bad argument");
+    if (B == 0) return MACHIP_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    int nl = 0;
+    ST_TRY(prepare_lanes(p, B, false, &nl));
     std::atomic<int> next{0};
     std::vector<int> lane_status((size_t)nl, MACHIP_OK);
     std::vector<std::string> lane_err((size_t)nl);
@@ -820,6 +839,59 @@ int machip_eval_batch(machip_problem* p, int B, const double* X, double tol, int
             }
             lambda2[b] = lam;
             if (status) status[b] = st;
+            if (st != MACHIP_OK && st != MACHIP_NOT_CONVERGED && st != MACHIP_DISCONNECTED) {
+                lane_status[(size_t)l] = st; lane_err[(size_t)l] = g_err;     // hard failure: stop this lane
+                return;
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int l = 1; l < nl; ++l) th.emplace_back(work, l);
+    work(0);
+    for (auto& t : th) t.join();
+    for (int l = 0; l < nl; ++l)
+        if (lane_status[(size_t)l] != MACHIP_OK) return fail((machip_status)lane_status[(size_t)l], lane_err[(size_t)l]);
+    return MACHIP_OK;
+}
+
+int machip_fw_sweep(machip_problem* p, int B, const int64_t* ks, const double* X0, int max_iters, double gap_tol,
+                    double grad_tol, double tol, int max_steps, int warm_start, int round_decimals, double* X_out,
+                    double* R_out, double* upper, double* f_traj, int* iters, int* status) {
+    if (!p || p->csr_only || p->is_lane || B < 0 || max_iters < 0 || (B && (!ks || !X0 || !X_out || !upper || !iters || !status)))
+        return fail(MACHIP_BAD_ARG, "machip_fw_sweep: bad argument");
+    if (p->nranks > 1) return fail(MACHIP_BAD_ARG, "machip_fw_sweep: not on a handle that belongs to a communicator");
+    if (B == 0) return MACHIP_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    int nl = 0;
+    ST_TRY(prepare_lanes(p, B, true, &nl));
+    const size_t m = (size_t)p->m;
+    std::atomic<int> next{0};
+    std::vector<int> lane_status((size_t)nl, MACHIP_OK);
+    std::vector<std::string> lane_err((size_t)nl);
+    auto work = [&](int l) {
+        machip_problem* q = p->lanes[(size_t)l];
+        for (int b = next.fetch_add(1); b < B; b = next.fetch_add(1)) {
+            // every problem starts from a clean solver state: its result does not depend on which lane takes it or on
+            // what that lane solved before (= a fresh handle running the reference's loop, frankwolfe.py:53-76)
+            Solver& S = q->sol;
+            S.have_prev = false; S.hist_lan_steps = -1; S.hist_lob_iters = -1; S.last_steps = 0; S.last_steps_lowp = 0;
+            int st = machip_set_x(q, X0 + (size_t)b * m);
+            double u = std::numeric_limits<double>::infinity();
+            int done = 0;
+            for (int i = 0; i < max_iters && st == MACHIP_OK; ++i) {
+                double f = 0.0, dual = 0.0, gn = 0.0;
+                st = machip_fw_step(q, ks[b], i, tol, max_steps, warm_start && i > 0, &f, &dual, &gn, nullptr);
+                if (st != MACHIP_OK) break;
+                u = std::min(u, dual);
+                if (f_traj) f_traj[(size_t)b * (size_t)max_iters + (size_t)i] = f;
+                done = i + 1;
+                if (gn < grad_tol) break;                            // frankwolfe.py:65-68
+                if ((u - f) < gap_tol * std::fabs(f)) break;         // frankwolfe.py:70-74
+                st = machip_fw_commit(q);
+            }
+            if (st == MACHIP_OK) st = machip_get_x(q, X_out + (size_t)b * m);
+            if (st == MACHIP_OK && R_out) st = machip_round_nearest(q, ks[b], round_decimals, R_out + (size_t)b * m);
+            upper[b] = u; iters[b] = done; status[b] = st;
             if (st != MACHIP_OK && st != MACHIP_NOT_CONVERGED && st != MACHIP_DISCONNECTED) {
                 lane_status[(size_t)l] = st; lane_err[(size_t)l] = g_err;     // hard failure: stop this lane
                 return;

@@ -15,6 +15,7 @@
 #include <deque>
 #include <limits>
 #include <map>
+#include <mutex>
 #include <tuple>
 #include <vector>
 
@@ -258,6 +259,12 @@ inline void launch_pipe(const SpmvPlan& pl, hipStream_t s, const CsrViewT<float>
     else if (pl.block == 512) launch_pipe_b<512>(pl, s, A, L, jrel);
     else launch_pipe_b<256>(pl, s, A, L, jrel);
 }
+
+// Stream capture on one host thread and calls that touch the legacy stream on another (rocBLAS / hipBLASLt handle
+// creation, rocSOLVER's workspace management) do not mix: HIP fails the latter with "operation would make the legacy
+// stream depend on a capturing blocking stream" (seen with evaluation lanes on city10000: one lane capturing a chunk
+// graph, another building its Woodbury preconditioner).  Both sides take this lock; captures last ~0.1 ms.
+inline std::mutex& capture_mutex() { static std::mutex m; return m; }
 
 struct Solver {
     int n = 0;
@@ -539,6 +546,7 @@ struct Solver {
         hipGraphExec_t& ge = it->second[(size_t)(graph_flip++ & 1)];
         if (!ge) {
             hipGraph_t g = nullptr;
+            std::lock_guard<std::mutex> cap(capture_mutex());
             HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
             launch_chunk(A, pl, steps, f32);
             HIP_TRY(hipStreamEndCapture(stream, &g));
@@ -722,6 +730,7 @@ struct Solver {
         hipGraphExec_t& ge = it->second[(size_t)(graph_flip++ & 1)];
         if (!ge) {
             hipGraph_t g = nullptr;
+            std::lock_guard<std::mutex> cap(capture_mutex());
             HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
             lob_launch_chunk(AT, pl, L, steps);
             HIP_TRY(hipStreamEndCapture(stream, &g));
@@ -761,6 +770,7 @@ struct Solver {
         ST_TRY(dev_alloc(&wb_uc, (size_t)want)); ST_TRY(dev_alloc(&wb_g, (size_t)want)); ST_TRY(dev_alloc(&wb_h, (size_t)want));
         ST_TRY(dev_alloc(&wb_Cm, (size_t)want * (size_t)want));
         if (wb_handle) return MACHIP_OK;
+        std::lock_guard<std::mutex> cap(capture_mutex());
         if (rocblas_create_handle(&wb_handle) != rocblas_status_success) return fail(MACHIP_HIP_ERROR, "rocblas_create_handle failed");
         if (rocblas_set_stream(wb_handle, stream) != rocblas_status_success) return fail(MACHIP_HIP_ERROR, "rocblas_set_stream failed");
         return MACHIP_OK;
@@ -798,14 +808,20 @@ struct Solver {
         const int g2s = (int)std::min<long>(kMaxGrid, ((long)s * s + kBlock - 1) / kBlock);
         k_wb_cap<<<g2s, kBlock, 0, stream>>>(L, W);
         int* info = wb_counts + 1;
-        if (rocsolver_dpotrf(wb_handle, rocblas_fill_lower, s, wb_Cm, s, info) != rocblas_status_success)
-            return fail(MACHIP_HIP_ERROR, "rocsolver_dpotrf failed");
+        {
+            std::lock_guard<std::mutex> cap(capture_mutex());
+            if (rocsolver_dpotrf(wb_handle, rocblas_fill_lower, s, wb_Cm, s, info) != rocblas_status_success)
+                return fail(MACHIP_HIP_ERROR, "rocsolver_dpotrf failed");
+        }
         int hinfo = 0;
         HIP_TRY(hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         if (hinfo != 0) return MACHIP_NOT_CONVERGED;
-        if (rocsolver_dpotri(wb_handle, rocblas_fill_lower, s, wb_Cm, s, info) != rocblas_status_success)
-            return fail(MACHIP_HIP_ERROR, "rocsolver_dpotri failed");
+        {
+            std::lock_guard<std::mutex> cap(capture_mutex());
+            if (rocsolver_dpotri(wb_handle, rocblas_fill_lower, s, wb_Cm, s, info) != rocblas_status_success)
+                return fail(MACHIP_HIP_ERROR, "rocsolver_dpotri failed");
+        }
         k_wb_sym<<<g2s, kBlock, 0, stream>>>(W);
         wb_active = W;
         return MACHIP_OK;
@@ -871,7 +887,8 @@ struct Solver {
         ST_TRY(check_vector(A, pl, &rq, &r1));
         *spmvs = 1; *iters = 0; *restarts_out = 0;
         int hbad = 0;
-        HIP_TRY(hipMemcpy(&hbad, lx_bad, sizeof(int), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpyAsync(&hbad, lx_bad, sizeof(int), hipMemcpyDeviceToHost, stream));   // (never the legacy stream: another lane's thread may be capturing a graph)
+        HIP_TRY(hipStreamSynchronize(stream));
         if (hbad || !(rq == rq)) return MACHIP_NOT_CONVERGED;
         *lam = rq; *res = r1 / scale;
         if (*res < tol) return MACHIP_OK;

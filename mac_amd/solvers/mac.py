@@ -108,6 +108,38 @@ class MAC:
             cache.Q = v.reshape(-1, 1)
         return f, gradf
 
+    def solve_sweep(self, ks, x_inits, rounding="nearest", max_iters=5, relative_duality_gap_tol=1e-4, grad_norm_tol=1e-8,
+                    use_cache=False, seed=None):
+        """``solve`` for several budgets of this graph at once: the loop of examples/g2o_experiment.py:306-336
+        (``for pct: MAC.solve(k, w_init, ...)``) run concurrently on the device (machip_fw_sweep: one evaluation lane per
+        budget, up to 8 at a time).  ``ks`` budgets, ``x_inits`` the matching initial selections.  Returns a list of
+        ``(rounded, unrounded, upper)`` in the order of ``ks``; each equals what ``solve`` returns for that budget on a
+        fresh MAC object (same kernels, same start vector, same stop rules).  rounding: "nearest" (device, tie-broken by
+        edge weight like mac.py:209) or "madow" (host, one draw per budget from ``seed``)."""
+        m = len(self.weights)
+        ks = [int(k) for k in ks]
+        assert len(ks) == len(x_inits)
+        out = [None] * len(ks)
+        idx = [i for i, k in enumerate(ks) if k < m]
+        for i, k in enumerate(ks):
+            if k >= m:                                               # mac.py:173-180
+                ones = np.ones(m)
+                out[i] = (ones, ones, self.evaluate_objective(ones))
+        if idx:
+            X0 = np.stack([np.asarray(x_inits[i], dtype=np.float64) for i in idx])
+            assert X0.shape[1] == m                                  # mac.py:183
+            r = self._dev.fw_sweep([ks[i] for i in idx], X0, max_iters=max_iters, gap_tol=relative_duality_gap_tol,
+                                   grad_tol=grad_norm_tol, tol=1e-8, max_steps=self.max_lanczos_steps, warm_start=use_cache,
+                                   round_decimals=10, want_rounded=(rounding != "madow"))
+            for j, i in enumerate(idx):
+                if r["status"][j] != _lib.OK:
+                    _lib.check(int(r["status"][j]))
+                w = r["x"][j]
+                rounded = round_madow(w, ks[i], seed=seed) if rounding == "madow" else r["rounded"][j]
+                out[i] = (rounded, w, float(r["upper"][j]))
+            self.sweep_trace = r["f_traj"]
+        return out
+
     def solve(self, k, x_init=None, rounding="nearest", fallback=False, max_iters=5,
               relative_duality_gap_tol=1e-4, grad_norm_tol=1e-8, random_rounding_max_iters=1,
               verbose=False, return_rounding_time=False, use_cache=False):
