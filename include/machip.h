@@ -162,6 +162,16 @@ int machip_comm_init(machip_problem* p, int rank, int nranks, const void* id128)
  * gradient buffers bracketed by a host barrier; shard arithmetic and call site are those of the RCCL path.
  * Destroying one handle releases peers blocked in the collective with MACHIP_RCCL_ERROR. */
 int machip_comm_init_local(machip_problem** handles, int nranks);
+/* With 2..8 handles the in-process communicator also ROW-PARTITIONS THE EIGEN-SOLVE (MACHIP_SHARD_EIG=0 turns that off):
+ * inside machip_fw_step rank 0's solver drives every rank's stream; per Lanczos step each rank launches its share of
+ * the step's workgroups on its own copy of L(x) and of the gather operand and writes the records / partial sums it
+ * produces into every rank's copy (peer-mapped device pointers across xGMI; plain device memory when ranks share a
+ * GPU), steps ordered by HIP events; the Krylov basis is sharded by rows.  Workgroup w of the partitioned step does
+ * exactly what workgroup w of a single rank's launch does, so lambda_2, the Fiedler vector and everything after them
+ * are bit-identical to a single-rank run.
+ * machip_comm_mode: 0 = no communicator, 1 = RCCL (candidate shard, eigen-solve replicated), 2 = in-process with a
+ * replicated eigen-solve, 3 = in-process with the row-partitioned eigen-solve. */
+int machip_comm_mode(machip_problem* p);
 /* The candidate range [lo, hi) of `rank` and the padded shard length (host arithmetic only, no GPU needed):
  * shard = ceil(m / nranks), lo = min(m, rank shard), hi = min(m, lo + shard). */
 int machip_shard_plan(int64_t m, int nranks, int rank, int64_t* lo, int64_t* hi, int64_t* shard);

@@ -70,6 +70,7 @@ SIGNATURES = {
     "machip_comm_unique_id": (C.c_int, [C.c_void_p]),
     "machip_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "machip_comm_init_local": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "machip_comm_mode": (C.c_int, [C.c_void_p]),
     "machip_shard_plan": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "machip_eval_batch": (C.c_int, [C.c_void_p, C.c_int, _f64p, C.c_double, C.c_int, _f64p, C.POINTER(C.c_int)]),
     "machip_fw_sweep": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), _f64p, C.c_int, C.c_double, C.c_double, C.c_double,

@@ -431,6 +431,21 @@ using PipeView = PipeViewT<double>;
 
 struct PipeCoef { double alpha, mu, beta, inv, l1prev; };
 
+// Row-partitioned step (in-process communicator, machip_comm_init_local): rank r launches workgroups
+// [first, first + gridDim.x) of the SAME `total`-workgroup launch a single rank would run -- same rows per workgroup,
+// same partial sums, same order of additions, hence bit-identical results -- on its own copy of the matrix and of the
+// gather operand, and writes what it produces (next records, partial sums) into every rank's copy (peer-mapped pointers
+// across xGMI; plain device memory when the ranks share a GPU).  The basis column stays with the rank that owns the rows.
+constexpr int kMaxPeers = 8;
+struct PeerSet {
+    int n = 0;            // 0: not sharded (the kernel uses blockIdx / gridDim and its own buffers only)
+    int first = 0;        // global index of this launch's first workgroup
+    int total = 0;        // workgroups of the whole step
+    void* Z0[kMaxPeers];  // every rank's record buffers (ZRec<T>*)
+    void* Z1[kMaxPeers];
+    double* part[kMaxPeers];
+};
+
 // ---- wave64 sum on the VALU (DPP row shifts + row broadcasts), ~5x faster than the
 // ds_bpermute butterfly; the total lands in lane 63 and is broadcast through an SGPR. ----------
 template <int CTRL, int ROWMASK>
@@ -503,7 +518,8 @@ __device__ __forceinline__ PipeCoef pipe_coefs(const double (&a)[kNP], int n) {
 // coefficients, publish them to the workgroup through LDS (scoef) and -- workgroup 0 -- to the
 // tridiagonal record.  The other waves go straight to their CSR loads.
 template <class PV>
-__device__ __forceinline__ PipeCoef pipe_prologue_wave0(const PV& L, int jrel, int adv_jA, double* scoef, int* j_out) {
+__device__ __forceinline__ PipeCoef pipe_prologue_wave0(const PV& L, int jrel, int adv_jA, double* scoef, int* j_out, int bid = -1) {
+    if (bid < 0) bid = (int)blockIdx.x;     // (sharded step: the global workgroup index)
     const int lane = threadIdx.x;   // caller guarantees threadIdx.x < 64
     const int jA = L.st->jA;        // (requested first, consumed last: in flight together with the partial loads below)
     const double* __restrict__ pin = L.part + (size_t)(jrel & 1) * (kNP * kMaxGrid);
@@ -550,7 +566,7 @@ __device__ __forceinline__ PipeCoef pipe_prologue_wave0(const PV& L, int jrel, i
     const int j = jA + jrel;
     if (lane == 0) {
         scoef[0] = c.alpha; scoef[1] = c.beta; scoef[2] = c.mu; scoef[3] = c.inv; scoef[4] = (double)j;
-        if (blockIdx.x == 0) {
+        if (bid == 0) {
             if (j > 0) { L.tri[3 * (j - 1)] = c.alpha; L.tri[3 * (j - 1) + 2] = c.l1prev; }
             L.tri[3 * j + 1] = c.beta;
             if (adv_jA >= 0) L.st->jA = j;   // tail kernel: new chunk base
@@ -569,16 +585,23 @@ struct PipeRow {   // per-thread accumulation of the next step's partial sums
     // raw sums (L t)[r], (L v)[r] -> w_j[r]; v_j[r] from Z[r]; store V, next Z = {t_j, v_j}.
     template <typename T>
     __device__ __forceinline__ void finish(double alpha, double beta, double mu, double inv, const ZRec<T>& z,
-                                           double st, double sv, T* vj, ZRec<T>* Zn, int r) {
+                                           double st, double sv, T* vj, ZRec<T>* Zn, int r, const PeerSet* PS = nullptr, int par = 0) {
+        // Every product-sum below is an EXPLICIT fma (and nothing else may be fused): the generated code of two
+        // instantiations of this kernel -- deferred barrier or not, row-partitioned or not -- used to differ in which of these
+        // the compiler contracted, one unit in the last place apart, and the row-partitioned step must reproduce the
+        // single-rank run bit for bit.
+#pragma clang fp contract(off)
         const double zt = z.t, zv = z.v;
-        const double w = (st - alpha * sv) * inv;
+        const double w = __builtin_fma(-alpha, sv, st) * inv;
         ZRec<T> o;
-        o.v = (T)(((zt - alpha * zv) - mu) * inv);
-        o.t = (T)(w - beta * zv);                   // Paige's intermediate for the next step
+        o.v = (T)((__builtin_fma(-alpha, zv, zt) - mu) * inv);
+        o.t = (T)__builtin_fma(-beta, zv, w);       // Paige's intermediate for the next step
         const double v = o.v, t = o.t;              // the sums below are those of the vectors as stored
         vj[r] = o.v;
-        Zn[r] = o;
-        acc[0] += t * t; acc[1] += t * v; acc[2] += v * v;
+        if (PS && PS->n) {      // sharded step: the record goes into every rank's copy of the next operand
+            for (int q = 0; q < PS->n; ++q) reinterpret_cast<ZRec<T>*>(par ? PS->Z0[q] : PS->Z1[q])[r] = o;
+        } else Zn[r] = o;
+        acc[0] = __builtin_fma(t, t, acc[0]); acc[1] = __builtin_fma(t, v, acc[1]); acc[2] = __builtin_fma(v, v, acc[2]);
         acc[3] += t; acc[4] += v; acc[5] += fabs(v);
     }
     // One partial per quantity per workgroup.  sred: kNP x (BLOCK/64) x 64 doubles of LDS.  Round 2 (tools/ubench5.hip: "last
@@ -586,7 +609,7 @@ struct PipeRow {   // per-thread accumulation of the next step's partial sums
     // wave of the workgroup reducing all six quantities the SIMDs issued 6 x NW of them.  Now every lane parks its six
     // sums in LDS, and after the barrier wave q adds the NW values of its lane for quantity q and runs ONE wave total.
     template <int BLOCK, class PV>
-    __device__ __forceinline__ void store(const PV& L, int jrel, double* sred) {
+    __device__ __forceinline__ void store(const PV& L, int jrel, double* sred, const PeerSet* PS = nullptr) {
         constexpr int NW = BLOCK / 64;
         const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
@@ -597,7 +620,11 @@ struct PipeRow {   // per-thread accumulation of the next step's partial sums
 #pragma unroll
             for (int w = 0; w < NW; ++w) s += sred[(q * NW + w) * 64 + lane];
             s = wave_total(s);
-            if (lane == 0) L.part[(size_t)((jrel + 1) & 1) * (kNP * kMaxGrid) + q * kMaxGrid + blockIdx.x] = s;
+            if (lane == 0) {
+                const size_t at = (size_t)((jrel + 1) & 1) * (kNP * kMaxGrid) + q * kMaxGrid;
+                if (PS && PS->n) { for (int k = 0; k < PS->n; ++k) PS->part[k][at + PS->first + blockIdx.x] = s; }
+                else L.part[at + blockIdx.x] = s;
+            }
         }
     }
 };
@@ -624,13 +651,13 @@ __device__ __forceinline__ void pipe_row_sums(const CsrViewT<T>& A, const ZRec<T
 #pragma unroll
                 for (int q = 0; q < UNR; ++q) zz[q] = Zc[cc[q]];
 #pragma unroll
-                for (int q = 0; q < UNR; ++q) { st += (double)vv[q] * (double)zz[q].t; sv += (double)vv[q] * (double)zz[q].v; }
+                for (int q = 0; q < UNR; ++q) { st = __builtin_fma((double)vv[q], (double)zz[q].t, st); sv = __builtin_fma((double)vv[q], (double)zz[q].v, sv); }
             }
         }
         for (; p < e; p += G) {
             const double vv = A.val[p];
             const Z2 z = Zc[A.col[p]];
-            st += vv * (double)z.t; sv += vv * (double)z.v;
+            st = __builtin_fma(vv, (double)z.t, st); sv = __builtin_fma(vv, (double)z.v, sv);
         }
         st = group_sum<G>(st); sv = group_sum<G>(sv);
     }
@@ -641,9 +668,15 @@ __device__ __forceinline__ void pipe_row_sums(const CsrViewT<T>& A, const ZRec<T
 // row tile after 1.9-4.4 us: with the barrier behind the first tile the row waves sat idle for up to 2 us per step.
 // The coefficients are only needed by finish(), so the first DEFER tiles keep their raw sums in registers and the
 // barrier comes after them; finish() then runs in the same row order as before (bit-identical partial sums).
-template <int BLOCK, int G, int UNR = 1, bool DED = false, typename T = double, int DEFER = 3>
-__global__ __launch_bounds__(BLOCK) void k_pipe_vec(CsrViewT<T> A, PipeViewT<T> L, int jrel) {
+template <int BLOCK, int G, int UNR = 1, bool DED = false, typename T = double, int DEFER = 3, bool SH = false>
+__global__ __launch_bounds__(BLOCK) void k_pipe_vec(CsrViewT<T> A, PipeViewT<T> L, int jrel, PeerSet PS = PeerSet()) {
     using Z2 = ZRec<T>;
+    // SH: one rank's share of a row-partitioned step (PeerSet above); bid / gtot = this workgroup's index / the workgroup
+    // count of the whole step, so that rows, partial sums and their order are those of the unsharded launch
+    const int bid = SH ? PS.first + (int)blockIdx.x : (int)blockIdx.x;
+    const int gtot = SH ? PS.total : (int)gridDim.x;
+    const PeerSet* PSp = SH ? &PS : nullptr;
+    const int par = jrel & 1;
     __shared__ double smw[kNP * BLOCK];     // epilogue scratch: six sums per lane
     __shared__ double scoef[8];
     // DED: wave 0 does nothing but the prologue (its reduction chain is then off the critical
@@ -654,7 +687,7 @@ __global__ __launch_bounds__(BLOCK) void k_pipe_vec(CsrViewT<T> A, PipeViewT<T> 
     const int lane = wt >= 0 ? wt % G : 0, g = wt >= 0 ? wt / G : 0;
     PIPE_CLK(threadIdx.x == 0, 0);
     PIPE_CLK(wt == 0, 2);
-    if (threadIdx.x < 64) { int jdummy; (void)pipe_prologue_wave0(L, jrel, -1, scoef, &jdummy); }
+    if (threadIdx.x < 64) { int jdummy; (void)pipe_prologue_wave0(L, jrel, -1, scoef, &jdummy, bid); }
     PIPE_CLK(threadIdx.x == 0, 1);
     const Z2* __restrict__ Zc = (jrel & 1) ? L.Z1 : L.Z0;
     Z2* __restrict__ Zn = (jrel & 1) ? L.Z0 : L.Z1;
@@ -665,7 +698,7 @@ __global__ __launch_bounds__(BLOCK) void k_pipe_vec(CsrViewT<T> A, PipeViewT<T> 
     Z2 dzr[DEFER];
 #pragma unroll
     for (int i = 0; i < DEFER; ++i) {
-        const int r = (blockIdx.x + i * gridDim.x) * GPB + g;
+        const int r = (bid + i * gtot) * GPB + g;
         pipe_row_sums<G, UNR, T>(A, Zc, r, lane, wt >= 0 && r < A.n, dst[i], dsv[i], dzr[i]);
     }
     __syncthreads();     // the coefficients of wave 0 are in scoef
@@ -674,20 +707,20 @@ __global__ __launch_bounds__(BLOCK) void k_pipe_vec(CsrViewT<T> A, PipeViewT<T> 
     T* vj = L.V + (size_t)scoef[4] * (size_t)L.n;
 #pragma unroll
     for (int i = 0; i < DEFER; ++i) {
-        const int r = (blockIdx.x + i * gridDim.x) * GPB + g;
-        if (wt >= 0 && r < A.n && lane == 0) pr.template finish<T>(alpha, beta, mu, inv, dzr[i], dst[i], dsv[i], vj, Zn, r);
+        const int r = (bid + i * gtot) * GPB + g;
+        if (wt >= 0 && r < A.n && lane == 0) pr.template finish<T>(alpha, beta, mu, inv, dzr[i], dst[i], dsv[i], vj, Zn, r, PSp, par);
     }
     // ---- remaining tiles ----
-    for (int r0 = (blockIdx.x + DEFER * gridDim.x) * GPB; r0 < A.n; r0 += gridDim.x * GPB) {
+    for (int r0 = (bid + DEFER * gtot) * GPB; r0 < A.n; r0 += gtot * GPB) {
         const int r = r0 + g;
         const bool mine = wt >= 0 && r < A.n;
         double st, sv;
         Z2 zr;
         pipe_row_sums<G, UNR, T>(A, Zc, r, lane, mine, st, sv, zr);
-        if (mine && lane == 0) pr.template finish<T>(alpha, beta, mu, inv, zr, st, sv, vj, Zn, r);
+        if (mine && lane == 0) pr.template finish<T>(alpha, beta, mu, inv, zr, st, sv, vj, Zn, r, PSp, par);
     }
     PIPE_CLK(wt == 0, 5);
-    pr.template store<BLOCK>(L, jrel, smw);
+    pr.template store<BLOCK>(L, jrel, smw, PSp);
     PIPE_CLK(wt == 0, 6);
 }
 
@@ -831,14 +864,25 @@ __global__ __launch_bounds__(kBlock) void k_fill_start(double* __restrict__ u, i
 
 // Ritz vector y = V[:, 0:J) s, split over the Krylov dimension: grid (row tiles, KS); slice ks
 // accumulates columns ks, ks+KS, ... into ypart[ks*n + r].
+// Rows a rank owns in a row-partitioned step (PeerSet): row tile t = r / gpb is handled by global workgroup t mod gtot.
+struct RowOwner {
+    int gpb = 1, gtot = 0, g0 = 0, g1 = 0;      // gtot = 0: every row
+    __device__ __forceinline__ bool mine(int r) const {
+        if (gtot == 0) return true;
+        const int g = (r / gpb) % gtot;
+        return g >= g0 && g < g1;
+    }
+};
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_ritz_partial(const T* __restrict__ V, int n, int J,
                                                          const double* __restrict__ s,
-                                                         double* __restrict__ ypart) {
+                                                         double* __restrict__ ypart, RowOwner own = RowOwner()) {
     const int KS = gridDim.y, ks = blockIdx.y;
     constexpr int U = 8;   // columns in flight per thread: the basis columns are n*8 bytes apart, so
                            // every load is a fresh DRAM page / TLB entry -- keep many outstanding
     for (int r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
+        if (!own.mine(r)) continue;             // (sharded basis: the other rows live on other ranks)
         double acc = 0.0;
         for (int k0 = ks; k0 < J; k0 += U * KS) {
             double v[U], c[U];
@@ -871,6 +915,19 @@ __global__ __launch_bounds__(kBlock) void k_ritz_combine(const double* __restric
         part[blockIdx.x] = s1;
         part[kMaxGrid + blockIdx.x] = s2;
         part[2 * kMaxGrid + blockIdx.x] = s3;
+    }
+}
+
+// Sharded basis: a rank adds the KS slices of ITS rows and writes them into the leader's vector (same order of additions
+// as k_ritz_combine; the leader then takes the sums of the complete vector with k_vec_sums, the same row -> workgroup
+// mapping k_ritz_combine uses: bit-identical to the unsharded path).
+__global__ __launch_bounds__(kBlock) void k_ritz_own_rows(const double* __restrict__ ypart, int n, int KS,
+                                                          double* __restrict__ y_leader, RowOwner own) {
+    for (int r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
+        if (!own.mine(r)) continue;
+        double t = 0.0;
+        for (int ks = 0; ks < KS; ++ks) t += ypart[(size_t)ks * n + r];
+        y_leader[r] = t;
     }
 }
 

@@ -29,9 +29,22 @@ using namespace machip;
 // thread each (one GPU per handle, or several handles on one GPU); the all-gather is peer-to-peer device copies
 // between the handles' gradient buffers, bracketed by a host barrier.  Same shard arithmetic and the same call
 // site as the RCCL communicator.
+struct machip_problem;
 struct LocalGroup {
     int nranks = 0;
     std::vector<double*> g;     // every rank's gradient buffer (device)
+    // row-partitioned eigen-solve (solver.h ShardGroup): rank 0 leads, its results are handed to the peers
+    std::vector<machip_problem*> members;
+    ShardGroup sg;
+    bool shard_eig = false;
+    int lead_status = MACHIP_OK;
+    double lead_lam = 0.0;
+    machip_solve_stats lead_stats{};
+    std::string lead_err;
+    ~LocalGroup() {
+        for (ShardRank& r : sg.rk) for (hipEvent_t e : r.ev) if (e) (void)hipEventDestroy(e);
+        if (sg.fork) (void)hipEventDestroy(sg.fork);
+    }
     std::mutex mu;
     std::condition_variable cv;
     int waiting = 0;
@@ -312,6 +325,45 @@ int run_fiedler(machip_problem* p, double tol, int max_steps, const double* x0, 
     return st;
 }
 
+// Collective eigen-solve of an in-process communicator whose step is row-partitioned: every rank has assembled the same
+// L(x); rank 0's solver drives all ranks' streams (solver.h, ShardGroup) and hands lambda_2, the statistics and the
+// Fiedler vector to the peers.
+int group_fiedler(machip_problem* p, double tol, int max_steps, int warm_start, double* lambda2, machip_solve_stats* stats) {
+    LocalGroup& G = *p->lgroup;
+    if (!G.barrier()) return fail(MACHIP_RCCL_ERROR, "in-process communicator was shut down by another rank");   // everyone's L(x) is assembled
+    if (p->rank == 0) {
+        for (int r = 0; r < G.nranks; ++r) {
+            machip_problem* q = G.members[(size_t)r];
+            ShardRank& k = G.sg.rk[(size_t)r];
+            k.device = q->device; k.stream = q->stream; k.Z0 = q->sol.Z0; k.Z1 = q->sol.Z1; k.part = q->sol.part; k.V = q->sol.V;
+            k.ypart = q->sol.ypart; k.sdev = q->sol.sdev; k.yvec = q->sol.yvec; k.A = q->csr();
+        }
+        machip_solve_stats local;
+        memset(&local, 0, sizeof(local));
+        p->sol.shard = &G.sg;
+        int st = run_fiedler(p, tol, max_steps, nullptr, warm_start, &G.lead_lam, &local);
+        p->sol.shard = nullptr;
+        if (st == MACHIP_OK || st == MACHIP_NOT_CONVERGED || st == MACHIP_DISCONNECTED) {
+            const std::string keep = g_err;
+            for (int r = 1; r < G.nranks && (st == MACHIP_OK || st == MACHIP_NOT_CONVERGED || st == MACHIP_DISCONNECTED); ++r)
+                if (hipMemcpyAsync(G.sg.rk[(size_t)r].yvec, p->sol.yvec, sizeof(double) * (size_t)p->n, hipMemcpyDeviceToDevice, p->stream) != hipSuccess)
+                    st = fail(MACHIP_HIP_ERROR, "copy of the Fiedler vector to a peer failed");
+            if (hipStreamSynchronize(p->stream) != hipSuccess) st = fail(MACHIP_HIP_ERROR, "stream error after the row-partitioned solve");
+            else g_err = keep;
+        }
+        G.lead_status = st; G.lead_stats = local; G.lead_err = g_err;
+    }
+    if (!G.barrier()) return fail(MACHIP_RCCL_ERROR, "in-process communicator was shut down by another rank");
+    const int st = G.lead_status;
+    *lambda2 = G.lead_lam;
+    if (stats) { *stats = G.lead_stats; stats->support = p->support; }
+    if (p->rank != 0) {
+        g_err = G.lead_err;
+        p->have_vec = (st == MACHIP_OK || st == MACHIP_NOT_CONVERGED || st == MACHIP_DISCONNECTED);
+    }
+    return st;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -510,7 +562,8 @@ int machip_fw_step(machip_problem* p, int64_t k, int iter, double tol, int max_s
     HIP_TRY(hipSetDevice(p->device));
     ST_TRY(assemble(p));
     double lam = 0.0;
-    ST_TRY(run_fiedler(p, tol, max_steps, nullptr, warm_start, &lam, stats));
+    if (p->lgroup && p->lgroup->shard_eig) ST_TRY(group_fiedler(p, tol, max_steps, warm_start, &lam, stats));
+    else ST_TRY(run_fiedler(p, tol, max_steps, nullptr, warm_start, &lam, stats));
     ST_TRY(compute_gradient(p));
     ST_TRY(select_topk(p, (long)k));
     const int grid = std::max(1, (int)std::min<long>(kMaxGrid, (p->m + kBlock - 1) / kBlock));
@@ -726,6 +779,25 @@ int machip_comm_init_local(machip_problem** handles, int nranks) {
     auto G = std::make_shared<LocalGroup>();
     G->nranks = nranks;
     for (int r = 0; r < nranks; ++r) G->g.push_back(handles[r]->g);
+    // row-partitioned eigen-solve (MACHIP_SHARD_EIG=0: every rank runs the whole solve itself, as in round 2)
+    G->shard_eig = nranks > 1 && nranks <= kMaxPeers && env_int("MACHIP_SHARD_EIG", 1) != 0;
+    if (G->shard_eig) {
+        G->sg.rk.resize((size_t)nranks);
+        for (int r = 0; r < nranks; ++r) {
+            G->members.push_back(handles[r]);
+            HIP_TRY(hipSetDevice(handles[r]->device));
+            for (hipEvent_t& e : G->sg.rk[(size_t)r].ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            if (handles[r]->device != handles[0]->device) G->sg.same_device = false;
+            for (int q = 0; q < nranks; ++q)          // peers write each other's operand copies
+                if (handles[q]->device != handles[r]->device) {
+                    const hipError_t e = hipDeviceEnablePeerAccess(handles[q]->device, 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(MACHIP_HIP_ERROR, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+                    (void)hipGetLastError();
+                }
+        }
+        HIP_TRY(hipSetDevice(handles[0]->device));
+        HIP_TRY(hipEventCreateWithFlags(&G->sg.fork, hipEventDisableTiming));
+    }
     for (int r = 0; r < nranks; ++r) {
         machip_problem* p = handles[r];
         long lo, hi, shard;
@@ -734,6 +806,13 @@ int machip_comm_init_local(machip_problem** handles, int nranks) {
         p->rank = r; p->nranks = nranks; p->lgroup = G;
     }
     return MACHIP_OK;
+}
+
+int machip_comm_mode(machip_problem* p) {
+    if (!p) return -1;
+    if (p->comm) return 1;
+    if (p->lgroup) return p->lgroup->shard_eig ? 3 : 2;
+    return 0;
 }
 
 int machip_shard_plan(int64_t m, int nranks, int rank, int64_t* lo, int64_t* hi, int64_t* shard) {

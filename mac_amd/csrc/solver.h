@@ -241,6 +241,78 @@ inline void launch_pipe_b(const SpmvPlan& pl, hipStream_t s, const CsrView& A, c
     }
 }
 
+// One rank's share of a row-partitioned step: workgroups [PS.first, PS.first + grid) of the pl.grid-workgroup launch.
+// The SAME instantiation the unsharded switch picks (DEFER included: the deferred-barrier build is a different piece of
+// generated code, and its last bits differ from the plain one's at config 4).
+template <int BLOCK>
+inline void launch_pipe_shard_b(const SpmvPlan& pl, hipStream_t s, const CsrView& A, const PipeView& L, int jrel, const PeerSet& PS, int grid) {
+    const int key = pl.width * 10 + pl.unroll;
+    if (pl.defer >= 3) {
+        switch (key) {
+            case 41: k_pipe_vec<BLOCK, 4, 1, true, double, 3, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); return;
+            case 42: k_pipe_vec<BLOCK, 4, 2, true, double, 3, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); return;
+            case 82: k_pipe_vec<BLOCK, 8, 2, true, double, 3, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); return;
+            case 84: k_pipe_vec<BLOCK, 8, 4, true, double, 3, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); return;
+            case 162: k_pipe_vec<BLOCK, 16, 2, true, double, 3, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); return;
+            default: break;
+        }
+    }
+    switch (key) {
+        case 41: k_pipe_vec<BLOCK, 4, 1, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
+        case 42: k_pipe_vec<BLOCK, 4, 2, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
+        case 44: k_pipe_vec<BLOCK, 4, 4, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
+        case 81: k_pipe_vec<BLOCK, 8, 1, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
+        case 82: k_pipe_vec<BLOCK, 8, 2, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
+        case 84: k_pipe_vec<BLOCK, 8, 4, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
+        case 161: k_pipe_vec<BLOCK, 16, 1, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
+        case 162: k_pipe_vec<BLOCK, 16, 2, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
+        case 164: k_pipe_vec<BLOCK, 16, 4, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
+        case 321: k_pipe_vec<BLOCK, 32, 1, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
+        case 322: k_pipe_vec<BLOCK, 32, 2, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
+        case 641: k_pipe_vec<BLOCK, 64, 1, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
+        default: k_pipe_vec<BLOCK, 64, 2, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
+    }
+}
+// rows per workgroup tile of the instantiation the switches above pick (unlisted shapes run as G = 64)
+inline int pipe_gpb(const SpmvPlan& pl) {
+    int g = 64;
+    switch (pl.width * 10 + pl.unroll) {
+        case 41: case 42: case 44: g = 4; break;
+        case 81: case 82: case 84: g = 8; break;
+        case 161: case 162: case 164: g = 16; break;
+        case 321: case 322: g = 32; break;
+        default: g = 64; break;
+    }
+    return (pl.block - 64) / g;
+}
+
+// Row-partitioned eigen-solve of an in-process communicator (machip_comm_init_local): the LEADER's
+// solver (rank 0) drives every rank's stream -- per Lanczos step one launch per rank (that rank's share of the step's
+// workgroups, on that rank's copy of matrix and operand, writing next records and partial sums into every copy),
+// ordered by events: step s of rank r waits for step s - 1 of every rank.  Everything else of the solve (host analysis
+// of the tridiagonal, explicit residual check, restarts) runs on the leader alone; the converged vector is copied to
+// the peers.  The basis V is sharded by rows: each rank keeps the rows its workgroups produced and forms its part of
+// the Ritz vector.
+struct ShardRank {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Z2 *Z0 = nullptr, *Z1 = nullptr;
+    double *part = nullptr, *V = nullptr, *ypart = nullptr, *sdev = nullptr, *yvec = nullptr;
+    CsrView A{};                 // this rank's own assembled copy of L(x)
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int g0 = 0, g1 = 0;          // workgroups [g0, g1) of a step (set per solve from the plan)
+};
+struct ShardGroup {
+    std::vector<ShardRank> rk;   // rk[0] = the leader
+    hipEvent_t fork = nullptr;
+    bool same_device = true;
+};
+inline void launch_pipe_shard(const SpmvPlan& pl, hipStream_t s, const CsrView& A, const PipeView& L, int jrel, const PeerSet& PS, int grid) {
+    if (pl.block == 1024) launch_pipe_shard_b<1024>(pl, s, A, L, jrel, PS, grid);
+    else if (pl.block == 512) launch_pipe_shard_b<512>(pl, s, A, L, jrel, PS, grid);
+    else launch_pipe_shard_b<256>(pl, s, A, L, jrel, PS, grid);
+}
+
 inline void launch_pipe(const SpmvPlan& pl, hipStream_t s, const CsrView& A, const PipeView& L, int jrel) {
     if (pl.variant == kStream) {
         switch (pl.width) {
@@ -336,6 +408,10 @@ struct Solver {
     long hist_lan_steps = -1, hist_lob_iters = -1;   // steps / iterations of the last solve in each mode
     static constexpr int kLobCap = 100000;
     // column-panel step (panel.h): the panel form of the matrix being solved, rebuilt per solve from its CSR
+    bool seq_sharded = false;      // the running Krylov sequence is row-partitioned (its basis is spread over the ranks)
+    SpmvPlan seq_plan;             // ... with this launch shape
+    ShardGroup* shard = nullptr;   // set (by the leader's handle) for the duration of a row-partitioned solve
+    bool last_seq_sharded = false; // the basis of the last sequence is spread over the ranks (ritz_block cannot read it)
     bool pan_allowed = false;   // the CSR is one this library assembled (diagonal first, other columns ascending)
     PanPlan pan;
     PanView panv{};
@@ -512,6 +588,74 @@ struct Solver {
         else k_pan_fin<256><<<pan.grid2, 256, 0, stream>>>(panv, L, s);
     }
 
+    // ---- row-partitioned chunk: per step one launch per rank, ordered by events (ShardGroup) ----
+    void shard_split(const SpmvPlan& pl) {
+        const int R = (int)shard->rk.size();
+        for (int r = 0; r < R; ++r) { shard->rk[(size_t)r].g0 = (int)((long)pl.grid * r / R); shard->rk[(size_t)r].g1 = (int)((long)pl.grid * (r + 1) / R); }
+    }
+    PeerSet shard_peers(const ShardRank& me, const SpmvPlan& pl) const {
+        PeerSet PS;
+        PS.n = (int)shard->rk.size(); PS.first = me.g0; PS.total = pl.grid;
+        for (int q = 0; q < PS.n; ++q) { PS.Z0[q] = shard->rk[(size_t)q].Z0; PS.Z1[q] = shard->rk[(size_t)q].Z1; PS.part[q] = shard->rk[(size_t)q].part; }
+        return PS;
+    }
+    void launch_chunk_sharded(const SpmvPlan& pl, int steps) {
+        ShardGroup& G = *shard;
+        const int R = (int)G.rk.size();
+        shard_split(pl);
+        (void)hipEventRecord(G.fork, stream);
+        for (int q = 1; q < R; ++q) (void)hipStreamWaitEvent(G.rk[(size_t)q].stream, G.fork, 0);
+        for (int s = 0; s < steps; ++s) {
+            for (int r = 0; r < R; ++r) {
+                ShardRank& me = G.rk[(size_t)r];
+                if (s > 0) for (int q = 0; q < R; ++q) if (q != r) (void)hipStreamWaitEvent(me.stream, G.rk[(size_t)q].ev[(s - 1) & 1], 0);
+                if (me.g1 > me.g0) {
+                    if (!G.same_device) (void)hipSetDevice(me.device);
+                    PipeView L = pview(pl);                       // the leader's counters / tridiagonal records ...
+                    L.Z0 = me.Z0; L.Z1 = me.Z1; L.V = me.V; L.part = me.part;   // ... this rank's operand, basis rows and partial sums
+                    launch_pipe_shard(pl, me.stream, me.A, L, s, shard_peers(me, pl), me.g1 - me.g0);
+                }
+                (void)hipEventRecord(me.ev[s & 1], me.stream);
+            }
+        }
+        for (int q = 1; q < R; ++q) (void)hipStreamWaitEvent(stream, G.rk[(size_t)q].ev[(steps - 1) & 1], 0);
+        if (!G.same_device) (void)hipSetDevice(G.rk[0].device);
+        k_pipe_tail<<<1, 64, 0, stream>>>(pview(pl), steps);
+    }
+    // start of a sequence: the leader's k_pipe_init output (records of u, first partial sums) into every rank's copy
+    int shard_broadcast_init() {
+        ShardGroup& G = *shard;
+        for (size_t q = 1; q < G.rk.size(); ++q) {
+            HIP_TRY(hipMemcpyAsync(G.rk[q].Z0, Z0, sizeof(Z2) * (size_t)n, hipMemcpyDeviceToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(G.rk[q].part, part, sizeof(double) * 2 * kNP * kMaxGrid, hipMemcpyDeviceToDevice, stream));
+        }
+        return MACHIP_OK;
+    }
+    // y_raw = V[:, :J] s with V spread over the ranks by rows; sums of y_raw in part_c (the layout check_vector expects)
+    int shard_ritz(const SpmvPlan& pl, int J, const double* s_host) {
+        ShardGroup& G = *shard;
+        const int R = (int)G.rk.size(), g2 = vgrid();
+        const int KS = std::max(1, std::min(ks_max, J / 8));
+        memcpy(h_pin, s_host, sizeof(double) * (size_t)J);
+        shard_split(pl);
+        HIP_TRY(hipEventRecord(G.fork, stream));
+        for (int r = 0; r < R; ++r) {
+            ShardRank& me = G.rk[(size_t)r];
+            if (r) HIP_TRY(hipStreamWaitEvent(me.stream, G.fork, 0));
+            if (!G.same_device) HIP_TRY(hipSetDevice(me.device));
+            HIP_TRY(hipMemcpyAsync(me.sdev, h_pin, sizeof(double) * (size_t)J, hipMemcpyHostToDevice, me.stream));
+            RowOwner own; own.gpb = pipe_gpb(pl); own.gtot = pl.grid; own.g0 = me.g0; own.g1 = me.g1;
+            k_ritz_partial<<<dim3(g2, KS), kBlock, 0, me.stream>>>(me.V, n, J, me.sdev, me.ypart, own);
+            k_ritz_own_rows<<<g2, kBlock, 0, me.stream>>>(me.ypart, n, KS, y_raw, own);
+            HIP_TRY(hipEventRecord(me.ev[0], me.stream));
+        }
+        for (int q = 1; q < R; ++q) HIP_TRY(hipStreamWaitEvent(stream, G.rk[(size_t)q].ev[0], 0));
+        if (!G.same_device) HIP_TRY(hipSetDevice(G.rk[0].device));
+        k_vec_sums<<<g2, kBlock, 0, stream>>>(y_raw, n, part_c);
+        HIP_TRY(hipGetLastError());
+        return MACHIP_OK;
+    }
+
     // ---- one chunk = `steps` step kernels + the tail kernel ------------------------------------
     void launch_chunk(const CsrView& A, const SpmvPlan& pl, int steps, bool f32 = false) {
         if (pl.variant == kPanel) {
@@ -520,6 +664,7 @@ struct Solver {
             k_pipe_tail<<<1, 64, 0, stream>>>(L, steps);
             return;
         }
+        if (shard && pl.variant == kVec && !f32) { launch_chunk_sharded(pl, steps); return; }
         if (f32) {
             const PipeViewT<float> L = pview<float>(pl);
             const CsrViewT<float> Af{A.n, A.rowptr, A.col, valf};
@@ -532,13 +677,17 @@ struct Solver {
         k_pipe_tail<<<1, 64, 0, stream>>>(L, steps);
     }
     int enqueue_chunk(const CsrView& A, const SpmvPlan& pl, int steps, bool f32 = false) {
-        if (!use_graph) { launch_chunk(A, pl, steps, f32); HIP_TRY(hipGetLastError()); return MACHIP_OK; }
+        const bool sharded = shard && pl.variant == kVec && !f32;
+        // row-partitioned chunks are launched eagerly: a captured chunk would be one graph of steps x ranks kernel nodes with
+        // ranks - 1 cross-stream dependencies each (ROCm 7.2 crashes on it from 8 ranks on one device), and across devices
+        // a single graph is not an option anyway
+        if (!use_graph || sharded) { launch_chunk(A, pl, steps, f32); HIP_TRY(hipGetLastError()); return MACHIP_OK; }
         if (graph_csr_key != (const void*)A.val) {   // different matrix buffers: cached graphs are stale
             for (auto& kv : graphs) for (hipGraphExec_t ge : kv.second) if (ge) (void)hipGraphExecDestroy(ge);
             graphs.clear();
             graph_csr_key = (const void*)A.val;
         }
-        const auto key = std::make_tuple(pl.variant + (f32 ? 100 : 0) + 1000 * pl.defer, pl.width * 10 + pl.unroll, pl.grid, pl.block, steps);
+        const auto key = std::make_tuple(pl.variant + (f32 ? 100 : 0) + 1000 * pl.defer + (sharded ? 100000 * (int)shard->rk.size() : 0), pl.width * 10 + pl.unroll, pl.grid, pl.block, steps);
         auto it = graphs.find(key);
         if (it == graphs.end()) it = graphs.emplace(key, std::array<hipGraphExec_t, 2>{nullptr, nullptr}).first;
         // two executables per shape, used alternately: with one chunk running ahead, the same
@@ -560,6 +709,7 @@ struct Solver {
     // y = V[:, :J] s  -> normalised into yvec; w2 = L yvec; returns (rq, ||w2 - rq yvec||_1).
     int explicit_check(const CsrView& A, const SpmvPlan& pl, int J, const double* s_host, double* rq,
                        double* res_l1, bool f32 = false) {
+        if (seq_sharded) { ST_TRY(shard_ritz(seq_plan, J, s_host)); return check_vector(A, pl, rq, res_l1); }
         memcpy(h_pin, s_host, sizeof(double) * (size_t)J);
         HIP_TRY(hipMemcpyAsync(sdev, h_pin, sizeof(double) * (size_t)J, hipMemcpyHostToDevice, stream));
         const int g2 = vgrid();
@@ -1084,7 +1234,7 @@ struct Solver {
         // LDS-resident single-workgroup form when the matrix fits (classic recurrence: also fine after restarts)
         const bool pmode = env_int("MACHIP_PERSIST", 1) != 0 && chain_like && persist_fits(n, nnz - n - 2 * chain_edges);
         // column-panel step (panel.h) where the gather operand is too large for the caches (fp64 sequences only)
-        pan = plan_panel(n, nnz, maxlen_hint, pan_allowed && precision == 0 && !pmode && !classic && pp.variant == kVec);
+        pan = plan_panel(n, nnz, maxlen_hint, pan_allowed && precision == 0 && !pmode && !classic && pp.variant == kVec && !shard);   // (the row-partitioned solve shards the gather step)
         if (pan.on) {
             ST_TRY(ensure_panel(A, nnz, pan));
             pp.variant = kPanel; pp.grid = pan.grid2; pp.block = pan.block2;
@@ -1121,6 +1271,7 @@ struct Solver {
         }
         while (!done && steps_total < max_steps) {
             // ---- (re)start a Krylov sequence from u ----
+            seq_sharded = false;
             if (pmode) {
                 ++epoch;
                 k_persist_begin<<<g2, kBlock, 0, stream>>>(persist_view(), (int)epoch);
@@ -1133,6 +1284,10 @@ struct Solver {
             } else {
                 ++epoch;
                 k_pipe_init<<<pp.grid, kBlock, 0, stream>>>(L, u, (int)epoch);
+                if (shard && pp.variant == kVec) {       // row-partitioned sequence: every rank starts from the same records
+                    seq_sharded = true; seq_plan = pp;
+                    ST_TRY(shard_broadcast_init());
+                }
             }
             const double seq_tol = f32_seq ? f32_switch : tol;     // what this sequence's residual estimate aims for
             int J_enq = 0;        // steps enqueued in this sequence
@@ -1301,6 +1456,7 @@ struct Solver {
             if (!pend.empty()) HIP_TRY(hipStreamSynchronize(stream));
             pend.clear();
             last_seq_f32 = f32_seq;
+            last_seq_sharded = seq_sharded;
             if (converged) { done = true; break; }
             if (steps_total >= max_steps) break;
             // restart from the best Ritz vector found so far (it sits normalised in yvec)
@@ -1351,7 +1507,7 @@ struct Solver {
         const int Jeff = std::max(1, std::min(J_last, (int)ha.size()));
         const int ncand = std::min(Jeff, q + 6);
         std::vector<double> th, S;
-        if (!last_was_lob && !last_seq_f32) tri::smallest_block(ha.data(), hb.data(), Jeff, ncand, th, S, wk);   // (no Krylov basis after the preconditioned mode: X is completed with orthonormal filler)
+        if (!last_was_lob && !last_seq_f32 && !last_seq_sharded) tri::smallest_block(ha.data(), hb.data(), Jeff, ncand, th, S, wk);   // (no Krylov basis after the preconditioned mode: X is completed with orthonormal filler)
         const int g2 = vgrid();
         HIP_TRY(hipMemcpyAsync(X_host, yvec, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));

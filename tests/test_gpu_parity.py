@@ -795,6 +795,7 @@ def test_in_process_ranks_match_single_rank(R):
     assert not isinstance(single[0], Exception), single[0]
     Ps = [problem_of(g) for _ in range(R)]
     _lib.comm_init_local(Ps)
+    assert _lib.load().machip_comm_mode(Ps[0]._h) == 3      # candidate shard AND row-partitioned eigen-solve
     m = len(g["cw"])
     cover = []
     for r in range(R):
@@ -813,6 +814,91 @@ def test_in_process_ranks_match_single_rank(R):
         for a, b in zip(out[r], single[0]):
             assert np.array_equal(a, b), f"rank {r} of {R} differs from the single-rank run"
     assert np.allclose(single[0][0][:, 0], g["f_traj"][:iters], rtol=1e-6)
+    for P in Ps:
+        P.close()
+
+
+@pytest.mark.parametrize("cfg,R,iters", [("c2", 4, 3), ("c4", 2, 2), ("c4", 8, 2)])
+def test_row_partitioned_eigensolve_is_bit_identical_at_bench_sizes(cfg, R, iters):
+    """The row-partitioned Lanczos step of the in-process communicator (rank r launches its share of every step's
+    workgroups on its own copy of L(x) and of the operand, writes records and partial sums into every rank's copy, basis
+    sharded by rows) on the BENCH workloads: several row tiles per workgroup, deferred-barrier launch shapes, hundreds
+    of steps per solve, graph-captured multi-stream chunks.  f / dual bound / ||g|| / x on every rank are bit-identical
+    to a single handle running the same one-kernel step (MACHIP_PANEL=0: the column-panel form is not sharded)."""
+    import threading
+    import bench
+    w = bench.make_workload(cfg)
+    n, k = w["n"], w["k"]
+    start = reference_start_block(n)[:, 0].copy()
+    old = os.environ.get("MACHIP_PANEL")
+    os.environ["MACHIP_PANEL"] = "0"
+    try:
+        def mk():
+            return _lib.Problem(n, w["fi"], w["fj"], w["fw"], w["ci"], w["cj"], w["cw"])
+
+        def drive(P, out, i):
+            try:
+                P.set_start(start); P.set_x(w["x0"])
+                fs = []
+                for it in range(iters):
+                    fs.append(P.fw_step(k, it)); P.fw_commit()
+                out[i] = (np.array(fs), P.get_x(), int(P.stats.lanczos_steps))
+            except Exception as exc:
+                out[i] = exc
+                P.close()
+        single = [None]
+        P0 = mk(); drive(P0, single, 0); P0.close()
+        assert not isinstance(single[0], Exception), single[0]
+        Ps = [mk() for _ in range(R)]
+        _lib.comm_init_local(Ps)
+        assert _lib.load().machip_comm_mode(Ps[0]._h) == 3
+        out = [None] * R
+        th = [threading.Thread(target=drive, args=(Ps[r], out, r)) for r in range(R)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=600)
+        for r in range(R):
+            assert not isinstance(out[r], Exception), out[r]
+            assert np.array_equal(out[r][0], single[0][0]) and np.array_equal(out[r][1], single[0][1]), f"rank {r} of {R}"
+            assert out[r][2] == single[0][2] > 50
+        for P in Ps:
+            P.close()
+    finally:
+        if old is None:
+            os.environ.pop("MACHIP_PANEL", None)
+        else:
+            os.environ["MACHIP_PANEL"] = old
+
+
+def test_in_process_group_with_replicated_eigensolve_still_works():
+    """MACHIP_SHARD_EIG=0: round 2's mode (every rank runs the whole eigen-solve itself) stays available and agrees."""
+    import threading
+    g = load_golden("er2000_solve")
+    k = int(g["k"])
+    old = os.environ.get("MACHIP_SHARD_EIG")
+    os.environ["MACHIP_SHARD_EIG"] = "0"
+    try:
+        Ps = [problem_of(g) for _ in range(2)]
+        _lib.comm_init_local(Ps)
+        assert _lib.load().machip_comm_mode(Ps[0]._h) == 2
+    finally:
+        if old is None:
+            os.environ.pop("MACHIP_SHARD_EIG", None)
+        else:
+            os.environ["MACHIP_SHARD_EIG"] = old
+    out = [None, None]
+
+    def drive(i):
+        P = Ps[i]
+        P.set_start(reference_start_block(int(g["n"]))[:, 0].copy()); P.set_x(g["x_init"])
+        out[i] = [P.fw_step(k, it) + (P.fw_commit(),) for it in range(3)]
+    th = [threading.Thread(target=drive, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert out[0] == out[1] and np.allclose([o[0] for o in out[0]], g["f_traj"][:3], rtol=1e-6)
     for P in Ps:
         P.close()
 

@@ -11,9 +11,9 @@ from mac_amd.utils.fiedler import reference_start_block
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c4"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 # (panel on?, NP, NB, B2, G2); None = library default for that knob
-shapes = [(0, None, None, None, None), (1, None, None, None, None), (1, 7, 36, None, None), (1, 9, 28, None, None),
-          (1, 10, 25, None, None), (1, 14, 18, None, None), (1, 16, 16, None, None), (1, 12, 21, 512, None),
-          (1, 12, 21, 1024, None), (1, 12, 21, 256, 128), (1, 12, 42, None, None), (1, 8, 32, None, None)]
+shapes = [(0, None, None, None, None), (1, None, None, None, None), (1, 9, 28, None, None), (1, 10, 25, None, None),
+          (1, 11, 23, None, None), (1, 13, 19, None, None), (1, 14, 18, None, None), (1, 16, 16, None, None),
+          (1, 12, 21, 256, None), (1, 12, 21, 1024, None), (1, 12, 21, 512, 128), (1, 12, 21, 512, 196), (1, 12, 20, None, None)]
 if len(sys.argv) > 3:
     shapes = [shapes[int(t)] for t in sys.argv[3].split(",")]
 w = bench.make_workload(cfg)
