@@ -478,6 +478,17 @@ def main():
             "nnz_first_last": [rec[0][2], rec[-1][2]],
             "eig_ms_per_iter": float(np.mean([r[4] for r in rec])),
         }
+        if world > 1:
+            # what this mode can be expected to deliver, printed next to what it did
+            if replicas:
+                pred = 1.0 * world if args.config == "c5" else 0.8 * world
+                why = ("independent problems, no collective: R x the single-GPU rate x (mean rate / slowest rank's rate); the 1.5 K budget of the "
+                       "sweep has ~1.4x the nnz of the 0.5 K one" if args.config != "c5" else "independent pose graphs, one per GPU")
+            else:
+                pred = {2: 0.99, 4: 0.98, 8: 0.97}.get(world, 1.0 - 0.004 * world)
+                why = ("candidate shard: only the supergradient (0.4 % of an iteration) is divided, the all-gather of the 16 MB gradient costs more "
+                       "than it saves; the eigen-solve is replicated (the row-partitioned solve of DESIGN section 6 needs all ranks in one process)")
+            out["predicted_vs_1gpu"] = {"factor": pred, "why": why}
     # ---- roofline of the dominant kernel: in-solve duration from the hipEvents that bracket the Krylov chunks
     #      on the handle's stream (machip_solve_stats.step_ms / steps_timed), summed over EVERY timed pass ----
     if not args.no_roofline and rank == 0:

@@ -51,6 +51,16 @@ inline bool persist_fits(int n, long nc_max) {
            (size_t)nc_max * 20 + (size_t)n * 8 + ((size_t)n + 2) * 4 + 64 <= (size_t)kPersistPool;   // col 4 + val 8 + product 8 per overflow entry
 }
 
+// the filtered variant (k_lan_persist<.., CHEB = true>) keeps a second copy of the operand (double buffering)
+inline bool persist_fits_cheb(int n, long nc_max) {
+    return n <= kPersistThreads * kPersistMaxRows && nc_max >= 0 &&
+           (size_t)nc_max * 20 + (size_t)n * 16 + ((size_t)n + 2) * 4 + 64 <= (size_t)kPersistPool;
+}
+
+// Chebyshev filter of the filtered variant: the Lanczos operator is C = -T_d(M), M = c1 L - c0 I mapping [a, b] onto
+// [-1, 1] (solver.h chooses a > lambda_2 from a rigorous upper bound, b >= lambda_max, d even).
+struct PersistCheb { int deg = 0; double c0 = 0.0, c1 = 0.0; };
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
 // queue (s_waitcnt vmcnt(0)), i.e. it would wait ~1 us per step for the basis column v_j just stored
 // to HBM, which nothing in this kernel ever reads back.
@@ -111,8 +121,15 @@ __global__ void k_persist_begin(PersistViewT<T> L, int epoch) {
 // and the step cost 4 us, LDS-bound.)
 // T = float (mixed-precision mode): the row data, the operand in LDS, the vectors in registers and the basis column
 // are fp32 and the matrix-vector product runs in fp32; the two reductions of a step accumulate in fp64.
-template <int RPT, typename T = double>
-__global__ __launch_bounds__(kPersistThreads) void k_lan_persist(CsrView A, PersistViewT<T> L, int steps) {
+//
+// CHEB = true (fp64 only): a step applies C = -T_d(c1 L - c0 I) instead of L -- d matrix-vector products that need no
+// reduction at all (one LDS barrier each, the operand double-buffered) between the two reductions of a step.  The plain
+// step spends 2 160 of its 4 090 cycles in those two reductions (tools/ubench_persist.hip); on stiff pose graphs the
+// filtered recurrence needs about as many PRODUCTS as the plain one needs steps (Lanczos on a degree-d Chebyshev
+// polynomial of L with d << sqrt(lambda_max / a) converges d times faster per step), so the reductions, the basis
+// columns and the host's tridiagonal shrink d-fold.
+template <int RPT, typename T = double, bool CHEB = false>
+__global__ __launch_bounds__(kPersistThreads) void k_lan_persist(CsrView A, PersistViewT<T> L, int steps, PersistCheb ch = PersistCheb()) {
     __shared__ __align__(16) unsigned char pool[kPersistPool];
     __shared__ double red1[3 * kPersistThreads / 64], red2[2 * kPersistThreads / 64];
     __shared__ double srec[3 * (kPersistMaxSteps + 1)];   // (alpha, beta, l1) of this chunk
@@ -174,6 +191,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_lan_persist(CsrView A, Pers
     int* ccol = crow + (n + 1);
     T* cval = reinterpret_cast<T*>(pool + (((size_t)n * 8 + ((size_t)n + 1 + (size_t)nc) * 4 + 7) & ~(size_t)7));
     T* cprod = reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(cval) + (size_t)nc * 8);   // products of the overflow entries (per step)
+    T* svec2 = reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(cprod) + (size_t)nc * 8);  // CHEB: second operand buffer (persist_fits_cheb)
     bool any_over = false;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
@@ -243,32 +261,57 @@ __global__ __launch_bounds__(kPersistThreads) void k_lan_persist(CsrView A, Pers
         PCLK(s == 0, 4);
         // ---- w = L v_j: band and two closures per row from registers (independent LDS gathers, no
         // loops), the rare rows with more closures add theirs from the LDS CSR; alpha_j = v_j . w ----
+        // (x: the operand's own entries in registers, sv: the same vector in LDS, published before the last barrier)
+        auto spmv = [&](const T (&x)[RPT], const T* sv, T (&w)[RPT]) {
 #pragma unroll
-        for (int k = 0; k < RPT; ++k) {
-            const int r = t + k * kPersistThreads;
-            const int rm = max(r - 1, 0), rp = min(r + 1, n - 1);     // lo/up are 0 where the neighbour does not exist
-            T w = dg[k] * v[k];
-            if (r < n) w += lo[k] * svec[rm] + up[k] * svec[rp] + c0v[k] * svec[c0c[k]] + c1v[k] * svec[c1c[k]];
-            u[k] = w;
-        }
-        if (nc > 0) {   // workgroup-uniform
-            // Round 2: the entries beyond a row's two register slots used to be walked by the row's thread -- three
-            // dependent LDS reads per entry (column -> operand, value), a hub row of 10 entries holding up its wave and,
-            // at the next barrier, the workgroup (tools/ubench_persist.hip, 600 closures on 1 728 nodes: 2 360 of a step's
-            // 5 400 cycles).  Now all threads form the products of the flat entry list (gathers in parallel, perfectly
-            // balanced), and after one more LDS barrier the row's thread only adds its segment, in the same order as before.
-            for (int e = t; e < nc; e += kPersistThreads) cprod[e] = cval[e] * svec[ccol[e]];
-            lds_barrier();
-            if (any_over) {
+            for (int k = 0; k < RPT; ++k) {
+                const int r = t + k * kPersistThreads;
+                const int rm = max(r - 1, 0), rp = min(r + 1, n - 1);     // lo/up are 0 where the neighbour does not exist
+                T a = dg[k] * x[k];
+                if (r < n) a += lo[k] * sv[rm] + up[k] * sv[rp] + c0v[k] * sv[c0c[k]] + c1v[k] * sv[c1c[k]];
+                w[k] = a;
+            }
+            if (nc > 0) {   // workgroup-uniform
+                // Round 2: the entries beyond a row's two register slots used to be walked by the row's thread -- three
+                // dependent LDS reads per entry (column -> operand, value), a hub row of 10 entries holding up its wave and,
+                // at the next barrier, the workgroup (tools/ubench_persist.hip, 600 closures on 1 728 nodes: 2 360 of a step's
+                // 5 400 cycles).  Now all threads form the products of the flat entry list (gathers in parallel, perfectly
+                // balanced), and after one more LDS barrier the row's thread only adds its segment, in the same order as before.
+                for (int e = t; e < nc; e += kPersistThreads) cprod[e] = cval[e] * sv[ccol[e]];
+                lds_barrier();
+                if (any_over) {
 #pragma unroll
-                for (int k = 0; k < RPT; ++k) {
-                    const int r = t + k * kPersistThreads;
-                    if (r < n) {
-                        const int b = crow[r], e = crow[r + 1];
-                        for (int p = b; p < e; ++p) u[k] += cprod[p];
+                    for (int k = 0; k < RPT; ++k) {
+                        const int r = t + k * kPersistThreads;
+                        if (r < n) {
+                            const int b = crow[r], e = crow[r + 1];
+                            for (int p = b; p < e; ++p) w[k] += cprod[p];
+                        }
                     }
                 }
             }
+        };
+        spmv(v, svec, u);
+        if (CHEB) {
+            // u = L v  ->  t1 = M v;  t_{i+1} = 2 M t_i - t_{i-1};  C v = -t_d   (T_d is even: T_d(M) = T_d(-M))
+            const T c0 = (T)ch.c0, c1 = (T)ch.c1;
+            T t0[RPT], t1[RPT], w[RPT];
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) { t0[k] = v[k]; t1[k] = c1 * u[k] - c0 * v[k]; }
+            for (int i = 2; i <= ch.deg; ++i) {
+                T* sv = (i & 1) ? svec : svec2;           // (the buffer two products back: every thread is done reading it)
+#pragma unroll
+                for (int k = 0; k < RPT; ++k) { const int r = t + k * kPersistThreads; if (r < n) sv[r] = t1[k]; }
+                lds_barrier();
+                spmv(t1, sv, w);
+#pragma unroll
+                for (int k = 0; k < RPT; ++k) {
+                    const T t2 = (T)2 * (c1 * w[k] - c0 * t1[k]) - t0[k];
+                    t0[k] = t1[k]; t1[k] = (t + k * kPersistThreads < n) ? t2 : (T)0;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) u[k] = -t1[k];
         }
 #pragma unroll
         for (int k = 0; k < RPT; ++k) al += (double)v[k] * (double)u[k];

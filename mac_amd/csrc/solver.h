@@ -535,7 +535,16 @@ struct Solver {
             default: k_lan_persist<6, T><<<1, kPersistThreads, 0, stream>>>(A, L, steps); break;
         }
     }
-    void launch_persist(const CsrView& A, int steps, bool f32 = false) {
+    void launch_persist(const CsrView& A, int steps, bool f32 = false, const PersistCheb& ch = PersistCheb()) {
+        if (ch.deg >= 2) {       // Chebyshev-filtered recurrence (fp64)
+            const PersistView L = persist_view<double>();
+            switch ((n + 2 * kPersistThreads - 1) / (2 * kPersistThreads)) {
+                case 1: k_lan_persist<2, double, true><<<1, kPersistThreads, 0, stream>>>(A, L, steps, ch); break;
+                case 2: k_lan_persist<4, double, true><<<1, kPersistThreads, 0, stream>>>(A, L, steps, ch); break;
+                default: k_lan_persist<6, double, true><<<1, kPersistThreads, 0, stream>>>(A, L, steps, ch); break;
+            }
+            return;
+        }
         if (f32) launch_persist_t<float>(A, steps); else launch_persist_t<double>(A, steps);
     }
 
@@ -1243,6 +1252,31 @@ struct Solver {
         const PipeView L = pview(pp);
         const int pchunk0 = std::min(kPersistMaxSteps, std::max(2, env_int("MACHIP_PCHUNK", 64)));
         const bool debug = env_int("MACHIP_DEBUG", 0) != 0;
+        // ---- Chebyshev-filtered recurrence for the single-workgroup kernel (persist.h, CHEB): after a short plain
+        // sequence has produced a Ritz vector -- its Rayleigh quotient rq is a RIGOROUS upper bound of lambda_2 (unit
+        // vector orthogonal to 1) -- the solve restarts from that vector on C = -T_d(M), M mapping [a, b] onto [-1, 1] with
+        // a = 1.25 rq > lambda_2 and b = ||L||_inf >= lambda_max.  T_d(M(lambda)) decreases monotonically on [0, a] and
+        // stays within [-1, 1] beyond, so C's smallest eigenvalue on 1-perp belongs to lambda_2's eigenvector and to no
+        // other; the converged pair is checked on L itself by the same explicit test as always.
+        PersistCheb cheb;                        // deg = 0: plain recurrence
+        bool cheb_started = false;
+        double cheb_a = 0.0, cheb_b = 0.0;
+        // Measured on MI355X (tools/cheb_probe.py, bench c3 / c5a, round 3): correct on every pose-graph test, but SLOWER than
+        // the plain recurrence -- a filtered step costs 3.2 us + 0.55 us per product against 2.35 us for a plain step, and
+        // with a = 1.25 rq ~ 20 lambda_2 after 32 plain steps the filter needs 1.4-4x the products (intel 420-435 against
+        // 488 it/s, sphere2500 900-1 013 against 1 049 for degrees 8-24).  Off by default (MACHIP_CHEB_DEG=8 turns it on).
+        const int cheb_deg_max = env_int("MACHIP_CHEB_DEG", 0) & ~1;
+        const bool cheb_ok = pmode && precision == 0 && cheb_deg_max >= 2 && persist_fits_cheb(n, nnz - n - 2 * chain_edges);
+        const int cheb_after = std::max(8, env_int("MACHIP_CHEB_AFTER", 32));      // plain steps before the hand-over
+        const int cheb_chunk = std::max(4, env_int("MACHIP_CHEB_CHUNK", 16) & ~1);  // filtered steps per launch
+        const int cheb_depth = std::max(1, env_int("MACHIP_CHEB_DEPTH", 2));
+        // T_d(x) and its derivative for x >= 1, and the inverse on that branch
+        auto cheb_T = [](int d, double x, double* dT) {
+            const double th = std::acosh(std::max(1.0, x));
+            const double sh = std::sqrt(std::max(0.0, x * x - 1.0));
+            if (dT) *dT = sh > 1e-8 ? d * std::sinh(d * th) / sh : (double)d * d;
+            return std::cosh(d * th);
+        };
         // ---- mixed precision (machip_set_precision(1)): the FIRST Krylov sequence stores matrix values, records and
         // basis in fp32 (inner products accumulated in fp64).  An fp32 recurrence cannot resolve lambda_2 beyond
         // ~eps_32 ||L||, so it only runs until its residual estimate reaches f32_switch ||L||_inf (or stalls); its Ritz
@@ -1315,7 +1349,8 @@ struct Solver {
                 const bool near = sched ? (to_go < 2.0 * chunk0 || (to_go >= 1e17 && est_latest < 1e3 * seq_tol * lnorm))
                                         : est_latest < 1e3 * seq_tol * lnorm;
                 const bool use_classic = classic && !pmode;
-                const int depth = (use_classic || near) ? 1 : ((sched && to_go > 8.0 * chunk0) ? 3 : 2);
+                int depth = (use_classic || near) ? 1 : ((sched && to_go > 8.0 * chunk0) ? 3 : 2);
+                if (cheb.deg) depth = (to_go < 3.0 * cheb_chunk * cheb.deg) ? 1 : std::min(2, cheb_depth);     // (chunks are ~80 us: little to hide, much to overshoot)
                 while ((int)pend.size() < depth && J_enq < jcap && steps_total < max_steps) {
                     // (the O(J) host analysis must keep up with the GPU: longer chunks once J is large -- a function of
                     // J only, so the step count at which convergence is noticed stays reproducible)
@@ -1325,6 +1360,11 @@ struct Solver {
                     if (pmode) {   // steps cost ~0.5 us here: long chunks, so the O(J) host analysis keeps up
                         chunk = pchunk0;
                         if (to_go < 1e17) chunk = std::min(pchunk0, std::max(16, ((int)(0.9 * to_go) + 1) & ~1));
+                        if (cheb_ok && cheb.deg == 0 && restarts == 0 && J_enq < cheb_after) chunk = std::min(chunk, cheb_after - J_enq);   // decide after a short plain sequence
+                        if (cheb.deg) {      // a filtered step is cheb.deg products (~5 us): short chunks, to_go counts products there
+                            chunk = std::min(chunk, cheb_chunk);
+                            if (to_go < 1e17) chunk = std::max(4, std::min(chunk, (int)(0.9 * to_go / cheb.deg) + 2) & ~1);
+                        }
                     }
                     if (use_classic) chunk = std::min(chunk, 16);
                     chunk = std::min(chunk, jcap - J_enq);
@@ -1338,7 +1378,7 @@ struct Solver {
                         for (int j = J_enq; j < hi; ++j) { h_tri[3 * (size_t)j] = qnan; h_tri[3 * (size_t)j + 2] = qnan; }   // alpha_j, l1_j
                     }
                     if (pmode) {
-                        launch_persist(A, chunk, f32_seq);
+                        launch_persist(A, chunk, f32_seq, cheb);
                         HIP_TRY(hipGetLastError());   // (157 KB of static LDS: a refused launch must surface, not time out)
                     } else if (classic) {
                         enqueue_classic(A, pl, chunk);
@@ -1361,7 +1401,7 @@ struct Solver {
                     }
                     pend.push_back(p);
                     J_enq = hi;
-                    steps_total += chunk; spmv_total += chunk;
+                    steps_total += chunk; spmv_total += cheb.deg ? (long)chunk * cheb.deg : chunk;
                     if (f32_seq) steps_lowp += chunk;
                 }
                 if (pend.empty()) { need_restart = true; break; }
@@ -1404,8 +1444,9 @@ struct Solver {
                 // ---- breakdown: beta_j ~ 0 means span(v_0..v_{j-1}) is invariant ----
                 int Jeff = J;
                 bool broke = false;
+                const double bscale = cheb.deg ? 1.0 : tiny_l;         // (the filtered operator's spectrum is O(1))
                 for (int j = std::max(1, Jold); j <= J; ++j) {
-                    if (!(hb[(size_t)j] > 1e-13 * tiny_l)) { Jeff = j; broke = true; break; }
+                    if (!(hb[(size_t)j] > 1e-13 * bscale)) { Jeff = j; broke = true; break; }
                 }
                 // ---- host: smallest Ritz pair of T_Jeff ----
                 tri::smallest_eigpair(ha.data(), hb.data(), Jeff, guess.data(), (int)guess.size(), theta_prev, sm, wk);
@@ -1413,7 +1454,16 @@ struct Solver {
                 theta_prev = sm.theta;
                 const double rho = broke ? 0.0 : std::fabs(hb[(size_t)Jeff] * sm.s[(size_t)Jeff - 1]);
                 const double l1v = hl1[(size_t)Jeff - 1] > 0 ? hl1[(size_t)Jeff - 1] : std::sqrt((double)n);
-                const double est = rho * l1v;   // predicted ||r||_1 (r = rho v_J; ||v_J||_1 ~ ||v_{J-1}||_1)
+                double est = rho * l1v;   // predicted ||r||_1 (r = rho v_J; ||v_J||_1 ~ ||v_{J-1}||_1)
+                if (cheb.deg) {
+                    // residual of C = -p(L) -> residual of L: (C + p(lambda)) y ~ -p'(lambda) (L - lambda) y near an eigenpair,
+                    // lambda from the Ritz value through the inverse of p on [0, a]
+                    const double pv = -sm.theta;                                   // p(lambda-hat)
+                    double x = 1.0, dT = (double)cheb.deg * cheb.deg;
+                    if (pv > 1.0) { x = std::cosh(std::acosh(pv) / cheb.deg); (void)cheb_T(cheb.deg, x, &dT); }
+                    const double dp = dT * 2.0 / (cheb_b - cheb_a);                 // |p'(lambda-hat)| (>= its value at a)
+                    est /= dp;
+                }
                 est_latest = est;
                 if (!broke && est > 0.0) {
                     hist.emplace_back(J, std::log(est));
@@ -1421,14 +1471,17 @@ struct Solver {
                     to_go = 1e18;
                     if (hist.front().first < J) {
                         const double slope = (hist.front().second - hist.back().second) / (double)(J - hist.front().first);
-                        if (slope > 1e-7) to_go = std::max(0.0, (hist.back().second - ltarget) / slope);
+                        if (slope > 1e-7) to_go = std::max(0.0, (hist.back().second - ltarget) / slope) * (cheb.deg ? cheb.deg : 1);
                     }
                 }
                 const bool at_cap = (J >= jcap) || (steps_total >= max_steps && pend.empty());
                 const bool trig = broke || est < trigger_slack * seq_tol * lnorm;
 
                 if (debug) fprintf(stderr, "[machip] %s J=%d Jeff=%d theta=%.15g est=%.3e to_go=%.0f broke=%d pend=%zu passes=%d\n", pmode ? "persist" : (classic ? "classic" : "pipe"), J, Jeff, sm.theta, lnorm > 0 ? est / lnorm : est, std::min(to_go, 1e9), (int)broke, pend.size(), sm.passes);
-                if ((trig && est < 0.5 * last_check_est) || broke || at_cap) {
+                bool handover = false;
+                if (cheb_ok && cheb.deg == 0 && restarts == 0 && !trig && !broke && !at_cap && J >= cheb_after &&
+                    (to_go > 4.0 * cheb_after || to_go >= 1e17)) handover = true;     // far from done: the filtered recurrence pays
+                if ((trig && est < 0.5 * last_check_est) || broke || at_cap || handover) {
                     double rq = 0.0, r1 = 0.0;
                     HIP_TRY(hipEventRecord(evs1, stream));   // everything enqueued so far = steps [J_timed, J_enq)
                     ST_TRY(explicit_check(A, pl, Jeff, sm.s.data(), &rq, &r1, f32_seq));   // syncs the stream
@@ -1446,6 +1499,18 @@ struct Solver {
                     res = lnorm > 0 ? r1 / lnorm : r1;
                     if (debug) fprintf(stderr, "[machip]    check J=%d rq=%.15g res=%.3e (tol %.1e)\n", Jeff, rq, res, tol);
                     if (res < tol) { converged = true; status = MACHIP_OK; break; }
+                    if (handover) {
+                        // rq = Rayleigh quotient of the unit Ritz vector (orthogonal to 1) >= lambda_2
+                        cheb_a = 1.25 * rq; cheb_b = 1.0001 * tiny_l;
+                        int d = cheb_deg_max;
+                        if (cheb_a > 0.0 && cheb_b > 4.0 * cheb_a) d = std::min(d, 2 * (int)(0.25 * std::sqrt(cheb_b / cheb_a)));
+                        else d = 0;
+                        if (d >= 2) {
+                            cheb.deg = d; cheb.c1 = 2.0 / (cheb_b - cheb_a); cheb.c0 = (cheb_b + cheb_a) / (cheb_b - cheb_a);
+                            if (debug) fprintf(stderr, "[machip]    hand-over to the filtered recurrence: a=%.6g b=%.6g deg=%d\n", cheb_a, cheb_b, d);
+                            need_restart = true; break;
+                        }
+                    }
                     if (broke || at_cap || f32_seq) { need_restart = true; break; }   // fp32 sequence: one check, then fp64
                 }
             }
@@ -1461,6 +1526,7 @@ struct Solver {
             if (steps_total >= max_steps) break;
             // restart from the best Ritz vector found so far (it sits normalised in yvec)
             HIP_TRY(hipMemcpyAsync(u, yvec, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream));
+            if (cheb.deg && !cheb_started) { cheb_started = true; continue; }   // the planned hand-over to the filtered recurrence
             if (f32_seq) {
                 f32_seq = false;   // the planned hand-over to fp64, not counted as a restart
                 // a start vector this good makes the pipelined beta a difference of nearly equal terms (it would report

@@ -1005,6 +1005,35 @@ print("RESULT", out)
         assert rel <= LAM_RTOL and dv <= 2e-6 and res < 1e-8
 
 
+@pytest.mark.parametrize("nm", ["intel", "sphere2500"])
+def test_chebyshev_filtered_single_workgroup_recurrence_matches_goldens(nm):
+    """MACHIP_CHEB_DEG=8: the single-workgroup Lanczos kernel run on C = -T_8(M(L)) after a short plain sequence (persist.h,
+    CHEB; off by default because it measured slower) must still deliver the reference's lambda_2 / vector:
+    the filter interval starts above a rigorous upper bound of lambda_2, so the pair it converges to is the Fiedler pair."""
+    code = r'''
+import sys; sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import numpy as np
+from conftest import load_golden, sign_align
+from mac_amd import _lib
+from mac_amd.utils.fiedler import reference_start_block
+g = load_golden("g2o_NAME")
+P = _lib.Problem(int(g["n"]), g["fi"], g["fj"], g["fw"], g["ci"], g["cj"], g["cw"])
+P.set_start(reference_start_block(int(g["n"]))[:, 0].copy())
+P.set_x(g["x_init"])
+lam, v, _ = P.fiedler(tol=1e-8)
+fs = []
+for it in range(6):
+    fs.append(P.fw_step(int(g["k"]), it)[0]); P.fw_commit()
+print("RESULT", [abs(lam - float(g["lam_init"])) / float(g["lam_init"]), float(np.abs(sign_align(v, g["v_init"]) - g["v_init"]).max()),
+                 float(np.max(np.abs(np.array(fs) - g["f_traj"][:6]) / g["f_traj"][:6])), int(P.stats.spmv_total > P.stats.lanczos_steps)])
+'''.replace("NAME", nm)
+    e = dict(os.environ); e["MACHIP_CHEB_DEG"] = "8"
+    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rel, dv, traj, filtered = eval([l for l in r.stdout.splitlines() if l.startswith("RESULT")][0][len("RESULT"):])
+    assert rel <= LAM_RTOL and dv <= 2e-6 and traj <= 1e-6 and filtered == 1
+
+
 def test_degenerate_inputs():
     # n = 2: single fixed edge, no candidates (the smallest problem the reference's asserts admit)
     mac = MAC([Edge(0, 1, 2.5)], [], 2)
