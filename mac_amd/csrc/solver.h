@@ -56,7 +56,8 @@ inline int env_int(const char* name, int dflt) {
 // that traffic grows with grid^2: cap the grid (grid-stride loops cover the rest of the rows).
 inline int grid_cap() { return std::max(1, std::min(kMaxGrid, env_int("MACHIP_MAXGRID", 256))); }
 
-inline SpmvPlan plan_spmv(int n, long nnz, int forced_variant) {
+inline SpmvPlan plan_spmv(int n, long nnz, int forced_variant, int cap = 0) {
+    if (cap <= 0) cap = grid_cap();
     SpmvPlan pl;
     const double mean = n > 0 ? (double)nnz / (double)n : 1.0;
     int variant = forced_variant;
@@ -69,11 +70,11 @@ inline SpmvPlan plan_spmv(int n, long nnz, int forced_variant) {
     pl.variant = variant;
     if (variant == kStream) {
         int tpr = 16;
-        while (tpr > 1 && ((long)n * tpr / kBlock > 4L * grid_cap() || tpr > std::max(2.0, mean))) tpr >>= 1;
+        while (tpr > 1 && ((long)n * tpr / kBlock > 4L * cap || tpr > std::max(2.0, mean))) tpr >>= 1;
         tpr = env_int("MACHIP_TPR", tpr);
         pl.width = tpr;
         const int R = kBlock / tpr;
-        pl.grid = (int)std::min<long>(grid_cap(), ((long)n + R - 1) / R);
+        pl.grid = (int)std::min<long>(cap, ((long)n + R - 1) / R);
     } else {
         int g = 4;
         while (g < 64 && g < mean * 0.75) g <<= 1;
@@ -81,7 +82,7 @@ inline SpmvPlan plan_spmv(int n, long nnz, int forced_variant) {
         g = env_int("MACHIP_G", g);
         pl.width = g;
         const int gpb = kBlock / g;
-        pl.grid = (int)std::min<long>(grid_cap(), ((long)n + gpb - 1) / gpb);
+        pl.grid = (int)std::min<long>(cap, ((long)n + gpb - 1) / gpb);
     }
     if (pl.grid < 1) pl.grid = 1;
     return pl;
@@ -1210,7 +1211,9 @@ struct Solver {
 
     int solve_lanczos(const CsrView& A, long nnz, double lnorm, double tol, int max_steps, int start_mode,
                       int forced_variant, double* lambda2, machip_solve_stats* stats) {
-        const SpmvPlan pl = plan_spmv(n, nnz, forced_variant);   // explicit-check kernels
+        // explicit-check kernels: run once or twice per solve, nobody re-reduces their partials per step -- at large n they may
+        // use the whole chip (config 4: 84 us per check with 256 workgroups of 8 rows each)
+        const SpmvPlan pl = plan_spmv(n, nnz, forced_variant, n > 32768 ? kMaxGrid : 0);
         SpmvPlan pp = plan_pipe(n, nnz, maxlen_hint);            // fused Lanczos-step kernel
         const int g2 = vgrid();
         HIP_TRY(hipEventRecord(ev0, stream));
