@@ -1005,6 +1005,59 @@ print("RESULT", out)
         assert rel <= LAM_RTOL and dv <= 2e-6 and res < 1e-8
 
 
+def test_panel_step_multi_round_windows_hub_rows_and_odd_sizes():
+    """Corners of the column-panel step (panel.h) the bench matrices do not reach: (a) dense rows -- a worker wave's tiles
+    hold more chunks than its registers (kPanCH = 20), so the multi-round path runs; (b) n not a multiple of 64 nor of the
+    panel width, last row block mostly empty; (c) a hub row right at the 127-entry limit (panel step still on) and one beyond
+    it (plan_panel must fall back to the gather step).  lambda_2 of the panel step equals the gather step's to 1e-12 and
+    SciPy's to 1e-8; the vectors agree."""
+    import scipy.sparse.linalg as spla
+    rng = np.random.default_rng(11)
+    for n, deg, hub in ((70001, 64, 0), (66003, 20, 126), (66003, 20, 140)):
+        m0 = n * deg // 2
+        a = rng.integers(0, n, m0); b = rng.integers(0, n, m0)
+        keep = (a != b) & (np.abs(a - b) != 1)
+        lo, hi = np.minimum(a[keep], b[keep]), np.maximum(a[keep], b[keep])
+        if hub:          # a hub: node 7 joined to `hub` further nodes (its row: chain 2 + diagonal + closures)
+            extra = rng.choice(np.arange(100, n), hub, replace=False)
+            lo = np.concatenate([lo, np.full(hub, 7)]); hi = np.concatenate([hi, extra])
+        key = np.unique(lo.astype(np.int64) * n + hi)
+        ci, cj = (key // n).astype(np.int32), (key % n).astype(np.int32)
+        if hub:          # keep the hub row's length exact: drop random edges at node 7 other than the planted ones
+            planted = np.isin(ci.astype(np.int64) * n + cj, 7 * np.int64(n) + np.sort(extra))
+            drop = ((ci == 7) | (cj == 7)) & ~planted
+            ci, cj = ci[~drop], cj[~drop]
+        m = len(ci)
+        cw = 0.5 + rng.random(m)
+        fi = np.arange(n - 1, dtype=np.int32)
+        P = _lib.Problem(n, fi, fi + 1, np.ones(n - 1), ci, cj, cw)
+        P.set_start(reference_start_block(n)[:, 0].copy())
+        x = np.ones(m)
+        P.set_x(x)
+        res = {}
+        old = os.environ.get("MACHIP_PANEL")
+        try:
+            for mode in ("0", "1"):
+                os.environ["MACHIP_PANEL"] = mode
+                lam, v, _ = P.fiedler(tol=1e-10)
+                res[mode] = (lam, v, int(P.stats.lanczos_steps))
+        finally:
+            if old is None:
+                os.environ.pop("MACHIP_PANEL", None)
+            else:
+                os.environ["MACHIP_PANEL"] = old
+        assert abs(res["1"][0] - res["0"][0]) <= 1e-12 * res["0"][0], (n, deg, hub, res["0"][0], res["1"][0])
+        assert np.abs(sign_align(res["1"][1], res["0"][1]) - res["0"][1]).max() <= 1e-7
+        ip, ix, da = P.laplacian_csr()
+        L = sp.csr_matrix((da, ix, ip), shape=(n, n))
+        assert int(np.diff(ip).max()) == (hub + 3 if hub else int(np.diff(ip).max()))
+        v1 = res["1"][1]
+        assert np.abs(L @ v1 - res["1"][0] * v1).sum() / abs(L).sum(axis=1).max() < 1e-8      # nx:246 on SciPy's SpMV
+        w = spla.eigsh(L, k=2, which="SA", tol=1e-10, ncv=64, v0=np.ones(n) + 0.01 * rng.random(n), return_eigenvectors=False)
+        assert abs(np.sort(w)[1] - res["1"][0]) <= 1e-8 * res["1"][0]
+        P.close()
+
+
 @pytest.mark.parametrize("nm", ["intel", "sphere2500"])
 def test_chebyshev_filtered_single_workgroup_recurrence_matches_goldens(nm):
     """MACHIP_CHEB_DEG=8: the single-workgroup Lanczos kernel run on C = -T_8(M(L)) after a short plain sequence (persist.h,
