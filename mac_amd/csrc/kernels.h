@@ -61,10 +61,15 @@ struct LanView {
 // weight_graph_lap_from_edges, mac/utils/graphs.py:58-98)
 // ------------------------------------------------------------------------------------------
 // Pass 1: active entries per row (+1 for the diagonal) and one total per workgroup.
+constexpr long long kAsmInactive = 0x7ff8dead00000001ll;   // a NaN payload no arithmetic produces: "slot not active"
+// (round 3: the value of every slot -- x_k w_k, the fixed weight, or the marker above for an inactive slot -- is parked in slot order
+// here, so that the fill pass streams it instead of gathering x[k] a second time: the pattern walk used to fetch ~10x the
+// algorithmic bytes, two random 8-byte gathers per slot being most of it.)
 template <int G>
 __global__ __launch_bounds__(kBlock) void k_asm_count(PatternView P, const double* __restrict__ x,
                                                       double tol, int rows_per_block,
-                                                      int* __restrict__ cnt, int* __restrict__ blk_sum) {
+                                                      int* __restrict__ cnt, int* __restrict__ blk_sum,
+                                                      double* __restrict__ sval) {
     __shared__ int sm[4];
     constexpr int GPB = kBlock / G;
     const int lane = threadIdx.x % G, g = threadIdx.x / G;
@@ -77,7 +82,11 @@ __global__ __launch_bounds__(kBlock) void k_asm_count(PatternView P, const doubl
         for (int p = b + lane; p < e; p += G) {
             const int k = P.pk[p];
             const bool cand = k >= 0;
-            const bool act = !cand || (x[k] > tol);
+            const double wgt = P.pw[p];
+            double v = wgt;
+            bool act = true;
+            if (cand) { const double xk = x[k]; act = xk > tol; v = xk * wgt; }
+            sval[p] = act ? v : __longlong_as_double(kAsmInactive);
             c += act;
             sc += (cand && act && P.pcol[p] > r);   // each candidate counted once (upper slot)
         }
@@ -108,8 +117,8 @@ __global__ __launch_bounds__(kBlock) void k_asm_count(PatternView P, const doubl
 // counts in LDS; each G-lane group compacts the active slots of its rows (ballot + popcount,
 // order preserved => columns stay sorted) behind the diagonal entry.
 template <int G>
-__global__ __launch_bounds__(kBlock) void k_asm_fill(PatternView P, const double* __restrict__ x,
-                                                     double tol, int rows_per_block,
+__global__ __launch_bounds__(kBlock) void k_asm_fill(PatternView P, const double* __restrict__ sval,
+                                                     int rows_per_block,
                                                      const int* __restrict__ cnt,
                                                      const int* __restrict__ blk_sum,
                                                      int* __restrict__ rowptr, int* __restrict__ col,
@@ -164,14 +173,9 @@ __global__ __launch_bounds__(kBlock) void k_asm_fill(PatternView P, const double
         for (int p0 = b; p0 < e; p0 += G) {
             const int p = p0 + lane;
             const bool in = p < e;
-            const int k = in ? P.pk[p] : -1;
-            const double wgt = in ? P.pw[p] : 0.0;
-            double v = 0.0;
-            bool act = false;
-            if (in) {
-                if (k < 0) { act = true; v = wgt; }
-                else { const double xk = x[k]; if (xk > tol) { act = true; v = xk * wgt; } }
-            }
+            const double sv = in ? sval[p] : __longlong_as_double(kAsmInactive);
+            const bool act = __double_as_longlong(sv) != kAsmInactive;     // (a NaN that arithmetic produced stays an active entry)
+            const double v = act ? sv : 0.0;
             const unsigned long long bal = __ballot(act);
             unsigned long long gm;
             if (G == 64) gm = bal;

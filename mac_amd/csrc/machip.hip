@@ -83,7 +83,7 @@ struct machip_problem {
     double *x = nullptr, *x_next = nullptr, *g = nullptr, *s = nullptr, *scratch_m = nullptr;
     // assembled CSR (device)
     int *cnt = nullptr, *blk_sum = nullptr, *rowptr = nullptr, *col = nullptr;
-    double *val = nullptr, *blk_lnorm = nullptr;
+    double *val = nullptr, *blk_lnorm = nullptr, *sval = nullptr;   // sval: per-slot values of the running assembly
     long nnz = 0, support = 0;
     int maxlen = 0;           // longest row of the assembled L(x)
     double lnorm = 0.0;
@@ -204,9 +204,9 @@ int build_pattern(machip_problem* p, int64_t nf, const int32_t* fi, const int32_
 template <int G>
 void launch_asm(machip_problem* p) {
     const PatternView P = p->pattern();
-    k_asm_count<G><<<p->asm_grid, kBlock, 0, p->stream>>>(P, p->x, p->tol_sel, p->asm_rpb, p->cnt, p->blk_sum);
+    k_asm_count<G><<<p->asm_grid, kBlock, 0, p->stream>>>(P, p->x, p->tol_sel, p->asm_rpb, p->cnt, p->blk_sum, p->sval);
     const size_t lds = sizeof(int) * ((size_t)p->asm_rpb + 1);
-    k_asm_fill<G><<<p->asm_grid, kBlock, lds, p->stream>>>(P, p->x, p->tol_sel, p->asm_rpb, p->cnt, p->blk_sum,
+    k_asm_fill<G><<<p->asm_grid, kBlock, lds, p->stream>>>(P, p->sval, p->asm_rpb, p->cnt, p->blk_sum,
                                                            p->rowptr, p->col, p->val, p->blk_lnorm);
 }
 
@@ -416,7 +416,7 @@ int machip_create(int device, int64_t n, int64_t n_fixed, const int32_t* fi, con
         const size_t cap = (size_t)p->P + (size_t)n + 8;
         ST_TRY(dev_alloc(&p->cnt, (size_t)n + 1)); ST_TRY(dev_alloc(&p->blk_sum, 3 * kMaxGrid));
         ST_TRY(dev_alloc(&p->rowptr, (size_t)n + 1)); ST_TRY(dev_alloc(&p->col, cap)); ST_TRY(dev_alloc(&p->val, cap));
-        ST_TRY(dev_alloc(&p->blk_lnorm, kMaxGrid));
+        ST_TRY(dev_alloc(&p->blk_lnorm, kMaxGrid)); ST_TRY(dev_alloc(&p->sval, (size_t)p->P + 8));
         ST_TRY(dev_alloc(&p->hist, 6 * kBins)); ST_TRY(dev_alloc(&p->sel, 2)); ST_TRY(dev_alloc(&p->part_fw, 2 * kMaxGrid));
         ST_TRY(alloc_common(p));
         p->sol.csr_cap = cap;
@@ -452,7 +452,7 @@ void machip_destroy(machip_problem* p) {
     if (p->lgroup) p->lgroup->abort();      // peers blocked in the group's barrier return an error instead of hanging
     p->sol.destroy();
     void* ptrs[] = {p->prow, p->pcol, p->pk, p->pw, p->ci, p->cj, p->cw, p->x, p->x_next, p->g, p->s, p->scratch_m, p->cnt,
-                    p->blk_sum, p->rowptr, p->col, p->val, p->blk_lnorm, p->hist, p->sel, p->part_fw};
+                    p->blk_sum, p->rowptr, p->col, p->val, p->blk_lnorm, p->sval, p->hist, p->sel, p->part_fw};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     if (p->h_int) (void)hipHostFree(p->h_int);
     if (p->h_dbl) (void)hipHostFree(p->h_dbl);
@@ -837,7 +837,7 @@ int make_lane(machip_problem* p, machip_problem** out) {
         const size_t cap = (size_t)q->P + (size_t)q->n + 8;
         ST_TRY(dev_alloc(&q->cnt, (size_t)q->n + 1)); ST_TRY(dev_alloc(&q->blk_sum, 3 * kMaxGrid));
         ST_TRY(dev_alloc(&q->rowptr, (size_t)q->n + 1)); ST_TRY(dev_alloc(&q->col, cap)); ST_TRY(dev_alloc(&q->val, cap));
-        ST_TRY(dev_alloc(&q->blk_lnorm, kMaxGrid));
+        ST_TRY(dev_alloc(&q->blk_lnorm, kMaxGrid)); ST_TRY(dev_alloc(&q->sval, (size_t)q->P + 8));
         // every lane keeps its own Krylov basis: a share of the handle's budget each (MACHIP_LANE_VBUDGET_MB, default
         // MACHIP_VBUDGET_MB / 8 = 512 MB: 8 lanes together hold what the handle itself holds)
         ST_TRY(alloc_common(q, std::max(16, env_int("MACHIP_LANE_VBUDGET_MB", std::max(16, env_int("MACHIP_VBUDGET_MB", 4096) / 8)))));
