@@ -233,6 +233,11 @@ int machip_synchronize(machip_problem* p);
  * tridiagonal with diagonal a[0..J) and off-diagonal b[1..J) (b[0] unused): the O(J) analysis the Lanczos driver
  * runs on every chunk of steps; exported so that `-m "not gpu"` tests can check it against LAPACK. */
 int machip_membench(int device, int64_t bytes, int reps, double* read_gbs, double* triad_gbs);
+/* Host only, no GPU: the shape the column-panel Lanczos step (mac_amd/csrc/panel.h) would use for a matrix of n rows, nnz
+ * entries and longest row maxlen -- out8 = {on, NP panels, C columns per panel, NB row blocks, NTB 64-row tiles per block,
+ * TWW tiles per worker wave, RPT records per worker thread, workgroups of k_pan_fin} -- under the current environment
+ * (MACHIP_PANEL etc.).  For CPU tests of the shape arithmetic (coverage of all rows / columns, LDS and register limits). */
+int machip_panel_plan(int64_t n, int64_t nnz, int maxlen, int* out8);
 /* machip_fiedler_csr keeps one CSR-only handle (stream, device buffers, chunk graphs) between calls and reuses it when
  * device and n match and the matrix fits -- every solve still starts from a clean solver state.  This frees it (the
  * Python layer calls it at interpreter exit). */

@@ -81,6 +81,7 @@ SIGNATURES = {
     "machip_membench": (C.c_int, [C.c_int, C.c_int64, C.c_int, _f64p, _f64p]),
     "machip_host_tridiag_smallest": (C.c_int, [_f64p, _f64p, C.c_int, _f64p, _f64p]),
     "machip_release_cache": (None, []),
+    "machip_panel_plan": (C.c_int, [C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_int)]),
 }
 
 

@@ -815,6 +815,13 @@ int machip_comm_mode(machip_problem* p) {
     return 0;
 }
 
+int machip_panel_plan(int64_t n, int64_t nnz, int maxlen, int* out8) {
+    if (n < 1 || n > 2000000000ll || nnz < 0 || !out8) return fail(MACHIP_BAD_ARG, "machip_panel_plan: bad argument");
+    const PanPlan pp = plan_panel((int)n, (long)nnz, maxlen, true);
+    out8[0] = pp.on ? 1 : 0; out8[1] = pp.NP; out8[2] = pp.C; out8[3] = pp.NB; out8[4] = pp.NTB; out8[5] = pp.TWW; out8[6] = pp.RPT; out8[7] = pp.grid2;
+    return MACHIP_OK;
+}
+
 int machip_shard_plan(int64_t m, int nranks, int rank, int64_t* lo, int64_t* hi, int64_t* shard) {
     if (m < 0 || nranks < 1 || rank < 0 || rank >= nranks || !lo || !hi || !shard) return fail(MACHIP_BAD_ARG, "machip_shard_plan: bad argument");
     long a, b, c;

@@ -113,7 +113,8 @@ __device__ __forceinline__ int pan_row_count(const PanView& P, int n, int r, int
 }
 
 // Pass 1, one workgroup per (row block, panel): sort the block's rows by length (counting sort; ties in arrival order
-// -- a row's sum does not depend on the slot it lands in, so the tie order never shows in a result) and record
+// -- a row's sum does not depend on the slot it lands in, PROVIDED the multiply-accumulate of k_pan_mul rounds the same
+// way at every chunk position: see the contraction note there -- so the tie order never shows in a result) and record
 // slot -> row and the tile sizes.
 __global__ __launch_bounds__(kPanThreads) void k_pan_count(CsrView A, PanView P) {
     __shared__ int hist[kPanMaxLen + 1], start[kPanMaxLen + 1], fill[kPanMaxLen + 1];
@@ -280,6 +281,11 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul(PanView A, PipeView L, 
     PAN_CLK(tid == 64, 5);
     double acc = 0.0;
     for (int cb = 0; cb < nch; cb += kPanCH) {
+        // No contraction in this block: a product and its addition to the row's sum stay two roundings for EVERY chunk.
+        // (Left to the compiler, some of the 20 unrolled chunk positions were fused into fmas and others not; which positions
+        // a row's entries occupy depends on the tile it was dealt to, ties among rows of equal length are dealt in arrival
+        // order -- and lambda_2 differed in the last digit from run to run.  Found by tools/soak.sh / tools/det_probe.py.)
+#pragma clang fp contract(off)
         if (cb) {     // more chunks than the registers hold: next round (one more round trip)
 #pragma unroll
             for (int c = 0; c < kPanCH; ++c)

@@ -1704,6 +1704,37 @@ def test_trajectory_is_bit_reproducible_run_to_run():
         assert np.array_equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1] and np.array_equal(runs[0][2], runs[1][2]), nm
 
 
+def test_column_panel_step_is_bit_reproducible_run_to_run():
+    """The panel form deals rows of equal length to tiles in ARRIVAL order (LDS atomics in k_pan_count), so two builds of the same
+    matrix differ by a permutation among such rows.  Results must not: the product-sum of k_pan_mul rounds the same way at every
+    chunk position (no contraction), which makes a row's sum independent of the slot it lands in.  Regression test for a last-digit
+    run-to-run difference of lambda_2 found by tools/soak.sh: six solves of a dense configs[3] iterate (multi-round chunk ranges),
+    panel step forced, must agree to the last bit -- lambda_2, the vector and the step count."""
+    import bench
+    w = bench.make_workload("c4")
+    P = _lib.Problem(w["n"], w["fi"], w["fj"], w["fw"], w["ci"], w["cj"], w["cw"])
+    P.set_start(reference_start_block(w["n"])[:, 0].copy())
+    P.set_x(w["x0"])
+    for it in range(7):
+        P.fw_step(w["k"], it); P.fw_commit()
+    old = os.environ.get("MACHIP_PANEL")
+    os.environ["MACHIP_PANEL"] = "1"
+    try:
+        outs = []
+        for rep in range(6):
+            P.assemble()                                   # new solve, panel form rebuilt
+            lam, v, _ = P.fiedler()
+            outs.append((lam, v.copy(), int(P.stats.lanczos_steps)))
+    finally:
+        if old is None:
+            os.environ.pop("MACHIP_PANEL", None)
+        else:
+            os.environ["MACHIP_PANEL"] = old
+    for o in outs[1:]:
+        assert o[0] == outs[0][0] and o[2] == outs[0][2] and np.array_equal(o[1], outs[0][1])
+    P.close()
+
+
 def test_new_entry_points_reject_bad_arguments():
     """BAD_ARG (-> AssertionError, like the reference's asserts) instead of undefined behaviour on the round-2 entry points."""
     g = load_golden("er300_solve")

@@ -178,3 +178,46 @@ def test_bench_refuses_to_launch_ranks_without_devices():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "c3"], env=env, capture_output=True,
                        text=True, timeout=120)
     assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout) and '"metric"' not in r.stdout
+
+
+def test_panel_plan_covers_every_row_and_column_within_the_kernel_limits():
+    """Shape arithmetic of the column-panel Lanczos step (solver.h plan_panel, exported as machip_panel_plan; host only):
+    the panels cover every column, the row blocks every row, a panel fits the LDS next to the row block's image
+    (RPT <= 13 records per worker thread), a worker wave owns at most 8 tiles, and the automatic rule turns the step on
+    only for large, dense-enough matrices with rows the build kernels can describe."""
+    import ctypes as C
+    lib = _lib.load()
+    out = (C.c_int * 8)()
+    old = {k: os.environ.pop(k, None) for k in ("MACHIP_PANEL", "MACHIP_PANEL_NP", "MACHIP_PANEL_NB")}
+    try:
+        # automatic rule (BASELINE configs[3]: on for the dense iterates only)
+        for n, nnz, maxlen, want in ((100000, 700344, 30, 0), (100000, 1747218, 40, 1), (100000, 4044528, 70, 1), (100000, 4044528, 200, 0),
+                                     (10000, 956618, 120, 0), (1728, 5496, 9, 0), (65536, 65536 * 20, 60, 1), (500000, 500000 * 30, 60, 0)):
+            assert lib.machip_panel_plan(n, nnz, maxlen, out) == _lib.OK
+            assert out[0] == want, (n, nnz, maxlen, list(out))
+        assert list(out)[:1] == [0]
+        lib.machip_panel_plan(100000, 2700000, 60, out)
+        assert list(out)[:7] == [1, 12, 8334, 21, 75, 5, 9]               # the shape profiles/r3_c4_panel.md measures
+        os.environ["MACHIP_PANEL"] = "1"
+        rng = np.random.default_rng(3)
+        for n in [128, 129, 300, 2000, 8448, 8449, 65536, 100000, 123457, 399999, 1000003] + [int(t) for t in rng.integers(130, 3000000, 40)]:
+            for extra in ({}, {"MACHIP_PANEL_NP": str(int(rng.integers(1, 40)))}, {"MACHIP_PANEL_NB": str(int(rng.integers(1, 400)))}):
+                for k_ in ("MACHIP_PANEL_NP", "MACHIP_PANEL_NB"):
+                    os.environ.pop(k_, None)
+                os.environ.update(extra)
+                assert lib.machip_panel_plan(n, 20 * n, 60, out) == _lib.OK
+                on, NP, Cc, NB, NTB, TWW, RPT, g2 = list(out)
+                if not on:
+                    continue
+                assert NP >= 1 and NP * Cc >= n and (NP - 1) * Cc < n          # every column in exactly one panel, none empty
+                assert NB * NTB * 64 >= n and (NB - 1) * NTB * 64 < n          # every row in exactly one block, none empty
+                assert 1 <= RPT <= 13 and RPT * 960 >= Cc                      # the panel fits LDS / registers
+                assert 1 <= TWW <= 8 and TWW * 15 >= NTB and NTB <= 120        # a worker wave's tiles
+                assert 1 <= g2 <= 1024
+        assert lib.machip_panel_plan(0, 0, 0, out) == _lib.BAD_ARG
+    finally:
+        for k_ in ("MACHIP_PANEL", "MACHIP_PANEL_NP", "MACHIP_PANEL_NB"):
+            os.environ.pop(k_, None)
+        for k_, v in old.items():
+            if v is not None:
+                os.environ[k_] = v
