@@ -2,7 +2,7 @@
 """bench.py -- Frank-Wolfe iterations/second (each including the full Fiedler solve) of the
 MAC hot path on MI355X, with the CPU paths timed beside it.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c4|c2|c3|c5a|c5b|c5] [--mode shard|replicas]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c4|c2|c3|c5a|c5b|c5|c5s] [--mode shard|replicas]
 
 One "step" = one Frank-Wolfe iteration (mac/optimization/frankwolfe.py:53-76 with
 problem = MAC.problem): assemble L(x) -> Fiedler pair to the reference's stop rule at tol 1e-8 ->
@@ -314,6 +314,69 @@ def bench_c5_batched(args):
 
 
 # ---------------------------------------------------------------------------------------------
+def bench_c5_sweep(args):
+    """The reference's real experiment on BASELINE.json configs[4]'s two pose graphs (examples/g2o_experiment.py:306-336: a
+    sweep of budgets, MAC.solve(max_iters = 20) each) on ONE GPU: per graph one handle whose evaluation lanes run the
+    budgets 10 % .. 90 % concurrently (machip_fw_sweep), the two graphs in two host threads.  A step = one
+    Frank-Wolfe iteration of one budget; value = all iterations of all budgets of both graphs / wall time.  Stop tests
+    disabled, cold eigen-solves, exactly as the other configs are timed."""
+    import threading
+    from mac_amd import _lib
+    from mac_amd.utils.fiedler import reference_start_block
+    ws = [make_workload("c5b"), make_workload("c5a")]
+    pcts = (0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9)
+    Ps, ks, X0 = [], [], []
+    for w in ws:
+        P = _lib.Problem(w["n"], w["fi"], w["fj"], w["fw"], w["ci"], w["cj"], w["cw"])
+        P.set_precision(args.precision)
+        P.set_start(reference_start_block(w["n"])[:, 0].copy())
+        m = len(w["cw"])
+        kk = [int(p_ * m) for p_ in pcts]
+        x0 = np.zeros((len(kk), m))
+        for j, k in enumerate(kk):
+            x0[j, np.argpartition(w["cw"], -k)[-k:]] = 1.0       # NaiveGreedy init per budget (mac/solvers/baseline.py:10-13)
+        P.fw_sweep(kk, x0, max_iters=max(1, args.warmup), gap_tol=0.0, grad_tol=0.0, want_rounded=False)   # lanes, graphs, buffers
+        Ps.append(P); ks.append(kk); X0.append(x0)
+    res = [None, None]
+
+    def work(i):
+        res[i] = Ps[i].fw_sweep(ks[i], X0[i], max_iters=args.steps, gap_tol=0.0, grad_tol=0.0, want_rounded=False)
+    passes = []
+    total = 0.0
+    while True:
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        el = time.perf_counter() - t0
+        passes.append(el); total += el
+        if total >= args.min_seconds or len(passes) >= args.max_repeats:
+            break
+    el = sorted(passes)[(len(passes) - 1) // 2]
+    its = sum(int(r["iters"].sum()) for r in res)
+    t1 = time.perf_counter()
+    for i in range(2):                    # the same budgets one after the other, one at a time (what a loop over MAC.solve does)
+        for j, k in enumerate(ks[i]):
+            run_pass(Ps[i], k, args.steps, X0[i][j])
+    seq = time.perf_counter() - t1
+    print(json.dumps({"metric": "frank_wolfe_iters_per_sec", "value": its / el, "unit": "iter/s", "n_gpus": 1,
+                      "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / its, "higher_is_better": True,
+                      "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.precision == 0 else "f32 iterate + f64 Rayleigh/residual refinement",
+                      "data": "dataset (tests/golden/data)",
+                      "config": {"workload": "configs[4] graphs as the reference's budget sweep: city10000.g2o + sphere2500.g2o, 9 budgets (10..90 percent of the loop "
+                                             f"closures) x {args.steps} Frank-Wolfe iterations each, concurrently on one GPU (machip_fw_sweep)",
+                                 "budgets_per_graph": len(pcts), "fw_iters_each": args.steps,
+                                 "parallelism": "evaluation lanes: up to 12 budgets per graph at a time, one host thread per lane"},
+                      "repeats": len(passes), "pass_ms": [round(1e3 * p, 3) for p in passes], "iterations_per_pass": its,
+                      "sequential_value": its / seq,
+                      "lambda2_last": [[float(r["f_traj"][j, -1]) for j in (0, len(pcts) - 1)] for r in res]}))
+    for P in Ps:
+        P.close()
+
+
+# ---------------------------------------------------------------------------------------------
 def self_launch(args):
     """--gpus N without a launcher: spawn N rank processes (one GPU each) of this script."""
     from mac_amd import _lib
@@ -394,6 +457,8 @@ def main():
 
     if args.config == "c5" and world == 1:
         return bench_c5_batched(args)
+    if args.config == "c5s" and world == 1:
+        return bench_c5_sweep(args)
     replicas = world > 1 and (args.mode == "replicas" or args.config == "c5")
     cfg = args.config
     if cfg == "c5":                      # one pose graph per rank (SURVEY 8(e) last row)
