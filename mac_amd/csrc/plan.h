@@ -1,0 +1,331 @@
+// plan.h -- launch-shape POLICY of the eigen-solver and the dispatch onto the kernel instantiations (mechanism lives in
+// kernels.h / panel.h / persist.h, the driver in solver.h).
+//
+//   plan_spmv   shape of the stand-alone SpMV kernels (explicit residual check, preconditioned mode)
+//   plan_pipe   shape of the one-kernel Lanczos step (lanes per row, load chains, workgroup size, deferred barrier)
+//   plan_panel  whether the column-panel form runs, and its panels / row blocks (panel.h)
+//   launch_*    the switch from a plan to a template instantiation; launch_pipe_shard: one rank's share of a
+//               row-partitioned step (ShardGroup below)
+//
+// Every number here was measured on MI355X (tools/ubench*.hip, tools/sweep_pipe.py, tools/sweep_panel.py); the comments say
+// which.  The environment knobs are read on every plan ON PURPOSE: a plan is made once per eigen-solve
+// (~40 getenv calls, a few microseconds against milliseconds of solve), and the sweep tools and the variant tests switch
+// shapes between solves of one process.  Nothing in here looks at timings, so a plan -- and with it every rounding of a
+// trajectory -- is a function of (n, nnz, longest row, knobs) only.
+#pragma once
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+#include "kernels.h"
+#include "panel.h"
+#include "persist.h"
+
+namespace machip {
+
+template <class T>
+inline int dev_alloc(T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    HIP_TRY(hipMalloc((void**)p, count * sizeof(T)));
+    return MACHIP_OK;
+}
+
+enum SpmvVariant { kAuto = 0, kStream = 1, kVec = 2, kPanel = 3 };
+
+struct SpmvPlan {
+    int variant = kVec;   // kStream or kVec
+    int width = 8;        // TPR for stream, G for vec
+    int grid = 1;
+    int block = kBlock;   // threads per workgroup of the fused step kernel (256, 512 or 1024)
+    int unroll = 1;       // independent (val, col, gather) chains per lane
+    int defer = 1;        // row tiles whose finish() waits behind the barrier (k_pipe_vec DEFER): 3 where a workgroup owns several
+};
+
+inline int env_int(const char* name, int dflt) {
+    const char* s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
+// Every workgroup of a step kernel re-reduces the previous step's per-workgroup partials, so
+// that traffic grows with grid^2: cap the grid (grid-stride loops cover the rest of the rows).
+inline int grid_cap() { return std::max(1, std::min(kMaxGrid, env_int("MACHIP_MAXGRID", 256))); }
+
+inline SpmvPlan plan_spmv(int n, long nnz, int forced_variant, int cap = 0) {
+    if (cap <= 0) cap = grid_cap();
+    SpmvPlan pl;
+    const double mean = n > 0 ? (double)nnz / (double)n : 1.0;
+    int variant = forced_variant;
+    if (variant == kAuto) {
+        const char* e = getenv("MACHIP_SPMV");
+        if (e && !strcmp(e, "stream")) variant = kStream;
+        else if (e && !strcmp(e, "vec")) variant = kVec;
+        else variant = mean < 24.0 ? kStream : kVec;
+    }
+    pl.variant = variant;
+    if (variant == kStream) {
+        int tpr = 16;
+        while (tpr > 1 && ((long)n * tpr / kBlock > 4L * cap || tpr > std::max(2.0, mean))) tpr >>= 1;
+        tpr = env_int("MACHIP_TPR", tpr);
+        pl.width = tpr;
+        const int R = kBlock / tpr;
+        pl.grid = (int)std::min<long>(cap, ((long)n + R - 1) / R);
+    } else {
+        int g = 4;
+        while (g < 64 && g < mean * 0.75) g <<= 1;
+        if (n <= 32768) g = std::min(g, 16);   // cache-resident operand: narrower groups, more rows in flight (17 -> 7 us at config 2)
+        g = env_int("MACHIP_G", g);
+        pl.width = g;
+        const int gpb = kBlock / g;
+        pl.grid = (int)std::min<long>(cap, ((long)n + gpb - 1) / gpb);
+    }
+    if (pl.grid < 1) pl.grid = 1;
+    return pl;
+}
+
+// Launch shape of the fused Lanczos-step kernel (tools/ubench.hip ablations, MI355X):
+// sub-wave groups of 4 lanes per row up to ~40 nnz/row, 16 beyond; at most grid_cap() workgroups
+// (each re-reads every workgroup's partials), so large n gets 1024-thread workgroups instead of
+// more of them.
+inline SpmvPlan plan_pipe(int n, long nnz, int maxlen) {
+    SpmvPlan pl;
+    const double mean = n > 0 ? (double)nnz / (double)n : 1.0;
+    const char* e = getenv("MACHIP_SPMV");
+    if (e && !strcmp(e, "stream")) {
+        pl = plan_spmv(n, nnz, kStream);
+        pl.block = kBlock;
+        return pl;
+    }
+    pl.variant = kVec;
+    // tools/ubench.hip, MI355X: 4 lanes per row up to ~16 nnz/row, 8 up to ~32 (and for every
+    // n <= 32k, where the gather operand is cache resident), 16 beyond; two independent load chains
+    // per lane from 8 lanes up.  Hub rows (Frank-Wolfe vertices concentrate the selected edges on
+    // few nodes) would serialise a narrow group: widen when the longest row is far above the mean.
+    // Round 2, in-solve sweep (tools/sweep_pipe.py, step time from the events around the Krylov chunks):
+    //   n <= 32k (config 2): 8 lanes, 4 load chains, 512-thread workgroups (179 of them at n = 10k) are best or tied
+    //     on every iterate, hub rows included: 7.2 us against 7.6 us step-weighted, 5.6 against 6.9 us on the first;
+    //   n = 100k (config 4): 4 lanes up to 16 nnz/row -- also when a Frank-Wolfe vertex has produced hub rows, where
+    //     the 16-lane groups chosen in round 1 sat mostly idle (14.0 against 17.4 us) -- two load chains once hubs
+    //     exist; 8 lanes up to 24 nnz/row, 16 beyond.
+    int g, unr, blk;
+    if (n <= 32768) {
+        g = 8; unr = 4; blk = 512;
+        if (mean < 8.0) { g = 4; unr = 2; blk = 256; }   // pose-graph rows (city10000: 5 nnz/row): 5.2 against 5.4 us
+    } else {
+        g = mean < 16.0 ? 4 : (mean < 24.0 ? 8 : 16);
+        if (g == 8 && maxlen > 8 * mean && maxlen > 128) g = 16;
+        unr = g == 4 ? (maxlen > 48 ? 2 : 1) : 2;
+        // at most grid_cap() workgroups (each re-reads every workgroup's partials): grow the workgroup instead of
+        // the grid (wave 0 of every workgroup only runs the prologue: BLOCK - 64 threads own rows)
+        blk = 256;
+        while (blk < 1024 && ((long)n + ((blk - 64) / g) - 1) / ((blk - 64) / g) > grid_cap()) blk <<= 1;
+    }
+    pl.width = env_int("MACHIP_G", g);
+    pl.unroll = env_int("MACHIP_UNROLL", unr);
+    pl.block = env_int("MACHIP_BLOCK", blk);
+    const int gpb = (pl.block - 64) / pl.width;
+    const long tiles = ((long)n + gpb - 1) / gpb;
+    pl.grid = (int)std::max<long>(1, std::min<long>(grid_cap(), tiles));
+    // a workgroup with several row tiles keeps the first three un-finished behind the barrier (the prologue's latency
+    // is then hidden); with one tile per workgroup that only costs registers
+    pl.defer = env_int("MACHIP_DEFER", tiles > 2L * pl.grid ? 3 : 1);
+    return pl;
+}
+
+// Column-panel step (panel.h): shape of the panel form for a matrix of n rows.  NP panels of C <= 16 384 columns (8 bytes
+// per column in LDS), NB row blocks of NTB 64-row tiles (TWW per worker wave), NB * NP <= 256 workgroups (one per CU: the panel takes most of
+// the CU's LDS).  Panel loads cost NB x 16 n bytes of coalesced L2 traffic per step, the partials 2 x NP x 8 n bytes: the
+// defaults balance the two (MACHIP_PANEL_NP / MACHIP_PANEL_NB override; swept on MI355X, profiles/r3_c4_panel.md).
+struct PanPlan {
+    bool on = false;
+    int NP = 1, C = 1, NB = 1, NTB = 1, TWW = 1, RPT = 1;
+    int grid2 = 1, block2 = 256;     // launch shape of k_pan_fin
+};
+inline PanPlan plan_panel(int n, long nnz, int maxlen, bool allowed) {
+    PanPlan pp;
+    const int mode = env_int("MACHIP_PANEL", -1);     // -1 auto, 0 off, 1 forced (tests: small graphs with several panels)
+    if (!allowed || mode == 0 || n < 128) return pp;
+    const double mean = (double)nnz / (double)std::max(n, 1);
+    // automatic: the operand must be too large for the gather path's caches to serve cheaply, and the matrix dense enough
+    // for the panel step's fixed costs (two launches, NB x 16 n bytes of panel loads, 2 x NP x 8 n bytes of partials) to
+    // pay: measured cross-over on MI355X at n = 1e5 (tools/sweep_panel.py, profiles/r3_c4_panel.md): ~17 entries per row
+    // (gather step 18.7 us and rising 4 us per million entries, panel step 18.3 us and rising 0.9 us per million)
+    if (maxlen > kPanMaxLen) return pp;               // the build kernels' length histograms stop at 127
+    if (mode < 0 && !(n >= env_int("MACHIP_PANEL_MIN_N", 65536) && n <= 400000 && mean >= 0.1 * env_int("MACHIP_PANEL_MIN_MEAN10", 170))) return pp;
+    int np = env_int("MACHIP_PANEL_NP", (n + 8447) / 8448);
+    np = std::max(1, std::min(np, 64));
+    int C = (n + np - 1) / np;
+    if (C > 13 * kPanWorkThreads) { np = (n + 13 * kPanWorkThreads - 1) / (13 * kPanWorkThreads); C = (n + np - 1) / np; }   // 13 records per thread: LDS (panel + un-sort stage) and registers
+    if (np > 64) return pp;
+    np = (n + C - 1) / C;                              // panels that actually hold columns
+    const int groups = (n + 63) / 64;
+    int nb = env_int("MACHIP_PANEL_NB", std::max(1, grid_cap() / np));
+    nb = std::max(1, std::min(nb, groups));
+    int ntb = (groups + nb - 1) / nb;                            // tiles per row block
+    ntb = std::min(ntb, kPanWork * kPanTW);                      // (the row block's LDS image holds 7 680 rows)
+    nb = (groups + ntb - 1) / ntb;
+    pp.on = true; pp.NP = np; pp.C = C; pp.NB = nb; pp.NTB = ntb; pp.TWW = (ntb + kPanWork - 1) / kPanWork;
+    pp.RPT = (C + kPanWorkThreads - 1) / kPanWorkThreads;
+    pp.block2 = env_int("MACHIP_PANEL_B2", 512);
+    if (pp.block2 != 256 && pp.block2 != 512 && pp.block2 != 1024) pp.block2 = 256;
+    pp.grid2 = (int)std::max<long>(1, std::min<long>(env_int("MACHIP_PANEL_G2", grid_cap()), ((long)n + pp.block2 - 1) / pp.block2));
+    return pp;
+}
+
+template <class Op>
+inline void launch_spmv(const SpmvPlan& pl, hipStream_t s, const CsrView& A, const double* x, const Op& op) {
+    if (pl.variant == kStream) {
+        switch (pl.width) {
+            case 1: k_spmv_stream<1, Op><<<pl.grid, kBlock, 0, s>>>(A, x, op); break;
+            case 2: k_spmv_stream<2, Op><<<pl.grid, kBlock, 0, s>>>(A, x, op); break;
+            case 4: k_spmv_stream<4, Op><<<pl.grid, kBlock, 0, s>>>(A, x, op); break;
+            case 8: k_spmv_stream<8, Op><<<pl.grid, kBlock, 0, s>>>(A, x, op); break;
+            default: k_spmv_stream<16, Op><<<pl.grid, kBlock, 0, s>>>(A, x, op); break;
+        }
+    } else {
+        switch (pl.width) {
+            case 2: k_spmv_vec<2, Op><<<pl.grid, kBlock, 0, s>>>(A, x, op); break;
+            case 4: k_spmv_vec<4, Op><<<pl.grid, kBlock, 0, s>>>(A, x, op); break;
+            case 8: k_spmv_vec<8, Op><<<pl.grid, kBlock, 0, s>>>(A, x, op); break;
+            case 16: k_spmv_vec<16, Op><<<pl.grid, kBlock, 0, s>>>(A, x, op); break;
+            case 32: k_spmv_vec<32, Op><<<pl.grid, kBlock, 0, s>>>(A, x, op); break;
+            default: k_spmv_vec<64, Op><<<pl.grid, kBlock, 0, s>>>(A, x, op); break;
+        }
+    }
+}
+
+// fp32 storage (mixed-precision mode): the shapes plan_pipe actually chooses; anything else maps to the nearest
+template <int BLOCK>
+inline void launch_pipe_b(const SpmvPlan& pl, hipStream_t s, const CsrViewT<float>& A, const PipeViewT<float>& L, int jrel) {
+    const int key = pl.width * 10 + pl.unroll;
+    switch (key) {
+        case 41: k_pipe_vec<BLOCK, 4, 1, true, float, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 42: case 44: k_pipe_vec<BLOCK, 4, 2, true, float, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 81: case 82: k_pipe_vec<BLOCK, 8, 2, true, float, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 84: k_pipe_vec<BLOCK, 8, 4, true, float, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        default: k_pipe_vec<BLOCK, 16, 2, true, float, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+    }
+}
+
+template <int BLOCK>
+inline void launch_pipe_b(const SpmvPlan& pl, hipStream_t s, const CsrView& A, const PipeView& L, int jrel) {
+    const int key = pl.width * 10 + pl.unroll;
+    if (pl.defer >= 3) {   // several row tiles per workgroup: the shapes plan_pipe picks there (others: DEFER = 1 below)
+        switch (key) {
+            case 41: k_pipe_vec<BLOCK, 4, 1, true, double, 3><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); return;
+            case 42: k_pipe_vec<BLOCK, 4, 2, true, double, 3><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); return;
+            case 82: k_pipe_vec<BLOCK, 8, 2, true, double, 3><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); return;
+            case 84: k_pipe_vec<BLOCK, 8, 4, true, double, 3><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); return;
+            case 162: k_pipe_vec<BLOCK, 16, 2, true, double, 3><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); return;
+            default: break;
+        }
+    }
+    switch (key) {
+        case 41: k_pipe_vec<BLOCK, 4, 1, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 42: k_pipe_vec<BLOCK, 4, 2, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 44: k_pipe_vec<BLOCK, 4, 4, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 84: k_pipe_vec<BLOCK, 8, 4, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 164: k_pipe_vec<BLOCK, 16, 4, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 81: k_pipe_vec<BLOCK, 8, 1, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 82: k_pipe_vec<BLOCK, 8, 2, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 161: k_pipe_vec<BLOCK, 16, 1, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 162: k_pipe_vec<BLOCK, 16, 2, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 321: k_pipe_vec<BLOCK, 32, 1, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 322: k_pipe_vec<BLOCK, 32, 2, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 641: k_pipe_vec<BLOCK, 64, 1, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        default: k_pipe_vec<BLOCK, 64, 2, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+    }
+}
+
+// One rank's share of a row-partitioned step: workgroups [PS.first, PS.first + grid) of the pl.grid-workgroup launch.
+// The SAME instantiation the unsharded switch picks (DEFER included: the deferred-barrier build is a different piece of
+// generated code, and its last bits differ from the plain one's at config 4).
+template <int BLOCK>
+inline void launch_pipe_shard_b(const SpmvPlan& pl, hipStream_t s, const CsrView& A, const PipeView& L, int jrel, const PeerSet& PS, int grid) {
+    const int key = pl.width * 10 + pl.unroll;
+    if (pl.defer >= 3) {
+        switch (key) {
+            case 41: k_pipe_vec<BLOCK, 4, 1, true, double, 3, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); return;
+            case 42: k_pipe_vec<BLOCK, 4, 2, true, double, 3, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); return;
+            case 82: k_pipe_vec<BLOCK, 8, 2, true, double, 3, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); return;
+            case 84: k_pipe_vec<BLOCK, 8, 4, true, double, 3, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); return;
+            case 162: k_pipe_vec<BLOCK, 16, 2, true, double, 3, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); return;
+            default: break;
+        }
+    }
+    switch (key) {
+        case 41: k_pipe_vec<BLOCK, 4, 1, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
+        case 42: k_pipe_vec<BLOCK, 4, 2, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
+        case 44: k_pipe_vec<BLOCK, 4, 4, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
+        case 81: k_pipe_vec<BLOCK, 8, 1, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
+        case 82: k_pipe_vec<BLOCK, 8, 2, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
+        case 84: k_pipe_vec<BLOCK, 8, 4, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
+        case 161: k_pipe_vec<BLOCK, 16, 1, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
+        case 162: k_pipe_vec<BLOCK, 16, 2, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
+        case 164: k_pipe_vec<BLOCK, 16, 4, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
+        case 321: k_pipe_vec<BLOCK, 32, 1, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
+        case 322: k_pipe_vec<BLOCK, 32, 2, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
+        case 641: k_pipe_vec<BLOCK, 64, 1, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
+        default: k_pipe_vec<BLOCK, 64, 2, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
+    }
+}
+// rows per workgroup tile of the instantiation the switches above pick (unlisted shapes run as G = 64)
+inline int pipe_gpb(const SpmvPlan& pl) {
+    int g = 64;
+    switch (pl.width * 10 + pl.unroll) {
+        case 41: case 42: case 44: g = 4; break;
+        case 81: case 82: case 84: g = 8; break;
+        case 161: case 162: case 164: g = 16; break;
+        case 321: case 322: g = 32; break;
+        default: g = 64; break;
+    }
+    return (pl.block - 64) / g;
+}
+
+// Row-partitioned eigen-solve of an in-process communicator (machip_comm_init_local): the LEADER's
+// solver (rank 0) drives every rank's stream -- per Lanczos step one launch per rank (that rank's share of the step's
+// workgroups, on that rank's copy of matrix and operand, writing next records and partial sums into every copy),
+// ordered by events: step s of rank r waits for step s - 1 of every rank.  Everything else of the solve (host analysis
+// of the tridiagonal, explicit residual check, restarts) runs on the leader alone; the converged vector is copied to
+// the peers.  The basis V is sharded by rows: each rank keeps the rows its workgroups produced and forms its part of
+// the Ritz vector.
+struct ShardRank {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Z2 *Z0 = nullptr, *Z1 = nullptr;
+    double *part = nullptr, *V = nullptr, *ypart = nullptr, *sdev = nullptr, *yvec = nullptr;
+    CsrView A{};                 // this rank's own assembled copy of L(x)
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int g0 = 0, g1 = 0;          // workgroups [g0, g1) of a step (set per solve from the plan)
+};
+struct ShardGroup {
+    std::vector<ShardRank> rk;   // rk[0] = the leader
+    hipEvent_t fork = nullptr;
+    bool same_device = true;
+};
+inline void launch_pipe_shard(const SpmvPlan& pl, hipStream_t s, const CsrView& A, const PipeView& L, int jrel, const PeerSet& PS, int grid) {
+    if (pl.block == 1024) launch_pipe_shard_b<1024>(pl, s, A, L, jrel, PS, grid);
+    else if (pl.block == 512) launch_pipe_shard_b<512>(pl, s, A, L, jrel, PS, grid);
+    else launch_pipe_shard_b<256>(pl, s, A, L, jrel, PS, grid);
+}
+
+inline void launch_pipe(const SpmvPlan& pl, hipStream_t s, const CsrView& A, const PipeView& L, int jrel) {
+    if (pl.variant == kStream) {
+        switch (pl.width) {
+            case 1: k_pipe_stream<1><<<pl.grid, kBlock, 0, s>>>(A, L, jrel); break;
+            case 2: k_pipe_stream<2><<<pl.grid, kBlock, 0, s>>>(A, L, jrel); break;
+            case 4: k_pipe_stream<4><<<pl.grid, kBlock, 0, s>>>(A, L, jrel); break;
+            case 8: k_pipe_stream<8><<<pl.grid, kBlock, 0, s>>>(A, L, jrel); break;
+            default: k_pipe_stream<16><<<pl.grid, kBlock, 0, s>>>(A, L, jrel); break;
+        }
+    } else if (pl.block == 1024) launch_pipe_b<1024>(pl, s, A, L, jrel);
+    else if (pl.block == 512) launch_pipe_b<512>(pl, s, A, L, jrel);
+    else launch_pipe_b<256>(pl, s, A, L, jrel);
+}
+inline void launch_pipe(const SpmvPlan& pl, hipStream_t s, const CsrViewT<float>& A, const PipeViewT<float>& L, int jrel) {
+    if (pl.block == 1024) launch_pipe_b<1024>(pl, s, A, L, jrel);      // (the LDS row-tile variant exists in fp64 only)
+    else if (pl.block == 512) launch_pipe_b<512>(pl, s, A, L, jrel);
+    else launch_pipe_b<256>(pl, s, A, L, jrel);
+}
+
+}  // namespace machip
