@@ -151,18 +151,40 @@ inline PanPlan plan_panel(int n, long nnz, int maxlen, bool allowed) {
     // pay: measured cross-over on MI355X at n = 1e5 (tools/sweep_panel.py, profiles/r3_c4_panel.md): ~17 entries per row
     // (gather step 18.7 us and rising 4 us per million entries, panel step 18.3 us and rising 0.9 us per million)
     if (maxlen > kPanMaxLen) return pp;               // the build kernels' length histograms stop at 127
-    if (mode < 0 && !(n >= env_int("MACHIP_PANEL_MIN_N", 65536) && n <= 400000 && mean >= 0.1 * env_int("MACHIP_PANEL_MIN_MEAN10", 170))) return pp;
-    int np = env_int("MACHIP_PANEL_NP", (n + 8447) / 8448);
-    np = std::max(1, std::min(np, 64));
-    int C = (n + np - 1) / np;
-    if (C > 13 * kPanWorkThreads) { np = (n + 13 * kPanWorkThreads - 1) / (13 * kPanWorkThreads); C = (n + np - 1) / np; }   // 13 records per thread: LDS (panel + un-sort stage) and registers
-    if (np > 64) return pp;
-    np = (n + C - 1) / C;                              // panels that actually hold columns
+    // (other sizes, tools/panel_size_probe.py: n = 66 000 .. 145 000 with a single wave of workgroups -- a tie at 23-26 entries
+    // per row, 1.3-1.5x at 43-46; beyond n = 1e5 the build's 0.25 ms per solve moves the break-even to ~26)
+    const int min_mean10 = env_int("MACHIP_PANEL_MIN_MEAN10", n <= 105000 ? 170 : 260);
+    if (mode < 0 && !(n >= env_int("MACHIP_PANEL_MIN_N", 65536) && mean >= 0.1 * min_mean10)) return pp;
+    // Shape: NP panels x NB row blocks with NB * NP <= 256 workgroups -- ONE wave of workgroups, one per CU (a second wave
+    // doubles the kernel: n = 131 072 with 16 x 18 = 288 workgroups ran 30.5 us per step against 24.9 for the gather step) --,
+    // panels of at most 13 x 960 columns (LDS next to the row block's image), row blocks of at most 120 tiles (that image).
+    // Preferred panel width ~8 448 columns (measured best at n = 1e5: 12 x 21); wider panels where the row blocks would
+    // otherwise not fit.  No such shape beyond n ~ 145 000: the automatic mode then stays with the gather step.
     const int groups = (n + 63) / 64;
-    int nb = env_int("MACHIP_PANEL_NB", std::max(1, grid_cap() / np));
+    const int cmax = 13 * kPanWorkThreads, tmax = kPanWork * kPanTW;
+    int np = 0, nb = 0;
+    const int np_env = env_int("MACHIP_PANEL_NP", 0), nb_env = env_int("MACHIP_PANEL_NB", 0);
+    if (np_env > 0 || nb_env > 0) {              // explicit shape (tests, sweeps): taken as given, clipped to what the kernels hold
+        np = std::max(1, std::min(np_env > 0 ? np_env : (n + 8447) / 8448, 64));
+        if ((n + np - 1) / np > cmax) np = (n + cmax - 1) / cmax;
+        nb = nb_env > 0 ? nb_env : std::max(1, grid_cap() / np);
+    } else {
+        for (int c = std::max(1, (n + 8447) / 8448); c >= 1; --c) {
+            if ((n + c - 1) / c > cmax) break;
+            const int b = std::max(1, grid_cap() / c);
+            if ((groups + b - 1) / b <= tmax) { np = c; nb = b; break; }
+        }
+        if (!np) {
+            if (mode < 0) return pp;             // no single-wave shape: not worth it (measured at n = 2e5 .. 4e5)
+            np = (n + cmax - 1) / cmax; nb = std::max(1, grid_cap() / np);   // forced: several waves of workgroups
+        }
+    }
+    if (np > 64) return pp;
+    int C = (n + np - 1) / np;
+    np = (n + C - 1) / C;                              // panels that actually hold columns
     nb = std::max(1, std::min(nb, groups));
     int ntb = (groups + nb - 1) / nb;                            // tiles per row block
-    ntb = std::min(ntb, kPanWork * kPanTW);                      // (the row block's LDS image holds 7 680 rows)
+    ntb = std::min(ntb, tmax);                                   // (the row block's LDS image holds 7 680 rows)
     nb = (groups + ntb - 1) / ntb;
     pp.on = true; pp.NP = np; pp.C = C; pp.NB = nb; pp.NTB = ntb; pp.TWW = (ntb + kPanWork - 1) / kPanWork;
     pp.RPT = (C + kPanWorkThreads - 1) / kPanWorkThreads;
