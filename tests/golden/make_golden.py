@@ -301,6 +301,33 @@ def er100k_arpack(meta):
     meta["er100k_arpack"] = {"iters": iters, "lam": [float(t) for t in lams], "max_residual": float(np.max(ress))}
 
 
+def g2o_sweep(meta):
+    """The reference's budget sweep (examples/g2o_experiment.py:306-336: for pct in 10 % .. 90 %: NaiveGreedy init,
+    MAC.solve(k, w_init, max_iters=20, rounding="nearest")) on intel and sphere2500: per budget the lambda_2 trajectory, the
+    dual upper bound, the unrounded x and the rounded selection.  Pins MAC.solve_sweep / machip_fw_sweep against the real
+    reference on every budget, not only the 20 % one of g2o_<name>.npz."""
+    _load_city()      # stubs `evo` and makes pose_graph_utils importable
+    from pose_graph_utils import read_g2o_file, split_edges, rpm_to_mac
+    import io, contextlib
+    for nm in ("intel", "sphere2500"):
+        meas, n = read_g2o_file(os.path.join(REF, "data", nm + ".g2o"))
+        odom, lc = split_edges(meas)
+        fixed, cand = rpm_to_mac(odom), rpm_to_mac(lc)
+        pcts = np.array([0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9])
+        ks, ups, fts, xs, rs = [], [], [], [], []
+        for pct in pcts:
+            k = int(pct * len(cand))
+            with contextlib.redirect_stdout(io.StringIO()):
+                x0 = NaiveGreedy(cand).subset(k)
+            mac, rounded, w, u, fs, gs, xs_ = run_solve(fixed, cand, n, k, x0, 20)
+            ft = np.full(20, np.nan); ft[:len(fs)] = fs
+            ks.append(k); ups.append(u); fts.append(ft); xs.append(w); rs.append(np.packbits(rounded > 0.5))
+            print("g2o_sweep", nm, pct, k, len(fs), u, flush=True)
+        save("g2o_sweep_" + nm, n=n, m=len(cand), pcts=pcts, ks=np.array(ks), upper=np.array(ups), f_traj=np.array(fts),
+             unrounded=np.array(xs), rounded_bits=np.array(rs))
+        meta["g2o_sweep_" + nm] = {"budgets": len(ks)}
+
+
 def main(only=None):
     meta_path = os.path.join(OUT, "golden_meta.json")
     if only and os.path.exists(meta_path):
@@ -317,6 +344,8 @@ def main(only=None):
         return er100k_x0(meta), json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
     if only == "city10000_vertices":
         return city10000_vertices(meta), json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
+    if only == "g2o_sweep":
+        return g2o_sweep(meta), json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
     if only == "er10k_vertices":
         return er10k_vertices(meta), json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
     if only == "er100k_arpack":

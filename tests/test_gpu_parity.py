@@ -1638,6 +1638,35 @@ def test_concurrent_budget_sweep_is_bit_identical_to_sequential_solves(nm):
     assert np.array_equal(both[0][0], np.ones(m)) and np.array_equal(both[1][1], seq[1][1]) and both[1][0].sum() == ks[1]
 
 
+@pytest.mark.parametrize("nm", ["intel", "sphere2500"])
+def test_concurrent_budget_sweep_matches_the_reference_on_every_budget(nm):
+    """MAC.solve_sweep against the REFERENCE's own budget sweep (tests/golden/g2o_sweep_<name>.npz, generated by running
+    examples/g2o_experiment.py:306-336's loop -- NaiveGreedy init, MAC.solve(max_iters = 20), nearest rounding -- through the
+    real reference for 10 .. 90 % of the loop closures): per budget the number of Frank-Wolfe iterations (the 60-90 %
+    budgets of intel stop early on the duality gap), the lambda_2 trajectory to 1e-6 like the other trajectory tests, the dual
+    bound, the relaxed x and the rounded selection."""
+    g = load_golden("g2o_" + nm); gs = load_golden("g2o_sweep_" + nm)
+    cand = edges_of(g, "c")
+    mac = MAC(edges_of(g, "f"), cand, int(g["n"]))
+    m = len(cand)
+    ks = [int(k) for k in gs["ks"]]
+    naive = NaiveGreedy(cand)
+    res = mac.solve_sweep(ks, [naive.subset(k) for k in ks], max_iters=20)
+    for j, k in enumerate(ks):
+        ref = gs["f_traj"][j]
+        nref = int(np.sum(~np.isnan(ref)))
+        ft = mac.sweep_trace[j]
+        assert int(np.sum(~np.isnan(ft))) == nref, (j, nref)
+        assert np.allclose(ft[:nref], ref[:nref], rtol=1e-6), j
+        rounded, w, u = res[j]
+        assert abs(u - gs["upper"][j]) <= 1e-5 * gs["upper"][j]
+        assert np.abs(w - gs["unrounded"][j]).max() <= 1e-6
+        ref_rounded = np.unpackbits(gs["rounded_bits"][j])[:m].astype(np.float64)
+        assert rounded.sum() == k == ref_rounded.sum()
+        assert np.array_equal(rounded, ref_rounded) or \
+            abs(mac.evaluate_objective(rounded) - mac.evaluate_objective(ref_rounded)) <= 1e-6 * mac.evaluate_objective(ref_rounded)
+
+
 def test_bench_refuses_more_ranks_than_gpus():
     """bench.py --gpus N without a launcher spawns N ranks itself and must refuse -- loudly, non-zero -- when fewer than
     N devices are visible (round 1: `--gpus 8` silently ran and reported a 1-GPU job)."""

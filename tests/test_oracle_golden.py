@@ -147,3 +147,23 @@ def test_city10000_reference_vertices():
         assert abs(f - gv["f_traj"][it]) <= 1e-9 * abs(f)
         assert np.array_equal(np.nonzero(s)[0], gv["ref_s"][it])
         x = x + oracle.naive_stepsize(it) * (s - x)
+
+
+def test_budget_sweep_goldens_early_stops():
+    """tests/golden/g2o_sweep_intel.npz (the reference's budget sweep, make_golden.py g2o_sweep): the oracle's Frank-Wolfe stops
+    where the reference's does -- the 70 / 80 / 90 % budgets end after 7 / 4 / 3 iterations on the duality-gap test
+    (frankwolfe.py:70-74) -- with the same lambda_2 trajectory and dual bound."""
+    g = load_golden("g2o_intel"); gs = load_golden("g2o_sweep_intel")
+    mo = oracle.MacOracle(g["fi"], g["fj"], g["fw"], g["ci"], g["cj"], g["cw"], int(g["n"]))
+    assert int(gs["m"]) == len(g["cw"]) and int(gs["ks"][1]) == int(g["k"])
+    assert np.allclose(gs["f_traj"][1], g["f_traj"], rtol=1e-7) and abs(gs["upper"][1] - g["upper"]) <= 1e-9 * g["upper"]
+    for j in (6, 7, 8):
+        k = int(gs["ks"][j])
+        trace = []
+        rounded, w, u = mo.solve(k, oracle.naive_greedy_subset(g["cw"], k), max_iters=20, trace=trace)
+        ref = gs["f_traj"][j]
+        nref = int(np.sum(~np.isnan(ref)))
+        assert len(trace) == nref and nref < 20
+        assert np.allclose([t[0] for t in trace], ref[:nref], rtol=1e-7)
+        assert abs(u - gs["upper"][j]) <= 1e-8 * gs["upper"][j]
+        assert np.allclose(w, gs["unrounded"][j], atol=1e-9)
