@@ -106,6 +106,77 @@ __device__ __forceinline__ void persist_sum3(double& a, double& b, double& c, do
     a = sa; b = sb; c = sc;
 }
 
+// Per-matrix packed form of what a launch of k_lan_persist keeps in registers and LDS, built ONCE per solve by
+// k_persist_pack.  (Rounds 1-2 walked the CSR inside every launch: dependent rowptr -> col -> val loads per row, a prefix
+// scan and a second walk -- 11.5 us at intel, 20 us at sphere2500 per launch (tools/ubench_persist.hip), 12-16 % of a
+// 64-step chunk.  A launch now issues one round of coalesced loads.)
+constexpr int kPersistPad = kPersistThreads * kPersistMaxRows;    // plane stride of the packed arrays
+struct PersistPack {
+    double* band;   // 5 planes x kPersistPad: diagonal, sub-, super-diagonal, first and second off-band value of every row
+    int* cc;        // 2 planes x kPersistPad: columns of those two off-band entries
+    int* crow;      // kPersistPad + 1: offsets of the rows' further off-band entries (crow[n] = their number)
+    int* ccol;      // ... their columns and values, row by row in CSR order
+    double* cval;
+};
+constexpr size_t kPersistPackEntries = (size_t)kPersistPool / 20 + 8;    // capacity of ccol / cval (persist_fits bounds nc)
+
+__global__ __launch_bounds__(1024) void k_persist_pack(CsrView A, PersistPack P) {
+    __shared__ int s_scan[1024];
+    const int t = threadIdx.x, n = A.n;
+    for (int r = t; r < kPersistPad; r += 1024) {
+        double dgd = 0.0, lod = 0.0, upd = 0.0, v0 = 0.0, v1 = 0.0;
+        int c0 = 0, c1 = 0, c = 0;
+        if (r < n) {
+            for (int p = A.rowptr[r]; p < A.rowptr[r + 1]; ++p) {
+                const int col = A.col[p];
+                const double x = A.val[p];
+                if (col == r) dgd += x;
+                else if (col == r - 1) lod += x;
+                else if (col == r + 1) upd += x;
+                else {
+                    if (c == 0) { c0 = col; v0 = x; }
+                    else if (c == 1) { c1 = col; v1 = x; }
+                    ++c;
+                }
+            }
+        }
+        P.band[r] = dgd; P.band[kPersistPad + r] = lod; P.band[2 * kPersistPad + r] = upd;
+        P.band[3 * kPersistPad + r] = v0; P.band[4 * kPersistPad + r] = v1;
+        P.cc[r] = c0; P.cc[kPersistPad + r] = c1;
+        P.crow[r + 1] = max(0, c - 2);
+    }
+    if (t == 0) P.crow[0] = 0;
+    __syncthreads();
+    // inclusive prefix sum of crow[1..n]: contiguous segment per thread, then a scan of the segment totals
+    {
+        const int seg = (n + 1023) / 1024;
+        const int b0 = 1 + t * seg, e0 = min(n + 1, b0 + seg);
+        int tot = 0;
+        for (int i = b0; i < e0; ++i) tot += P.crow[i];
+        s_scan[t] = tot;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int add = t >= o ? s_scan[t - o] : 0;
+            __syncthreads();
+            s_scan[t] += add;
+            __syncthreads();
+        }
+        int run = s_scan[t] - tot;
+        for (int i = b0; i < e0; ++i) { run += P.crow[i]; P.crow[i] = run; }
+        __syncthreads();
+    }
+    for (int r = t; r < n; r += 1024) {
+        int q = P.crow[r], c = 0;
+        for (int p = A.rowptr[r]; p < A.rowptr[r + 1]; ++p) {
+            const int col = A.col[p];
+            if (col < r - 1 || col > r + 1) {
+                if (c >= 2) { P.ccol[q] = col; P.cval[q] = A.val[p]; ++q; }
+                ++c;
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ void k_persist_begin(PersistViewT<T> L, int epoch) {
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < L.n; r += gridDim.x * blockDim.x) L.vprev[r] = 0.0;
@@ -129,84 +200,39 @@ __global__ void k_persist_begin(PersistViewT<T> L, int epoch) {
 // polynomial of L with d << sqrt(lambda_max / a) converges d times faster per step), so the reductions, the basis
 // columns and the host's tridiagonal shrink d-fold.
 template <int RPT, typename T = double, bool CHEB = false>
-__global__ __launch_bounds__(kPersistThreads) void k_lan_persist(CsrView A, PersistViewT<T> L, int steps, PersistCheb ch = PersistCheb()) {
+__global__ __launch_bounds__(kPersistThreads) void k_lan_persist(PersistPack P, PersistViewT<T> L, int steps, PersistCheb ch = PersistCheb()) {
     __shared__ __align__(16) unsigned char pool[kPersistPool];
     __shared__ double red1[3 * kPersistThreads / 64], red2[2 * kPersistThreads / 64];
     __shared__ double srec[3 * (kPersistMaxSteps + 1)];   // (alpha, beta, l1) of this chunk
-    __shared__ int s_scan[kPersistThreads];
-    const int t = threadIdx.x, n = A.n;
+    const int t = threadIdx.x, n = L.n;
     PCLK(true, 0);
 #ifdef PERSIST_CLOCKS
     if (t == 0) L.clk[10] = wall_clock64();
 #endif
     T* svec = reinterpret_cast<T*>(pool);
     int* crow = reinterpret_cast<int*>(pool + (size_t)n * 8);   // n + 1 offsets of the out-of-band entries (same layout for both T)
-    // ---- band and the first two off-band entries -> registers; count the overflow of every row ----
+    // ---- band and the first two off-band entries -> registers, the further ones -> LDS (all from the packed form) ----
     T dg[RPT], lo[RPT], up[RPT], c0v[RPT], c1v[RPT];
     int c0c[RPT], c1c[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int r = t + k * kPersistThreads;
-        double dgd = 0.0, lod = 0.0, upd = 0.0;
-        c0v[k] = 0; c1v[k] = 0; c0c[k] = 0; c1c[k] = 0;
-        if (r < n) {
-            int c = 0;
-            for (int p = A.rowptr[r]; p < A.rowptr[r + 1]; ++p) {
-                const int col = A.col[p];
-                const double x = A.val[p];
-                if (col == r) dgd += x;
-                else if (col == r - 1) lod += x;
-                else if (col == r + 1) upd += x;
-                else {
-                    if (c == 0) { c0c[k] = col; c0v[k] = (T)x; }
-                    else if (c == 1) { c1c[k] = col; c1v[k] = (T)x; }
-                    ++c;
-                }
-            }
-            crow[r + 1] = max(0, c - 2);
-        }
-        dg[k] = (T)dgd; lo[k] = (T)lod; up[k] = (T)upd;
+        dg[k] = (T)P.band[r]; lo[k] = (T)P.band[kPersistPad + r]; up[k] = (T)P.band[2 * kPersistPad + r];
+        c0v[k] = (T)P.band[3 * kPersistPad + r]; c1v[k] = (T)P.band[4 * kPersistPad + r];
+        c0c[k] = P.cc[r]; c1c[k] = P.cc[kPersistPad + r];
     }
-    if (t == 0) crow[0] = 0;
-    __syncthreads();
-    // inclusive prefix sum of crow[1..n]: contiguous segment per thread, then a scan of the segment totals
-    {
-        const int seg = (n + kPersistThreads - 1) / kPersistThreads;
-        const int b0 = 1 + t * seg, e0 = min(n + 1, b0 + seg);
-        int tot = 0;
-        for (int i = b0; i < e0; ++i) tot += crow[i];
-        s_scan[t] = tot;
-        __syncthreads();
-        for (int o = 1; o < kPersistThreads; o <<= 1) {
-            const int add = t >= o ? s_scan[t - o] : 0;
-            __syncthreads();
-            s_scan[t] += add;
-            __syncthreads();
-        }
-        int run = s_scan[t] - tot;
-        for (int i = b0; i < e0; ++i) { run += crow[i]; crow[i] = run; }
-        __syncthreads();
-    }
-    const int nc = crow[n];
+    const int nc = P.crow[n];
     int* ccol = crow + (n + 1);
     T* cval = reinterpret_cast<T*>(pool + (((size_t)n * 8 + ((size_t)n + 1 + (size_t)nc) * 4 + 7) & ~(size_t)7));
     T* cprod = reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(cval) + (size_t)nc * 8);   // products of the overflow entries (per step)
     T* svec2 = reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(cprod) + (size_t)nc * 8);  // CHEB: second operand buffer (persist_fits_cheb)
+    for (int i = t; i <= n; i += kPersistThreads) crow[i] = P.crow[i];
+    for (int e = t; e < nc; e += kPersistThreads) { ccol[e] = P.ccol[e]; cval[e] = (T)P.cval[e]; }
     bool any_over = false;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int r = t + k * kPersistThreads;
-        if (r < n) {
-            int q = crow[r], c = 0;
-            any_over = any_over || crow[r + 1] > q;
-            for (int p = A.rowptr[r]; p < A.rowptr[r + 1]; ++p) {
-                const int col = A.col[p];
-                if (col < r - 1 || col > r + 1) {
-                    if (c >= 2) { ccol[q] = col; cval[q] = (T)A.val[p]; ++q; }
-                    ++c;
-                }
-            }
-        }
+        if (r < n) any_over = any_over || P.crow[r + 1] > P.crow[r];
     }
     const int J0 = L.st->jA;
     T u[RPT], vp[RPT], v[RPT];

@@ -96,6 +96,7 @@ struct Solver {
     WbView wb_active{};          // s > 0 while the running solve uses it
     double *lx_part = nullptr, *lx_partR = nullptr;
     int *lx_colT = nullptr, *lx_bad = nullptr;
+    PersistPack ppack{};         // packed registers / LDS image of the single-workgroup kernel (persist.h), per matrix
     size_t lx_colT_cap = 0;
     LobState* lx_st = nullptr;
     double *h_lrec = nullptr, *d_hlrec = nullptr;
@@ -168,6 +169,8 @@ struct Solver {
         {
             void* pb[] = {panv.tptr, panv.thead, panv.bval, panv.bcol, panv.ypart, panv.coef, panv.tcount, panv.ps};
             for (void* q : pb) if (q) (void)hipFree(q);
+            void* pk[] = {ppack.band, ppack.cc, ppack.crow, ppack.ccol, ppack.cval};
+            for (void* q : pk) if (q) (void)hipFree(q);
         }
         if (h_lrec) (void)hipHostFree(h_lrec);
         if (wb_handle) (void)rocblas_destroy_handle(wb_handle);
@@ -226,22 +229,33 @@ struct Solver {
         L.n = n; L.st = st; L.u = u; L.vprev = wc; L.V = reinterpret_cast<T*>(V); L.tri = tri; L.htri = d_htri; L.hflag = d_hflag;
         return L;
     }
+    // Build the packed form of A for this solve (one single-workgroup launch; the chunks then start from coalesced loads).
+    int pack_persist(const CsrView& A) {
+        if (!ppack.band) {
+            ST_TRY(dev_alloc(&ppack.band, 5 * (size_t)kPersistPad)); ST_TRY(dev_alloc(&ppack.cc, 2 * (size_t)kPersistPad));
+            ST_TRY(dev_alloc(&ppack.crow, (size_t)kPersistPad + 1));
+            ST_TRY(dev_alloc(&ppack.ccol, kPersistPackEntries)); ST_TRY(dev_alloc(&ppack.cval, kPersistPackEntries));
+        }
+        k_persist_pack<<<1, 1024, 0, stream>>>(A, ppack);
+        HIP_TRY(hipGetLastError());
+        return MACHIP_OK;
+    }
     template <typename T>
     void launch_persist_t(const CsrView& A, int steps) {
         const PersistViewT<T> L = persist_view<T>();
         switch ((n + 2 * kPersistThreads - 1) / (2 * kPersistThreads)) {   // rows per thread, rounded up to 2
-            case 1: k_lan_persist<2, T><<<1, kPersistThreads, 0, stream>>>(A, L, steps); break;
-            case 2: k_lan_persist<4, T><<<1, kPersistThreads, 0, stream>>>(A, L, steps); break;
-            default: k_lan_persist<6, T><<<1, kPersistThreads, 0, stream>>>(A, L, steps); break;
+            case 1: k_lan_persist<2, T><<<1, kPersistThreads, 0, stream>>>(ppack, L, steps); break;
+            case 2: k_lan_persist<4, T><<<1, kPersistThreads, 0, stream>>>(ppack, L, steps); break;
+            default: k_lan_persist<6, T><<<1, kPersistThreads, 0, stream>>>(ppack, L, steps); break;
         }
     }
     void launch_persist(const CsrView& A, int steps, bool f32 = false, const PersistCheb& ch = PersistCheb()) {
         if (ch.deg >= 2) {       // Chebyshev-filtered recurrence (fp64)
             const PersistView L = persist_view<double>();
             switch ((n + 2 * kPersistThreads - 1) / (2 * kPersistThreads)) {
-                case 1: k_lan_persist<2, double, true><<<1, kPersistThreads, 0, stream>>>(A, L, steps, ch); break;
-                case 2: k_lan_persist<4, double, true><<<1, kPersistThreads, 0, stream>>>(A, L, steps, ch); break;
-                default: k_lan_persist<6, double, true><<<1, kPersistThreads, 0, stream>>>(A, L, steps, ch); break;
+                case 1: k_lan_persist<2, double, true><<<1, kPersistThreads, 0, stream>>>(ppack, L, steps, ch); break;
+                case 2: k_lan_persist<4, double, true><<<1, kPersistThreads, 0, stream>>>(ppack, L, steps, ch); break;
+                default: k_lan_persist<6, double, true><<<1, kPersistThreads, 0, stream>>>(ppack, L, steps, ch); break;
             }
             return;
         }
@@ -1005,6 +1019,7 @@ struct Solver {
             }
             k_to_f32<<<(int)std::min<long>(kMaxGrid, (nnz + kBlock - 1) / kBlock), kBlock, 0, stream>>>(A.val, valf, nnz);
         }
+        if (pmode) ST_TRY(pack_persist(A));
         while (!done && steps_total < max_steps) {
             // ---- (re)start a Krylov sequence from u ----
             seq_sharded = false;

@@ -27,6 +27,9 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&drp, (n + 1) * 4)); CK(hipMalloc(&dcol, nnz * 4)); CK(hipMalloc(&dval, nnz * 8));
     CK(hipMemcpy(drp, rp.data(), (n + 1) * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dcol, col.data(), nnz * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dval, val.data(), nnz * 8, hipMemcpyHostToDevice));
     CsrView A{n, drp, dcol, dval};
+    PersistPack P;
+    CK(hipMalloc(&P.band, 5 * kPersistPad * 8)); CK(hipMalloc(&P.cc, 2 * kPersistPad * 4)); CK(hipMalloc(&P.crow, (kPersistPad + 1) * 4));
+    CK(hipMalloc(&P.ccol, kPersistPackEntries * 4)); CK(hipMalloc(&P.cval, kPersistPackEntries * 8));
     PersistView L; L.n = n;
     const int cap = 4096;
     CK(hipMalloc(&L.st, sizeof(LanState))); CK(hipMalloc(&L.u, n * 8)); CK(hipMalloc(&L.vprev, n * 8)); CK(hipMalloc(&L.V, (size_t)n * cap * 8));
@@ -43,11 +46,12 @@ int main(int argc, char** argv) {
         for (int rep = 0; rep < 3; ++rep) {
             CK(hipMemcpyAsync(L.u, u0.data(), n * 8, hipMemcpyHostToDevice, s));
             k_persist_begin<<<8, 256, 0, s>>>(L, 1);
+            k_persist_pack<<<1, 1024, 0, s>>>(A, P);
             CK(hipEventRecord(e0, s));
             switch ((n + 2 * kPersistThreads - 1) / (2 * kPersistThreads)) {   // rows per thread, rounded up to 2
-                case 1: k_lan_persist<2><<<1, kPersistThreads, 0, s>>>(A, L, steps); break;
-                case 2: k_lan_persist<4><<<1, kPersistThreads, 0, s>>>(A, L, steps); break;
-                default: k_lan_persist<6><<<1, kPersistThreads, 0, s>>>(A, L, steps); break;
+                case 1: k_lan_persist<2><<<1, kPersistThreads, 0, s>>>(P, L, steps); break;
+                case 2: k_lan_persist<4><<<1, kPersistThreads, 0, s>>>(P, L, steps); break;
+                default: k_lan_persist<6><<<1, kPersistThreads, 0, s>>>(P, L, steps); break;
             }
             CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
