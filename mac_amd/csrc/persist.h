@@ -210,7 +210,6 @@ __global__ __launch_bounds__(kPersistThreads) void k_lan_persist(PersistPack P, 
     if (t == 0) L.clk[10] = wall_clock64();
 #endif
     T* svec = reinterpret_cast<T*>(pool);
-    int* crow = reinterpret_cast<int*>(pool + (size_t)n * 8);   // n + 1 offsets of the out-of-band entries (same layout for both T)
     // ---- band and the first two off-band entries -> registers, the further ones -> LDS (all from the packed form) ----
     T dg[RPT], lo[RPT], up[RPT], c0v[RPT], c1v[RPT];
     int c0c[RPT], c1c[RPT];
@@ -222,18 +221,21 @@ __global__ __launch_bounds__(kPersistThreads) void k_lan_persist(PersistPack P, 
         c0c[k] = P.cc[r]; c1c[k] = P.cc[kPersistPad + r];
     }
     const int nc = P.crow[n];
-    int* ccol = crow + (n + 1);
-    T* cval = reinterpret_cast<T*>(pool + (((size_t)n * 8 + ((size_t)n + 1 + (size_t)nc) * 4 + 7) & ~(size_t)7));
+    int* ccol = reinterpret_cast<int*>(pool + (size_t)n * 8);
+    T* cval = reinterpret_cast<T*>(pool + (((size_t)n * 8 + (size_t)nc * 4 + 7) & ~(size_t)7));
     T* cprod = reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(cval) + (size_t)nc * 8);   // products of the overflow entries (per step)
     T* svec2 = reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(cprod) + (size_t)nc * 8);  // CHEB: second operand buffer (persist_fits_cheb)
-    for (int i = t; i <= n; i += kPersistThreads) crow[i] = P.crow[i];
     for (int e = t; e < nc; e += kPersistThreads) { ccol[e] = P.ccol[e]; cval[e] = (T)P.cval[e]; }
-    bool any_over = false;
+    int ob[RPT], ol[RPT];      // the row's segment of that list: offset, length (registers: no LDS look-up per step)
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int r = t + k * kPersistThreads;
-        if (r < n) any_over = any_over || P.crow[r + 1] > P.crow[r];
+        ob[k] = P.crow[r];
+        ol[k] = r < n ? P.crow[r + 1] - ob[k] : 0;
     }
+    bool any_over = false;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) any_over = any_over || ol[k] > 0;
     const int J0 = L.st->jA;
     T u[RPT], vp[RPT], v[RPT];
 #pragma unroll
@@ -302,18 +304,14 @@ __global__ __launch_bounds__(kPersistThreads) void k_lan_persist(PersistPack P, 
                 // dependent LDS reads per entry (column -> operand, value), a hub row of 10 entries holding up its wave and,
                 // at the next barrier, the workgroup (tools/ubench_persist.hip, 600 closures on 1 728 nodes: 2 360 of a step's
                 // 5 400 cycles).  Now all threads form the products of the flat entry list (gathers in parallel, perfectly
-                // balanced), and after one more LDS barrier the row's thread only adds its segment, in the same order as before.
+                // balanced), and after one more LDS barrier the row's thread only adds its segment, in the same order as before
+                // (round 3: segment offset and length come from registers, not from a row-pointer array in LDS).
                 for (int e = t; e < nc; e += kPersistThreads) cprod[e] = cval[e] * sv[ccol[e]];
                 lds_barrier();
                 if (any_over) {
 #pragma unroll
-                    for (int k = 0; k < RPT; ++k) {
-                        const int r = t + k * kPersistThreads;
-                        if (r < n) {
-                            const int b = crow[r], e = crow[r + 1];
-                            for (int p = b; p < e; ++p) w[k] += cprod[p];
-                        }
-                    }
+                    for (int k = 0; k < RPT; ++k)
+                        for (int p = ob[k], e = ob[k] + ol[k]; p < e; ++p) w[k] += cprod[p];
                 }
             }
         };
