@@ -225,7 +225,18 @@ __global__ __launch_bounds__(kPersistThreads) void k_lan_persist(PersistPack P, 
     T* cval = reinterpret_cast<T*>(pool + (((size_t)n * 8 + (size_t)nc * 4 + 7) & ~(size_t)7));
     T* cprod = reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(cval) + (size_t)nc * 8);   // products of the overflow entries (per step)
     T* svec2 = reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(cprod) + (size_t)nc * 8);  // CHEB: second operand buffer (persist_fits_cheb)
-    for (int e = t; e < nc; e += kPersistThreads) { ccol[e] = P.ccol[e]; cval[e] = (T)P.cval[e]; }
+    // the flat list's entries e = t, t + 512 of this thread stay in registers (intel: at most 189 entries in all); longer
+    // lists are read from LDS in every step
+    constexpr int kFlat = 2;
+    const bool flat_regs = nc <= kFlat * kPersistThreads;
+    int fcol[kFlat]; T fval[kFlat];
+#pragma unroll
+    for (int q = 0; q < kFlat; ++q) {
+        const int e = t + q * kPersistThreads;
+        fcol[q] = e < nc ? P.ccol[e] : 0;
+        fval[q] = e < nc ? (T)P.cval[e] : (T)0;
+    }
+    if (!flat_regs) for (int e = t; e < nc; e += kPersistThreads) { ccol[e] = P.ccol[e]; cval[e] = (T)P.cval[e]; }
     int ob[RPT], ol[RPT];      // the row's segment of that list: offset, length (registers: no LDS look-up per step)
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
@@ -306,7 +317,12 @@ __global__ __launch_bounds__(kPersistThreads) void k_lan_persist(PersistPack P, 
                 // 5 400 cycles).  Now all threads form the products of the flat entry list (gathers in parallel, perfectly
                 // balanced), and after one more LDS barrier the row's thread only adds its segment, in the same order as before
                 // (round 3: segment offset and length come from registers, not from a row-pointer array in LDS).
-                for (int e = t; e < nc; e += kPersistThreads) cprod[e] = cval[e] * sv[ccol[e]];
+                if (flat_regs) {
+#pragma unroll
+                    for (int q = 0; q < kFlat; ++q) { const int e = t + q * kPersistThreads; if (e < nc) cprod[e] = fval[q] * sv[fcol[q]]; }
+                } else {
+                    for (int e = t; e < nc; e += kPersistThreads) cprod[e] = cval[e] * sv[ccol[e]];
+                }
                 lds_barrier();
                 if (any_over) {
 #pragma unroll
