@@ -68,42 +68,39 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// Sum two values over the workgroup; `red` = 2 x kPersistThreads/64 doubles, two of them used alternately.
+// The eight wave totals of a value, added as a balanced tree (three dependent additions instead of eight; round 3:
+// tools/ubench_persist.hip had 420 of a step's 3 200 cycles in the serial sums of the first reduction).
+static_assert(kPersistThreads / 64 == 8, "persist_tree8 adds exactly eight wave totals");
+__device__ __forceinline__ double persist_tree8(const double* r) {
+    return ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+}
+
+// Sum two values over the workgroup; `red` = 3 x kPersistThreads/64 doubles, two such buffers used alternately.
 __device__ __forceinline__ void persist_sum2(double& a, double& b, double* red) {
     { double v[2] = {a, b}; wave_total_n<2>(v); a = v[0]; b = v[1]; }
     const int w = threadIdx.x >> 6;
     constexpr int W = kPersistThreads / 64;
     if ((threadIdx.x & 63) == 0) { red[w] = a; red[W + w] = b; }
     lds_barrier();
-    double sa = 0.0, sb = 0.0;
-#pragma unroll
-    for (int k = 0; k < W; ++k) { sa += red[k]; sb += red[W + k]; }
-    a = sa; b = sb;
+    a = persist_tree8(red); b = persist_tree8(red + W);
 }
 
 // One value (the alpha reduction of a step).
 __device__ __forceinline__ void persist_sum1(double& a, double* red) {
     a = wave_total(a);
     const int w = threadIdx.x >> 6;
-    constexpr int W = kPersistThreads / 64;
     if ((threadIdx.x & 63) == 0) red[w] = a;
     lds_barrier();
-    double sa = 0.0;
-#pragma unroll
-    for (int k = 0; k < W; ++k) sa += red[k];
-    a = sa;
+    a = persist_tree8(red);
 }
-// Three values (chunk end).
+// Three values (chunk end; the first two exactly as persist_sum2 adds them).
 __device__ __forceinline__ void persist_sum3(double& a, double& b, double& c, double* red) {
     { double v[3] = {a, b, c}; wave_total_n<3>(v); a = v[0]; b = v[1]; c = v[2]; }
     const int w = threadIdx.x >> 6;
     constexpr int W = kPersistThreads / 64;
     if ((threadIdx.x & 63) == 0) { red[w] = a; red[W + w] = b; red[2 * W + w] = c; }
     lds_barrier();
-    double sa = 0.0, sb = 0.0, sc = 0.0;
-#pragma unroll
-    for (int k = 0; k < W; ++k) { sa += red[k]; sb += red[W + k]; sc += red[2 * W + k]; }
-    a = sa; b = sb; c = sc;
+    a = persist_tree8(red); b = persist_tree8(red + W); c = persist_tree8(red + 2 * W);
 }
 
 // Per-matrix packed form of what a launch of k_lan_persist keeps in registers and LDS, built ONCE per solve by
@@ -260,7 +257,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_lan_persist(PersistPack P, 
     PCLK(true, 1);
     for (int s = 0; s <= steps; ++s) {
         const int j = J0 + s;
-        PCLK(s == 1, 8);
+        PCLK(s == 9, 8);
         // ---- beta_j = ||u - mean||, v_j = (u - mean) / beta_j  (nx:209-213 project()) ----
         // (round 2, tools/ubench_persist.hip: a wave-wide fp64 DPP total costs ~400 shader cycles per VALUE on the step's
         // critical path, the barrier around it ~250: merging the two reductions of a step into one four-value reduction
@@ -277,7 +274,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_lan_persist(PersistPack P, 
         } else {
             persist_sum2(s1, s2, red1);
         }
-        PCLK(s == 0, 2);
+        PCLK(s == 8, 2);
         const double mu = s1 * rdn;
         const double nrm2 = s2 - dn * mu * mu;
         const double rs = nrm2 > 1e-290 ? rsqrt(nrm2) : 0.0;
@@ -295,9 +292,9 @@ __global__ __launch_bounds__(kPersistThreads) void k_lan_persist(PersistPack P, 
             v[k] = (T)(((double)u[k] - mu) * inv);
             if (r < n) { svec[r] = v[k]; vj[r] = v[k]; } else v[k] = 0;
         }
-        PCLK(s == 0, 3);
+        PCLK(s == 8, 3);
         lds_barrier();
-        PCLK(s == 0, 4);
+        PCLK(s == 8, 4);
         // ---- w = L v_j: band and two closures per row from registers (independent LDS gathers, no
         // loops), the rare rows with more closures add theirs from the LDS CSR; alpha_j = v_j . w ----
         // (x: the operand's own entries in registers, sv: the same vector in LDS, published before the last barrier)
@@ -355,9 +352,9 @@ __global__ __launch_bounds__(kPersistThreads) void k_lan_persist(PersistPack P, 
         }
 #pragma unroll
         for (int k = 0; k < RPT; ++k) al += (double)v[k] * (double)u[k];
-        PCLK(s == 0, 5);
+        PCLK(s == 8, 5);
         persist_sum1(al, red2);
-        PCLK(s == 0, 6);
+        PCLK(s == 8, 6);
         // ---- u_{j+1} = w - alpha_j v_j - beta_j v_{j-1} ----
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
@@ -365,7 +362,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_lan_persist(PersistPack P, 
             vp[k] = v[k];
         }
         if (t == 0) { srec[3 * s] = al; srec[3 * s + 1] = beta; srec[3 * s + 2] = 0.0; }
-        PCLK(s == 0, 7);
+        PCLK(s == 8, 7);
     }
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
