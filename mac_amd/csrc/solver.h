@@ -243,9 +243,11 @@ struct Solver {
     template <typename T>
     void launch_persist_t(const CsrView& A, int steps) {
         const PersistViewT<T> L = persist_view<T>();
-        switch ((n + 2 * kPersistThreads - 1) / (2 * kPersistThreads)) {   // rows per thread, rounded up to 2
-            case 1: k_lan_persist<2, T><<<1, kPersistThreads, 0, stream>>>(ppack, L, steps); break;
-            case 2: k_lan_persist<4, T><<<1, kPersistThreads, 0, stream>>>(ppack, L, steps); break;
+        switch ((n + kPersistThreads - 1) / kPersistThreads) {   // rows per thread (sphere2500: 5 -- every row slot costs LDS reads in every step)
+            case 1: case 2: k_lan_persist<2, T><<<1, kPersistThreads, 0, stream>>>(ppack, L, steps); break;
+            case 3: k_lan_persist<3, T><<<1, kPersistThreads, 0, stream>>>(ppack, L, steps); break;
+            case 4: k_lan_persist<4, T><<<1, kPersistThreads, 0, stream>>>(ppack, L, steps); break;
+            case 5: k_lan_persist<5, T><<<1, kPersistThreads, 0, stream>>>(ppack, L, steps); break;
             default: k_lan_persist<6, T><<<1, kPersistThreads, 0, stream>>>(ppack, L, steps); break;
         }
     }
