@@ -276,6 +276,34 @@ def test_solver_modes_agree_on_random_chain_graphs(seed):
     P.close()
 
 
+@pytest.mark.parametrize("hub_deg", [40, 600, 1500])
+def test_single_workgroup_kernel_with_hub_rows(hub_deg):
+    """The single-workgroup Lanczos kernel (persist.h) keeps a row's band and two closures in registers; further closures go
+    through a flat product list -- held in registers up to 1 024 entries, in LDS beyond.  A hub node with 40 / 600 / 1 500
+    closures (plus random ones) exercises both forms and long row segments, against a dense eigen-solve."""
+    rng = np.random.default_rng(hub_deg)
+    n = 2000
+    fi = np.arange(n - 1, dtype=np.int32)
+    fw = rng.uniform(50.0, 300.0, n - 1)
+    hub = 700
+    others = rng.choice(np.setdiff1d(np.arange(n), [hub - 1, hub, hub + 1]), hub_deg, replace=False)
+    a = np.r_[np.full(hub_deg, hub), rng.integers(0, n, 200)]; b = np.r_[others, rng.integers(0, n, 200)]
+    keep = np.abs(a - b) > 1
+    ci = np.minimum(a, b)[keep].astype(np.int32); cj = np.maximum(a, b)[keep].astype(np.int32)
+    cw = rng.uniform(1.0, 50.0, len(ci))
+    x = np.ones(len(ci))
+    P = _lib.Problem(n, fi, fi + 1, fw, ci, cj, cw)
+    P.set_x(x)
+    P.set_solver(1)
+    lam, v, _ = P.fiedler()
+    L = oracle.mac_laplacian(oracle.laplacian_from_edges(fi, fi + 1, fw, n), ci.astype(np.int64), cj.astype(np.int64), cw, x, n)
+    w = np.linalg.eigvalsh(L.toarray())
+    assert abs(lam - w[1]) <= LAM_RTOL * w[1] and P.stats.residual < 1e-8
+    lam2, v2, _ = P.fiedler()
+    assert lam2 == lam and np.array_equal(v, v2)          # run-to-run identical
+    P.close()
+
+
 def test_auto_mode_picks_preconditioned_solver_on_sparse_chain_graphs():
     """Automatic selection: a chain with few closures runs the preconditioned mode (an order of
     magnitude fewer dependent launches), a dense-closure graph the Lanczos mode; same lambda_2."""
