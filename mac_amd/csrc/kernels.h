@@ -69,7 +69,7 @@ template <int G>
 __global__ __launch_bounds__(kBlock) void k_asm_count(PatternView P, const double* __restrict__ x,
                                                       double tol, int rows_per_block,
                                                       int* __restrict__ cnt, int* __restrict__ blk_sum,
-                                                      double* __restrict__ sval) {
+                                                      double* __restrict__ sval, int* __restrict__ hsum = nullptr) {
     __shared__ int sm[4];
     constexpr int GPB = kBlock / G;
     const int lane = threadIdx.x % G, g = threadIdx.x / G;
@@ -109,7 +109,11 @@ __global__ __launch_bounds__(kBlock) void k_asm_count(PatternView P, const doubl
     if (threadIdx.x == 0) {
         blk_sum[blockIdx.x] = tot;
         blk_sum[kMaxGrid + blockIdx.x] = stot;                                   // active candidates
-        blk_sum[2 * kMaxGrid + blockIdx.x] = max(max(sm[0], sm[1]), max(sm[2], sm[3]));   // longest row
+        const int longest = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
+        blk_sum[2 * kMaxGrid + blockIdx.x] = longest;                            // longest row
+        if (hsum) {     // the host's copy, written straight into mapped pinned memory (no copy kernel behind the launch)
+            hsum[blockIdx.x] = tot; hsum[kMaxGrid + blockIdx.x] = stot; hsum[2 * kMaxGrid + blockIdx.x] = longest;
+        }
     }
 }
 
@@ -939,7 +943,8 @@ __global__ __launch_bounds__(kBlock) void k_ritz_own_rows(const double* __restri
 // unit vector v): the reference's convergence test numerator (nx:246).
 __global__ __launch_bounds__(kBlock) void k_resid_l1(const double* __restrict__ w, const double* __restrict__ v,
                                                      int n, const double* __restrict__ part_a, int P_a,
-                                                     double* __restrict__ part_out, double* __restrict__ rq_out) {
+                                                     double* __restrict__ part_out, double* __restrict__ rq_out,
+                                                     double* __restrict__ rq_host = nullptr) {
     __shared__ double sm[4];
     const double rq = reduce_partials(part_a, P_a, sm);
     double s = 0.0;
@@ -948,7 +953,7 @@ __global__ __launch_bounds__(kBlock) void k_resid_l1(const double* __restrict__ 
     s = block_sum(s, sm);
     if (threadIdx.x == 0) {
         part_out[blockIdx.x] = s;
-        if (blockIdx.x == 0) *rq_out = rq;
+        if (blockIdx.x == 0) { *rq_out = rq; if (rq_host) *rq_host = rq; }
     }
 }
 
@@ -1226,7 +1231,8 @@ __global__ __launch_bounds__(kBlock) void k_mb_triad(double2* __restrict__ a, co
     }
 }
 
-__global__ void k_sel_init(SelState* st, long long k) {
+__global__ void k_sel_init(SelState* st, long long k, unsigned int* __restrict__ hist = nullptr, int nhist = 0) {
+    for (int i = threadIdx.x; i < nhist; i += blockDim.x) hist[i] = 0u;      // (was a separate fill kernel per select)
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         st->prefix = 0; st->kk = k; st->cnt_eq = 0; st->T = 0; st->tie_limit = -1; st->k = k;
         for (int i = 0; i < 8; ++i) st->ticket[i] = 0;

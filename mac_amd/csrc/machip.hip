@@ -93,8 +93,10 @@ struct machip_problem {
     SelState* sel = nullptr;
     double* part_fw = nullptr;
     // pinned host
-    int* h_int = nullptr;
+    int* h_int = nullptr;        // mapped pinned memory; d_hint / d_hdbl = the device's view of it
     double* h_dbl = nullptr;
+    int* d_hint = nullptr;
+    double* d_hdbl = nullptr;
     Solver sol;
     // multi-GPU
     ncclComm_t comm = nullptr;
@@ -204,10 +206,10 @@ int build_pattern(machip_problem* p, int64_t nf, const int32_t* fi, const int32_
 template <int G>
 void launch_asm(machip_problem* p) {
     const PatternView P = p->pattern();
-    k_asm_count<G><<<p->asm_grid, kBlock, 0, p->stream>>>(P, p->x, p->tol_sel, p->asm_rpb, p->cnt, p->blk_sum, p->sval);
+    k_asm_count<G><<<p->asm_grid, kBlock, 0, p->stream>>>(P, p->x, p->tol_sel, p->asm_rpb, p->cnt, p->blk_sum, p->sval, p->d_hint);
     const size_t lds = sizeof(int) * ((size_t)p->asm_rpb + 1);
     k_asm_fill<G><<<p->asm_grid, kBlock, lds, p->stream>>>(P, p->sval, p->asm_rpb, p->cnt, p->blk_sum,
-                                                           p->rowptr, p->col, p->val, p->blk_lnorm);
+                                                           p->rowptr, p->col, p->val, p->d_hdbl);   // (row-sum maxima: host only)
 }
 
 int assemble(machip_problem* p) {
@@ -221,9 +223,7 @@ int assemble(machip_problem* p) {
     }
     HIP_TRY(hipGetLastError());       // a refused launch must not leave stale row offsets behind a MACHIP_OK
     const int gb = p->asm_grid;
-    HIP_TRY(hipMemcpyAsync(p->h_int, p->blk_sum, sizeof(int) * 3 * kMaxGrid, hipMemcpyDeviceToHost, p->stream));
-    HIP_TRY(hipMemcpyAsync(p->h_dbl, p->blk_lnorm, sizeof(double) * (size_t)gb, hipMemcpyDeviceToHost, p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));      // (both kernels wrote the host's copies into mapped pinned memory)
     long nnz = 0, supp = 0;
     int maxlen = 0;
     double ln = 0.0;
@@ -238,8 +238,10 @@ int assemble(machip_problem* p) {
 
 int alloc_common(machip_problem* p, int vbudget_mb = 0) {
     ST_TRY(p->sol.init(p->n, p->stream, vbudget_mb));
-    HIP_TRY(hipHostMalloc((void**)&p->h_int, sizeof(int) * 3 * kMaxGrid, hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc((void**)&p->h_dbl, sizeof(double) * 4 * kMaxGrid, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&p->h_int, sizeof(int) * 3 * kMaxGrid, hipHostMallocMapped));
+    HIP_TRY(hipHostMalloc((void**)&p->h_dbl, sizeof(double) * 4 * kMaxGrid, hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer((void**)&p->d_hint, p->h_int, 0));
+    HIP_TRY(hipHostGetDevicePointer((void**)&p->d_hdbl, p->h_dbl, 0));
     return MACHIP_OK;
 }
 
@@ -248,8 +250,7 @@ int select_on(machip_problem* p, const double* keys, long k, SelState* st, int p
     const long m = p->m;
     if (k < 0) k = 0;
     if (k > m) k = m;
-    HIP_TRY(hipMemsetAsync(p->hist, 0, sizeof(unsigned int) * 6 * kBins, p->stream));
-    k_sel_init<<<1, 64, 0, p->stream>>>(st, (long long)k);
+    k_sel_init<<<1, 1024, 0, p->stream>>>(st, (long long)k, p->hist, 6 * kBins);
     if (k > 0) {
         // <= 256 workgroups: every arrival is one serialized device-scope atomic on the ticket word
         const int grid = (int)std::min<long>(256, (m + kBlock * 4 - 1) / (kBlock * 4));
@@ -568,9 +569,8 @@ int machip_fw_step(machip_problem* p, int64_t k, int iter, double tol, int max_s
     ST_TRY(select_topk(p, (long)k));
     const int grid = std::max(1, (int)std::min<long>(kMaxGrid, (p->m + kBlock - 1) / kBlock));
     const double gamma = 2.0 / ((double)iter + 2.0);   // frankwolfe.py:7-8
-    k_fw_final<<<grid, kBlock, 0, p->stream>>>(p->g, p->x, p->m, p->sel, gamma, p->x_next, nullptr, p->part_fw);
+    k_fw_final<<<grid, kBlock, 0, p->stream>>>(p->g, p->x, p->m, p->sel, gamma, p->x_next, nullptr, p->d_hdbl);   // partials: host only
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(p->h_dbl, p->part_fw, sizeof(double) * 2 * kMaxGrid, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
     double d = 0.0, q2 = 0.0;
     for (int b = 0; b < grid; ++b) { d += p->h_dbl[b]; q2 += p->h_dbl[kMaxGrid + b]; }

@@ -63,6 +63,7 @@ struct Solver {
     // pinned host staging
     double* h_tri = nullptr;    // mirror of tri (pinned, device-mapped: the tail kernel writes it)
     double* d_htri = nullptr;   // device view of h_tri
+    double* d_hpin = nullptr;   // device view of h_pin (kernels write the host's small results there themselves)
     unsigned long long* h_flag = nullptr;   // pinned completion flag polled by the host
     unsigned long long* d_hflag = nullptr;
     unsigned int epoch = 0;
@@ -153,7 +154,8 @@ struct Solver {
         HIP_TRY(hipHostMalloc((void**)&h_flag, 64, hipHostMallocMapped));
         HIP_TRY(hipHostGetDevicePointer((void**)&d_hflag, h_flag, 0));
         *h_flag = 0;
-        HIP_TRY(hipHostMalloc((void**)&h_pin, (4 * (vcap + 2) + 2 * kMaxGrid + 64) * sizeof(double), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&h_pin, (4 * (vcap + 2) + 2 * kMaxGrid + 64) * sizeof(double), hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void**)&d_hpin, h_pin, 0));
         HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
         HIP_TRY(hipEventCreate(&evs0)); HIP_TRY(hipEventCreate(&evs1));
         return MACHIP_OK;
@@ -454,10 +456,11 @@ struct Solver {
         OpLanczos op;
         op.L = check_view(pl);
         launch_spmv(pl, stream, A, y_raw, op);
-        k_resid_l1<<<g2, kBlock, 0, stream>>>(w2, yvec, n, part_a2, pl.grid, part_r, rq_dev);
+        // (the partials and the Rayleigh quotient go straight into mapped pinned memory: two copy kernels less per check)
         double* hp = h_pin + (vcap + 2);
-        HIP_TRY(hipMemcpyAsync(hp, part_r, sizeof(double) * (size_t)g2, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(hp + kMaxGrid, rq_dev, sizeof(double), hipMemcpyDeviceToHost, stream));
+        double* dhp = d_hpin + (vcap + 2);
+        k_resid_l1<<<g2, kBlock, 0, stream>>>(w2, yvec, n, part_a2, pl.grid, dhp, rq_dev, dhp + kMaxGrid);
+        HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream));
         double s = 0.0;
         for (int i = 0; i < g2; ++i) s += hp[i];
