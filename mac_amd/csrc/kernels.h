@@ -1128,6 +1128,93 @@ __global__ __launch_bounds__(1024) void k_sel_ties(const double* __restrict__ g,
     if (tid == 0) st->tie_limit = prefer_high ? -1 : 0x7fffffffffffffffll;
 }
 
+// The whole select (state reset, digit passes, tie rule) in ONE single-workgroup launch for short key vectors (pose graphs:
+// 785 ... 10 688 candidates), where k_sel_init + six k_sel_pass + k_sel_ties are eight launches of 1-8 us with nothing to do.
+// Same digit walk, same early exit, same tie rule: the SelState it leaves is identical to the multi-launch form's.
+constexpr long kSelSmallMax = 32768;
+__global__ __launch_bounds__(1024) void k_sel_small(const double* __restrict__ g, long m, long long k, SelState* st, int prefer_high) {
+    __shared__ unsigned int lh[kBins];
+    __shared__ unsigned int s_w[16];
+    __shared__ unsigned long long s_prefix, s_T;
+    __shared__ long long s_kk, s_eq, s_found;
+    __shared__ int s_done, s_cnt[16];
+    const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+    if (tid == 0) { s_prefix = 0; s_T = 0; s_kk = k; s_eq = 0; s_done = 0; s_found = -1; }
+    __syncthreads();
+    for (int pass = 0; pass < 6 && k > 0; ++pass) {
+        if (s_done) break;                                   // (workgroup-uniform: read behind a barrier)
+        for (int i = tid; i < kBins; i += 1024) lh[i] = 0;
+        __syncthreads();
+        const int sh = sel_shift(pass), nb = sel_bits(pass);
+        const unsigned long long prefix = s_prefix;
+        const unsigned int mask = (1u << nb) - 1u;
+        unsigned int cur = 0xffffffffu, run = 0;
+        for (long i = tid; i < m; i += 1024) {
+            const unsigned long long key = f64_key(g[i]);
+            if (pass == 0 || (key >> (sh + nb)) == prefix) {
+                const unsigned int bin = (unsigned int)(key >> sh) & mask;
+                if (bin == cur) ++run;
+                else { if (run) atomicAdd(&lh[cur], run); cur = bin; run = 1; }
+            }
+        }
+        if (run) atomicAdd(&lh[cur], run);
+        __syncthreads();
+        // walk the bins from the top until the cumulative count reaches kk: two bins per thread, thread 0 owns the top ones
+        const long long kk = s_kk;
+        const int nbins = 1 << nb;
+        unsigned int c[2], tsum = 0;
+        for (int q = 0; q < 2; ++q) { const int bin = nbins - 1 - (tid * 2 + q); c[q] = bin >= 0 ? lh[bin] : 0u; tsum += c[q]; }
+        unsigned int x = tsum;                               // inclusive scan over the 1 024 per-thread sums
+        for (int o = 1; o < 64; o <<= 1) { const unsigned int y = __shfl_up(x, o, kWave); if (ln >= o) x += y; }
+        if (ln == 63) s_w[wv] = x;
+        __syncthreads();
+        for (int q = 0; q < wv; ++q) x += s_w[q];
+        const long long pre = (long long)x;
+        if (pre >= kk && pre - (long long)tsum < kk) {       // exactly one thread owns the kk-th key
+            long long rem = kk - (pre - (long long)tsum);
+            int q = 0;
+            for (; q < 2; ++q) { if ((long long)c[q] >= rem) break; rem -= c[q]; }
+            const int bin = nbins - 1 - (tid * 2 + q);
+            s_kk = rem;
+            s_prefix = (prefix << nb) | (unsigned long long)bin;
+            if (pass == 5) { s_T = (prefix << nb) | (unsigned long long)bin; s_eq = (long long)c[q]; }
+            else if ((long long)c[q] == rem) { s_T = ((prefix << nb) | (unsigned long long)bin) << sh; s_eq = rem; s_done = 1; }
+        }
+        __syncthreads();
+    }
+    const long long need = s_kk, eq = s_eq;
+    const unsigned long long T = s_T;
+    if (tid == 0) {
+        st->prefix = s_prefix; st->kk = need; st->cnt_eq = eq; st->T = T; st->k = k;
+        for (int i = 0; i < 7; ++i) st->ticket[i] = 0;
+        st->ticket[7] = (unsigned int)s_done;
+    }
+    // ---- tie rule (k_sel_ties) ----
+    if (k <= 0) { if (tid == 0) st->tie_limit = prefer_high ? 0x7fffffffffffffffll : -1; return; }
+    if (need >= eq) { if (tid == 0) st->tie_limit = prefer_high ? -1 : 0x7fffffffffffffffll; return; }
+    long long runs = 0;
+    for (long base = 0; base < m; base += 1024) {
+        const long ii = base + tid;
+        const long i = prefer_high ? m - 1 - ii : ii;
+        const bool is = ii < m && f64_key(g[i]) == T;
+        const unsigned long long bal = __ballot(is);
+        __syncthreads();
+        if (ln == 0) s_cnt[wv] = __popcll(bal);
+        __syncthreads();
+        int before = 0, tot = 0;
+        for (int q = 0; q < 16; ++q) { if (q < wv) before += s_cnt[q]; tot += s_cnt[q]; }
+        if (runs + tot >= need) {
+            const int rank = before + __popcll(bal & ((1ull << ln) - 1ull));
+            if (is && runs + rank + 1 == need) s_found = i;
+            __syncthreads();
+            if (tid == 0) st->tie_limit = s_found;
+            return;
+        }
+        runs += tot;
+    }
+    if (tid == 0) st->tie_limit = prefer_high ? -1 : 0x7fffffffffffffffll;
+}
+
 // Final fused Frank-Wolfe pass (mac/optimization/frankwolfe.py:59-76): s from the threshold,
 // partials of g.(s - x) and g.g, x_next = x + gamma (s - x) (same rounding as NumPy: no fma).
 __global__ __launch_bounds__(kBlock) void k_fw_final(const double* __restrict__ g, const double* __restrict__ x,

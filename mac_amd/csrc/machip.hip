@@ -250,6 +250,11 @@ int select_on(machip_problem* p, const double* keys, long k, SelState* st, int p
     const long m = p->m;
     if (k < 0) k = 0;
     if (k > m) k = m;
+    if (m <= kSelSmallMax && env_int("MACHIP_SEL_SMALL", 1)) {      // short key vectors: the whole select in one launch
+        k_sel_small<<<1, 1024, 0, p->stream>>>(keys, m, (long long)k, st, prefer_high);
+        HIP_TRY(hipGetLastError());
+        return MACHIP_OK;
+    }
     k_sel_init<<<1, 1024, 0, p->stream>>>(st, (long long)k, p->hist, 6 * kBins);
     if (k > 0) {
         // <= 256 workgroups: every arrival is one serialized device-scope atomic on the ticket word

@@ -69,6 +69,7 @@ struct Solver {
     unsigned int epoch = 0;
     double* h_pin = nullptr;    // misc
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evs0 = nullptr, evs1 = nullptr;   // evs*: bracket the Krylov chunks only
+    bool ev1_at_check = false;  // ev1 was recorded behind the last explicit check's kernels (and that check has been waited for)
     std::vector<hipEvent_t> ev_pool;
     // cached chunk graphs: (variant, width, grid, steps) -> exec
     std::map<std::tuple<int, int, int, int, int>, std::array<hipGraphExec_t, 2>> graphs;
@@ -461,7 +462,9 @@ struct Solver {
         double* dhp = d_hpin + (vcap + 2);
         k_resid_l1<<<g2, kBlock, 0, stream>>>(w2, yvec, n, part_a2, pl.grid, dhp, rq_dev, dhp + kMaxGrid);
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ev1, stream));     // end of the solve's device time if this check passes (no second wait then)
         HIP_TRY(hipStreamSynchronize(stream));
+        ev1_at_check = true;
         double s = 0.0;
         for (int i = 0; i < g2; ++i) s += hp[i];
         *res_l1 = s;
@@ -935,6 +938,7 @@ struct Solver {
         SpmvPlan pp = plan_pipe(n, nnz, maxlen_hint);            // fused Lanczos-step kernel
         const int g2 = vgrid();
         HIP_TRY(hipEventRecord(ev0, stream));
+        ev1_at_check = false;
         if (max_steps <= 0) max_steps = 200000;
         long steps_total = 0, spmv_total = 0, restarts = 0;
         double step_ms_acc = 0.0;   // stream time of the Krylov chunks alone (step kernels + one tail kernel per chunk)
@@ -1263,8 +1267,10 @@ struct Solver {
         have_prev = true;
         last_steps = steps_total;
         last_steps_lowp = steps_lowp;
-        HIP_TRY(hipEventRecord(ev1, stream));
-        HIP_TRY(hipEventSynchronize(ev1));
+        if (!(ev1_at_check && status == MACHIP_OK)) {     // (a converged Lanczos solve ends with its explicit check: ev1 is there)
+            HIP_TRY(hipEventRecord(ev1, stream));
+            HIP_TRY(hipEventSynchronize(ev1));
+        }
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
         *lambda2 = lam;
