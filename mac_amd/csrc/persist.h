@@ -175,8 +175,9 @@ __global__ __launch_bounds__(1024) void k_persist_pack(CsrView A, PersistPack P)
 }
 
 template <typename T>
-__global__ void k_persist_begin(PersistViewT<T> L, int epoch) {
-    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < L.n; r += gridDim.x * blockDim.x) L.vprev[r] = 0.0;
+__global__ void k_persist_begin(PersistViewT<T> L, int epoch, const double* __restrict__ src = nullptr) {
+    // (src: the start vector of the sequence, copied into the state u here instead of by a copy kernel of its own)
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < L.n; r += gridDim.x * blockDim.x) { L.vprev[r] = 0.0; if (src) L.u[r] = src[r]; }
     if (blockIdx.x == 0 && threadIdx.x == 0) { L.st->jA = 0; L.st->epoch = epoch; }
 }
 

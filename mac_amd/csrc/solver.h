@@ -949,10 +949,15 @@ struct Solver {
         if (n < 2) { *lambda2 = 0.0; return fail(MACHIP_BAD_ARG, "graph with a single node has no Fiedler pair"); }
 
         // ---- start vector ----
+        // (single-workgroup form: k_persist_begin of the first sequence copies it -- one launch less per solve)
+        const bool pmode_early = env_int("MACHIP_PERSIST", 1) != 0 && chain_like && persist_fits(n, nnz - n - 2 * chain_edges);
+        const double* begin_src = nullptr;
         if (start_mode == 1 && have_prev) {
-            HIP_TRY(hipMemcpyAsync(u, yvec, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream));
+            if (pmode_early) begin_src = yvec;
+            else HIP_TRY(hipMemcpyAsync(u, yvec, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream));
         } else if (have_start) {
-            HIP_TRY(hipMemcpyAsync(u, start, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream));
+            if (pmode_early) begin_src = start;
+            else HIP_TRY(hipMemcpyAsync(u, start, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream));
         } else {
             k_fill_start<<<g2, kBlock, 0, stream>>>(u, n, 0x1234567ull);
         }
@@ -966,7 +971,7 @@ struct Solver {
 
         bool classic = n <= env_int("MACHIP_CLASSIC_N", 256);
         // LDS-resident single-workgroup form when the matrix fits (classic recurrence: also fine after restarts)
-        const bool pmode = env_int("MACHIP_PERSIST", 1) != 0 && chain_like && persist_fits(n, nnz - n - 2 * chain_edges);
+        const bool pmode = pmode_early;
         // column-panel step (panel.h) where the gather operand is too large for the caches (fp64 sequences only)
         pan = plan_panel(n, nnz, maxlen_hint, pan_allowed && precision == 0 && !pmode && !classic && pp.variant == kVec && !shard);   // (the row-partitioned solve shards the gather step)
         if (pan.on) {
@@ -1034,7 +1039,8 @@ struct Solver {
             seq_sharded = false;
             if (pmode) {
                 ++epoch;
-                k_persist_begin<<<g2, kBlock, 0, stream>>>(persist_view(), (int)epoch);
+                k_persist_begin<<<g2, kBlock, 0, stream>>>(persist_view(), (int)epoch, begin_src);
+                begin_src = nullptr;            // (restarts continue from u)
             } else if (classic) {
                 k_vec_sums<<<g2, kBlock, 0, stream>>>(u, n, part_u);
                 k_set_state<<<1, 64, 0, stream>>>(stc, 0);
