@@ -112,13 +112,27 @@ __device__ __forceinline__ int pan_row_count(const PanView& P, int n, int r, int
     return min(P.ps[(size_t)(p + 1) * n + r] - st + (r / P.C == p ? 1 : 0), kPanMaxLen);
 }
 
+// Build kernels: workgroup id -> (row block b, panel p) such that the NP workgroups of one row block have the same id % 8,
+// i.e. run on ONE XCD (workgroups are dealt round-robin to the 8 XCDs): they read the same CSR rows -- a row's run inside a
+// panel is ~2.5 entries, so every 128-byte line is wanted by several panels -- and with b = id / NP each line was fetched into
+// eight different L2s (k_pan_fill: 338 MB fetched per launch for a 36 MB matrix).  Launch with pan_build_grid() workgroups.
+__host__ __device__ inline int pan_build_grid(int NB, int NP) { return ((NB + 7) / 8) * 8 * NP; }
+__device__ __forceinline__ bool pan_build_bp(int id, int NB, int NP, int* b, int* p) {
+    const int rest = id >> 3;
+    *p = rest % NP;
+    *b = (rest / NP) * 8 + (id & 7);
+    return *b < NB;
+}
+
 // Pass 1, one workgroup per (row block, panel): sort the block's rows by length (counting sort; ties in arrival order
 // -- a row's sum does not depend on the slot it lands in, PROVIDED the multiply-accumulate of k_pan_mul rounds the same
 // way at every chunk position: see the contraction note there -- so the tie order never shows in a result) and record
 // slot -> row and the tile sizes.
 __global__ __launch_bounds__(kPanThreads) void k_pan_count(CsrView A, PanView P) {
     __shared__ int hist[kPanMaxLen + 1], start[kPanMaxLen + 1], fill[kPanMaxLen + 1];
-    const int b = blockIdx.x / P.NP, p = blockIdx.x - b * P.NP, tid = threadIdx.x;
+    int b, p;
+    if (!pan_build_bp((int)blockIdx.x, P.NB, P.NP, &b, &p)) return;
+    const int tid = threadIdx.x;
     const int R = 64 * P.NTB, NTP = kPanWork * P.TWW;
     if (tid <= kPanMaxLen) { hist[tid] = 0; fill[tid] = 0; }
     __syncthreads();
@@ -176,7 +190,9 @@ __global__ __launch_bounds__(1024) void k_pan_scan(PanView P) {
 // Pass 3, one workgroup per (row block, panel): every slot copies its row's entries of the panel, zero-padded to the
 // tile's height (writes coalesced along the lanes).
 __global__ __launch_bounds__(kPanThreads) void k_pan_fill(CsrView A, PanView P) {
-    const int b = blockIdx.x / P.NP, p = blockIdx.x - b * P.NP, tid = threadIdx.x;
+    int b, p;
+    if (!pan_build_bp((int)blockIdx.x, P.NB, P.NP, &b, &p)) return;
+    const int tid = threadIdx.x;
     const int R = 64 * P.NTB, NTP = kPanWork * P.TWW;
     const int c0 = p * P.C;
     const size_t vtb = (size_t)(b * P.NP + p) * NTP;

@@ -296,9 +296,9 @@ struct Solver {
         if (!panv.coef) ST_TRY(dev_alloc(&panv.coef, 8));
         panv.n = n; panv.NP = pn.NP; panv.C = pn.C; panv.NB = pn.NB; panv.NTB = pn.NTB; panv.TWW = pn.TWW;
         k_pan_rows<<<(n + kBlock - 1) / kBlock, kBlock, 0, stream>>>(A, panv);
-        k_pan_count<<<pn.NB * pn.NP, kPanThreads, 0, stream>>>(A, panv);
+        k_pan_count<<<pan_build_grid(pn.NB, pn.NP), kPanThreads, 0, stream>>>(A, panv);
         k_pan_scan<<<1, 1024, 0, stream>>>(panv);
-        k_pan_fill<<<pn.NB * pn.NP, kPanThreads, 0, stream>>>(A, panv);
+        k_pan_fill<<<pan_build_grid(pn.NB, pn.NP), kPanThreads, 0, stream>>>(A, panv);
         HIP_TRY(hipGetLastError());
         return MACHIP_OK;
     }

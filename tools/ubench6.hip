@@ -92,7 +92,7 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&P.coef, 64)); CK(hipMalloc(&P.clk, 16 * 8 * kMaxGrid)); CK(hipMemset(P.clk, 0, 16 * 8 * kMaxGrid));
         hipEvent_t a0, a1; CK(hipEventCreate(&a0)); CK(hipEventCreate(&a1));
         CK(hipEventRecord(a0, s));
-        k_pan_rows<<<(n + kBlock - 1) / kBlock, kBlock, 0, s>>>(A, P); k_pan_count<<<P.NB * P.NP, kPanThreads, 0, s>>>(A, P); k_pan_scan<<<1, 1024, 0, s>>>(P); k_pan_fill<<<P.NB * P.NP, kPanThreads, 0, s>>>(A, P);
+        k_pan_rows<<<(n + kBlock - 1) / kBlock, kBlock, 0, s>>>(A, P); k_pan_count<<<pan_build_grid(P.NB, P.NP), kPanThreads, 0, s>>>(A, P); k_pan_scan<<<1, 1024, 0, s>>>(P); k_pan_fill<<<pan_build_grid(P.NB, P.NP), kPanThreads, 0, s>>>(A, P);
         CK(hipEventRecord(a1, s)); CK(hipEventSynchronize(a1));
         float bms; CK(hipEventElapsedTime(&bms, a0, a1));
         std::vector<double> u0((size_t)n); for (int i = 0; i < n; ++i) u0[i] = (double)((i * 2654435761u) % 1000) / 500.0 - 1.0;
