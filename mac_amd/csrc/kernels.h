@@ -639,14 +639,17 @@ struct PipeRow {   // per-thread accumulation of the next step's partial sums
 
 // ---- sub-wave vector form: G lanes per row, BLOCK threads per workgroup -------------------------
 // Raw sums (L t)[r], (L v)[r] of one row by its G-lane group, and the row's own record (lane 0).
-template <int G, int UNR, typename T>
+// ELLW > 0: the matrix is in padded fixed-width form (k_ell_build: ELLW slots per row, CSR order, padded with zero
+// values on the row's own column), so a row's entries sit at r * ELLW -- no row-pointer load in front of the value / column
+// loads, one dependent memory round trip less per step.  Zero products change nothing: the sums are those of the CSR walk.
+template <int G, int UNR, typename T, int ELLW = 0>
 __device__ __forceinline__ void pipe_row_sums(const CsrViewT<T>& A, const ZRec<T>* __restrict__ Zc, int r, int lane, bool mine,
                                               double& st, double& sv, ZRec<T>& zr) {
     using Z2 = ZRec<T>;
     st = 0.0; sv = 0.0;
     zr.t = 0; zr.v = 0;
     if (mine) {
-        const int b = A.rowptr[r], e = A.rowptr[r + 1];
+        const int b = ELLW ? r * ELLW : A.rowptr[r], e = ELLW ? b + ELLW : A.rowptr[r + 1];
         if (lane == 0) zr = Zc[r];
         int p = b + lane;
         if (UNR > 1) {   // several independent (val, col, gather) chains in flight per lane
@@ -676,7 +679,7 @@ __device__ __forceinline__ void pipe_row_sums(const CsrViewT<T>& A, const ZRec<T
 // row tile after 1.9-4.4 us: with the barrier behind the first tile the row waves sat idle for up to 2 us per step.
 // The coefficients are only needed by finish(), so the first DEFER tiles keep their raw sums in registers and the
 // barrier comes after them; finish() then runs in the same row order as before (bit-identical partial sums).
-template <int BLOCK, int G, int UNR = 1, bool DED = false, typename T = double, int DEFER = 3, bool SH = false>
+template <int BLOCK, int G, int UNR = 1, bool DED = false, typename T = double, int DEFER = 3, bool SH = false, int ELLW = 0>
 __global__ __launch_bounds__(BLOCK) void k_pipe_vec(CsrViewT<T> A, PipeViewT<T> L, int jrel, PeerSet PS = PeerSet()) {
     using Z2 = ZRec<T>;
     // SH: one rank's share of a row-partitioned step (PeerSet above); bid / gtot = this workgroup's index / the workgroup
@@ -707,7 +710,7 @@ __global__ __launch_bounds__(BLOCK) void k_pipe_vec(CsrViewT<T> A, PipeViewT<T> 
 #pragma unroll
     for (int i = 0; i < DEFER; ++i) {
         const int r = (bid + i * gtot) * GPB + g;
-        pipe_row_sums<G, UNR, T>(A, Zc, r, lane, wt >= 0 && r < A.n, dst[i], dsv[i], dzr[i]);
+        pipe_row_sums<G, UNR, T, ELLW>(A, Zc, r, lane, wt >= 0 && r < A.n, dst[i], dsv[i], dzr[i]);
     }
     __syncthreads();     // the coefficients of wave 0 are in scoef
     PIPE_CLK(wt == 0, 4);
@@ -724,12 +727,24 @@ __global__ __launch_bounds__(BLOCK) void k_pipe_vec(CsrViewT<T> A, PipeViewT<T> 
         const bool mine = wt >= 0 && r < A.n;
         double st, sv;
         Z2 zr;
-        pipe_row_sums<G, UNR, T>(A, Zc, r, lane, mine, st, sv, zr);
+        pipe_row_sums<G, UNR, T, ELLW>(A, Zc, r, lane, mine, st, sv, zr);
         if (mine && lane == 0) pr.template finish<T>(alpha, beta, mu, inv, zr, st, sv, vj, Zn, r, PSp, par);
     }
     PIPE_CLK(wt == 0, 5);
     pr.template store<BLOCK>(L, jrel, smw, PSp);
     PIPE_CLK(wt == 0, 6);
+}
+
+// Padded fixed-width copy of a short-row matrix (pose graphs beyond the single-workgroup kernel: city10000 has 3-13 entries
+// per row): W slots per row in CSR order, the rest zero on the row's own column.
+__global__ __launch_bounds__(kBlock) void k_ell_build(CsrView A, int W, int* __restrict__ ecol, double* __restrict__ eval) {
+    const long tot = (long)A.n * W;
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < tot; i += (long)gridDim.x * kBlock) {
+        const int r = (int)(i / W), j = (int)(i - (long)r * W);
+        const int b = A.rowptr[r], len = A.rowptr[r + 1] - b;
+        ecol[i] = j < len ? A.col[b + j] : r;
+        eval[i] = j < len ? A.val[b + j] : 0.0;
+    }
 }
 
 // ---- LDS row-tile ("CSR-stream") form ------------------------------------------------------------

@@ -31,7 +31,7 @@ inline int dev_alloc(T** p, size_t count) {
     return MACHIP_OK;
 }
 
-enum SpmvVariant { kAuto = 0, kStream = 1, kVec = 2, kPanel = 3 };
+enum SpmvVariant { kAuto = 0, kStream = 1, kVec = 2, kPanel = 3, kEll = 4 };   // kEll: k_pipe_vec on the padded fixed-width copy (4 lanes per row)
 
 struct SpmvPlan {
     int variant = kVec;   // kStream or kVec
@@ -331,8 +331,20 @@ inline void launch_pipe_shard(const SpmvPlan& pl, hipStream_t s, const CsrView& 
     else launch_pipe_shard_b<256>(pl, s, A, L, jrel, PS, grid);
 }
 
+// Padded fixed-width form (kEll): 4 lanes per row, all of a row's W = 8 / 16 slots in flight at once, one row tile per
+// workgroup (A.col / A.val are the padded arrays, A.rowptr is not read).
+template <int BLOCK>
+inline void launch_pipe_ell_b(const SpmvPlan& pl, hipStream_t s, const CsrView& A, const PipeView& L, int jrel) {
+    if (pl.unroll == 2) k_pipe_vec<BLOCK, 4, 2, true, double, 1, false, 8><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel);
+    else k_pipe_vec<BLOCK, 4, 4, true, double, 1, false, 16><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel);
+}
+
 inline void launch_pipe(const SpmvPlan& pl, hipStream_t s, const CsrView& A, const PipeView& L, int jrel) {
-    if (pl.variant == kStream) {
+    if (pl.variant == kEll) {
+        if (pl.block == 1024) launch_pipe_ell_b<1024>(pl, s, A, L, jrel);
+        else if (pl.block == 512) launch_pipe_ell_b<512>(pl, s, A, L, jrel);
+        else launch_pipe_ell_b<256>(pl, s, A, L, jrel);
+    } else if (pl.variant == kStream) {
         switch (pl.width) {
             case 1: k_pipe_stream<1><<<pl.grid, kBlock, 0, s>>>(A, L, jrel); break;
             case 2: k_pipe_stream<2><<<pl.grid, kBlock, 0, s>>>(A, L, jrel); break;

@@ -99,6 +99,9 @@ struct Solver {
     double *lx_part = nullptr, *lx_partR = nullptr;
     int *lx_colT = nullptr, *lx_bad = nullptr;
     PersistPack ppack{};         // packed registers / LDS image of the single-workgroup kernel (persist.h), per matrix
+    int* ell_col = nullptr;      // padded fixed-width copy of a short-row matrix (k_ell_build; 16 slots per row at most)
+    double* ell_val = nullptr;
+    CsrView ell_view{};          // {n, nullptr, ell_col, ell_val} while the current solve steps on it
     size_t lx_colT_cap = 0;
     LobState* lx_st = nullptr;
     double *h_lrec = nullptr, *d_hlrec = nullptr;
@@ -172,7 +175,7 @@ struct Solver {
         {
             void* pb[] = {panv.tptr, panv.thead, panv.bval, panv.bcol, panv.ypart, panv.coef, panv.tcount, panv.ps};
             for (void* q : pb) if (q) (void)hipFree(q);
-            void* pk[] = {ppack.band, ppack.cc, ppack.crow, ppack.ccol, ppack.cval};
+            void* pk[] = {ppack.band, ppack.cc, ppack.crow, ppack.ccol, ppack.cval, ell_col, ell_val};
             for (void* q : pk) if (q) (void)hipFree(q);
         }
         if (h_lrec) (void)hipHostFree(h_lrec);
@@ -401,7 +404,8 @@ struct Solver {
             return;
         }
         const PipeView L = pview(pl);
-        for (int s = 0; s < steps; ++s) launch_pipe(pl, stream, A, L, s);
+        const CsrView& As = pl.variant == kEll ? ell_view : A;
+        for (int s = 0; s < steps; ++s) launch_pipe(pl, stream, As, L, s);
         k_pipe_tail<<<1, 64, 0, stream>>>(L, steps);
     }
     int enqueue_chunk(const CsrView& A, const SpmvPlan& pl, int steps, bool f32 = false) {
@@ -974,6 +978,16 @@ struct Solver {
         const bool pmode = pmode_early;
         // column-panel step (panel.h) where the gather operand is too large for the caches (fp64 sequences only)
         pan = plan_panel(n, nnz, maxlen_hint, pan_allowed && precision == 0 && !pmode && !classic && pp.variant == kVec && !shard);   // (the row-partitioned solve shards the gather step)
+        // padded fixed-width form for short rows (pose graphs beyond the single-workgroup kernel): no row-pointer round trip
+        if (!pan.on && !pmode && !classic && !shard && precision == 0 && pp.variant == kVec && pp.width == 4 && pp.defer < 3 &&
+            maxlen_hint >= 1 && maxlen_hint <= 16 && env_int("MACHIP_ELL", 1) != 0) {
+            const int W = maxlen_hint <= 8 ? 8 : 16;
+            if (!ell_col) { ST_TRY(dev_alloc(&ell_col, (size_t)n * 16)); ST_TRY(dev_alloc(&ell_val, (size_t)n * 16)); }
+            k_ell_build<<<(int)std::min<long>(kMaxGrid, ((long)n * W + kBlock - 1) / kBlock), kBlock, 0, stream>>>(A, W, ell_col, ell_val);
+            HIP_TRY(hipGetLastError());
+            ell_view = CsrView{n, nullptr, ell_col, ell_val};
+            pp.variant = kEll; pp.unroll = W / 4;
+        }
         if (pan.on) {
             ST_TRY(ensure_panel(A, nnz, pan));
             pp.variant = kPanel; pp.grid = pan.grid2; pp.block = pan.block2;

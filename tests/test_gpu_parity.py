@@ -1033,6 +1033,38 @@ print("RESULT", out)
         assert rel <= LAM_RTOL and dv <= 2e-6 and res < 1e-8
 
 
+@pytest.mark.parametrize("hub", [0, 9, 20])
+def test_padded_fixed_width_step_is_bit_identical_to_the_csr_step(hub):
+    """Pose graphs beyond the single-workgroup kernel (city10000-like: 3-13 entries per row) step on a padded fixed-width
+    copy of L(x) (k_ell_build, 8 or 16 slots per row; `MACHIP_ELL`): same products in the same order plus zeros, so lambda_2
+    and the vector must equal the CSR step's bit for bit.  hub = 9: a 12-entry row (16-slot form); hub = 20: longer than 16,
+    the padded form must not be chosen (and the result is the same anyway)."""
+    rng = np.random.default_rng(5 + hub)
+    n = 6001
+    fi = np.arange(n - 1, dtype=np.int32)
+    fw = rng.uniform(50.0, 300.0, n - 1)
+    a = rng.integers(0, n, 1500); b = rng.integers(0, n, 1500)
+    if hub:
+        a = np.r_[a, np.full(hub, 1234)]; b = np.r_[b, rng.choice(np.arange(2000, n), hub, replace=False)]
+    keep = np.abs(a - b) > 1
+    ci = np.minimum(a, b)[keep].astype(np.int32); cj = np.maximum(a, b)[keep].astype(np.int32)
+    cw = rng.uniform(50.0, 150.0, len(ci))
+    P = _lib.Problem(n, fi, fi + 1, fw, ci, cj, cw)
+    P.set_x(np.ones(len(ci)))
+    P.set_solver(1)
+    res = {}
+    for ell in ("0", "1"):
+        os.environ["MACHIP_ELL"] = ell
+        try:
+            lam, v, _ = P.fiedler()
+        finally:
+            os.environ.pop("MACHIP_ELL", None)
+        assert P.stats.residual < 1e-8
+        res[ell] = (lam, v.copy(), int(P.stats.lanczos_steps))
+    assert res["0"][0] == res["1"][0] and res["0"][2] == res["1"][2] and np.array_equal(res["0"][1], res["1"][1])
+    P.close()
+
+
 def test_panel_step_multi_round_windows_hub_rows_and_odd_sizes():
     """Corners of the column-panel step (panel.h) the bench matrices do not reach: (a) dense rows -- a worker wave's tiles
     hold more chunks than its registers (kPanCH = 20), so the multi-round path runs; (b) n not a multiple of 64 nor of the
