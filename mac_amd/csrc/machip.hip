@@ -112,6 +112,12 @@ struct machip_problem {
     PatternView pattern() const { return PatternView{n, prow, pcol, pk, pw}; }
 };
 
+// ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) per process; kernels of streams that share a queue
+// run one after another.  The concurrent budget sweep keeps up to 12 single-CU solves in flight (machip_fw_sweep, one stream per
+// lane): with 4 queues it saturates at ~2.8x, with 16 at 7x (intel 1 764 -> 4 155 it/s, sphere2500 3 660 -> 6 288).  The variable
+// is read when the HIP runtime initialises, so it is set -- unless the application chose a value -- when this library is loaded.
+static const int g_hw_queues_set = [] { return setenv("GPU_MAX_HW_QUEUES", "16", 0); }();
+
 namespace {
 
 std::mutex g_csr_mu;                        // machip_fiedler_csr's cached handle
@@ -875,7 +881,11 @@ int ensure_lane_fw(machip_problem* q) {
 
 // Lanes [0, *nl_out) of the handle, created on demand, on the handle's solver mode / precision / start vector.
 int prepare_lanes(machip_problem* p, int B, bool fw, int* nl_out) {
-    int nl = std::max(1, std::min(B, std::min(16, env_int("MACHIP_LANES", 12))));
+    // Lanes: 12 where a solve is the single-workgroup kernel (one CU each; every lane's stream gets a hardware queue of its own,
+    // see the GPU_MAX_HW_QUEUES note at the top of this file), 4 where the solves launch chip-filling step kernels -- more than
+    // four hardware queues of those at once collapse (city10000 sweep: 597 it/s with 4 lanes, 250 with 8, 186 with 12).
+    const bool small = p->sol.chain_like && persist_fits(p->n, std::max(0l, (long)p->P - 2 * p->sol.chain_edges));   // (P: off-diagonal slots of the union pattern)
+    int nl = std::max(1, std::min(B, std::min(16, env_int("MACHIP_LANES", small ? 12 : 4))));
     while ((int)p->lanes.size() < nl) {
         machip_problem* q = nullptr;
         const int st = make_lane(p, &q);
