@@ -1353,6 +1353,41 @@ def test_solve_rounding_matches_reference_goldens():
         assert np.array_equal(mac._dev.round_nearest(int(g["k"]), decimals=10), g["rounded"])
 
 
+def test_one_launch_select_equals_the_multi_launch_select():
+    """Short candidate lists (<= 32 768: every pose graph) run the whole top-K select in one single-workgroup launch
+    (k_sel_small, `MACHIP_SEL_SMALL`); it must leave exactly the selection of the six-pass form -- rounding with its
+    prefer-high tie rule and the LP vertex with its lowest-index rule, on tie-heavy and on generic iterates, for every k from
+    nothing to everything -- and both must equal the oracle's."""
+    rng = np.random.default_rng(17)
+    for n, m in ((40, 7), (600, 1000), (3000, 32768)):
+        a = rng.integers(0, n, 3 * m); b = rng.integers(0, n, 3 * m)
+        keep = np.abs(a - b) > 1
+        pairs = np.unique(np.stack([np.minimum(a, b)[keep], np.maximum(a, b)[keep]], 1), axis=0)[:m]
+        m = len(pairs)
+        ci, cj = pairs[:, 0].astype(np.int32), pairs[:, 1].astype(np.int32)
+        cw = rng.choice(np.array([1.0, 2.0, 3.5]), size=m)
+        fi = np.arange(n - 1, dtype=np.int32)
+        P = _lib.Problem(n, fi, fi + 1, np.ones(n - 1), ci, cj, cw)
+        P.set_start(reference_start_block(n)[:, 0].copy())
+        for kind in ("ties", "generic"):
+            x = rng.choice(np.array([0.0, 0.0, 1.0 / 3.0, 0.4, 0.4, 0.6, 2.0 / 3.0, 1.0]), size=m) if kind == "ties" else rng.random(m)
+            P.set_x(x)
+            P.assemble(); P.fiedler(want_vec=False); g = P.gradient()
+            for k in sorted({0, 1, m // 7, m // 2, m - 1, m}):
+                got = {}
+                for flag in ("0", "1"):
+                    os.environ["MACHIP_SEL_SMALL"] = flag
+                    try:
+                        got[flag] = (P.round_nearest(k, decimals=10), P.lp_topk(k))
+                    finally:
+                        os.environ.pop("MACHIP_SEL_SMALL", None)
+                assert np.array_equal(got["0"][0], got["1"][0]) and np.array_equal(got["0"][1], got["1"][1]), (n, kind, k)
+                assert np.array_equal(got["1"][0], oracle.round_nearest(x, k, cw, 10)), (n, kind, k)
+                s = got["1"][1]
+                assert int(s.sum()) == k and (k in (0, m) or g[s > 0].min() >= g[s == 0].max())
+        P.close()
+
+
 def test_selection_is_deterministic_on_massive_ties():
     """Regression for a race in the radix select: the last workgroup could read a histogram bin before
     every workgroup's (fire-and-forget) add had been performed at the memory side; with rounded iterates
