@@ -24,7 +24,7 @@ for cfg in (sys.argv[1:] or ["c3", "c5a", "c5b"]):
         P.set_x(x); single.append(P.fiedler(want_vec=False)[0])
     t1 = time.perf_counter()
     out = {}
-    for lanes in (1, 2, 4, 8):
+    for lanes in (1, 2, 4, 8, 12):
         os.environ["MACHIP_LANES"] = str(lanes)
         t2 = time.perf_counter()
         lam, st = P.eval_batch(X)
