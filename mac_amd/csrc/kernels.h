@@ -637,6 +637,8 @@ struct PipeRow {   // per-thread accumulation of the next step's partial sums
     }
 };
 
+#define PIPE_ARGS(A, L, jrel) (A).rowptr, (A).col, (A).val, (((jrel) & 1) ? (L).Z1 : (L).Z0), (L).part, (L).st, (A).n, (A), (L), (jrel)
+
 // ---- sub-wave vector form: G lanes per row, BLOCK threads per workgroup -------------------------
 // Raw sums (L t)[r], (L v)[r] of one row by its G-lane group, and the row's own record (lane 0).
 // ELLW > 0: the matrix is in padded fixed-width form (k_ell_build: ELLW slots per row, CSR order, padded with zero
@@ -680,8 +682,18 @@ __device__ __forceinline__ void pipe_row_sums(const CsrViewT<T>& A, const ZRec<T
 // The coefficients are only needed by finish(), so the first DEFER tiles keep their raw sums in registers and the
 // barrier comes after them; finish() then runs in the same row order as before (bit-identical partial sums).
 template <int BLOCK, int G, int UNR = 1, bool DED = false, typename T = double, int DEFER = 3, bool SH = false, int ELLW = 0>
-__global__ __launch_bounds__(BLOCK) void k_pipe_vec(CsrViewT<T> A, PipeViewT<T> L, int jrel, PeerSet PS = PeerSet()) {
+__global__ __launch_bounds__(BLOCK) void k_pipe_vec(const int* __restrict__ a_rowptr, const int* __restrict__ a_col, const T* __restrict__ a_val,
+                                                    const ZRec<T>* __restrict__ z_cur, double* l_part, LanState* l_st, int a_n,
+                                                    CsrViewT<T> A_, PipeViewT<T> L_, int jrel, PeerSet PS = PeerSet()) {
     using Z2 = ZRec<T>;
+    // The pointers every wave needs for its FIRST loads come as leading scalar arguments (PIPE_ARGS): with
+    // -amdgpu-kernarg-preload-count they are in SGPRs when the wave starts, instead of behind a scalar load of the argument
+    // block (itself a cold round trip at the head of every step).  A_ / L_ carry the rest.
+    // (Not for the padded fixed-width form: there every wave's value / column loads leave at kernel entry anyway, and having
+    // them out even before wave 0's partial-sum loads measured 1.7 % slower on city10000.)
+    const CsrViewT<T> A = ELLW ? A_ : CsrViewT<T>{a_n, a_rowptr, a_col, a_val};
+    PipeViewT<T> L = L_;
+    if (!ELLW) { L.part = l_part; L.st = l_st; }
     // SH: one rank's share of a row-partitioned step (PeerSet above); bid / gtot = this workgroup's index / the workgroup
     // count of the whole step, so that rows, partial sums and their order are those of the unsharded launch
     const int bid = SH ? PS.first + (int)blockIdx.x : (int)blockIdx.x;
@@ -700,7 +712,7 @@ __global__ __launch_bounds__(BLOCK) void k_pipe_vec(CsrViewT<T> A, PipeViewT<T> 
     PIPE_CLK(wt == 0, 2);
     if (threadIdx.x < 64) { int jdummy; (void)pipe_prologue_wave0(L, jrel, -1, scoef, &jdummy, bid); }
     PIPE_CLK(threadIdx.x == 0, 1);
-    const Z2* __restrict__ Zc = (jrel & 1) ? L.Z1 : L.Z0;
+    const Z2* __restrict__ Zc = ELLW ? ((jrel & 1) ? L.Z1 : L.Z0) : z_cur;
     Z2* __restrict__ Zn = (jrel & 1) ? L.Z0 : L.Z1;
     PipeRow pr;
     pr.clear();

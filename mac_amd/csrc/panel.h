@@ -219,8 +219,17 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_fill(CsrView A, PanView P) 
 // ------------------------------------------------------------------------------------------
 // Step kernel 1: y_p = L[block b, panel p] v_j
 // ------------------------------------------------------------------------------------------
+#define PAN_MUL_ARGS(P, L, jrel) (((jrel) & 1) ? (L).Z1 : (L).Z0), (L).part, (L).st, (P).tptr, (P).thead, (P).n, (P).C, (P).NP, (P).TWW, (P), (L), (jrel)
+#define PAN_FIN_ARGS(P, L, jrel) (((jrel) & 1) ? (L).Z1 : (L).Z0), (P).coef, (P).ypart, (P).n, (P).NP, (P), (L), (jrel)
 template <int RPT>   // records per worker thread: the panel holds at most RPT * 960 columns
-__global__ __launch_bounds__(kPanThreads) void k_pan_mul(PanView A, PipeView L, int jrel) {
+__global__ __launch_bounds__(kPanThreads) void k_pan_mul(const Z2* __restrict__ z_cur, double* l_part, LanState* l_st,
+                                                          const int* __restrict__ a_tptr, const unsigned short* __restrict__ a_thead,
+                                                          int a_n, int a_C, int a_NP, int a_TWW, PanView A_, PipeView L_, int jrel) {
+    // (leading scalars = what the first loads need, preloaded into SGPRs with the wave: PAN_MUL_ARGS, cf. PIPE_ARGS in kernels.h)
+    PanView A = A_;
+    A.tptr = const_cast<int*>(a_tptr); A.thead = const_cast<unsigned short*>(a_thead); A.n = a_n; A.C = a_C; A.NP = a_NP; A.TWW = a_TWW;
+    PipeView L = L_;
+    L.part = l_part; L.st = l_st;
     __shared__ double sv[RPT * kPanWorkThreads];
     __shared__ double yblk[kPanRows];
     __shared__ double scoef[8];
@@ -250,7 +259,7 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul(PanView A, PipeView L, 
 #ifdef PAN_HEADSTART
     __builtin_amdgcn_s_sleep(PAN_HEADSTART);     // (experiment: let wave 0's partial loads into the memory pipeline first)
 #endif
-    const Z2* __restrict__ Zc = ((jrel & 1) ? L.Z1 : L.Z0) + c0;
+    const Z2* __restrict__ Zc = z_cur + c0;
     // the panel's records, all requested at once (clamped index: unconditional loads stay batched, cf. the prologue)
     Z2 z[RPT];
 #pragma unroll
@@ -346,11 +355,14 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul(PanView A, PipeView L, 
 // Step kernel 2: w = sum_p y_p, record / basis column / inner products of the step (row-parallel)
 // ------------------------------------------------------------------------------------------
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_pan_fin(PanView A, PipeView L, int jrel) {
+__global__ __launch_bounds__(BLOCK) void k_pan_fin(const Z2* __restrict__ z_cur, const double* __restrict__ a_coef,
+                                                    const double* __restrict__ a_ypart, int a_n, int a_NP, PanView A_, PipeView L, int jrel) {
     __shared__ double smw[kNP * BLOCK];
+    PanView A = A_;
+    A.coef = const_cast<double*>(a_coef); A.ypart = const_cast<double*>(a_ypart); A.n = a_n; A.NP = a_NP;     // (PAN_FIN_ARGS: preloaded)
     const double alpha = A.coef[0], beta = A.coef[1], mu = A.coef[2], inv = A.coef[3];
     const int j = (int)A.coef[4];
-    const Z2* __restrict__ Zc = (jrel & 1) ? L.Z1 : L.Z0;
+    const Z2* __restrict__ Zc = z_cur;
     Z2* __restrict__ Zn = (jrel & 1) ? L.Z0 : L.Z1;
     double* __restrict__ vj = L.V + (size_t)j * (size_t)L.n;
     PipeRow pr;

@@ -221,11 +221,11 @@ template <int BLOCK>
 inline void launch_pipe_b(const SpmvPlan& pl, hipStream_t s, const CsrViewT<float>& A, const PipeViewT<float>& L, int jrel) {
     const int key = pl.width * 10 + pl.unroll;
     switch (key) {
-        case 41: k_pipe_vec<BLOCK, 4, 1, true, float, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 42: case 44: k_pipe_vec<BLOCK, 4, 2, true, float, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 81: case 82: k_pipe_vec<BLOCK, 8, 2, true, float, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 84: k_pipe_vec<BLOCK, 8, 4, true, float, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        default: k_pipe_vec<BLOCK, 16, 2, true, float, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 41: k_pipe_vec<BLOCK, 4, 1, true, float, 1><<<pl.grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel)); break;
+        case 42: case 44: k_pipe_vec<BLOCK, 4, 2, true, float, 1><<<pl.grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel)); break;
+        case 81: case 82: k_pipe_vec<BLOCK, 8, 2, true, float, 1><<<pl.grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel)); break;
+        case 84: k_pipe_vec<BLOCK, 8, 4, true, float, 1><<<pl.grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel)); break;
+        default: k_pipe_vec<BLOCK, 16, 2, true, float, 1><<<pl.grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel)); break;
     }
 }
 
@@ -234,28 +234,28 @@ inline void launch_pipe_b(const SpmvPlan& pl, hipStream_t s, const CsrView& A, c
     const int key = pl.width * 10 + pl.unroll;
     if (pl.defer >= 3) {   // several row tiles per workgroup: the shapes plan_pipe picks there (others: DEFER = 1 below)
         switch (key) {
-            case 41: k_pipe_vec<BLOCK, 4, 1, true, double, 3><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); return;
-            case 42: k_pipe_vec<BLOCK, 4, 2, true, double, 3><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); return;
-            case 82: k_pipe_vec<BLOCK, 8, 2, true, double, 3><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); return;
-            case 84: k_pipe_vec<BLOCK, 8, 4, true, double, 3><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); return;
-            case 162: k_pipe_vec<BLOCK, 16, 2, true, double, 3><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); return;
+            case 41: k_pipe_vec<BLOCK, 4, 1, true, double, 3><<<pl.grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel)); return;
+            case 42: k_pipe_vec<BLOCK, 4, 2, true, double, 3><<<pl.grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel)); return;
+            case 82: k_pipe_vec<BLOCK, 8, 2, true, double, 3><<<pl.grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel)); return;
+            case 84: k_pipe_vec<BLOCK, 8, 4, true, double, 3><<<pl.grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel)); return;
+            case 162: k_pipe_vec<BLOCK, 16, 2, true, double, 3><<<pl.grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel)); return;
             default: break;
         }
     }
     switch (key) {
-        case 41: k_pipe_vec<BLOCK, 4, 1, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 42: k_pipe_vec<BLOCK, 4, 2, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 44: k_pipe_vec<BLOCK, 4, 4, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 84: k_pipe_vec<BLOCK, 8, 4, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 164: k_pipe_vec<BLOCK, 16, 4, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 81: k_pipe_vec<BLOCK, 8, 1, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 82: k_pipe_vec<BLOCK, 8, 2, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 161: k_pipe_vec<BLOCK, 16, 1, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 162: k_pipe_vec<BLOCK, 16, 2, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 321: k_pipe_vec<BLOCK, 32, 1, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 322: k_pipe_vec<BLOCK, 32, 2, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        case 641: k_pipe_vec<BLOCK, 64, 1, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
-        default: k_pipe_vec<BLOCK, 64, 2, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel); break;
+        case 41: k_pipe_vec<BLOCK, 4, 1, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel)); break;
+        case 42: k_pipe_vec<BLOCK, 4, 2, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel)); break;
+        case 44: k_pipe_vec<BLOCK, 4, 4, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel)); break;
+        case 84: k_pipe_vec<BLOCK, 8, 4, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel)); break;
+        case 164: k_pipe_vec<BLOCK, 16, 4, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel)); break;
+        case 81: k_pipe_vec<BLOCK, 8, 1, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel)); break;
+        case 82: k_pipe_vec<BLOCK, 8, 2, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel)); break;
+        case 161: k_pipe_vec<BLOCK, 16, 1, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel)); break;
+        case 162: k_pipe_vec<BLOCK, 16, 2, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel)); break;
+        case 321: k_pipe_vec<BLOCK, 32, 1, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel)); break;
+        case 322: k_pipe_vec<BLOCK, 32, 2, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel)); break;
+        case 641: k_pipe_vec<BLOCK, 64, 1, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel)); break;
+        default: k_pipe_vec<BLOCK, 64, 2, true, double, 1><<<pl.grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel)); break;
     }
 }
 
@@ -267,28 +267,28 @@ inline void launch_pipe_shard_b(const SpmvPlan& pl, hipStream_t s, const CsrView
     const int key = pl.width * 10 + pl.unroll;
     if (pl.defer >= 3) {
         switch (key) {
-            case 41: k_pipe_vec<BLOCK, 4, 1, true, double, 3, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); return;
-            case 42: k_pipe_vec<BLOCK, 4, 2, true, double, 3, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); return;
-            case 82: k_pipe_vec<BLOCK, 8, 2, true, double, 3, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); return;
-            case 84: k_pipe_vec<BLOCK, 8, 4, true, double, 3, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); return;
-            case 162: k_pipe_vec<BLOCK, 16, 2, true, double, 3, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); return;
+            case 41: k_pipe_vec<BLOCK, 4, 1, true, double, 3, true><<<grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel), PS); return;
+            case 42: k_pipe_vec<BLOCK, 4, 2, true, double, 3, true><<<grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel), PS); return;
+            case 82: k_pipe_vec<BLOCK, 8, 2, true, double, 3, true><<<grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel), PS); return;
+            case 84: k_pipe_vec<BLOCK, 8, 4, true, double, 3, true><<<grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel), PS); return;
+            case 162: k_pipe_vec<BLOCK, 16, 2, true, double, 3, true><<<grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel), PS); return;
             default: break;
         }
     }
     switch (key) {
-        case 41: k_pipe_vec<BLOCK, 4, 1, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
-        case 42: k_pipe_vec<BLOCK, 4, 2, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
-        case 44: k_pipe_vec<BLOCK, 4, 4, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
-        case 81: k_pipe_vec<BLOCK, 8, 1, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
-        case 82: k_pipe_vec<BLOCK, 8, 2, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
-        case 84: k_pipe_vec<BLOCK, 8, 4, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
-        case 161: k_pipe_vec<BLOCK, 16, 1, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
-        case 162: k_pipe_vec<BLOCK, 16, 2, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
-        case 164: k_pipe_vec<BLOCK, 16, 4, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
-        case 321: k_pipe_vec<BLOCK, 32, 1, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
-        case 322: k_pipe_vec<BLOCK, 32, 2, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
-        case 641: k_pipe_vec<BLOCK, 64, 1, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
-        default: k_pipe_vec<BLOCK, 64, 2, true, double, 1, true><<<grid, BLOCK, 0, s>>>(A, L, jrel, PS); break;
+        case 41: k_pipe_vec<BLOCK, 4, 1, true, double, 1, true><<<grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel), PS); break;
+        case 42: k_pipe_vec<BLOCK, 4, 2, true, double, 1, true><<<grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel), PS); break;
+        case 44: k_pipe_vec<BLOCK, 4, 4, true, double, 1, true><<<grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel), PS); break;
+        case 81: k_pipe_vec<BLOCK, 8, 1, true, double, 1, true><<<grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel), PS); break;
+        case 82: k_pipe_vec<BLOCK, 8, 2, true, double, 1, true><<<grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel), PS); break;
+        case 84: k_pipe_vec<BLOCK, 8, 4, true, double, 1, true><<<grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel), PS); break;
+        case 161: k_pipe_vec<BLOCK, 16, 1, true, double, 1, true><<<grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel), PS); break;
+        case 162: k_pipe_vec<BLOCK, 16, 2, true, double, 1, true><<<grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel), PS); break;
+        case 164: k_pipe_vec<BLOCK, 16, 4, true, double, 1, true><<<grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel), PS); break;
+        case 321: k_pipe_vec<BLOCK, 32, 1, true, double, 1, true><<<grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel), PS); break;
+        case 322: k_pipe_vec<BLOCK, 32, 2, true, double, 1, true><<<grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel), PS); break;
+        case 641: k_pipe_vec<BLOCK, 64, 1, true, double, 1, true><<<grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel), PS); break;
+        default: k_pipe_vec<BLOCK, 64, 2, true, double, 1, true><<<grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel), PS); break;
     }
 }
 // rows per workgroup tile of the instantiation the switches above pick (unlisted shapes run as G = 64)
@@ -335,8 +335,8 @@ inline void launch_pipe_shard(const SpmvPlan& pl, hipStream_t s, const CsrView& 
 // workgroup (A.col / A.val are the padded arrays, A.rowptr is not read).
 template <int BLOCK>
 inline void launch_pipe_ell_b(const SpmvPlan& pl, hipStream_t s, const CsrView& A, const PipeView& L, int jrel) {
-    if (pl.unroll == 2) k_pipe_vec<BLOCK, 4, 2, true, double, 1, false, 8><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel);
-    else k_pipe_vec<BLOCK, 4, 4, true, double, 1, false, 16><<<pl.grid, BLOCK, 0, s>>>(A, L, jrel);
+    if (pl.unroll == 2) k_pipe_vec<BLOCK, 4, 2, true, double, 1, false, 8><<<pl.grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel));
+    else k_pipe_vec<BLOCK, 4, 4, true, double, 1, false, 16><<<pl.grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, jrel));
 }
 
 inline void launch_pipe(const SpmvPlan& pl, hipStream_t s, const CsrView& A, const PipeView& L, int jrel) {

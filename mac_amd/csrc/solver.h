@@ -308,15 +308,15 @@ struct Solver {
     void launch_pan_step(const PipeView& L, int s) {
         const int g1 = pan.NB * pan.NP;
         switch (pan.RPT) {
-#define MACHIP_PAN_CASE(R) case R: k_pan_mul<R><<<g1, kPanThreads, 0, stream>>>(panv, L, s); break;
+#define MACHIP_PAN_CASE(R) case R: k_pan_mul<R><<<g1, kPanThreads, 0, stream>>>(PAN_MUL_ARGS(panv, L, s)); break;
             MACHIP_PAN_CASE(1) MACHIP_PAN_CASE(2) MACHIP_PAN_CASE(3) MACHIP_PAN_CASE(4) MACHIP_PAN_CASE(5) MACHIP_PAN_CASE(6)
             MACHIP_PAN_CASE(7) MACHIP_PAN_CASE(8) MACHIP_PAN_CASE(9) MACHIP_PAN_CASE(10) MACHIP_PAN_CASE(11) MACHIP_PAN_CASE(12)
 #undef MACHIP_PAN_CASE
-            default: k_pan_mul<13><<<g1, kPanThreads, 0, stream>>>(panv, L, s); break;
+            default: k_pan_mul<13><<<g1, kPanThreads, 0, stream>>>(PAN_MUL_ARGS(panv, L, s)); break;
         }
-        if (pan.block2 == 1024) k_pan_fin<1024><<<pan.grid2, 1024, 0, stream>>>(panv, L, s);
-        else if (pan.block2 == 512) k_pan_fin<512><<<pan.grid2, 512, 0, stream>>>(panv, L, s);
-        else k_pan_fin<256><<<pan.grid2, 256, 0, stream>>>(panv, L, s);
+        if (pan.block2 == 1024) k_pan_fin<1024><<<pan.grid2, 1024, 0, stream>>>(PAN_FIN_ARGS(panv, L, s));
+        else if (pan.block2 == 512) k_pan_fin<512><<<pan.grid2, 512, 0, stream>>>(PAN_FIN_ARGS(panv, L, s));
+        else k_pan_fin<256><<<pan.grid2, 256, 0, stream>>>(PAN_FIN_ARGS(panv, L, s));
     }
 
     // ---- row-partitioned chunk: per step one launch per rank, ordered by events (ShardGroup) ----

@@ -36,7 +36,7 @@ void run_pipe(const CsrView& A, PipeView L, int cap, hipStream_t s, long nnz) {
     const int gpb = (DED ? BLOCK - 64 : BLOCK) / G;
     const int grid = std::min(cap, (A.n + gpb - 1) / gpb);
     L.P = grid;
-    const double us = time_us([&] { k_pipe_vec<BLOCK, G, UNR, DED><<<grid, BLOCK, 0, s>>>(A, L, 0); }, 400, s);
+    const double us = time_us([&] { k_pipe_vec<BLOCK, G, UNR, DED><<<grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, 0)); }, 400, s);
     printf("  k_pipe_vec blk=%-4d G=%-2d unr=%d ded=%d grid=%-4d : %7.2f us  (%6.0f GB/s on 12*nnz+56*n)\n", BLOCK, G, UNR, (int)DED, grid, us,
            (nnz * 12.0 + 56.0 * A.n) / us / 1e3);
 }

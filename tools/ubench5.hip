@@ -21,9 +21,9 @@ void run(const char* nm, CsrView A, PipeView L, hipStream_t s, long nnz, std::ve
     k_pipe_init<<<grid, kBlock, 0, s>>>(L, u0, 1);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int steps = 40;
-    for (int j = 0; j < 8; ++j) k_pipe_vec<BLOCK, G, UNR, true><<<grid, BLOCK, 0, s>>>(A, L, j);   // jA stays 0: j = jrel (V columns 0..47 exist)
+    for (int j = 0; j < 8; ++j) k_pipe_vec<BLOCK, G, UNR, true><<<grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, j));   // jA stays 0: j = jrel (V columns 0..47 exist)
     CK(hipEventRecord(e0, s));
-    for (int j = 8; j < 8 + steps; ++j) k_pipe_vec<BLOCK, G, UNR, true><<<grid, BLOCK, 0, s>>>(A, L, j);
+    for (int j = 8; j < 8 + steps; ++j) k_pipe_vec<BLOCK, G, UNR, true><<<grid, BLOCK, 0, s>>>(PIPE_ARGS(A, L, j));
     CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     CK(hipGetLastError());

@@ -22,11 +22,11 @@ void run(PanView P, PipeView L, hipStream_t s, long nnz, std::vector<double>& u0
     k_pipe_init<<<g2, kBlock, 0, s>>>(L, u0, 1);
     hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
     const int steps = 40;
-    for (int j = 0; j < 8; ++j) { k_pan_mul<RPT><<<g1, kPanThreads, 0, s>>>(P, L, j); k_pan_fin<256><<<g2, 256, 0, s>>>(P, L, j); }
+    for (int j = 0; j < 8; ++j) { k_pan_mul<RPT><<<g1, kPanThreads, 0, s>>>(PAN_MUL_ARGS(P, L, j)); k_pan_fin<256><<<g2, 256, 0, s>>>(PAN_FIN_ARGS(P, L, j)); }
     CK(hipEventRecord(e0, s));
-    for (int j = 8; j < 8 + steps; ++j) { k_pan_mul<RPT><<<g1, kPanThreads, 0, s>>>(P, L, j); k_pan_fin<256><<<g2, 256, 0, s>>>(P, L, j); }
+    for (int j = 8; j < 8 + steps; ++j) { k_pan_mul<RPT><<<g1, kPanThreads, 0, s>>>(PAN_MUL_ARGS(P, L, j)); k_pan_fin<256><<<g2, 256, 0, s>>>(PAN_FIN_ARGS(P, L, j)); }
     CK(hipEventRecord(e1, s));
-    for (int j = 0; j < steps; ++j) k_pan_mul<RPT><<<g1, kPanThreads, 0, s>>>(P, L, 1);     // K1 alone, back to back (same operand)
+    for (int j = 0; j < steps; ++j) k_pan_mul<RPT><<<g1, kPanThreads, 0, s>>>(PAN_MUL_ARGS(P, L, 1));     // K1 alone, back to back (same operand)
     CK(hipEventRecord(e2, s)); CK(hipEventSynchronize(e2));
     float ms, ms2; CK(hipEventElapsedTime(&ms, e0, e1)); CK(hipEventElapsedTime(&ms2, e1, e2));
     CK(hipGetLastError());
