@@ -693,7 +693,7 @@ __global__ __launch_bounds__(BLOCK) void k_pipe_vec(const int* __restrict__ a_ro
     // them out even before wave 0's partial-sum loads measured 1.7 % slower on city10000.)
     const CsrViewT<T> A = ELLW ? A_ : CsrViewT<T>{a_n, a_rowptr, a_col, a_val};
     PipeViewT<T> L = L_;
-    if (!ELLW) { L.part = l_part; L.st = l_st; }
+    L.part = l_part; L.st = l_st;      // (the prologue's pointers are preloaded in either form: its chain is the longest)
     // SH: one rank's share of a row-partitioned step (PeerSet above); bid / gtot = this workgroup's index / the workgroup
     // count of the whole step, so that rows, partial sums and their order are those of the unsharded launch
     const int bid = SH ? PS.first + (int)blockIdx.x : (int)blockIdx.x;
