@@ -221,3 +221,18 @@ def test_panel_plan_covers_every_row_and_column_within_the_kernel_limits():
         for k_, v in old.items():
             if v is not None:
                 os.environ[k_] = v
+
+
+def test_loading_the_library_reserves_a_hardware_queue_per_lane():
+    """The concurrent budget sweep keeps up to 12 streams busy; ROCm maps a process's streams onto GPU_MAX_HW_QUEUES (default
+    4) hardware queues and reads the variable when the HIP runtime initialises, so the binding (and, for C callers, the library's
+    own load-time initialiser) sets it to 16 -- unless the application chose a value, which must survive."""
+    import subprocess
+    import sys
+    code = "import os, sys; sys.path.insert(0, '.'); from mac_amd import _lib; _lib.load(); print(os.environ.get('GPU_MAX_HW_QUEUES'))"
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=ROOT, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == "16", out.stderr[-500:]
+    env["GPU_MAX_HW_QUEUES"] = "6"
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=ROOT, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == "6", out.stderr[-500:]
