@@ -12,6 +12,7 @@
 // This file is the DRIVER (allocation, chunk graphs, host analysis, mode selection, restarts); launch shapes and the
 // dispatch onto kernel instantiations are in plan.h, kernels in kernels.h / panel.h / persist.h / precond.h / woodbury.h.
 #pragma once
+#include <functional>
 #include <dlfcn.h>
 
 #include <array>
@@ -70,6 +71,11 @@ struct Solver {
     double* h_pin = nullptr;    // misc
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evs0 = nullptr, evs1 = nullptr;   // evs*: bracket the Krylov chunks only
     bool ev1_at_check = false;  // ev1 was recorded behind the last explicit check's kernels (and that check has been waited for)
+    // Speculative epilogue: work the caller wants behind a PASSING explicit check (machip_fw_step: gradient, top-K, Frank-Wolfe
+    // bookkeeping) is enqueued behind EVERY check's kernels, before the host waits for the check -- if the check passes, its
+    // results are there at the same wait (one host round trip less per iteration); if not, it runs again behind the next check.
+    std::function<void()> after_check;
+    long check_seq = 0, hook_seq = -1, final_check_seq = -2;    // hook results are valid iff hook_seq == final_check_seq
     std::vector<hipEvent_t> ev_pool;
     // cached chunk graphs: (variant, width, grid, steps) -> exec
     std::map<std::tuple<int, int, int, int, int>, std::array<hipGraphExec_t, 2>> graphs;
@@ -467,6 +473,8 @@ struct Solver {
         k_resid_l1<<<g2, kBlock, 0, stream>>>(w2, yvec, n, part_a2, pl.grid, dhp, rq_dev, dhp + kMaxGrid);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev1, stream));     // end of the solve's device time if this check passes (no second wait then)
+        ++check_seq;
+        if (after_check) { after_check(); hook_seq = check_seq; }
         HIP_TRY(hipStreamSynchronize(stream));
         ev1_at_check = true;
         double s = 0.0;
@@ -895,6 +903,7 @@ struct Solver {
         const bool want = chain_dominated &&
                           (mode == 2 || (mode == 0 && chain_like && support_hint >= 0 && ((sparse && !slow_lob) || stiff)));
         last_was_lob = false;
+        final_check_seq = -2;
         if (eligible && want) {
             HIP_TRY(hipEventRecord(ev0, stream));
             double lam = 0.0, res = 0.0;
@@ -1244,7 +1253,7 @@ struct Solver {
                     lam = rq;
                     res = lnorm > 0 ? r1 / lnorm : r1;
                     if (debug) fprintf(stderr, "[machip]    check J=%d rq=%.15g res=%.3e (tol %.1e)\n", Jeff, rq, res, tol);
-                    if (res < tol) { converged = true; status = MACHIP_OK; break; }
+                    if (res < tol) { converged = true; status = MACHIP_OK; final_check_seq = check_seq; break; }
                     if (handover) {
                         // rq = Rayleigh quotient of the unit Ritz vector (orthogonal to 1) >= lambda_2
                         cheb_a = 1.25 * rq; cheb_b = 1.0001 * tiny_l;
