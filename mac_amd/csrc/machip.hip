@@ -549,6 +549,7 @@ int machip_gradient(machip_problem* p, double* g_out) {
     if (!p || p->csr_only) return fail(MACHIP_BAD_ARG, "bad handle");
     GroupGuard guard{p};
     HIP_TRY(hipSetDevice(p->device));
+    if (!p->have_vec) { guard.ok = true; return fail(MACHIP_BAD_ARG, "no Fiedler vector on the device: call machip_fiedler first"); }   // (argument error before any barrier: the group stays usable)
     ST_TRY(compute_gradient(p));
     if (g_out) HIP_TRY(hipMemcpyAsync(g_out, p->g, sizeof(double) * (size_t)p->m, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
@@ -588,14 +589,20 @@ int machip_fw_step(machip_problem* p, int64_t k, int iter, double tol, int max_s
         epi_status = st;
     };
     bool done = false;
-    if (p->lgroup && p->lgroup->shard_eig) ST_TRY(group_fiedler(p, tol, max_steps, warm_start, &lam, stats));
-    else {
+    // A soft status (step cap reached, disconnected selection) reaches every rank of a communicator alike -- replicated solves
+    // are deterministic, the row-partitioned one hands the leader's status round -- and nobody is left in a barrier: the group
+    // stays usable (a retry with a larger max_steps, the next iteration).  Only hard errors shut it down.
+    auto soft = [](int st) { return st == MACHIP_NOT_CONVERGED || st == MACHIP_DISCONNECTED; };
+    if (p->lgroup && p->lgroup->shard_eig) {
+        const int st = group_fiedler(p, tol, max_steps, warm_start, &lam, stats);
+        if (st != MACHIP_OK) { guard.ok = soft(st); return st; }
+    } else {
         // single rank: the epilogue rides behind the solve's explicit check (solver.h, after_check) -- no exchange step in it
         const bool spec = p->nranks <= 1 && env_int("MACHIP_SPEC_EPILOGUE", 1) != 0;
         if (spec) p->sol.after_check = [&] { epilogue(true); };
         const int st = run_fiedler(p, tol, max_steps, nullptr, warm_start, &lam, stats);
         p->sol.after_check = nullptr;
-        if (st != MACHIP_OK) return st;
+        if (st != MACHIP_OK) { guard.ok = soft(st); return st; }
         done = spec && p->sol.hook_seq == p->sol.final_check_seq && epi_status == MACHIP_OK;     // (the passing check's wait covered it)
     }
     if (!done) {

@@ -61,6 +61,9 @@ struct PanView {
     unsigned short* bcol;   // column minus the panel's first column
     double* ypart;          // [NP][n] per-panel partial products
     double* coef;           // 8 doubles: (alpha, beta, mu, inv, j) of the running step, published by k_pan_mul for k_pan_fin
+    unsigned int* tick;     // [NB] one-launch step (k_pan_step): arrivals of a row block's NP workgroups, monotonic over a sequence
+    unsigned int* claim;    // [NB * NP] ... and which step's share (row block b, rows of slice p) has been taken
+    int spin_ticks;         // ... how long (100 MHz ticks) a workgroup waits for its row block before leaving its share to the last arriver
     int* tcount;            // [tiles] entries (with padding) per tile (assembly scratch)
     int* ps;                // [(NP+1)][n] first off-diagonal entry of row r at or behind panel p (assembly scratch)
 #ifdef PAN_CLOCKS
@@ -380,14 +383,250 @@ __global__ __launch_bounds__(BLOCK) void k_pan_fin(const Z2* __restrict__ z_cur,
         }
         Z2 o;
         o.v = pan_vj(alpha, mu, inv, z.t, z.v);
-        o.t = w - beta * z.v;                       // Paige's intermediate for the next step
+        o.t = __builtin_fma(-beta, z.v, w);         // Paige's intermediate for the next step (explicit fma: k_pan_step rounds alike)
         vj[r] = o.v;
         Zn[r] = o;
         const double t = o.t, v = o.v;
-        pr.acc[0] += t * t; pr.acc[1] += t * v; pr.acc[2] += v * v;
+        pr.acc[0] = __builtin_fma(t, t, pr.acc[0]); pr.acc[1] = __builtin_fma(t, v, pr.acc[1]); pr.acc[2] = __builtin_fma(v, v, pr.acc[2]);
         pr.acc[3] += t; pr.acc[4] += v; pr.acc[5] += fabs(v);
     }
     pr.template store<BLOCK>(L, jrel, smw);
+}
+
+
+// ------------------------------------------------------------------------------------------
+// ONE launch per step (round 4): k_pan_mul's product + k_pan_fin's row work behind a per-row-block arrival ticket.
+// ------------------------------------------------------------------------------------------
+// The NP workgroups (b, 0..NP-1) of row block b publish their partial products y_p[rows of b] with WRITE-THROUGH stores
+// (`sc1`: the bytes are in memory when the store has been acknowledged -- no release fence, which would write back the
+// whole XCD's L2; MI355X_MICROARCH.md "publish-large": 3.0 against 8.2 us), drain them (s_waitcnt vmcnt(0)), and take ONE
+// device-scope ticket of the row block (monotonic counter: step j of a sequence is complete at (j + 1) NP arrivals; the
+// solver zeroes the counters when it starts a sequence).  The row block's 64 NTB rows are cut into NP slices; slice p is
+// finished -- w = sum_p y_p[r] in panel order, Paige's t_j, the record, the basis column, the six measured inner products:
+// the arithmetic of k_pan_fin, row for row -- by whoever CLAIMS it (compare-and-swap on a per-slice word, j -> j + 1):
+//   * a workgroup that sees its row block complete within `spin_ticks` claims its own slice p (the normal case: all 252
+//     workgroups are resident, the arrival skew inside a row block is 1-3 us);
+//   * the LAST arriver (ticket == (j+1) NP - 1) takes its own slice and then every slice nobody has taken;
+//   * everybody else leaves.  Nobody waits for a workgroup that has not been scheduled: no co-residency assumption, no
+//     deadlock when other streams (evaluation lanes) share the chip; every slice is finished exactly once, by identical
+//     arithmetic whoever does it, and its six sums go to the slice's own slot of the partial-sum array (P = NB NP) --
+//     bit-reproducible.
+// The partials are read back with `sc1` loads (served by L2 / memory, never by this CU's L1).
+// 16-byte write-through store / L1-bypassing load of two consecutive partials (8-byte `sc1` accesses run at ~0.4-0.6 of the
+// 16-byte rate; every row block and slice starts at an even row, the partial-product planes have an even stride)
+typedef double pan_d2 __attribute__((ext_vector_type(2)));
+struct PanPair { double a, b; };
+__device__ __forceinline__ void pan_store_wt2(double* p, double a, double b) {
+    pan_d2 v; v.x = a; v.y = b;
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+}
+// (the caller waits: s_waitcnt vmcnt(0) behind a batch of these -- the compiler does not count asm loads)
+__device__ __forceinline__ pan_d2 pan_load_wt2(const double* p) {
+    pan_d2 r;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+
+#define PAN_STEP_ARGS(P, L, jrel) (((jrel) & 1) ? (L).Z1 : (L).Z0), (L).part, (L).st, (P).tptr, (P).thead, (P).n, (P).C, (P).NP, (P).TWW, (P), (L), (jrel)
+template <int RPT>
+__global__ __launch_bounds__(kPanThreads) void k_pan_step(const Z2* __restrict__ z_cur, double* l_part, LanState* l_st,
+                                                           const int* __restrict__ a_tptr, const unsigned short* __restrict__ a_thead,
+                                                           int a_n, int a_C, int a_NP, int a_TWW, PanView A_, PipeView L_, int jrel) {
+    PanView A = A_;
+    A.tptr = const_cast<int*>(a_tptr); A.thead = const_cast<unsigned short*>(a_thead); A.n = a_n; A.C = a_C; A.NP = a_NP; A.TWW = a_TWW;
+    PipeView L = L_;
+    L.part = l_part; L.st = l_st;
+    __shared__ double sv[RPT * kPanWorkThreads];
+    __shared__ double yblk[kPanRows];        // row-block image of the product phase; scratch of the slice epilogue afterwards
+    __shared__ double scoef[8];
+    __shared__ unsigned int sflag[4];
+    static_assert((RPT * kPanWorkThreads + kPanRows + 8) * 8 + 16 <= 163840, "panel + row-block image exceed the LDS");
+    static_assert(kNP * kPanWaves * 64 <= kPanRows, "slice epilogue scratch must fit the row-block image");
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x / A.NP, p = blockIdx.x - b * A.NP;
+    const int c0 = p * A.C;
+    const int Cp = min(A.C, A.n - c0);
+    const int R = 64 * A.NTB;
+    PAN_CLK(tid == 0, 0); PAN_CLK(tid == 64, 1);
+    if (wv == 0) {      // wave 0: step j-1's reductions (the coefficients everyone waits for)
+        int jd;
+        (void)pipe_prologue_wave0(L, jrel, -1, scoef, &jd);
+        PAN_CLK(tid == 0, 3);
+        __syncthreads();
+        __syncthreads();
+        __syncthreads();
+    } else {
+        const int wt = tid - 64, ww = wv - 1;
+        const Z2* __restrict__ Zc = z_cur + c0;
+        Z2 z[RPT];
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) z[i] = Zc[min(wt + kPanWorkThreads * i, Cp - 1)];
+        const int vt0 = ((b * A.NP + p) * kPanWork + ww) * A.TWW;
+        int ro[kPanTW], cend[kPanTW];
+        int E0;
+        {
+            int tp[kPanTW + 1];
+#pragma unroll
+            for (int q = 0; q <= kPanTW; ++q) tp[q] = __builtin_amdgcn_readfirstlane(A.tptr[vt0 + min(q, A.TWW)]);
+#pragma unroll
+            for (int q = 0; q < kPanTW; ++q) ro[q] = A.thead[(size_t)(vt0 + min(q, A.TWW - 1)) * 64 + lane];
+            E0 = tp[0];
+#pragma unroll
+            for (int q = 0; q < kPanTW; ++q) cend[q] = (tp[q + 1] - E0) >> 6;
+        }
+        const int nch = cend[kPanTW - 1];
+        const double* __restrict__ bv = A.bval + E0 + lane;
+        const unsigned short* __restrict__ bc = A.bcol + E0 + lane;
+        double pv[kPanCH];
+        int pk[kPanCH];
+#pragma unroll
+        for (int c = 0; c < kPanCH; ++c) { pv[c] = 0.0; pk[c] = 0; }
+#pragma unroll
+        for (int c = 0; c < kPanCH; ++c)
+            if (c < nch) { pv[c] = bv[c * 64]; pk[c] = bc[c * 64]; }
+        __syncthreads();
+        PAN_CLK(tid == 64, 4);
+        {
+            const double alpha = scoef[0], mu = scoef[2], inv = scoef[3];
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const int c = wt + kPanWorkThreads * i;
+                if (c < Cp) sv[c] = pan_vj(alpha, mu, inv, z[i].t, z[i].v);
+            }
+            for (int rl = wt; rl < R; rl += kPanWorkThreads) yblk[rl] = 0.0;
+        }
+        __syncthreads();
+        PAN_CLK(tid == 64, 5);
+        double acc = 0.0;
+        for (int cb = 0; cb < nch; cb += kPanCH) {
+#pragma clang fp contract(off)      // (two roundings at every chunk position: see k_pan_mul)
+            if (cb) {
+#pragma unroll
+                for (int c = 0; c < kPanCH; ++c)
+                    if (cb + c < nch) { pv[c] = bv[(cb + c) * 64]; pk[c] = bc[(cb + c) * 64]; }
+            }
+#pragma unroll
+            for (int c = 0; c < kPanCH; ++c) pv[c] *= sv[min(pk[c], Cp - 1)];
+            PAN_CLK(tid == 64 && cb == 0, 6);
+            unsigned endmask = 0;
+#pragma unroll
+            for (int q = 0; q < kPanTW; ++q) {
+                const int prev = q ? cend[q - 1] : 0, last = cend[q] - 1 - cb;
+                if (q < A.TWW && cend[q] > prev && last >= 0 && last < kPanCH) endmask |= 1u << last;
+            }
+#pragma unroll
+            for (int c = 0; c < kPanCH; ++c) {
+                if (cb + c < nch) {
+                    acc += pv[c];
+                    if (endmask & (1u << c)) {
+#pragma unroll
+                        for (int q = 0; q < kPanTW; ++q)
+                            if (cb + c + 1 == cend[q] && (q == 0 ? cend[0] > 0 : cend[q] > cend[q - 1])) yblk[ro[q]] = acc;
+                        acc = 0.0;
+                    }
+                }
+            }
+        }
+        PAN_CLK(tid == 64, 7);
+        __syncthreads();
+        // the row block's sums of this panel, un-sorted by the LDS image: coalesced WRITE-THROUGH stores, drained
+        {
+            const size_t ys = (size_t)((A.n + 1) & ~1);            // plane stride (even: 16-byte aligned pairs)
+            for (int rl = 2 * wt; rl < R; rl += 2 * kPanWorkThreads) {
+                const int row = b * R + rl;
+                if (row < A.n) pan_store_wt2(A.ypart + (size_t)p * ys + row, yblk[rl], yblk[rl + 1]);     // (R is even; a pair may run one past n: the plane is padded)
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PAN_CLK(tid == 64, 8);
+    }
+    __syncthreads();                      // every partial of this workgroup is in memory
+    const int j = (int)scoef[4];
+    const unsigned target = (unsigned)(j + 1) * (unsigned)A.NP;
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(A.tick + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned state = old + 1 == target ? 2u : 0u;       // 2: last arriver of the row block
+        if (!state && A.spin_ticks > 0) {
+            const long long t0 = wall_clock64();
+            do {
+                if (__hip_atomic_load(A.tick + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { state = 1u; break; }
+                __builtin_amdgcn_s_sleep(8);
+            } while (wall_clock64() - t0 < (long long)A.spin_ticks);
+        }
+        sflag[0] = state;
+    }
+    __syncthreads();
+    const unsigned state = sflag[0];
+    PAN_CLK(tid == 64, 9);
+    if (!state) return;                   // the row block is not complete and this workgroup has waited long enough
+    // ---- slices of row block b: own slice first; the last arriver then sweeps the rest ----
+    const int S = ((R + A.NP - 1) / A.NP + 1) & ~1;  // rows per slice (even)
+    const double alpha = scoef[0], beta = scoef[1], mu = scoef[2], inv = scoef[3];
+    const Z2* __restrict__ Zr = z_cur;
+    Z2* __restrict__ Zn = (jrel & 1) ? L.Z0 : L.Z1;
+    double* __restrict__ vj = L.V + (size_t)j * (size_t)L.n;
+    const int n = A.n, NP = A.NP;
+    const int nsweep = state == 2u ? NP : 1;
+    for (int k = 0; k < nsweep; ++k) {
+        const int sl = (p + k) % NP;
+        if (tid == 0) {
+            unsigned expect = (unsigned)j;
+            sflag[1] = __hip_atomic_compare_exchange_strong(A.claim + (size_t)b * NP + sl, &expect, (unsigned)(j + 1), __ATOMIC_RELAXED,
+                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
+        }
+        __syncthreads();
+        const bool mine = sflag[1] != 0u;
+        __syncthreads();
+        if (!mine) continue;
+        PipeRow pr;
+        pr.clear();
+        const size_t ys = (size_t)((n + 1) & ~1);
+        const int r_lo = b * R + sl * S, r_hi = min(min(r_lo + S, (b + 1) * R), n);     // (S even: pairs of rows)
+        for (int r = r_lo + 2 * tid; r < r_hi; r += 2 * kPanThreads) {
+            const bool two = r + 1 < r_hi;
+            const Z2 z0 = Zr[r], z1 = Zr[two ? r + 1 : r];
+            double w0 = 0.0, w1 = 0.0;
+            for (int p0 = 0; p0 < NP; p0 += 12) {     // twelve panels in flight; added in panel order
+                pan_d2 y[12];
+#pragma unroll
+                for (int q = 0; q < 12; ++q) y[q] = pan_load_wt2(A.ypart + (size_t)min(p0 + q, NP - 1) * ys + r);
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]), "+v"(y[6]), "+v"(y[7]),
+                             "+v"(y[8]), "+v"(y[9]), "+v"(y[10]), "+v"(y[11]) :: "memory");      // (ties the values to the wait)
+#pragma unroll
+                for (int q = 0; q < 12; ++q) { w0 += (p0 + q < NP) ? y[q].x : 0.0; w1 += (p0 + q < NP) ? y[q].y : 0.0; }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (h && !two) break;
+                const Z2 z = h ? z1 : z0;
+                const double w = h ? w1 : w0;
+                Z2 o;
+                o.v = pan_vj(alpha, mu, inv, z.t, z.v);
+                o.t = __builtin_fma(-beta, z.v, w);      // Paige's intermediate for the next step
+                vj[r + h] = o.v;
+                Zn[r + h] = o;
+                const double t = o.t, v = o.v;
+                pr.acc[0] = __builtin_fma(t, t, pr.acc[0]); pr.acc[1] = __builtin_fma(t, v, pr.acc[1]); pr.acc[2] = __builtin_fma(v, v, pr.acc[2]);
+                pr.acc[3] += t; pr.acc[4] += v; pr.acc[5] += fabs(v);
+            }
+        }
+        // six sums of the slice -> its slot (b NP + sl) of the partial-sum array (PipeRow::store with the slot made explicit)
+        {
+            constexpr int NW = kPanWaves;
+#pragma unroll
+            for (int q = 0; q < kNP; ++q) yblk[(q * NW + wv) * 64 + lane] = pr.acc[q];
+            __syncthreads();
+            for (int q = wv; q < kNP; q += NW) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) sacc += yblk[(q * NW + w) * 64 + lane];
+                sacc = wave_total(sacc);
+                if (lane == 0) L.part[(size_t)((jrel + 1) & 1) * (kNP * kMaxGrid) + q * kMaxGrid + (b * NP + sl)] = sacc;
+            }
+            __syncthreads();
+        }
+    }
+    PAN_CLK(tid == 64, 10); PAN_CLK(tid == 1023, 11);
 }
 
 }  // namespace machip

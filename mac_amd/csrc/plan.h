@@ -140,6 +140,7 @@ struct PanPlan {
     bool on = false;
     int NP = 1, C = 1, NB = 1, NTB = 1, TWW = 1, RPT = 1;
     int grid2 = 1, block2 = 256;     // launch shape of k_pan_fin
+    bool fused = false;              // one launch per step (k_pan_step) instead of k_pan_mul + k_pan_fin (measured SLOWER: profiles/r4_c4_one_launch_step.md)
 };
 inline PanPlan plan_panel(int n, long nnz, int maxlen, bool allowed) {
     PanPlan pp;
@@ -188,6 +189,9 @@ inline PanPlan plan_panel(int n, long nnz, int maxlen, bool allowed) {
     nb = (groups + ntb - 1) / ntb;
     pp.on = true; pp.NP = np; pp.C = C; pp.NB = nb; pp.NTB = ntb; pp.TWW = (ntb + kPanWork - 1) / kPanWork;
     pp.RPT = (C + kPanWorkThreads - 1) / kPanWorkThreads;
+    // MACHIP_PANEL_FUSED=1: the one-launch form (k_pan_step; tickets for 256 row blocks, one partial-sum slot per slice).  Off by
+    // default: 26.9 against 19.1 us per step at configs[3] -- the in-launch hand-off costs more than the launch it saves.
+    pp.fused = env_int("MACHIP_PANEL_FUSED", 0) != 0 && nb <= 256 && nb * np <= 256;
     pp.block2 = env_int("MACHIP_PANEL_B2", 512);
     if (pp.block2 != 256 && pp.block2 != 512 && pp.block2 != 1024) pp.block2 = 256;
     pp.grid2 = (int)std::max<long>(1, std::min<long>(env_int("MACHIP_PANEL_G2", grid_cap()), ((long)n + pp.block2 - 1) / pp.block2));

@@ -593,6 +593,9 @@ __device__ __forceinline__ LobCoef lob_rayleigh_ritz(const double* s, int n, boo
 }
 
 // ---- x, p, Lx, Lp, r of the next iteration -----------------------------------------------------
+// JAC: diagonal (Jacobi) preconditioner -- w = r / diag(L) is formed right here (L.tdinv = 1 / diag in natural order,
+// c = 1: the chunk-transposed layout is the identity), so an iteration is two launches: SpMV + inner products, update.
+template <bool JAC = false>
 __global__ __launch_bounds__(kBlock) void k_lob_update(LobView L, int jrel) {
     __shared__ double sc[8];
     __shared__ double sm[4];
@@ -651,14 +654,25 @@ __global__ __launch_bounds__(kBlock) void k_lob_update(LobView L, int jrel) {
         const double lxn = z0 * L.Lx[r] + lpn;
         L.p[r] = pn; L.Lp[r] = lpn; L.x[r] = xn; L.Lx[r] = lxn;
         const double res = lxn - th * xn;
-        L.rT[k] = res;
+        if (JAC) L.wT[k] = res * L.tdinv[k]; else L.rT[k] = res;
         l1 += fabs(res);
     }
     l1 = block_sum(l1, sm);
     if (threadIdx.x == 0) L.partR[(size_t)(itn & 1) * kMaxGrid + blockIdx.x] = l1;
 }
 
+// 1 / diag(L) in natural order (Jacobi preconditioner; any CSR: the row is searched for its diagonal entry)
+__global__ __launch_bounds__(kBlock) void k_jac_dinv(CsrView A, double* __restrict__ dinv, int* bad) {
+    for (int r = blockIdx.x * kBlock + threadIdx.x; r < A.n; r += gridDim.x * kBlock) {
+        double d = 0.0;
+        for (int p = A.rowptr[r]; p < A.rowptr[r + 1]; ++p) if (A.col[p] == r) d += A.val[p];
+        if (!(d > 0.0)) { *bad = 1; d = 1.0; }
+        dinv[r] = 1.0 / d;
+    }
+}
+
 // First residual of a (re)started recurrence: x = yvec (unit, mean free), Lx = w2 = L yvec.
+template <bool JAC = false>
 __global__ __launch_bounds__(kBlock) void k_lob_start(LobView L, const double* __restrict__ xin, const double* __restrict__ lxin,
                                                       const double* __restrict__ rq, int it0, unsigned int epoch) {
     __shared__ double sm[4];
@@ -668,7 +682,7 @@ __global__ __launch_bounds__(kBlock) void k_lob_start(LobView L, const double* _
         const double x = xin[r], lx = lxin[r];
         L.x[r] = x; L.Lx[r] = lx; L.p[r] = 0.0; L.Lp[r] = 0.0;
         const double res = lx - th * x;
-        L.rT[tri_perm(r, L.c, L.stride)] = res;
+        if (JAC) L.wT[r] = res * L.tdinv[r]; else L.rT[tri_perm(r, L.c, L.stride)] = res;
         l1 += fabs(res);
     }
     l1 = block_sum(l1, sm);

@@ -179,7 +179,7 @@ struct Solver {
                         lx_ys, lx_pas, lx_as, lx_bs, lx_maps, lx_ba, lx_bd, lx_bu, wb_ui, wb_uj, wb_counts, wb_uc, wb_g, wb_h, wb_Zt, wb_Cm, wb_pas, wb_maps,
                         lx_colT, lx_bad, lx_st, valf};
         {
-            void* pb[] = {panv.tptr, panv.thead, panv.bval, panv.bcol, panv.ypart, panv.coef, panv.tcount, panv.ps};
+            void* pb[] = {panv.tptr, panv.thead, panv.bval, panv.bcol, panv.ypart, panv.coef, panv.tcount, panv.ps, panv.tick, panv.claim};
             for (void* q : pb) if (q) (void)hipFree(q);
             void* pk[] = {ppack.band, ppack.cc, ppack.crow, ppack.ccol, ppack.cval, ell_col, ell_val};
             for (void* q : pk) if (q) (void)hipFree(q);
@@ -298,11 +298,13 @@ struct Solver {
             pan_cap = want;
         }
         if ((size_t)pn.NP * (size_t)n > pan_y_cap) {
-            ST_TRY(regrow(&panv.ypart, (size_t)pn.NP * (size_t)n));
+            ST_TRY(regrow(&panv.ypart, (size_t)pn.NP * ((size_t)n + 2)));     // (k_pan_step: even plane stride, pairs of rows)
             ST_TRY(regrow(&panv.ps, ((size_t)pn.NP + 1) * (size_t)n));
             pan_y_cap = (size_t)pn.NP * (size_t)n;
         }
         if (!panv.coef) ST_TRY(dev_alloc(&panv.coef, 8));
+        if (!panv.tick) { ST_TRY(dev_alloc(&panv.tick, 256)); ST_TRY(dev_alloc(&panv.claim, 4096)); }     // (NB <= 256, NB NP <= 4096: plan_panel)
+        panv.spin_ticks = env_int("MACHIP_PANEL_SPIN_US", 20) * 100;
         panv.n = n; panv.NP = pn.NP; panv.C = pn.C; panv.NB = pn.NB; panv.NTB = pn.NTB; panv.TWW = pn.TWW;
         k_pan_rows<<<(n + kBlock - 1) / kBlock, kBlock, 0, stream>>>(A, panv);
         k_pan_count<<<pan_build_grid(pn.NB, pn.NP), kPanThreads, 0, stream>>>(A, panv);
@@ -313,6 +315,16 @@ struct Solver {
     }
     void launch_pan_step(const PipeView& L, int s) {
         const int g1 = pan.NB * pan.NP;
+        if (pan.fused) {     // one launch per step (k_pan_step)
+            switch (pan.RPT) {
+#define MACHIP_PAN_CASE(R) case R: k_pan_step<R><<<g1, kPanThreads, 0, stream>>>(PAN_STEP_ARGS(panv, L, s)); break;
+                MACHIP_PAN_CASE(1) MACHIP_PAN_CASE(2) MACHIP_PAN_CASE(3) MACHIP_PAN_CASE(4) MACHIP_PAN_CASE(5) MACHIP_PAN_CASE(6)
+                MACHIP_PAN_CASE(7) MACHIP_PAN_CASE(8) MACHIP_PAN_CASE(9) MACHIP_PAN_CASE(10) MACHIP_PAN_CASE(11) MACHIP_PAN_CASE(12)
+#undef MACHIP_PAN_CASE
+                default: k_pan_step<13><<<g1, kPanThreads, 0, stream>>>(PAN_STEP_ARGS(panv, L, s)); break;
+            }
+            return;
+        }
         switch (pan.RPT) {
 #define MACHIP_PAN_CASE(R) case R: k_pan_mul<R><<<g1, kPanThreads, 0, stream>>>(PAN_MUL_ARGS(panv, L, s)); break;
             MACHIP_PAN_CASE(1) MACHIP_PAN_CASE(2) MACHIP_PAN_CASE(3) MACHIP_PAN_CASE(4) MACHIP_PAN_CASE(5) MACHIP_PAN_CASE(6)
@@ -522,13 +534,16 @@ struct Solver {
         if (!lob_ready) {
             ST_TRY(dev_alloc(&lx_x, n)); ST_TRY(dev_alloc(&lx_Lx, n)); ST_TRY(dev_alloc(&lx_p, n));
             ST_TRY(dev_alloc(&lx_Lp, n)); ST_TRY(dev_alloc(&lx_Lw, n));
-            const size_t tcap = (size_t)lob_c() * (size_t)lob_stride();   // chunk-transposed, zero padded past n
+            const bool jsave = lob_jacobi;
+            lob_jacobi = false;
+            const size_t tcap = std::max((size_t)lob_c() * (size_t)lob_stride(), (size_t)n);   // chunk-transposed, zero padded past n
+            lob_jacobi = jsave;
             double** tr[] = {&lx_rT, &lx_wT, &lx_tl, &lx_tdinv, &lx_tcu, &lx_ba, &lx_bd, &lx_bu};
             for (double** q : tr) {
                 ST_TRY(dev_alloc(q, tcap));
                 HIP_TRY(hipMemsetAsync(*q, 0, sizeof(double) * tcap, stream));
             }
-            if (n > kTriMaxN) {
+            if (n > kTriMaxN && n <= kTriBigMaxN) {
                 const size_t fcap = (size_t)kTriThreads * (size_t)((n + kTriThreads - 1) / kTriThreads);
                 ST_TRY(dev_alloc(&lx_ys, tcap)); ST_TRY(dev_alloc(&lx_pas, tcap));
                 ST_TRY(dev_alloc(&lx_as, fcap)); ST_TRY(dev_alloc(&lx_bs, fcap));
@@ -550,8 +565,10 @@ struct Solver {
     }
     // layout of the tridiagonal solver: up to n = 16 384 one workgroup, c = ceil(n/1024) unknowns per thread;
     // beyond, 4 unknowns per thread and as many 1024-thread workgroups as that takes
-    int lob_c() const { return n > kTriMaxN ? kTriBigC : (n + kTriThreads - 1) / kTriThreads; }
+    bool lob_jacobi = false;   // the running preconditioned solve uses the diagonal preconditioner (natural layout, c = 1)
+    int lob_c() const { return lob_jacobi ? 1 : n > kTriMaxN ? kTriBigC : (n + kTriThreads - 1) / kTriThreads; }
     int lob_stride() const {
+        if (lob_jacobi) return n;
         if (n <= kTriMaxN) return kTriThreads;
         const int q = (n + kTriBigC - 1) / kTriBigC;
         return (q + kTriThreads - 1) / kTriThreads * kTriThreads;
@@ -580,11 +597,21 @@ struct Solver {
                 k_wb_w<<<(int)std::min<size_t>(kMaxGrid, (W.cap + kBlock - 1) / kBlock), kBlock, 0, stream>>>(L, W);
             }
             launch_spmv(pl, stream, AT, L.wT, op);
-            k_lob_update<<<L.P_a, kBlock, 0, stream>>>(L, s);
+            k_lob_update<false><<<L.P_a, kBlock, 0, stream>>>(L, s);
         }
         k_lob_tail<<<1, 64, 0, stream>>>(L, steps);
     }
     void lob_launch_chunk(const CsrView& AT, const SpmvPlan& pl, const LobView& L, int steps) {
+        if (lob_jacobi) {          // diagonal preconditioner: two launches per iteration
+            OpLob op;
+            op.L = L;
+            for (int s = 0; s < steps; ++s) {
+                launch_spmv(pl, stream, AT, L.wT, op);
+                k_lob_update<true><<<L.P_a, kBlock, 0, stream>>>(L, s);
+            }
+            k_lob_tail<<<1, 64, 0, stream>>>(L, steps);
+            return;
+        }
         if (n > kTriMaxN) {
             OpLob op;
             op.L = L;
@@ -600,7 +627,7 @@ struct Solver {
                     k_wb_w<<<(int)std::min<size_t>(kMaxGrid, (W.cap + kBlock - 1) / kBlock), kBlock, 0, stream>>>(L, W);
                 }
                 launch_spmv(pl, stream, AT, L.wT, op);
-                k_lob_update<<<L.P_a, kBlock, 0, stream>>>(L, s);
+                k_lob_update<false><<<L.P_a, kBlock, 0, stream>>>(L, s);
             }
             k_lob_tail<<<1, 64, 0, stream>>>(L, steps);
             return;
@@ -617,7 +644,7 @@ struct Solver {
     int lob_enqueue_chunk(const CsrView& A, const CsrView& AT, const SpmvPlan& pl, const LobView& L, int steps) {
         if (!use_graph || wb_active.s > 0) { lob_launch_chunk(AT, pl, L, steps); return MACHIP_OK; }   // (closure count is baked into the launches)
         if (graph_csr_key != (const void*)A.val) { drop_graphs(); graph_csr_key = (const void*)A.val; }
-        const auto key = std::make_tuple(1000 + pl.variant, pl.width, pl.grid, L.c + (n > kTriMaxN ? 100 : 0), steps);
+        const auto key = std::make_tuple(1000 + pl.variant, pl.width, pl.grid, L.c + (n > kTriMaxN ? 100 : 0) + (lob_jacobi ? 1000 : 0), steps);
         auto it = graphs.find(key);
         if (it == graphs.end()) it = graphs.emplace(key, std::array<hipGraphExec_t, 2>{nullptr, nullptr}).first;
         hipGraphExec_t& ge = it->second[(size_t)(graph_flip++ & 1)];
@@ -723,8 +750,9 @@ struct Solver {
     // Returns MACHIP_OK (converged: yvec, *lam, *res set), MACHIP_NOT_CONVERGED (caller falls back to
     // Lanczos) or an error.
     int solve_lob(const CsrView& A, long nnz, double lnorm, double tol, int max_steps, int start_mode,
-                  double* lam, double* res, long* iters, long* spmvs, long* restarts_out) {
-        ST_TRY(lob_alloc(nnz));
+                  double* lam, double* res, long* iters, long* spmvs, long* restarts_out, bool jacobi = false) {
+        lob_jacobi = jacobi;
+        ST_TRY(lob_alloc(jacobi ? 0 : nnz));
         const SpmvPlan pl = plan_spmv(n, nnz, kAuto);
         const LobView L = lview(pl);
         const int g2 = vgrid();
@@ -734,7 +762,7 @@ struct Solver {
         wb_active.s = 0;
         int wb_s = 0;
         lob_escalate = false;
-        const bool wb_enabled = env_int("MACHIP_WOODBURY", 1) != 0 && chain_like && support_hint >= 0;
+        const bool wb_enabled = !jacobi && env_int("MACHIP_WOODBURY", 1) != 0 && chain_like && support_hint >= 0;
         const bool may_escalate = wb_enabled && support_hint > wb_limit_now && support_hint <= wb_hard();
         if (wb_enabled && support_hint <= wb_limit_now) {
             ST_TRY(wb_alloc());
@@ -751,7 +779,8 @@ struct Solver {
         // the device; gather indices in the solver's layout ----
         const double sigma = (wb_s > 0 ? 1e-8 : 2.5e-7) * scale;
         HIP_TRY(hipMemsetAsync(lx_bad, 0, sizeof(int), stream));
-        if (n > kTriMaxN) k_tri_factor_big<<<1, kTriThreads, 0, stream>>>(A, L.stride, sigma, lx_tl, lx_tdinv, lx_tcu, lx_as, lx_bs, lx_bad, chain_only);
+        if (jacobi) k_jac_dinv<<<g2, kBlock, 0, stream>>>(A, lx_tdinv, lx_bad);
+        else if (n > kTriMaxN) k_tri_factor_big<<<1, kTriThreads, 0, stream>>>(A, L.stride, sigma, lx_tl, lx_tdinv, lx_tcu, lx_as, lx_bs, lx_bad, chain_only);
         else {
             k_tri_band<<<g2, kBlock, 0, stream>>>(A, L.c, L.stride, lx_ba, lx_bd, lx_bu);
             switch (L.c) {
@@ -763,9 +792,11 @@ struct Solver {
             default: k_tri_factor<16><<<1, kTriThreads, 0, stream>>>(n, lx_ba, lx_bd, lx_bu, sigma, lx_tl, lx_tdinv, lx_tcu, lx_bad, chain_only); break;
             }
         }
-        k_lob_perm_cols<<<(int)std::min<long>(kMaxGrid, (nnz + kBlock - 1) / kBlock), kBlock, 0, stream>>>(A.col, nnz, L.c, L.stride, lx_colT);
         CsrView AT = A;
-        AT.col = lx_colT;
+        if (!jacobi) {
+            k_lob_perm_cols<<<(int)std::min<long>(kMaxGrid, (nnz + kBlock - 1) / kBlock), kBlock, 0, stream>>>(A.col, nnz, L.c, L.stride, lx_colT);
+            AT.col = lx_colT;
+        }
         if (wb_s > 0) {
             const int st = wb_build(L, wb_s);
             if (st != MACHIP_OK && st != MACHIP_NOT_CONVERGED) return st;
@@ -796,7 +827,8 @@ struct Solver {
         int best_it = 0;
         while (true) {
             ++epoch;
-            k_lob_start<<<g2, kBlock, 0, stream>>>(L, yvec, w2, rq_dev, it_enq, epoch);
+            if (jacobi) k_lob_start<true><<<g2, kBlock, 0, stream>>>(L, yvec, w2, rq_dev, it_enq, epoch);
+            else k_lob_start<false><<<g2, kBlock, 0, stream>>>(L, yvec, w2, rq_dev, it_enq, epoch);
             std::deque<int> pend;
             std::deque<std::pair<int, double>> hist;
             double to_go = 1e18, est = 1e300;
@@ -876,6 +908,7 @@ struct Solver {
         if (const char* e = getenv("MACHIP_SOLVER")) {
             if (!strcmp(e, "lanczos")) mode = 1;
             else if (!strcmp(e, "lobpcg")) mode = 2;
+            else if (!strcmp(e, "jacobi")) mode = 3;
             else if (!strcmp(e, "auto")) mode = 0;
         }
         // auto: chain-dominated graphs with few active closures per node (measured cross-over)
@@ -904,12 +937,13 @@ struct Solver {
                           (mode == 2 || (mode == 0 && chain_like && support_hint >= 0 && ((sparse && !slow_lob) || stiff)));
         last_was_lob = false;
         final_check_seq = -2;
-        if (eligible && want) {
+        const bool want_jac = mode == 3 && n > 256;
+        if ((eligible && want) || want_jac) {
             HIP_TRY(hipEventRecord(ev0, stream));
             double lam = 0.0, res = 0.0;
             long iters = 0, spmvs = 0, rst = 0;
             wb_limit_now = wb_soft();
-            int st = solve_lob(A, nnz, lnorm, tol, max_steps, start_mode, &lam, &res, &iters, &spmvs, &rst);
+            int st = solve_lob(A, nnz, lnorm, tol, max_steps, start_mode, &lam, &res, &iters, &spmvs, &rst, want_jac);
             if (st == MACHIP_NOT_CONVERGED && lob_escalate) {
                 long it1 = iters, sp1 = spmvs;
                 wb_limit_now = wb_hard();
@@ -999,8 +1033,8 @@ struct Solver {
         }
         if (pan.on) {
             ST_TRY(ensure_panel(A, nnz, pan));
-            pp.variant = kPanel; pp.grid = pan.grid2; pp.block = pan.block2;
-            pp.width = pan.NP * 100 + pan.RPT; pp.unroll = pan.TWW; pp.defer = pan.NB;
+            pp.variant = kPanel; pp.grid = pan.fused ? pan.NB * pan.NP : pan.grid2; pp.block = pan.fused ? kBlock : pan.block2;   // (grid = partial sums per quantity)
+            pp.width = pan.NP * 100 + pan.RPT; pp.unroll = pan.TWW; pp.defer = pan.NB + (pan.fused ? 1000 : 0);
         }
         const PipeView L = pview(pp);
         const int pchunk0 = std::min(kPersistMaxSteps, std::max(2, env_int("MACHIP_PCHUNK", 64)));
@@ -1073,6 +1107,10 @@ struct Solver {
             } else {
                 ++epoch;
                 k_pipe_init<<<pp.grid, kBlock, 0, stream>>>(L, u, (int)epoch);
+                if (pan.on && pan.fused) {      // arrival tickets / slice claims of k_pan_step count from the sequence's step 0
+                    HIP_TRY(hipMemsetAsync(panv.tick, 0, sizeof(unsigned int) * 256, stream));
+                    HIP_TRY(hipMemsetAsync(panv.claim, 0, sizeof(unsigned int) * 4096, stream));
+                }
                 if (shard && pp.variant == kVec) {       // row-partitioned sequence: every rank starts from the same records
                     seq_sharded = true; seq_plan = pp;
                     ST_TRY(shard_broadcast_init());
