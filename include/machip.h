@@ -179,8 +179,8 @@ int machip_shard_plan(int64_t m, int nranks, int rank, int64_t* lo, int64_t* hi,
 /* MAC.evaluate_objective for B selection vectors at once (mac/solvers/mac.py:91-102 as called in a loop by
  * round_madow(value_fn=evaluate_objective, max_iters > 1), mac/utils/rounding.py:63-75, and by the budget sweep of
  * examples/g2o_experiment.py:347-376).  X: B x m row-major on the host; lambda2: B doubles; status (may be NULL): B
- * machip_status values (OK / NOT_CONVERGED / DISCONNECTED per entry).  The handle keeps up to MACHIP_LANES (default 12)
- * evaluation lanes -- own x, CSR buffers, eigen-solver state and stream, sharing the pattern and the candidate
+ * machip_status values (OK / NOT_CONVERGED / DISCONNECTED per entry).  The handle keeps up to MACHIP_LANES (default 16 for
+ * single-workgroup solves, 4 otherwise) evaluation lanes -- own x, CSR buffers, eigen-solver state and stream, sharing the pattern and the candidate
  * arrays -- driven by one host thread each, so the small latency-bound solves of a pose graph overlap on the GPU.
  * Cold starts from the handle's start vector (machip_set_start), solver mode / precision of the handle; the
  * handle's own x, gradient and Fiedler vector are not touched.  Returns the first hard error, else MACHIP_OK. */
@@ -194,9 +194,12 @@ int machip_eval_batch(machip_problem* p, int B, const double* X, double tol, int
  * top-ks[b], gamma_i = 2/(i+2), dual bound from the pre-update x, stop when ||g|| < grad_tol or
  * (upper - f) < gap_tol |f|, at most max_iters iterations -- from X0[b] (B x m row-major, host), on one of the handle's
  * evaluation lanes (own x / gradient / CSR / eigen-solver state / stream, sharing pattern and candidate arrays; up to
- * MACHIP_LANES = 12 run concurrently, one host thread each).  Every problem starts from a clean solver state and the
- * handle's start vector: its results are bit-identical to a fresh handle running machip_fw_step / machip_fw_commit in a
- * loop, whatever lane takes it.
+ * MACHIP_LANES run concurrently, one host thread each, each stream on a hardware queue of its own).  Every problem starts
+ * from a clean solver state and the handle's start vector: its results are bit-identical to a fresh handle running
+ * machip_fw_step / machip_fw_commit in a loop, whatever lane takes it -- as long as no single Krylov sequence outgrows the
+ * lane's basis (a lane holds MACHIP_LANE_VBUDGET_MB = 1/8 of the handle's basis budget: 6 710 columns against 10 010 at
+ * n = 1e4, 671 against 5 368 at n = 1e5); a longer sequence restarts earlier on a lane than on the handle and then agrees
+ * with it to the solver tolerance, not bit for bit.
  * Outputs (host): X_out B x m final relaxed x (what MAC.solve returns as `unrounded`); R_out (may be NULL) B x m
  * round_nearest(x, ks[b], weights, round_decimals) as machip_round_nearest computes it; upper[B] dual upper bounds;
  * f_traj (may be NULL) B x max_iters lambda_2 per iteration; iters[B] iterations done; status[B] per problem

@@ -7,8 +7,6 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# one hardware queue per evaluation lane (read by the HIP runtime at initialisation; see machip.hip)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 LIB_PATH = os.environ.get("MACHIP_LIB") or os.path.join(_HERE, "libmachip.so")   # MACHIP_LIB: developer override (sanitizer builds)
 
 OK, NOT_CONVERGED, DISCONNECTED, BAD_ARG, HIP_ERROR, RCCL_ERROR, NO_DEVICE = range(7)

@@ -103,7 +103,7 @@ struct machip_problem {
     std::shared_ptr<LocalGroup> lgroup;
     int rank = 0, nranks = 1;
     // evaluation lanes (machip_eval_batch): lightweight copies that share the pattern and the candidate arrays
-    bool is_lane = false;
+    bool is_lane = false, lane_fw_ready = false;
     std::vector<machip_problem*> lanes;
     unsigned long start_version = 0;          // bumped whenever sol.start changes
     unsigned long seen_start_version = ~0ul;  // (lane) the owner's start_version this lane last copied
@@ -112,11 +112,28 @@ struct machip_problem {
     PatternView pattern() const { return PatternView{n, prow, pcol, pk, pw}; }
 };
 
-// ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) per process; kernels of streams that share a queue
+// ROCm maps a process's HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); kernels of streams that share a queue
 // run one after another.  The concurrent budget sweep keeps up to 12 single-CU solves in flight (machip_fw_sweep, one stream per
-// lane): with 4 queues it saturates at ~2.8x, with 16 at 7x (intel 1 764 -> 4 155 it/s, sphere2500 3 660 -> 6 288).  The variable
-// is read when the HIP runtime initialises, so it is set -- unless the application chose a value -- when this library is loaded.
-static const int g_hw_queues_set = [] { return setenv("GPU_MAX_HW_QUEUES", "16", 0); }();
+// lane): on 4 shared queues it saturates at ~2.8x, with a queue per lane at 5-7x (intel 1 764 -> 4 155 it/s).  Round 3 raised
+// the process-wide variable when the library was loaded -- a side effect on every other HIP user of the process, and silently
+// ineffective once HIP was initialised.  Round 4: a lane's stream is created WITH A CU MASK (all CUs enabled): the runtime
+// gives a CU-masked stream a hardware queue of its own (the mask is a property of the queue) instead of one from the shared
+// pool -- per stream, no environment, no effect on anybody else.  MACHIP_LANE_QUEUES=shared takes plain streams.
+static int create_lane_stream(int device, hipStream_t* out) {
+    const char* mode = getenv("MACHIP_LANE_QUEUES");
+    if (!(mode && !strcmp(mode, "shared"))) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
+            const int words = (prop.multiProcessorCount + 31) / 32;
+            std::vector<uint32_t> mask((size_t)words, 0xffffffffu);
+            if (prop.multiProcessorCount % 32) mask.back() = (1u << (prop.multiProcessorCount % 32)) - 1u;
+            if (hipExtStreamCreateWithCUMask(out, (uint32_t)words, mask.data()) == hipSuccess) return MACHIP_OK;
+            (void)hipGetLastError();     // (no such queue available: a plain stream serves, more slowly)
+        }
+    }
+    HIP_TRY(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    return MACHIP_OK;
+}
 
 namespace {
 
@@ -662,17 +679,19 @@ int machip_fiedler_csr(int device, int64_t n, const int32_t* indptr, const int32
     if (!indptr || !indices || !data || !lambda2) return fail(MACHIP_BAD_ARG, "NULL argument");
     if (n < 2 || n > 2000000000ll) return fail(MACHIP_BAD_ARG, "n must be in [2, 2e9]");
     if (X_out && (q < 1 || q > 4)) return fail(MACHIP_BAD_ARG, "q must be in [1,4]");
-    if (machip_device_count() <= 0) return fail(MACHIP_NO_DEVICE, "no HIP device visible");
-    HIP_TRY(hipSetDevice(device));
+    // The row pointers are validated as a whole BEFORE anything is read through them (this entry point takes arbitrary
+    // caller matrices): first entry 0, monotone, hence every row's range inside [0, indptr[n]) -- and all of that on the
+    // host, before the first device call, so a malformed matrix is a BAD_ARG on any machine.
     const long nnz = indptr[n];
-    if (indptr[0] != 0 || nnz < 0) return fail(MACHIP_BAD_ARG, "bad indptr");
+    if (indptr[0] != 0 || nnz < 0) return fail(MACHIP_BAD_ARG, "bad indptr: indptr[0] must be 0 and indptr[n] >= 0 (int32 row pointers: nnz < 2^31)");
+    for (int64_t r = 0; r < n; ++r)
+        if (indptr[r + 1] < indptr[r]) return fail(MACHIP_BAD_ARG, "indptr not monotone");
     double lnorm = 0.0;
     int maxlen_csr = 0;
     long chain_cnt = 0;   // super-diagonal entries: a pose-graph Laplacian carries the chain (i, i+1)
     for (int64_t r = 0; r < n; ++r) {
-        if (indptr[r + 1] < indptr[r]) return fail(MACHIP_BAD_ARG, "indptr not monotone");
         double s = 0.0;
-        for (int pp = indptr[r]; pp < indptr[r + 1]; ++pp) {
+        for (long pp = indptr[r]; pp < (long)indptr[r + 1]; ++pp) {
             if (indices[pp] < 0 || indices[pp] >= n) return fail(MACHIP_BAD_ARG, "column index out of range");
             s += std::fabs(data[pp]);
             if (indices[pp] == r + 1 && data[pp] != 0.0) ++chain_cnt;
@@ -680,6 +699,8 @@ int machip_fiedler_csr(int device, int64_t n, const int32_t* indptr, const int32
         lnorm = std::max(lnorm, s);   // nx:232
         maxlen_csr = std::max(maxlen_csr, (int)(indptr[r + 1] - indptr[r]));
     }
+    if (machip_device_count() <= 0) return fail(MACHIP_NO_DEVICE, "no HIP device visible");
+    HIP_TRY(hipSetDevice(device));
     // One CSR-only handle is kept between calls (stream, ~25 device buffers, pinned mirrors, chunk graphs: creating them
     // costs more than a small solve -- a Madow loop or a sweep through find_fiedler_pair paid it per call).  It is reused
     // when device and n match and the matrix fits; every solve starts from a clean solver state, so a cached handle
@@ -877,14 +898,15 @@ int make_lane(machip_problem* p, machip_problem** out) {
     q->asm_G = p->asm_G; q->asm_rpb = p->asm_rpb; q->asm_grid = p->asm_grid;
     q->ci = p->ci; q->cj = p->cj; q->cw = p->cw;
     auto body = [&]() -> int {
-        HIP_TRY(hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking));
+        ST_TRY(create_lane_stream(q->device, &q->stream));
         ST_TRY(dev_alloc(&q->x, (size_t)q->m + 64));
         const size_t cap = (size_t)q->P + (size_t)q->n + 8;
         ST_TRY(dev_alloc(&q->cnt, (size_t)q->n + 1)); ST_TRY(dev_alloc(&q->blk_sum, 3 * kMaxGrid));
         ST_TRY(dev_alloc(&q->rowptr, (size_t)q->n + 1)); ST_TRY(dev_alloc(&q->col, cap)); ST_TRY(dev_alloc(&q->val, cap));
         ST_TRY(dev_alloc(&q->blk_lnorm, kMaxGrid)); ST_TRY(dev_alloc(&q->sval, (size_t)q->P + 8));
         // every lane keeps its own Krylov basis: a share of the handle's budget each (MACHIP_LANE_VBUDGET_MB, default
-        // MACHIP_VBUDGET_MB / 8 = 512 MB: 8 lanes together hold what the handle itself holds)
+        // MACHIP_VBUDGET_MB / 8 = 512 MB: 16 lanes together hold twice what the handle itself holds; a sequence longer than
+        // the lane's share restarts earlier than it would on the handle -- include/machip.h states the guarantee accordingly)
         ST_TRY(alloc_common(q, std::max(16, env_int("MACHIP_LANE_VBUDGET_MB", std::max(16, env_int("MACHIP_VBUDGET_MB", 4096) / 8)))));
         q->sol.csr_cap = cap;
         q->sol.chain_like = p->sol.chain_like; q->sol.chain_edges = p->sol.chain_edges;
@@ -898,21 +920,28 @@ int make_lane(machip_problem* p, machip_problem** out) {
 
 // FW state of a lane (gradient, LP vertex, next iterate, select scratch): only the sweep needs it
 int ensure_lane_fw(machip_problem* q) {
-    if (q->g) return MACHIP_OK;
+    if (q->lane_fw_ready) return MACHIP_OK;
     const size_t mp = (size_t)q->m + 64 * 8;
-    ST_TRY(dev_alloc(&q->x_next, mp)); ST_TRY(dev_alloc(&q->g, mp)); ST_TRY(dev_alloc(&q->s, mp));
-    HIP_TRY(hipMemset(q->g, 0, sizeof(double) * mp));
-    ST_TRY(dev_alloc(&q->hist, 6 * kBins)); ST_TRY(dev_alloc(&q->sel, 2)); ST_TRY(dev_alloc(&q->part_fw, 2 * kMaxGrid));
+    // each pointer guarded on its own: a failed allocation half way leaves nothing to leak when the next call retries
+    if (!q->x_next) ST_TRY(dev_alloc(&q->x_next, mp));
+    if (!q->g) ST_TRY(dev_alloc(&q->g, mp));
+    if (!q->s) ST_TRY(dev_alloc(&q->s, mp));
+    if (!q->hist) ST_TRY(dev_alloc(&q->hist, 6 * kBins));
+    if (!q->sel) ST_TRY(dev_alloc(&q->sel, 2));
+    if (!q->part_fw) ST_TRY(dev_alloc(&q->part_fw, 2 * kMaxGrid));
+    HIP_TRY(hipMemsetAsync(q->g, 0, sizeof(double) * mp, q->stream));     // (never the legacy stream: another lane's thread may be capturing a graph)
+    HIP_TRY(hipStreamSynchronize(q->stream));
+    q->lane_fw_ready = true;
     return MACHIP_OK;
 }
 
 // Lanes [0, *nl_out) of the handle, created on demand, on the handle's solver mode / precision / start vector.
 int prepare_lanes(machip_problem* p, int B, bool fw, int* nl_out) {
-    // Lanes: 12 where a solve is the single-workgroup kernel (one CU each; every lane's stream gets a hardware queue of its own,
-    // see the GPU_MAX_HW_QUEUES note at the top of this file), 4 where the solves launch chip-filling step kernels -- more than
-    // four hardware queues of those at once collapse (city10000 sweep: 597 it/s with 4 lanes, 250 with 8, 186 with 12).
+    // Lanes: 16 where a solve is the single-workgroup kernel (one CU each; every lane's stream has a hardware queue of its own,
+    // see create_lane_stream at the top of this file), 4 where the solves launch chip-filling step kernels -- more than
+    // four hardware queues of those at once collapse (city10000 sweep: 647 it/s with 4 lanes, 277 with 8, 240 with 12).
     const bool small = p->sol.chain_like && persist_fits(p->n, std::max(0l, (long)p->P - 2 * p->sol.chain_edges));   // (P: off-diagonal slots of the union pattern)
-    int nl = std::max(1, std::min(B, std::min(16, env_int("MACHIP_LANES", small ? 12 : 4))));
+    int nl = std::max(1, std::min(B, std::min(16, env_int("MACHIP_LANES", small ? 16 : 4))));
     while ((int)p->lanes.size() < nl) {
         machip_problem* q = nullptr;
         const int st = make_lane(p, &q);

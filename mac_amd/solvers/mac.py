@@ -112,9 +112,10 @@ class MAC:
                     use_cache=False, seed=None):
         """``solve`` for several budgets of this graph at once: the loop of examples/g2o_experiment.py:306-336
         (``for pct: MAC.solve(k, w_init, ...)``) run concurrently on the device (machip_fw_sweep: one evaluation lane per
-        budget, up to 8 at a time).  ``ks`` budgets, ``x_inits`` the matching initial selections.  Returns a list of
-        ``(rounded, unrounded, upper)`` in the order of ``ks``; each equals what ``solve`` returns for that budget on a
-        fresh MAC object (same kernels, same start vector, same stop rules).  rounding: "nearest" (device, tie-broken by
+        budget, up to 16 at a time -- MACHIP_LANES).  ``ks`` budgets, ``x_inits`` the matching initial selections.  Returns a
+        list of ``(rounded, unrounded, upper)`` in the order of ``ks``; each equals what ``solve`` returns for that budget on
+        a fresh MAC object (same kernels, same start vector, same stop rules; bit for bit unless an eigen-solve needs more
+        Lanczos steps in one sequence than a lane's share of the basis memory holds -- then to the solver tolerance).  rounding: "nearest" (device, tie-broken by
         edge weight like mac.py:209) or "madow" (host, one draw per budget from ``seed``)."""
         m = len(self.weights)
         ks = [int(k) for k in ks]

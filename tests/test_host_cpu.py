@@ -223,16 +223,36 @@ def test_panel_plan_covers_every_row_and_column_within_the_kernel_limits():
                 os.environ[k_] = v
 
 
-def test_loading_the_library_reserves_a_hardware_queue_per_lane():
-    """The concurrent budget sweep keeps up to 12 streams busy; ROCm maps a process's streams onto GPU_MAX_HW_QUEUES (default
-    4) hardware queues and reads the variable when the HIP runtime initialises, so the binding (and, for C callers, the library's
-    own load-time initialiser) sets it to 16 -- unless the application chose a value, which must survive."""
+def test_loading_the_library_leaves_the_process_environment_alone():
+    """Round 3 set GPU_MAX_HW_QUEUES=16 when the library was loaded (a hardware queue per evaluation lane); VERDICT r3 item 7 /
+    ADVICE: a drop-in must not mutate the host's environment.  The lanes' streams now get their own hardware queue by being
+    created with a CU mask (machip.hip, create_lane_stream; measured: profiles/r4_lane_queues.txt), so importing the binding
+    and loading libmachip.so must leave the variable exactly as the application set it -- or unset."""
     import subprocess
     import sys
     code = "import os, sys; sys.path.insert(0, '.'); from mac_amd import _lib; _lib.load(); print(os.environ.get('GPU_MAX_HW_QUEUES'))"
     env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=ROOT, timeout=120)
-    assert out.returncode == 0 and out.stdout.strip() == "16", out.stderr[-500:]
+    assert out.returncode == 0 and out.stdout.strip() == "None", (out.stdout, out.stderr[-500:])
     env["GPU_MAX_HW_QUEUES"] = "6"
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=ROOT, timeout=120)
     assert out.returncode == 0 and out.stdout.strip() == "6", out.stderr[-500:]
+    hip_src = open(os.path.join(ROOT, "mac_amd", "csrc", "machip.hip")).read()
+    assert "setenv(" not in hip_src and "putenv" not in hip_src
+    assert "GPU_MAX_HW_QUEUES" not in open(os.path.join(ROOT, "mac_amd", "_lib.py")).read()
+
+
+def test_fiedler_csr_rejects_malformed_row_pointers_before_touching_the_matrix():
+    """machip_fiedler_csr takes arbitrary caller matrices (the bare find_fiedler_pair(L) surface, mac/utils/fiedler.py:9-44): the
+    row pointers are validated as a whole on the host before anything is read through them and before the first device call
+    (`indptr = [0, 100, 5]` used to walk 100 entries of a 5-entry array).  BAD_ARG on any machine."""
+    import pytest
+    from mac_amd import _lib
+    idx = np.zeros(5, dtype=np.int32); dat = np.ones(5)
+    for indptr, what in [([0, 100, 5], "monotone"), ([1, 2, 3], "indptr[0]"), ([0, 2, -1], "indptr")]:
+        with pytest.raises(_lib.MachipError) as e:
+            _lib.fiedler_csr(np.array(indptr, dtype=np.int32), idx, dat, 2)
+        assert e.value.status == _lib.BAD_ARG and what in str(e.value), str(e.value)
+    with pytest.raises(_lib.MachipError) as e:          # column out of range: also found on the host
+        _lib.fiedler_csr(np.array([0, 2, 4], dtype=np.int32), np.array([0, 7, 0, 1], dtype=np.int32), np.ones(4), 2)
+    assert e.value.status == _lib.BAD_ARG and "column" in str(e.value)
