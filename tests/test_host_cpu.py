@@ -249,10 +249,11 @@ def test_fiedler_csr_rejects_malformed_row_pointers_before_touching_the_matrix()
     import pytest
     from mac_amd import _lib
     idx = np.zeros(5, dtype=np.int32); dat = np.ones(5)
+    # (BAD_ARG surfaces as AssertionError in the binding: the reference asserts on bad sizes, mac/utils/fiedler.py:35-36)
     for indptr, what in [([0, 100, 5], "monotone"), ([1, 2, 3], "indptr[0]"), ([0, 2, -1], "indptr")]:
-        with pytest.raises(_lib.MachipError) as e:
+        with pytest.raises(AssertionError) as e:
             _lib.fiedler_csr(np.array(indptr, dtype=np.int32), idx, dat, 2)
-        assert e.value.status == _lib.BAD_ARG and what in str(e.value), str(e.value)
-    with pytest.raises(_lib.MachipError) as e:          # column out of range: also found on the host
+        assert "BAD_ARG" in str(e.value) and what in str(e.value), str(e.value)
+    with pytest.raises(AssertionError) as e:          # column out of range: also found on the host
         _lib.fiedler_csr(np.array([0, 2, 4], dtype=np.int32), np.array([0, 7, 0, 1], dtype=np.int32), np.ones(4), 2)
-    assert e.value.status == _lib.BAD_ARG and "column" in str(e.value)
+    assert "BAD_ARG" in str(e.value) and "column" in str(e.value)
