@@ -7,6 +7,6 @@ ROCM=${ROCM_PATH:-/opt/rocm}
 # -amdgpu-kernarg-preload-count: leading scalar kernel arguments arrive in SGPRs with the wave instead of behind a scalar
 # load of the argument block (k_pipe_vec takes its first-load pointers that way, PIPE_ARGS in kernels.h: config 2 +3.5 %)
 "$ROCM/bin/hipcc" --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC machip.hip -mllvm -amdgpu-kernarg-preload-count=16 \
-    -o ../libmachip.build.$$.so -L"$ROCM/lib" -lrccl -lrocsolver -lrocblas -ldl -Wl,-rpath,"$ROCM/lib" -Wall -Wno-unused-function
+    -o ../libmachip.build.$$.so -L"$ROCM/lib" -lrccl -ldl -Wl,-rpath,"$ROCM/lib" -Wall -Wno-unused-function
 mv -f ../libmachip.build.$$.so ../libmachip.so
 echo "built $(cd .. && pwd)/libmachip.so"

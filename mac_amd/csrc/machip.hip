@@ -959,6 +959,7 @@ int prepare_lanes(machip_problem* p, int B, bool fw, int* nl_out) {
     for (int l = 0; l < nl; ++l) {
         machip_problem* q = p->lanes[(size_t)l];
         q->sol.solver_mode = p->sol.solver_mode; q->sol.precision = p->sol.precision;
+        q->sol.throughput_lane = true;
         if (p->sol.have_start && q->seen_start_version != p->start_version) {     // per lane: a batch may use fewer lanes than exist
             HIP_TRY(hipMemcpy(q->sol.start, p->sol.start, sizeof(double) * (size_t)p->n, hipMemcpyDeviceToDevice));
             q->sol.have_start = true;
@@ -992,6 +993,9 @@ int machip_eval_batch(machip_problem* p, int B, const double* X, double tol, int
             } else {
                 q->assembled = false;
                 st = assemble(q);
+                // clean solver state per entry (no step-count history from whatever this lane solved before: the automatic
+                // mode choice reads it): an entry's result does not depend on the lane that takes it or on its place in the batch
+                q->sol.have_prev = false; q->sol.hist_lan_steps = -1; q->sol.hist_lob_iters = -1; q->sol.last_steps = 0; q->sol.last_steps_lowp = 0;
                 if (st == MACHIP_OK) st = run_fiedler(q, tol, max_steps, nullptr, 0, &lam, nullptr);
             }
             lambda2[b] = lam;

@@ -33,11 +33,10 @@
 
 namespace machip {
 
-// Stream capture on one host thread and calls that touch the legacy stream on another (rocBLAS / hipBLASLt handle
-// creation, rocSOLVER's workspace management) do not mix: HIP fails the latter with "operation would make the legacy
-// stream depend on a capturing blocking stream" (seen with evaluation lanes on city10000: one lane capturing a chunk
-// graph, another building its Woodbury preconditioner).  Both sides take this lock; captures last ~0.1 ms.
-inline std::mutex& capture_mutex() { static std::mutex m; return m; }
+// (Rounds 2-3 serialised stream captures against rocBLAS / rocSOLVER calls of other threads behind a process-wide lock: those
+// libraries touch the legacy stream, which HIP refuses while another thread captures.  Round 4 removed the libraries -- the dense
+// inverse is hand-written, woodbury.h -- and the lock with them: captures are thread-local, every other call of this library
+// names its own non-blocking stream.)
 
 struct Solver {
     int n = 0;
@@ -100,7 +99,7 @@ struct Solver {
     double *wb_uc = nullptr, *wb_g = nullptr, *wb_h = nullptr, *wb_Zt = nullptr, *wb_Cm = nullptr;
     size_t wb_Zt_cap = 0, wb_pas_cap = 0;
     double *wb_pas = nullptr, *wb_maps = nullptr;   // batched multi-workgroup column solves (n > 16 384)
-    rocblas_handle wb_handle = nullptr;
+    double* wb_Cm2 = nullptr;    // second buffer of the blocked Gauss-Jordan inversion (ping-pong)
     WbView wb_active{};          // s > 0 while the running solve uses it
     double *lx_part = nullptr, *lx_partR = nullptr;
     int *lx_colT = nullptr, *lx_bad = nullptr;
@@ -113,6 +112,8 @@ struct Solver {
     double *h_lrec = nullptr, *d_hlrec = nullptr;
     bool lob_ready = false, last_was_lob = false;
     int solver_mode = 0;        // 0 = auto, 1 = Lanczos, 2 = preconditioned (LOBPCG + tridiagonal solve)
+    bool throughput_lane = false;   // this solver serves an evaluation lane (machip_eval_batch / machip_fw_sweep): many solves run at
+                                    // once, so the automatic mode keeps to kernels that occupy ONE CU per solve where it can
     int precision = 0;          // 0 = fp64; 1 = fp32 Krylov iterate + fp64 refinement (machip_set_precision)
     bool chain_like = false;    // the fixed edges contain (nearly) the whole chain (i, i+1)
     long chain_edges = 0;       // how many of them
@@ -176,7 +177,7 @@ struct Solver {
         void* ptrs[] = {u, V, tri, part, Z0, Z1, st, st2, y_raw, w2, yvec, ypart, sdev,
                         part_c, part_a2, part_r, scratch3, rq_dev, start, wc, ctri, part_u, part_a, stc,
                         lx_x, lx_Lx, lx_p, lx_Lp, lx_Lw, lx_rT, lx_wT, lx_tl, lx_tdinv, lx_tcu, lx_part, lx_partR,
-                        lx_ys, lx_pas, lx_as, lx_bs, lx_maps, lx_ba, lx_bd, lx_bu, wb_ui, wb_uj, wb_counts, wb_uc, wb_g, wb_h, wb_Zt, wb_Cm, wb_pas, wb_maps,
+                        lx_ys, lx_pas, lx_as, lx_bs, lx_maps, lx_ba, lx_bd, lx_bu, wb_ui, wb_uj, wb_counts, wb_uc, wb_g, wb_h, wb_Zt, wb_Cm, wb_Cm2, wb_pas, wb_maps,
                         lx_colT, lx_bad, lx_st, valf};
         {
             void* pb[] = {panv.tptr, panv.thead, panv.bval, panv.bcol, panv.ypart, panv.coef, panv.tcount, panv.ps, panv.tick, panv.claim};
@@ -185,7 +186,6 @@ struct Solver {
             for (void* q : pk) if (q) (void)hipFree(q);
         }
         if (h_lrec) (void)hipHostFree(h_lrec);
-        if (wb_handle) (void)rocblas_destroy_handle(wb_handle);
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (h_tri) (void)hipHostFree(h_tri);
         if (h_flag) (void)hipHostFree(h_flag);
@@ -445,7 +445,6 @@ struct Solver {
         hipGraphExec_t& ge = it->second[(size_t)(graph_flip++ & 1)];
         if (!ge) {
             hipGraph_t g = nullptr;
-            std::lock_guard<std::mutex> cap(capture_mutex());
             HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
             launch_chunk(A, pl, steps, f32);
             HIP_TRY(hipStreamEndCapture(stream, &g));
@@ -594,7 +593,7 @@ struct Solver {
                 const WbView& W = wb_active;
                 k_wb_g<<<(W.s + kBlock - 1) / kBlock, kBlock, 0, stream>>>(L, W);
                 k_wb_h<<<std::min(kMaxGrid, (W.s + 3) / 4), kBlock, 0, stream>>>(W);
-                k_wb_w<<<(int)std::min<size_t>(kMaxGrid, (W.cap + kBlock - 1) / kBlock), kBlock, 0, stream>>>(L, W);
+                k_wb_w<<<(int)std::min<size_t>(kMaxGrid, W.cap / 64), kWbwThreads, 0, stream>>>(L, W);
             }
             launch_spmv(pl, stream, AT, L.wT, op);
             k_lob_update<false><<<L.P_a, kBlock, 0, stream>>>(L, s);
@@ -624,7 +623,7 @@ struct Solver {
                     const WbView& W = wb_active;
                     k_wb_g<<<(W.s + kBlock - 1) / kBlock, kBlock, 0, stream>>>(L, W);
                     k_wb_h<<<std::min(kMaxGrid, (W.s + 3) / 4), kBlock, 0, stream>>>(W);
-                    k_wb_w<<<(int)std::min<size_t>(kMaxGrid, (W.cap + kBlock - 1) / kBlock), kBlock, 0, stream>>>(L, W);
+                    k_wb_w<<<(int)std::min<size_t>(kMaxGrid, W.cap / 64), kWbwThreads, 0, stream>>>(L, W);
                 }
                 launch_spmv(pl, stream, AT, L.wT, op);
                 k_lob_update<false><<<L.P_a, kBlock, 0, stream>>>(L, s);
@@ -650,7 +649,6 @@ struct Solver {
         hipGraphExec_t& ge = it->second[(size_t)(graph_flip++ & 1)];
         if (!ge) {
             hipGraph_t g = nullptr;
-            std::lock_guard<std::mutex> cap(capture_mutex());
             HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
             lob_launch_chunk(AT, pl, L, steps);
             HIP_TRY(hipStreamEndCapture(stream, &g));
@@ -681,18 +679,15 @@ struct Solver {
         if (wb_ui) {
             HIP_TRY(hipStreamSynchronize(stream));
             drop_graphs();          // cached chunk graphs carry the old addresses
-            void* old[] = {wb_ui, wb_uj, wb_counts, wb_uc, wb_g, wb_h, wb_Cm, wb_maps};
+            void* old[] = {wb_ui, wb_uj, wb_counts, wb_uc, wb_g, wb_h, wb_Cm, wb_Cm2, wb_maps};
             for (void* q : old) if (q) (void)hipFree(q);
-            wb_ui = wb_uj = wb_counts = nullptr; wb_uc = wb_g = wb_h = wb_Cm = wb_maps = nullptr;
+            wb_ui = wb_uj = wb_counts = nullptr; wb_uc = wb_g = wb_h = wb_Cm = wb_Cm2 = wb_maps = nullptr;
         }
         wb_cap_s = want;
         ST_TRY(dev_alloc(&wb_ui, (size_t)want)); ST_TRY(dev_alloc(&wb_uj, (size_t)want)); ST_TRY(dev_alloc(&wb_counts, 2));
         ST_TRY(dev_alloc(&wb_uc, (size_t)want)); ST_TRY(dev_alloc(&wb_g, (size_t)want)); ST_TRY(dev_alloc(&wb_h, (size_t)want));
-        ST_TRY(dev_alloc(&wb_Cm, (size_t)want * (size_t)want));
-        if (wb_handle) return MACHIP_OK;
-        std::lock_guard<std::mutex> cap(capture_mutex());
-        if (rocblas_create_handle(&wb_handle) != rocblas_status_success) return fail(MACHIP_HIP_ERROR, "rocblas_create_handle failed");
-        if (rocblas_set_stream(wb_handle, stream) != rocblas_status_success) return fail(MACHIP_HIP_ERROR, "rocblas_set_stream failed");
+        const size_t ldw = ((size_t)want + kGjT - 1) / kGjT * kGjT;      // whole 64 x 64 tiles (k_gj_step)
+        ST_TRY(dev_alloc(&wb_Cm, ldw * ldw)); ST_TRY(dev_alloc(&wb_Cm2, ldw * ldw));
         return MACHIP_OK;
     }
     // Z = T^-1 U, C = D^-1 + U^T Z, C^-1 (rocSOLVER).  MACHIP_NOT_CONVERGED when C is not positive definite.
@@ -705,6 +700,7 @@ struct Solver {
         }
         WbView W;
         W.s = s; W.cap = cap; W.ui = wb_ui; W.uj = wb_uj; W.uc = wb_uc; W.Zt = wb_Zt; W.Cm = wb_Cm; W.g = wb_g; W.h = wb_h;
+        W.ld = (s + kGjT - 1) / kGjT * kGjT;
         if (n > kTriMaxN) {   // batched multi-workgroup solves: grid = (workgroups per system, closures)
             const int gw = L.stride / kTriThreads;
             if (cap * (size_t)s > wb_pas_cap) {
@@ -725,24 +721,23 @@ struct Solver {
 #undef MACHIP_LOB_CASE
             default: k_wb_cols<16><<<s, kTriThreads, 0, stream>>>(L, W); break;
         }
-        const int g2s = (int)std::min<long>(kMaxGrid, ((long)s * s + kBlock - 1) / kBlock);
+        const int g2s = (int)std::min<long>(kMaxGrid, ((long)W.ld * W.ld + kBlock - 1) / kBlock);
         k_wb_cap<<<g2s, kBlock, 0, stream>>>(L, W);
+        // C^-1: ld / 32 blocked Gauss-Jordan steps on the matrix cores, ping-pong between the two buffers (woodbury.h)
         int* info = wb_counts + 1;
-        {
-            std::lock_guard<std::mutex> cap(capture_mutex());
-            if (rocsolver_dpotrf(wb_handle, rocblas_fill_lower, s, wb_Cm, s, info) != rocblas_status_success)
-                return fail(MACHIP_HIP_ERROR, "rocsolver_dpotrf failed");
+        HIP_TRY(hipMemsetAsync(info, 0, sizeof(int), stream));
+        const int tiles = W.ld / kGjT;
+        double *src = wb_Cm, *dst = wb_Cm2;
+        for (int kb = 0; kb < W.ld; kb += kGjB) {
+            k_gj_step<0><<<dim3(tiles, tiles), 256, 0, stream>>>(src, dst, W.ld, kb, info);
+            std::swap(src, dst);
         }
+        HIP_TRY(hipGetLastError());
+        W.Cm = src;                                  // (the last step's output)
         int hinfo = 0;
         HIP_TRY(hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        if (hinfo != 0) return MACHIP_NOT_CONVERGED;
-        {
-            std::lock_guard<std::mutex> cap(capture_mutex());
-            if (rocsolver_dpotri(wb_handle, rocblas_fill_lower, s, wb_Cm, s, info) != rocblas_status_success)
-                return fail(MACHIP_HIP_ERROR, "rocsolver_dpotri failed");
-        }
-        k_wb_sym<<<g2s, kBlock, 0, stream>>>(W);
+        if (hinfo != 0) return MACHIP_NOT_CONVERGED;     // a non-positive pivot: C is not positive definite numerically
         wb_active = W;
         return MACHIP_OK;
     }
@@ -772,6 +767,21 @@ struct Solver {
             HIP_TRY(hipMemcpyAsync(&hc[0], wb_counts, sizeof(int), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipMemcpyAsync(&hc[1], lx_bad, sizeof(int), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
+            if (hc[0] > wb_cap_s && hc[0] <= wb_limit_now && !hc[1]) {
+                // more off-chain entries than the buffers were sized for (support_hint counts active CANDIDATES; fixed edges off
+                // the chain are closures too): grow to what is there and extract again -- these are the stiff cases the exact
+                // preconditioner exists for, it must not be skipped silently
+                const long keep = support_hint;
+                support_hint = hc[0];
+                const int st_grow = wb_alloc();
+                support_hint = keep;
+                if (st_grow != MACHIP_OK) return st_grow;
+                HIP_TRY(hipMemsetAsync(lx_bad, 0, sizeof(int), stream));
+                k_wb_extract<<<1, kTriThreads, 0, stream>>>(A, (n + kTriThreads - 1) / kTriThreads, wb_cap_s, wb_ui, wb_uj, wb_uc, wb_counts, lx_bad);
+                HIP_TRY(hipMemcpyAsync(&hc[0], wb_counts, sizeof(int), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipMemcpyAsync(&hc[1], lx_bad, sizeof(int), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+            }
             if (hc[0] > 0 && hc[0] <= wb_cap_s && !hc[1]) wb_s = hc[0];
         }
         const int chain_only = wb_s > 0 ? 1 : 0;
@@ -933,8 +943,21 @@ struct Solver {
         const bool chain_dominated = support_hint < 0 || support_hint <= 2 * (long)n;
         const bool stiff = hist_lan_steps > 2500 && (hist_lob_iters < 0 || hist_lob_iters * ratio < hist_lan_steps);
         const bool slow_lob = hist_lan_steps > 0 && hist_lob_iters > 0 && hist_lob_iters * ratio > 2 * hist_lan_steps;
+        // Round 4: with the hand-written inverse (woodbury.h: 0.08 ms at 157 closures, 0.28 ms at 645, where rocSOLVER took
+        // 0.3-1.25 ms) and the parallel n x s product, the EXACT chain + closures preconditioner beats the single-workgroup Lanczos
+        // on small pose graphs up to several hundred active closures (intel, 157-645 closures: 0.90 against 1.60 ms per solve,
+        // 12 iterations against 830 steps).  Cost model in launch equivalents (~4.7 us), counts only: Lanczos = steps x 0.4
+        // (single-workgroup step 1.9 us); exact = 60 (set-up, checks) + 2.7 per 32 closures (one inverse launch) + 7.5 per
+        // iteration.  Without a Lanczos history the closure count alone decides (MACHIP_LOB_SMALL_S).
+        const long lob_it_guess = hist_lob_iters > 0 ? hist_lob_iters : 14;
+        const double cost_lob = 60.0 + 2.7 * ((double)support_hint / 32.0) + 7.5 * (double)lob_it_guess;
+        // (Not on evaluation lanes: there 16 single-CU Lanczos solves run side by side -- intel sweep 4 670 it/s aggregate against
+        // 2 460 when every lane launches the exact mode's chip-wide kernels; profiles/r4_exact_small.txt.)
+        const bool exact_small = small && !throughput_lane && precision == 0 && support_hint >= 0 && support_hint <= env_int("MACHIP_LOB_SMALL_S", 700) &&
+                                 support_hint <= wb_soft() && env_int("MACHIP_WOODBURY", 1) != 0 &&
+                                 (hist_lan_steps <= 0 || cost_lob < 0.4 * (double)hist_lan_steps);
         const bool want = chain_dominated &&
-                          (mode == 2 || (mode == 0 && chain_like && support_hint >= 0 && ((sparse && !slow_lob) || stiff)));
+                          (mode == 2 || (mode == 0 && chain_like && support_hint >= 0 && ((sparse && !slow_lob) || stiff || exact_small)));
         last_was_lob = false;
         final_check_seq = -2;
         const bool want_jac = mode == 3 && n > 256;

@@ -6,16 +6,13 @@
 // T = (chain Laplacian) + sigma I is tridiagonal SPD, U = [e_i - e_j] (n x s), D = diag(x_k w_k), so
 //     (L + sigma I)^-1 r = y - Z C^-1 U^T y,   y = T^-1 r,  Z = T^-1 U,  C = D^-1 + U^T Z   (s x s, SPD)
 // (Sherman-Morrison-Woodbury).  Per solve: s tridiagonal solves in ONE launch (one workgroup each,
-// the kernel of precond.h with a two-entry right-hand side), C assembled by gathers, factored and
-// inverted by rocSOLVER (dpotrf + dpotri: 0.3 ms at s = 160, 1.2 ms at s = 400, 5 ms at s = 1 600 --
-// the dense factorisation is a library call, everything else is hand-written), then every
-// application costs the tridiagonal solve + an s x s GEMV + an n x s GEMV.  LOBPCG with this M^-1
+// the kernel of precond.h with a two-entry right-hand side), C assembled by gathers and inverted by a
+// hand-written blocked Gauss-Jordan elimination on the matrix cores (k_gj_step below, v_mfma_f64_16x16x4_f64;
+// rounds 1-3 called rocSOLVER's dpotrf + dpotri here: 0.3 ms at s = 160, 1.2 ms at s = 400, 5 ms at s = 1 600),
+// then every application costs the tridiagonal solve + an s x s GEMV + an n x s GEMV.  LOBPCG with this M^-1
 // converges in 5-18 iterations where the tridiagonal one needed hundreds to thousands (NumPy
 // prototype; the same counts on the device).
 #pragma once
-#include <rocblas/rocblas.h>
-#include <rocsolver/rocsolver.h>
-
 #include "precond.h"
 
 namespace machip {
@@ -28,7 +25,8 @@ struct WbView {
     const int *ui, *uj;    // closure endpoints
     const double* uc;      // closure weights x_k w_k (> 0)
     double* Zt;            // T^-1 U, chunk-transposed columns
-    double* Cm;            // capacitance matrix / its inverse, column-major s x s
+    int ld;                // leading dimension of Cm: s rounded up to whole 64 x 64 tiles (identity beyond s)
+    double* Cm;            // capacitance matrix / its inverse, ld x ld
     double *g, *h;         // s-vectors
 };
 
@@ -107,22 +105,196 @@ __global__ __launch_bounds__(kTriThreads) void k_wb_big_fin(LobView L, WbView W,
 
 // ---- C = D^-1 + U^T Z ----
 __global__ __launch_bounds__(kBlock) void k_wb_cap(LobView L, WbView W) {
-    const long s = W.s;
-    for (long idx = (long)blockIdx.x * kBlock + threadIdx.x; idx < s * s; idx += (long)gridDim.x * kBlock) {
-        const int a = (int)(idx % s), b = (int)(idx / s);
-        const double* z = W.Zt + (size_t)b * W.cap;
-        double v = z[tri_perm(W.ui[a], L.c, L.stride)] - z[tri_perm(W.uj[a], L.c, L.stride)];
-        if (a == b) v += 1.0 / W.uc[a];
+    const long s = W.s, ld = W.ld;
+    for (long idx = (long)blockIdx.x * kBlock + threadIdx.x; idx < ld * ld; idx += (long)gridDim.x * kBlock) {
+        const int a = (int)(idx % ld), b = (int)(idx / ld);
+        double v = a == b ? 1.0 : 0.0;                     // identity beyond s: whole tiles for k_gj_step, inverse unchanged
+        if (a < s && b < s) {
+            const double* z = W.Zt + (size_t)b * W.cap;
+            v = z[tri_perm(W.ui[a], L.c, L.stride)] - z[tri_perm(W.uj[a], L.c, L.stride)];
+            if (a == b) v += 1.0 / W.uc[a];
+        }
         W.Cm[idx] = v;
     }
 }
-// dpotri leaves the inverse in the lower triangle: mirror it so the GEMV can read contiguous columns
-__global__ __launch_bounds__(kBlock) void k_wb_sym(WbView W) {
-    const long s = W.s;
-    for (long idx = (long)blockIdx.x * kBlock + threadIdx.x; idx < s * s; idx += (long)gridDim.x * kBlock) {
-        const int a = (int)(idx % s), b = (int)(idx / s);      // element (row a, column b)
-        if (a < b) W.Cm[idx] = W.Cm[(size_t)b + (size_t)a * s];
+
+// ---- C^-1 by blocked Gauss-Jordan elimination on the matrix cores (round 4: replaces rocSOLVER's dpotrf + dpotri, the one
+// vendor-library call the path had; nx:79-107 `_LUSolver` semantics: an exact solve per application) ----
+// In-place Gauss-Jordan without pivoting (C is symmetric positive definite: every pivot block is a Schur complement, SPD
+// itself), pivot blocks of 32: step k maps  A -> A'  with  P = A_KK^-1,
+//     A'_ij = A_ij - A_iK P A_Kj (i, j not in K),   A'_iK = -A_iK P,   A'_Kj = P A_Kj,   A'_KK = P,
+// and after all ld/32 steps A' = C^-1 -- the inverse comes out directly, so applying it stays a GEMV (two triangular solves
+// per application would be a chain of s dependent steps).  One launch per step, ping-pong between two buffers (a tile reads
+// the old pivot row / column blocks that other workgroups rewrite).  Workgroup = one 64 x 64 tile of A', 4 waves:
+//   * wave 0 inverts the 32 x 32 pivot block (scalar Gauss-Jordan, the block in registers as 4 x 4 sub-blocks per lane, only
+//     row / column p through LDS) while waves 1-3 stage A_iK / A_Kj; every workgroup does it redundantly -- a separate
+//     launch would cost more than the few us it takes;
+//   * -(A_iK P) by v_mfma_f64_16x16x4_f64 (rows inside K: P itself), then the tile as ONE uniform product
+//     A' = base + (-A_iK P) * B  with  B = A_Kj (columns inside K: identity columns)  and  base = A_ij (0 on pivot rows /
+//     columns): 32 MFMAs per wave; lane layout of the f64 MFMA: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15],
+//     D[row = (l >> 4) + 4 reg][col = l & 15].
+// 2 s^3 flops in all (six times a Cholesky factorisation, at matrix-core rate): 22 launches, ~0.15 ms at s = 645.
+// bad <- 1 on a non-positive scalar pivot (C not positive definite numerically: the caller falls back to Lanczos).
+constexpr int kGjB = 32;
+constexpr int kGjT = 64;
+typedef double gj_d4 __attribute__((ext_vector_type(4)));
+
+template <int VAR = 0>     // (VAR != 0: timing builds of tools/ubench_gj.hip -- 1: no pivot-block inversion, 2: nor the products)
+__global__ __launch_bounds__(256) void k_gj_step(const double* __restrict__ src, double* __restrict__ dst, int ld, int kb, int* bad) {
+    __shared__ double sP[2][kGjB][kGjB + 1];
+    __shared__ double sA[kGjT][kGjB + 1];      // A_iK: rows of the tile x pivot columns
+    __shared__ double sT[kGjT][kGjB + 1];      // -(A_iK P); rows inside the pivot block: P
+    __shared__ double sB[kGjB][kGjT + 1];      // A_Kj: pivot rows x columns of the tile; columns inside the pivot block: identity
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r0 = blockIdx.y * kGjT, c0 = blockIdx.x * kGjT;
+    const int li = lane & 15, lk = lane >> 4;
+    // wave 0 inverts the pivot block (below); waves 1-3 stage A_iK and A_Kj in LDS meanwhile
+    const int br = lane >> 3, bc = lane & 7;         // wave 0: lane (br, bc) keeps the 4 x 4 sub-block (4 br.., 4 bc..) of A_KK in registers
+    double m[4][4];
+    if (wv == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[i][j] = src[(size_t)(kb + 4 * br + i) * ld + kb + 4 * bc + j];
+    } else {
+        // all 22 loads of a thread in flight at once (unconditional, clamped index; a loop with a run-time trip count is
+        // compiled into one load -> wait -> LDS store round trip per element: 11 dependent cold misses, 7 of the first
+        // build's 10 us of "loads")
+        constexpr int NE = kGjT * kGjB, NQ = (NE + 191) / 192;
+        double va[NQ], vb[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = min(tid - 64 + 192 * q, NE - 1);
+            va[q] = src[(size_t)(r0 + e / kGjB) * ld + kb + e % kGjB];
+            vb[q] = src[(size_t)(kb + e / kGjT) * ld + c0 + e % kGjT];
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = tid - 64 + 192 * q;
+            if (e < NE) {
+                sA[e / kGjB][e % kGjB] = va[q];
+                const int r = e / kGjT, gc = c0 + e % kGjT;
+                const bool in_k = gc >= kb && gc < kb + kGjB;
+                sB[r][e % kGjT] = in_k ? (gc - kb == r ? 1.0 : 0.0) : vb[q];
+            }
+        }
     }
+    // the tile itself, already in the MFMA's result layout (zero on pivot rows / columns)
+    const int wr = wv >> 1, wc = wv & 1;
+    gj_d4 acc[2][2];
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = r0 + 32 * wr + 16 * bi + lk + 4 * q, col = c0 + 32 * wc + 16 * bj + li;
+                const bool piv = (row >= kb && row < kb + kGjB) || (col >= kb && col < kb + kGjB);
+                acc[bi][bj][q] = piv ? 0.0 : src[(size_t)row * ld + col];
+            }
+    // ---- P = A_KK^-1: scalar Gauss-Jordan by ONE wave, the block in registers (first build: all 256 threads on an LDS copy,
+    // one barrier per pivot -- 0.53 us per pivot, 17 of the kernel's 28 us).  Per pivot p only row p and column p travel:
+    // their owners park them in LDS, every lane reads the 4 + 4 entries its sub-block needs (a wave's LDS traffic is ordered:
+    // no barrier), 16 multiply-adds per lane. ----
+    int isbad = 0;
+    if (wv == 0 && !VAR) {
+        double* rowp = &sP[1][0][0];                   // [32] row p, then [32] column p (scratch: sP[1] is otherwise unused)
+        double* colp = rowp + kGjB;
+        for (int pb = 0; pb < kGjB / 4; ++pb) {
+#pragma unroll
+            for (int pj = 0; pj < 4; ++pj) {
+                const int p = 4 * pb + pj;
+                if (br == pb) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) rowp[4 * bc + j] = m[pj][j];
+                }
+                if (bc == pb) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) colp[4 * br + i] = m[i][pj];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const double piv = rowp[p];
+                double rp[4], cp[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rp[j] = rowp[4 * bc + j];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cp[i] = colp[4 * br + i];
+                if (!(piv > 0.0) || !(piv < 1e300)) isbad = 1;
+                double ip = __builtin_amdgcn_rcp(piv);     // hardware reciprocal + two Newton steps (no IEEE division on the chain)
+                ip = ip * __builtin_fma(-piv, ip, 2.0);
+                ip = ip * __builtin_fma(-piv, ip, 2.0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool rp_ = 4 * br + i == p, cp_ = 4 * bc + j == p;
+                        const double sc = rp[j] * ip;
+                        double v = __builtin_fma(-cp[i], sc, m[i][j]);
+                        if (rp_) v = cp_ ? ip : sc;
+                        else if (cp_) v = -cp[i] * ip;
+                        m[i][j] = v;
+                    }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();          // (everybody has read row / column p before the next pivot's owners overwrite them)
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sP[0][4 * br + i][4 * bc + j] = m[i][j];
+    } else if (wv == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sP[0][4 * br + i][4 * bc + j] = m[i][j];
+    }
+    __syncthreads();
+    if (isbad && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) *bad = 1;
+    // ---- sT = -(A_iK P): wave w owns rows 16 w .. 16 w + 15, both 16-column halves ----
+    if (VAR < 2) {
+        gj_d4 t[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) { t[cb][0] = 0.0; t[cb][1] = 0.0; t[cb][2] = 0.0; t[cb][3] = 0.0; }
+#pragma unroll
+        for (int kk = 0; kk < kGjB / 4; ++kk) {
+            const double a = sA[16 * wv + li][4 * kk + lk];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) t[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sP[0][4 * kk + lk][16 * cb + li], t[cb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rl = 16 * wv + lk + 4 * q, cl = 16 * cb + li, row = r0 + rl;
+                const bool in_k = row >= kb && row < kb + kGjB;
+                sT[rl][cl] = in_k ? sP[0][row - kb][cl] : -t[cb][q];
+            }
+    }
+    __syncthreads();
+    // ---- the tile: base + sT * sB, a 32 x 32 quadrant per wave ----
+#pragma unroll
+    for (int kk = 0; kk < (VAR < 2 ? kGjB / 4 : 0); ++kk) {
+        double a[2], b[2];
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi) a[bi] = sT[32 * wr + 16 * bi + li][4 * kk + lk];
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj) b[bj] = sB[4 * kk + lk][32 * wc + 16 * bj + li];
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int bj = 0; bj < 2; ++bj) acc[bi][bj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[bi], b[bj], acc[bi][bj], 0, 0, 0);
+    }
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = r0 + 32 * wr + 16 * bi + lk + 4 * q, col = c0 + 32 * wc + 16 * bj + li;
+                dst[(size_t)row * ld + col] = acc[bi][bj][q];
+            }
 }
 
 // ---- application: w <- y - Z C^-1 U^T y with y = T^-1 r already in wT ----
@@ -130,31 +302,48 @@ __global__ __launch_bounds__(kBlock) void k_wb_g(LobView L, WbView W) {
     for (int a = blockIdx.x * kBlock + threadIdx.x; a < W.s; a += gridDim.x * kBlock)
         W.g[a] = L.wT[tri_perm(W.ui[a], L.c, L.stride)] - L.wT[tri_perm(W.uj[a], L.c, L.stride)];
 }
-__global__ __launch_bounds__(kBlock) void k_wb_h(WbView W) {      // h = Cinv g: one wave per entry, column a of the symmetric Cinv
+__global__ __launch_bounds__(kBlock) void k_wb_h(WbView W) {      // h = Cinv g: one wave per entry, row a of Cinv (contiguous)
     const int lane = threadIdx.x & 63;
     const int s = W.s;
     for (int a = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); a < s; a += gridDim.x * (kBlock / 64)) {
-        const double* col = W.Cm + (size_t)a * s;
+        const double* col = W.Cm + (size_t)a * (size_t)W.ld;
         double acc = 0.0;
         for (int b = lane; b < s; b += 64) acc += col[b] * W.g[b];
         acc = wave_total(acc);
         if (lane == 0) W.h[a] = acc;
     }
 }
-__global__ __launch_bounds__(kBlock) void k_wb_w(LobView L, WbView W) {
+// w <- y - Z h: the n x s product by 64-row tiles, the s columns dealt to the 16 waves of a workgroup (8 column loads in
+// flight per lane), wave sums added in wave order through LDS -- deterministic.  (Rounds 1-3: one thread per row walking all s
+// columns, 8 workgroups in all: 33 us per application at s = 645 on intel, a fifth of the whole preconditioned solve.)
+constexpr int kWbwThreads = 1024;
+__global__ __launch_bounds__(kWbwThreads) void k_wb_w(LobView L, WbView W) {
+    __shared__ double sred[kWbwThreads / 64][64];
     const size_t cap = W.cap;
-    const int s = W.s;
-    for (size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x; k < cap; k += (size_t)gridDim.x * kBlock) {
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        int b = 0;
-        for (; b + 3 < s; b += 4) {
-            a0 += W.Zt[k + (size_t)b * cap] * W.h[b];
-            a1 += W.Zt[k + (size_t)(b + 1) * cap] * W.h[b + 1];
-            a2 += W.Zt[k + (size_t)(b + 2) * cap] * W.h[b + 2];
-            a3 += W.Zt[k + (size_t)(b + 3) * cap] * W.h[b + 3];
+    const int s = W.s, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int NW = kWbwThreads / 64;
+    const int per = (s + NW - 1) / NW, b0 = wv * per, b1 = min(s, b0 + per);
+    for (size_t k0 = (size_t)blockIdx.x * 64; k0 < cap; k0 += (size_t)gridDim.x * 64) {
+        const size_t k = k0 + lane;          // (cap is a multiple of 1024)
+        double acc = 0.0;
+        int b = b0;
+        for (; b + 7 < b1; b += 8) {
+            double z[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) z[q] = W.Zt[k + (size_t)(b + q) * cap];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc = __builtin_fma(z[q], W.h[b + q], acc);
         }
-        for (; b < s; ++b) a0 += W.Zt[k + (size_t)b * cap] * W.h[b];
-        L.wT[k] -= (a0 + a1) + (a2 + a3);
+        for (; b < b1; ++b) acc = __builtin_fma(W.Zt[k + (size_t)b * cap], W.h[b], acc);
+        sred[wv][lane] = acc;
+        __syncthreads();
+        if (wv == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += sred[w][lane];
+            L.wT[k] -= t;
+        }
+        __syncthreads();
     }
 }
 
