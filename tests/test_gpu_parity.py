@@ -133,21 +133,42 @@ def test_fiedler_pair_and_gradient_vs_reference(nm):
     P.close()
 
 
-@pytest.mark.parametrize("nm", ["intel", "sphere2500", "city10000", "kitti_05"])
+def golden_lambda(g, key):
+    """lambda_2 to compare with at 1e-8.  kitti_02 / ais2klinik (round 4) are stiff chains, lambda_2 / ||L||_inf down to 1e-8:
+    there the reference's own stop rule (nx:246) leaves ITS lambda_2 accurate to 8e-9 / 3e-7 relative only, so those fixtures also
+    hold lambda_2 of the reference's own MAC.laplacian(x) from SciPy's shift-invert Lanczos (`<key>_exact`, make_golden.py
+    g2o_extra).  The HIP value must hit the exact one to 1e-8; the reference's must lie within its own measured deviation."""
+    if key + "_exact" in g:
+        exact = float(g[key + "_exact"])
+        assert abs(float(g[key]) - exact) <= 5e-7 * exact          # (documents how far the reference itself is off)
+        return exact
+    return float(g[key])
+
+
+def golden_grad(g):
+    """Supergradient at x_init to compare with: the exact one where the fixture holds it (stiff chains: the reference's 1e-8
+    residual leaves its eigenvector -- and with it its gradient -- off by up to 2e-3 of the largest entry; bounded here)."""
+    if "grad_init_exact" in g:
+        assert np.abs(g["grad_init"] - g["grad_init_exact"]).max() <= 5e-3 * np.abs(g["grad_init_exact"]).max()
+        return g["grad_init_exact"]
+    return g["grad_init"]
+
+
+@pytest.mark.parametrize("nm", ["intel", "sphere2500", "city10000", "kitti_05", "kitti_02", "ais2klinik"])
 def test_pose_graph_fiedler(nm):
     g = load_golden("g2o_" + nm)
     mac = MAC(edges_of(g, "f"), edges_of(g, "c"), int(g["n"]))
     lam = mac.evaluate_objective(g["x_init"])
-    assert abs(lam - g["lam_init"]) <= LAM_RTOL * g["lam_init"]
+    assert abs(lam - golden_lambda(g, "lam_init")) <= LAM_RTOL * g["lam_init"]
     f, grad = mac.problem(g["x_init"])
-    assert abs(f - g["lam_init"]) <= LAM_RTOL * g["lam_init"]
-    assert np.abs(grad - g["grad_init"]).max() <= 2e-4 * np.abs(g["grad_init"]).max()
+    assert abs(f - golden_lambda(g, "lam_init")) <= LAM_RTOL * g["lam_init"]
+    assert np.abs(grad - golden_grad(g)).max() <= 2e-4 * np.abs(g["grad_init"]).max()
     lam_all = mac.evaluate_objective(np.ones(len(g["cw"])))
-    assert abs(lam_all - g["lam_all"]) <= LAM_RTOL * g["lam_all"]
+    assert abs(lam_all - golden_lambda(g, "lam_all")) <= LAM_RTOL * g["lam_all"]
 
 
 # ---- preconditioned eigen-solver mode (LOBPCG + tridiagonal chain solve, precond.h) ----------
-@pytest.mark.parametrize("nm", ["intel", "sphere2500", "city10000", "kitti_05"])
+@pytest.mark.parametrize("nm", ["intel", "sphere2500", "city10000", "kitti_05", "kitti_02", "ais2klinik"])
 def test_preconditioned_mode_on_pose_graphs(nm):
     """fiedler_method='tracemin_pcg' (the reference's preconditioned flavour) routes to the
     preconditioned HIP mode; same pair as the reference / the Lanczos mode to the same tolerances."""
@@ -156,13 +177,13 @@ def test_preconditioned_mode_on_pose_graphs(nm):
     ref = MAC(edges_of(g, "f"), edges_of(g, "c"), int(g["n"]), fiedler_method="hip_lanczos")
     for x, key in [(g["x_init"], "lam_init"), (np.ones(len(g["cw"])), "lam_all")]:
         lam = mac.evaluate_objective(x)
-        assert abs(lam - g[key]) <= LAM_RTOL * g[key]
+        assert abs(lam - golden_lambda(g, key)) <= LAM_RTOL * g[key]
         assert mac.last_stats["residual"] < 1e-8
     f, grad = mac.problem(g["x_init"])
     f2, grad2 = ref.problem(g["x_init"])
     assert abs(f - f2) <= LAM_RTOL * f2
     assert np.abs(grad - grad2).max() <= 2e-4 * np.abs(grad2).max()   # both eigenvectors carry the 1e-8 residual
-    assert np.abs(grad - g["grad_init"]).max() <= 2e-4 * np.abs(g["grad_init"]).max()
+    assert np.abs(grad - golden_grad(g)).max() <= 2e-4 * np.abs(g["grad_init"]).max()
     v = mac._dev.fiedler()[1]
     assert abs(np.linalg.norm(v) - 1) < 1e-12 and abs(v.sum()) < 1e-9
 
@@ -409,7 +430,7 @@ def test_er_solve_trajectory(nm):
     assert abs(u - g["upper"]) <= 1e-6 * abs(g["upper"])
 
 
-@pytest.mark.parametrize("nm", ["intel", "sphere2500", "kitti_05", "city10000"])
+@pytest.mark.parametrize("nm", ["intel", "sphere2500", "kitti_05", "city10000", "kitti_02", "ais2klinik"])
 def test_pose_graph_solve_trajectory(nm):
     g = load_golden("g2o_" + nm)
     mac = MAC(edges_of(g, "f"), edges_of(g, "c"), int(g["n"]))
@@ -1585,10 +1606,10 @@ def test_non_finite_input_fails_fast():
     P.close()
 
 
-@pytest.mark.parametrize("nm", ["intel", "kitti_05", "city10000"])
+@pytest.mark.parametrize("nm", ["intel", "kitti_05", "city10000", "kitti_02", "ais2klinik"])
 def test_exact_chain_plus_closures_preconditioner(nm):
     """woodbury.h: with at most 2 048 active closures the preconditioned mode inverts L + sigma I exactly
-    (chain tridiagonal + low-rank closures, capacitance matrix by rocSOLVER) and converges in a handful of
+    (chain tridiagonal + low-rank closures, capacitance matrix inverted by the hand-written k_gj_step) and converges in a handful of
     iterations; same pair as the tridiagonal-preconditioned mode and as an independent SciPy solve."""
     import scipy.sparse.linalg as spla
     g = load_golden("g2o_" + nm)

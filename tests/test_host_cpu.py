@@ -141,7 +141,7 @@ def test_method_strings_map_to_solver_modes():
         solver_mode("lobpcg")
 
 
-@pytest.mark.parametrize("nm", ["intel", "sphere2500", "city10000", "kitti_05"])
+@pytest.mark.parametrize("nm", ["intel", "sphere2500", "city10000", "kitti_05", "kitti_02", "ais2klinik"])
 def test_g2o_reader_matches_reference_golden(nm):
     """Edge arrays produced by the reference's own reader (examples/pose_graph_utils.py) were
     captured in tests/golden/g2o_*.npz; the product parser must reproduce them."""

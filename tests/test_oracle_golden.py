@@ -87,7 +87,7 @@ def test_er_fw_trajectory(nm):
     assert np.array_equal(rounded, g["rounded"])
 
 
-@pytest.mark.parametrize("nm", ["intel", "sphere2500", "kitti_05", "city10000"])
+@pytest.mark.parametrize("nm", ["intel", "sphere2500", "kitti_05", "city10000", "kitti_02", "ais2klinik"])
 def test_pose_graph_goldens(nm):
     g = load_golden("g2o_" + nm)
     i, j, kap, n = oracle.parse_g2o_edges(os.path.join(GOLDEN, "data", nm + ".g2o"))
@@ -107,7 +107,7 @@ def test_pose_graph_goldens(nm):
     assert np.allclose(g0, g["grad_init"], rtol=1e-4, atol=1e-8 * np.abs(g["grad_init"]).max())
     assert abs(mo.evaluate_objective(np.ones(len(g["cw"]))) - g["lam_all"]) <= 1e-9 * g["lam_all"]
     tr = []
-    iters = 3 if nm == "city10000" else 6        # (a city10000 iteration costs the oracle ~1.5 s)
+    iters = 3 if nm in ("city10000", "ais2klinik") else 6        # (a city10000 iteration costs the oracle ~1.5 s)
     rounded, w, u = mo.solve(k, g["x_init"], max_iters=iters, trace=tr)
     assert np.allclose([t[0] for t in tr], g["f_traj"][:iters], rtol=1e-7)
     assert np.array_equal([t[3] for t in tr], g["supp"][:iters])
