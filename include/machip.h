@@ -162,6 +162,22 @@ int machip_comm_init(machip_problem* p, int rank, int nranks, const void* id128)
  * gradient buffers bracketed by a host barrier; shard arithmetic and call site are those of the RCCL path.
  * Destroying one handle releases peers blocked in the collective with MACHIP_RCCL_ERROR. */
 int machip_comm_init_local(machip_problem** handles, int nranks);
+/* Communicator between PROCESSES (one per GPU: what `bench.py --gpus N` / torch.distributed.run launch) whose EIGEN-SOLVE is
+ * row-partitioned (SURVEY section 8(e) "Expected scaling ... unless the eigen-solve is also parallelised"; the reference is a
+ * single process, there is no reference line to match).  Every rank exports IPC handles of its Lanczos record buffers,
+ * partial sums, Ritz staging vector, gradient and flag words (machip_ipc_export -> a blob of machip_ipc_blob_bytes() bytes), the
+ * caller distributes the blobs (mac_amd.dist.FileGroup), every rank maps the peers' buffers (machip_comm_init_ipc: blobs =
+ * nranks blobs in rank order; hipIpcOpenMemHandle, peer access across devices).  A rank then launches its share of every
+ * fused Lanczos step's workgroups and writes records / partial sums into every rank's copy; steps are ordered ON THE
+ * DEVICE by flag words (no host, no cross-stream edge; bounded waits: a stalled or dead peer makes the call return
+ * MACHIP_RCCL_ERROR after timeout_s, default 10); every rank runs the same deterministic host logic, so results are bit-identical
+ * to a single rank's.  Composes with machip_comm_init: with an RCCL communicator the gradient shards travel by ncclAllGather,
+ * without one (ranks sharing a GPU) by peer writes through the mapped buffers.  machip_comm_close_ipc before machip_destroy
+ * marks an orderly exit (a handle destroyed without it raises abort on its peers). */
+int machip_ipc_blob_bytes(void);
+int machip_ipc_export(machip_problem* p, void* blob, int blob_bytes);
+int machip_comm_init_ipc(machip_problem* p, int rank, int nranks, const void* blobs, double timeout_s);
+int machip_comm_close_ipc(machip_problem* p);
 /* With 2..8 handles the in-process communicator also ROW-PARTITIONS THE EIGEN-SOLVE (MACHIP_SHARD_EIG=0 turns that off):
  * inside machip_fw_step rank 0's solver drives every rank's stream; per Lanczos step each rank launches its share of
  * the step's workgroups on its own copy of L(x) and of the gather operand and writes the records / partial sums it
@@ -170,7 +186,9 @@ int machip_comm_init_local(machip_problem** handles, int nranks);
  * exactly what workgroup w of a single rank's launch does, so lambda_2, the Fiedler vector and everything after them
  * are bit-identical to a single-rank run.
  * machip_comm_mode: 0 = no communicator, 1 = RCCL (candidate shard, eigen-solve replicated), 2 = in-process with a
- * replicated eigen-solve, 3 = in-process with the row-partitioned eigen-solve. */
+ * replicated eigen-solve, 3 = in-process with the row-partitioned eigen-solve, 4 = inter-process (machip_comm_init_ipc) with
+ * the row-partitioned eigen-solve enabled, 5 = ... and the LAST eigen-solve really ran row-partitioned (the fused Lanczos step;
+ * other solver modes run replicated on every rank), 6 = inter-process, gradient exchange only (MACHIP_SHARD_EIG=0). */
 int machip_comm_mode(machip_problem* p);
 /* The candidate range [lo, hi) of `rank` and the padded shard length (host arithmetic only, no GPU needed):
  * shard = ceil(m / nranks), lo = min(m, rank shard), hi = min(m, lo + shard). */

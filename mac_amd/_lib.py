@@ -70,6 +70,10 @@ SIGNATURES = {
     "machip_comm_unique_id": (C.c_int, [C.c_void_p]),
     "machip_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "machip_comm_init_local": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "machip_ipc_blob_bytes": (C.c_int, []),
+    "machip_ipc_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "machip_comm_init_ipc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_double]),
+    "machip_comm_close_ipc": (C.c_int, [C.c_void_p]),
     "machip_comm_mode": (C.c_int, [C.c_void_p]),
     "machip_shard_plan": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "machip_eval_batch": (C.c_int, [C.c_void_p, C.c_int, _f64p, C.c_double, C.c_int, _f64p, C.POINTER(C.c_int)]),
@@ -267,6 +271,23 @@ class Problem:
         with _stdout_to_stderr():
             st = self._lib.machip_comm_init(self._h, int(rank), int(nranks), buf)
         check(st)
+
+    def ipc_export(self) -> bytes:
+        """IPC handles of this handle's exchange buffers (machip_ipc_export): hand the blob to every peer process."""
+        nb = self._lib.machip_ipc_blob_bytes()
+        buf = C.create_string_buffer(nb)
+        check(self._lib.machip_ipc_export(self._h, buf, nb))
+        return buf.raw
+
+    def comm_init_ipc(self, rank, nranks, blobs, timeout_s=10.0):
+        """Map the peers' buffers (blobs: one per rank, in rank order) and row-partition the eigen-solve between the processes."""
+        nb = self._lib.machip_ipc_blob_bytes()
+        assert len(blobs) == nranks and all(len(b) == nb for b in blobs)
+        buf = C.create_string_buffer(b"".join(blobs), nb * nranks)
+        check(self._lib.machip_comm_init_ipc(self._h, int(rank), int(nranks), buf, float(timeout_s)))
+
+    def comm_close_ipc(self):
+        check(self._lib.machip_comm_close_ipc(self._h))
 
     def set_solver(self, mode):
         """0 = automatic, 1 = Lanczos, 2 = preconditioned (LOBPCG + tridiagonal chain solve)."""

@@ -454,6 +454,55 @@ struct PeerSet {
     double* part[kMaxPeers];
 };
 
+// ---- device-ordered exchange between PROCESSES (round 4; machip_comm_init_ipc) ----------------------------
+// Every rank maps the peers' record / partial-sum / vector / gradient buffers (hipIpcOpenMemHandle) and writes what it
+// produces into every copy (PeerSet).  Ordering needs no host and no cross-stream edge: per channel (Lanczos steps, Ritz
+// vector rows, gradient shards) a rank counts what it has published (`done`, its own memory) and publishes that count into a
+// flag word of every peer (system-scope release, behind the producing kernel on the same stream); a consumer spins --
+// bounded -- until every peer's count has reached its own.  All ranks run the same deterministic host logic on identical
+// tridiagonal records, so they issue the same launches in the same order and the counts stay aligned.
+constexpr int kIpcChannels = 4;          // 0 Lanczos steps, 1 Ritz-vector rows, 2 gradient shards, 3 spare
+struct IpcView {
+    int n = 0, rank = 0;                 // ranks in all (0: no IPC communicator), my rank
+    unsigned long long* done = nullptr;              // [kIpcChannels] my publish counts
+    unsigned long long* flags = nullptr;             // my flag words: [kIpcChannels][kMaxPeers], written by the peers (slot = writer's rank)
+    unsigned long long* peer_flags[kMaxPeers] = {};  // every rank's flag array (mine included)
+    int* err = nullptr;                  // mapped pinned host word: 1 = a wait timed out (a peer stalled or died), 2 = a peer raised abort
+    long long timeout_ticks = 0;         // bound of one wait (100 MHz ticks)
+};
+__global__ void k_ipc_publish(IpcView I, int ch) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long c = I.done[ch] + 1ull;
+    I.done[ch] = c;
+    __threadfence_system();              // (the producing kernel has ended; its writes are performed)
+    for (int q = 0; q < I.n; ++q)
+        if (q != I.rank) __hip_atomic_store(I.peer_flags[q] + ch * kMaxPeers + I.rank, c, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_ipc_wait(IpcView I, int ch) {
+    if (threadIdx.x != 0) return;
+    if (*I.err) return;                  // already broken: do not spin again (a dead peer must cost ONE timeout, not one per step)
+    const unsigned long long want = I.done[ch];
+    const long long t0 = wall_clock64();
+    for (int q = 0; q < I.n; ++q) {
+        if (q == I.rank) continue;
+        const unsigned long long* f = I.flags + ch * kMaxPeers + q;
+        for (;;) {
+            const unsigned long long v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // (relaxed poll: the consuming kernel's start is the acquire)
+            if (v == ~0ull) { *I.err = 2; __threadfence_system(); return; }          // the peer raised abort
+            if (v >= want) break;
+            if (wall_clock64() - t0 > I.timeout_ticks) { *I.err = 1; __threadfence_system(); return; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+}
+__global__ void k_ipc_abort(IpcView I) {   // best effort: release the peers' waits with an error
+    if (threadIdx.x != 0) return;
+    for (int q = 0; q < I.n; ++q)
+        if (q != I.rank)
+            for (int ch = 0; ch < kIpcChannels; ++ch) __hip_atomic_store(I.peer_flags[q] + ch * kMaxPeers + I.rank, ~0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+struct PeerVecs { int n = 0; double* v[kMaxPeers] = {}; };     // one vector per rank (y_raw, g)
+
 // ---- wave64 sum on the VALU (DPP row shifts + row broadcasts), ~5x faster than the
 // ds_bpermute butterfly; the total lands in lane 63 and is broadcast through an SGPR. ----------
 template <int CTRL, int ROWMASK>
@@ -527,7 +576,9 @@ __device__ __forceinline__ PipeCoef pipe_coefs(const double (&a)[kNP], int n) {
 // tridiagonal record.  The other waves go straight to their CSR loads.
 template <class PV>
 __device__ __forceinline__ PipeCoef pipe_prologue_wave0(const PV& L, int jrel, int adv_jA, double* scoef, int* j_out, int bid = -1) {
-    if (bid < 0) bid = (int)blockIdx.x;     // (sharded step: the global workgroup index)
+    // (sharded step: the tridiagonal records go to the launching rank's own arrays -- its first workgroup writes them; ranks of
+    // one process share the leader's arrays and all write the same values, ranks in different processes each keep their own)
+    bid = (int)blockIdx.x;
     const int lane = threadIdx.x;   // caller guarantees threadIdx.x < 64
     const int jA = L.st->jA;        // (requested first, consumed last: in flight together with the partial loads below)
     const double* __restrict__ pin = L.part + (size_t)(jrel & 1) * (kNP * kMaxGrid);
@@ -957,12 +1008,13 @@ __global__ __launch_bounds__(kBlock) void k_ritz_combine(const double* __restric
 // as k_ritz_combine; the leader then takes the sums of the complete vector with k_vec_sums, the same row -> workgroup
 // mapping k_ritz_combine uses: bit-identical to the unsharded path).
 __global__ __launch_bounds__(kBlock) void k_ritz_own_rows(const double* __restrict__ ypart, int n, int KS,
-                                                          double* __restrict__ y_leader, RowOwner own) {
+                                                          double* __restrict__ y_leader, RowOwner own, PeerVecs all = PeerVecs()) {
     for (int r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
         if (!own.mine(r)) continue;
         double t = 0.0;
         for (int ks = 0; ks < KS; ++ks) t += ypart[(size_t)ks * n + r];
-        y_leader[r] = t;
+        if (all.n) { for (int q = 0; q < all.n; ++q) all.v[q][r] = t; }      // (ranks in different processes: every rank's copy)
+        else y_leader[r] = t;
     }
 }
 
@@ -990,12 +1042,13 @@ __global__ __launch_bounds__(kBlock) void k_resid_l1(const double* __restrict__ 
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_grad(const int* __restrict__ ci, const int* __restrict__ cj,
                                                  const double* __restrict__ cw, const double* __restrict__ v,
-                                                 long lo, long hi, double* __restrict__ g) {
+                                                 long lo, long hi, double* __restrict__ g, PeerVecs all = PeerVecs()) {
 #pragma clang fp contract(off)   // plain operators under 'contract off': every op rounds once
     for (long k = lo + (long)blockIdx.x * kBlock + threadIdx.x; k < hi; k += (long)gridDim.x * kBlock) {
         const double d = v[ci[k]] - v[cj[k]];
         const double t = cw[k] * d;
-        g[k] = t * d;
+        if (all.n) { for (int q = 0; q < all.n; ++q) all.v[q][k] = t * d; }   // (IPC communicator: the shard goes into every rank's gradient)
+        else g[k] = t * d;
     }
 }
 

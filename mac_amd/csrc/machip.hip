@@ -1,5 +1,6 @@
 // machip.hip -- C ABI of libmachip.so (see include/machip.h).  gfx950 only.
 #include <rccl/rccl.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -101,6 +102,7 @@ struct machip_problem {
     // multi-GPU
     ncclComm_t comm = nullptr;
     std::shared_ptr<LocalGroup> lgroup;
+    std::unique_ptr<IpcGroup> ipcg;      // inter-process communicator with a row-partitioned eigen-solve (machip_comm_init_ipc)
     int rank = 0, nranks = 1;
     // evaluation lanes (machip_eval_batch): lightweight copies that share the pattern and the candidate arrays
     bool is_lane = false, lane_fw_ready = false;
@@ -319,10 +321,19 @@ int compute_gradient(machip_problem* p, bool have_vec_now = false) {
     const long m = p->m;
     long lo = 0, hi = m, shard = m;
     if (p->nranks > 1) shard_plan(m, p->nranks, p->rank, &lo, &hi, &shard);
+    const bool ipc_gather = p->nranks > 1 && !p->comm && p->ipcg;     // no RCCL communicator (ranks sharing a GPU): shards by peer writes
     if (hi > lo) {
         const int grid = (int)std::min<long>(kMaxGrid * 4, (hi - lo + kBlock - 1) / kBlock);
-        k_grad<<<grid, kBlock, 0, p->stream>>>(p->ci, p->cj, p->cw, p->sol.yvec, lo, hi, p->g);
+        PeerVecs all;
+        if (ipc_gather) { all.n = p->ipcg->nranks; for (int q = 0; q < all.n; ++q) all.v[q] = p->ipcg->g[q]; }
+        k_grad<<<grid, kBlock, 0, p->stream>>>(p->ci, p->cj, p->cw, p->sol.yvec, lo, hi, p->g, all);
         HIP_TRY(hipGetLastError());
+    }
+    if (ipc_gather) {
+        k_ipc_publish<<<1, 64, 0, p->stream>>>(p->ipcg->view, 2);
+        k_ipc_wait<<<1, 64, 0, p->stream>>>(p->ipcg->view, 2);
+        HIP_TRY(hipGetLastError());
+        return MACHIP_OK;
     }
     if (p->nranks > 1) {
         if (p->comm) NCCL_TRY(ncclAllGather(p->g + shard * p->rank, p->g, (size_t)shard, ncclDouble, p->comm, p->stream));
@@ -479,6 +490,15 @@ void machip_destroy(machip_problem* p) {
     if (p->is_lane) { p->prow = p->pcol = p->pk = nullptr; p->pw = nullptr; p->ci = p->cj = nullptr; p->cw = nullptr; }   // borrowed
     if (p->comm) (void)ncclCommDestroy(p->comm);
     if (p->lgroup) p->lgroup->abort();      // peers blocked in the group's barrier return an error instead of hanging
+    if (p->ipcg) {
+        IpcGroup& G = *p->ipcg;
+        if (!G.clean_exit) { k_ipc_abort<<<1, 64, 0, p->stream>>>(G.view); (void)hipStreamSynchronize(p->stream); }   // peers' waits end with an error, not a time-out
+        p->sol.ipc = nullptr;
+        for (void* q : G.opened) (void)hipIpcCloseMemHandle(q);
+        if (G.flags_mem) (void)hipFree(G.flags_mem);
+        if (G.h_err) (void)hipHostFree(G.h_err);
+        p->ipcg.reset();
+    }
     p->sol.destroy();
     void* ptrs[] = {p->prow, p->pcol, p->pk, p->pw, p->ci, p->cj, p->cw, p->x, p->x_next, p->g, p->s, p->scratch_m, p->cnt,
                     p->blk_sum, p->rowptr, p->col, p->val, p->blk_lnorm, p->sval, p->hist, p->sel, p->part_fw};
@@ -558,7 +578,10 @@ namespace {
 struct GroupGuard {
     machip_problem* p;
     bool ok = false;
-    ~GroupGuard() { if (!ok && p && p->lgroup) p->lgroup->abort(); }
+    ~GroupGuard() {
+        if (!ok && p && p->lgroup) p->lgroup->abort();
+        if (!ok && p && p->ipcg) { k_ipc_abort<<<1, 64, 0, p->stream>>>(p->ipcg->view); (void)hipStreamSynchronize(p->stream); }
+    }
 };
 }  // namespace
 
@@ -627,6 +650,7 @@ int machip_fw_step(machip_problem* p, int64_t k, int iter, double tol, int max_s
         if (epi_status != MACHIP_OK) return epi_status;
         HIP_TRY(hipStreamSynchronize(p->stream));
     }
+    if (p->ipcg) ST_TRY(p->sol.ipc_check_err("gradient exchange"));
     double d = 0.0, q2 = 0.0;
     for (int b = 0; b < grid; ++b) { d += p->h_dbl[b]; q2 += p->h_dbl[kMaxGrid + b]; }
     *f = lam;
@@ -828,6 +852,100 @@ int machip_comm_init(machip_problem* p, int rank, int nranks, const void* id128)
     return MACHIP_OK;
 }
 
+// ---- communicator between processes with a row-partitioned eigen-solve (round 4) ----
+// Blob a rank hands to its peers: IPC handles of its record buffers, partial sums, Ritz staging vector, gradient and flag words.
+namespace {
+struct IpcBlob {
+    unsigned long long magic;
+    int n; long m; int pid; int device;
+    hipIpcMemHandle_t Z0, Z1, part, yraw, g, flags;
+};
+constexpr unsigned long long kIpcMagic = 0x6d61636869706331ull;
+constexpr size_t kIpcFlagWords = (size_t)kIpcChannels * kMaxPeers + kIpcChannels + 8;
+}  // namespace
+
+int machip_ipc_blob_bytes(void) { return (int)sizeof(IpcBlob); }
+
+int machip_ipc_export(machip_problem* p, void* blob, int blob_bytes) {
+    if (!p || p->csr_only || !blob || blob_bytes < (int)sizeof(IpcBlob)) return fail(MACHIP_BAD_ARG, "machip_ipc_export: bad argument");
+    if (p->lgroup || p->ipcg) return fail(MACHIP_BAD_ARG, "machip_ipc_export: handle already belongs to a communicator");
+    HIP_TRY(hipSetDevice(p->device));
+    auto G = std::make_unique<IpcGroup>();
+    ST_TRY(dev_alloc(&G->flags_mem, kIpcFlagWords));
+    HIP_TRY(hipMemsetAsync(G->flags_mem, 0, sizeof(unsigned long long) * kIpcFlagWords, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipHostMalloc((void**)&G->h_err, 64, hipHostMallocMapped));
+    *G->h_err = 0;
+    IpcBlob b;
+    memset(&b, 0, sizeof(b));
+    b.magic = kIpcMagic; b.n = p->n; b.m = p->m; b.pid = (int)getpid(); b.device = p->device;
+    HIP_TRY(hipIpcGetMemHandle(&b.Z0, p->sol.Z0)); HIP_TRY(hipIpcGetMemHandle(&b.Z1, p->sol.Z1));
+    HIP_TRY(hipIpcGetMemHandle(&b.part, p->sol.part)); HIP_TRY(hipIpcGetMemHandle(&b.yraw, p->sol.y_raw));
+    HIP_TRY(hipIpcGetMemHandle(&b.g, p->g)); HIP_TRY(hipIpcGetMemHandle(&b.flags, G->flags_mem));
+    memcpy(blob, &b, sizeof(b));
+    p->ipcg = std::move(G);
+    return MACHIP_OK;
+}
+
+int machip_comm_init_ipc(machip_problem* p, int rank, int nranks, const void* blobs, double timeout_s) {
+    if (!p || p->csr_only || !blobs || nranks < 2 || nranks > kMaxPeers || rank < 0 || rank >= nranks)
+        return fail(MACHIP_BAD_ARG, "machip_comm_init_ipc: 2..8 ranks, a blob per rank");
+    if (!p->ipcg || p->ipcg->nranks) return fail(MACHIP_BAD_ARG, "machip_comm_init_ipc: call machip_ipc_export first (once)");
+    if (p->lgroup) return fail(MACHIP_BAD_ARG, "machip_comm_init_ipc: handle already belongs to an in-process communicator");
+    HIP_TRY(hipSetDevice(p->device));
+    IpcGroup& G = *p->ipcg;
+    const IpcBlob* B = static_cast<const IpcBlob*>(blobs);
+    for (int q = 0; q < nranks; ++q)
+        if (B[q].magic != kIpcMagic || B[q].n != p->n || B[q].m != p->m) return fail(MACHIP_BAD_ARG, "machip_comm_init_ipc: blob of a different problem / library");
+    if (B[rank].pid != (int)getpid()) return fail(MACHIP_BAD_ARG, "machip_comm_init_ipc: blob[rank] is not this process's");
+    auto open = [&](const hipIpcMemHandle_t& h, void** out, int peer_device) -> int {
+        if (peer_device != p->device) {     // distinct devices: the peer's memory is reached over xGMI
+            int can = 0;
+            HIP_TRY(hipDeviceCanAccessPeer(&can, p->device, peer_device));
+            if (!can) return fail(MACHIP_RCCL_ERROR, "machip_comm_init_ipc: no peer access between the ranks' devices");
+            const hipError_t e = hipDeviceEnablePeerAccess(peer_device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(MACHIP_HIP_ERROR, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+            (void)hipGetLastError();
+        }
+        const hipError_t e = hipIpcOpenMemHandle(out, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) { (void)hipGetLastError(); return fail(MACHIP_RCCL_ERROR, std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e) + " (HSA_ENABLE_IPC_MODE_LEGACY=0 set?)"); }
+        G.opened.push_back(*out);
+        return MACHIP_OK;
+    };
+    for (int q = 0; q < nranks; ++q) {
+        if (q == rank) {
+            G.Z0[q] = p->sol.Z0; G.Z1[q] = p->sol.Z1; G.part[q] = p->sol.part; G.yraw[q] = p->sol.y_raw; G.g[q] = p->g;
+            G.view.peer_flags[q] = G.flags_mem;
+            continue;
+        }
+        void* t = nullptr;
+        ST_TRY(open(B[q].Z0, &G.Z0[q], B[q].device)); ST_TRY(open(B[q].Z1, &G.Z1[q], B[q].device));
+        ST_TRY(open(B[q].part, &t, B[q].device)); G.part[q] = (double*)t;
+        ST_TRY(open(B[q].yraw, &t, B[q].device)); G.yraw[q] = (double*)t;
+        ST_TRY(open(B[q].g, &t, B[q].device)); G.g[q] = (double*)t;
+        ST_TRY(open(B[q].flags, &t, B[q].device)); G.view.peer_flags[q] = (unsigned long long*)t;
+    }
+    G.nranks = nranks; G.rank = rank;
+    G.view.n = nranks; G.view.rank = rank;
+    G.view.flags = G.flags_mem;
+    G.view.done = G.flags_mem + (size_t)kIpcChannels * kMaxPeers;
+    HIP_TRY(hipHostGetDevicePointer((void**)&G.view.err, G.h_err, 0));
+    if (!(timeout_s > 0.0)) timeout_s = 10.0;
+    G.view.timeout_ticks = (long long)(timeout_s * 1e8);
+    p->rank = rank; p->nranks = nranks;
+    long lo, hi, shard;
+    shard_plan(p->m, nranks, rank, &lo, &hi, &shard);
+    p->m_pad = shard * nranks;
+    if (env_int("MACHIP_SHARD_EIG", 1) != 0) p->sol.ipc = &G;      // (0: the eigen-solve stays replicated, only the gradient is exchanged)
+    return MACHIP_OK;
+}
+
+int machip_comm_close_ipc(machip_problem* p) {
+    if (!p || !p->ipcg) return fail(MACHIP_BAD_ARG, "machip_comm_close_ipc: no inter-process communicator");
+    p->ipcg->clean_exit = true;
+    return MACHIP_OK;
+}
+
 int machip_comm_init_local(machip_problem** handles, int nranks) {
     if (!handles || nranks < 1 || nranks > 64) return fail(MACHIP_BAD_ARG, "machip_comm_init_local: 1..64 handles");
     for (int r = 0; r < nranks; ++r) {
@@ -869,6 +987,7 @@ int machip_comm_init_local(machip_problem** handles, int nranks) {
 
 int machip_comm_mode(machip_problem* p) {
     if (!p) return -1;
+    if (p->ipcg && p->ipcg->nranks) return p->sol.ipc ? (p->sol.last_seq_sharded ? 5 : 4) : (p->comm ? 1 : 6);
     if (p->comm) return 1;
     if (p->lgroup) return p->lgroup->shard_eig ? 3 : 2;
     return 0;

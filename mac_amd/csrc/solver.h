@@ -38,6 +38,23 @@ namespace machip {
 // inverse is hand-written, woodbury.h -- and the lock with them: captures are thread-local, every other call of this library
 // names its own non-blocking stream.)
 
+// Communicator between PROCESSES whose eigen-solve is row-partitioned (machip_comm_init_ipc; kernels.h IpcView): this rank's
+// share of every Lanczos step, the peers' buffers mapped through hipIpcOpenMemHandle, ordering by flag words in device memory.
+struct IpcGroup {
+    int nranks = 0, rank = 0;
+    IpcView view;                        // flags / counters (kernel argument)
+    void* Z0[kMaxPeers] = {};            // every rank's record buffers, partial sums, Ritz-vector staging, gradient (index = rank;
+    void* Z1[kMaxPeers] = {};            // my own entries are my own pointers)
+    double* part[kMaxPeers] = {};
+    double* yraw[kMaxPeers] = {};
+    double* g[kMaxPeers] = {};
+    std::vector<void*> opened;           // what hipIpcCloseMemHandle must release
+    unsigned long long* flags_mem = nullptr;   // my flag words + counters (device, exported to the peers)
+    int* h_err = nullptr;                // mapped pinned
+    int g0 = 0, g1 = 0;                  // my workgroups of the running sequence's step launch
+    bool clean_exit = false;             // the owner said goodbye (machip_comm_close_ipc): destroying the handle raises no abort
+};
+
 struct Solver {
     int n = 0;
     hipStream_t stream = nullptr;
@@ -122,8 +139,10 @@ struct Solver {
     static constexpr int kLobCap = 100000;
     // column-panel step (panel.h): the panel form of the matrix being solved, rebuilt per solve from its CSR
     bool seq_sharded = false;      // the running Krylov sequence is row-partitioned (its basis is spread over the ranks)
+    bool seq_ipc = false;          // ... between processes (IpcGroup): every rank runs this host loop itself
     SpmvPlan seq_plan;             // ... with this launch shape
     ShardGroup* shard = nullptr;   // set (by the leader's handle) for the duration of a row-partitioned solve
+    IpcGroup* ipc = nullptr;       // set while this handle belongs to an inter-process communicator with a row-partitioned eigen-solve
     bool last_seq_sharded = false; // the basis of the last sequence is spread over the ranks (ritz_block cannot read it)
     bool pan_allowed = false;   // the CSR is one this library assembled (diagonal first, other columns ascending)
     PanPlan pan;
@@ -371,6 +390,53 @@ struct Solver {
         if (!G.same_device) (void)hipSetDevice(G.rk[0].device);
         k_pipe_tail<<<1, 64, 0, stream>>>(pview(pl), steps);
     }
+    // ---- row-partitioned chunk between processes: my workgroups only, ordered by flags in device memory (IpcGroup) ----
+    PeerSet ipc_peers(const SpmvPlan& pl) const {
+        PeerSet PS;
+        PS.n = ipc->nranks; PS.first = ipc->g0; PS.total = pl.grid;
+        for (int q = 0; q < PS.n; ++q) { PS.Z0[q] = ipc->Z0[q]; PS.Z1[q] = ipc->Z1[q]; PS.part[q] = ipc->part[q]; }
+        return PS;
+    }
+    void ipc_split(const SpmvPlan& pl) {
+        ipc->g0 = (int)((long)pl.grid * ipc->rank / ipc->nranks);
+        ipc->g1 = (int)((long)pl.grid * (ipc->rank + 1) / ipc->nranks);
+    }
+    void launch_chunk_ipc(const CsrView& A, const SpmvPlan& pl, int steps) {
+        ipc_split(pl);
+        const PipeView L = pview(pl);
+        const PeerSet PS = ipc_peers(pl);
+        for (int s = 0; s < steps; ++s) {
+            k_ipc_wait<<<1, 64, 0, stream>>>(ipc->view, 0);          // every peer has delivered its records / partial sums of the step before
+            launch_pipe_shard(pl, stream, A, L, s, PS, ipc->g1 - ipc->g0);
+            k_ipc_publish<<<1, 64, 0, stream>>>(ipc->view, 0);
+        }
+        k_ipc_wait<<<1, 64, 0, stream>>>(ipc->view, 0);
+        k_pipe_tail<<<1, 64, 0, stream>>>(L, steps);
+    }
+    // y_raw = V[:, :J] s: my rows of the basis -> my rows of EVERY rank's y_raw, then everybody holds the whole vector
+    int ipc_ritz(const SpmvPlan& pl, int J, const double* s_host) {
+        const int g2 = vgrid();
+        const int KS = std::max(1, std::min(ks_max, J / 8));
+        memcpy(h_pin, s_host, sizeof(double) * (size_t)J);
+        HIP_TRY(hipMemcpyAsync(sdev, h_pin, sizeof(double) * (size_t)J, hipMemcpyHostToDevice, stream));
+        ipc_split(pl);
+        RowOwner own; own.gpb = pipe_gpb(pl); own.gtot = pl.grid; own.g0 = ipc->g0; own.g1 = ipc->g1;
+        PeerVecs all; all.n = ipc->nranks;
+        for (int q = 0; q < all.n; ++q) all.v[q] = ipc->yraw[q];
+        k_ritz_partial<<<dim3(g2, KS), kBlock, 0, stream>>>(V, n, J, sdev, ypart, own);
+        k_ritz_own_rows<<<g2, kBlock, 0, stream>>>(ypart, n, KS, y_raw, own, all);
+        k_ipc_publish<<<1, 64, 0, stream>>>(ipc->view, 1);
+        k_ipc_wait<<<1, 64, 0, stream>>>(ipc->view, 1);
+        k_vec_sums<<<g2, kBlock, 0, stream>>>(y_raw, n, part_c);
+        HIP_TRY(hipGetLastError());
+        return MACHIP_OK;
+    }
+    int ipc_check_err(const char* where) {
+        if (ipc && ipc->h_err && *(volatile int*)ipc->h_err)
+            return fail(MACHIP_RCCL_ERROR, std::string("inter-process communicator: ") + (*(volatile int*)ipc->h_err == 2 ? "a peer rank raised abort" : "a peer rank did not deliver within the time limit (stalled or dead)") + " (" + where + ")");
+        return MACHIP_OK;
+    }
+
     // start of a sequence: the leader's k_pipe_init output (records of u, first partial sums) into every rank's copy
     int shard_broadcast_init() {
         ShardGroup& G = *shard;
@@ -414,6 +480,7 @@ struct Solver {
             return;
         }
         if (shard && pl.variant == kVec && !f32) { launch_chunk_sharded(pl, steps); return; }
+        if (seq_ipc && pl.variant == kVec && !f32) { launch_chunk_ipc(A, pl, steps); return; }
         if (f32) {
             const PipeViewT<float> L = pview<float>(pl);
             const CsrViewT<float> Af{A.n, A.rowptr, A.col, valf};
@@ -437,7 +504,7 @@ struct Solver {
             graphs.clear();
             graph_csr_key = (const void*)A.val;
         }
-        const auto key = std::make_tuple(pl.variant + (f32 ? 100 : 0) + 1000 * pl.defer + (sharded ? 100000 * (int)shard->rk.size() : 0), pl.width * 10 + pl.unroll, pl.grid, pl.block, steps);
+        const auto key = std::make_tuple(pl.variant + (f32 ? 100 : 0) + 1000 * pl.defer + (sharded ? 100000 * (int)shard->rk.size() : 0) + (seq_ipc && pl.variant == kVec && !f32 ? 10000000 : 0), pl.width * 10 + pl.unroll, pl.grid, pl.block, steps);
         auto it = graphs.find(key);
         if (it == graphs.end()) it = graphs.emplace(key, std::array<hipGraphExec_t, 2>{nullptr, nullptr}).first;
         // two executables per shape, used alternately: with one chunk running ahead, the same
@@ -458,6 +525,7 @@ struct Solver {
     // y = V[:, :J] s  -> normalised into yvec; w2 = L yvec; returns (rq, ||w2 - rq yvec||_1).
     int explicit_check(const CsrView& A, const SpmvPlan& pl, int J, const double* s_host, double* rq,
                        double* res_l1, bool f32 = false) {
+        if (seq_sharded && seq_ipc) { ST_TRY(ipc_ritz(seq_plan, J, s_host)); return check_vector(A, pl, rq, res_l1); }
         if (seq_sharded) { ST_TRY(shard_ritz(seq_plan, J, s_host)); return check_vector(A, pl, rq, res_l1); }
         memcpy(h_pin, s_host, sizeof(double) * (size_t)J);
         HIP_TRY(hipMemcpyAsync(sdev, h_pin, sizeof(double) * (size_t)J, hipMemcpyHostToDevice, stream));
@@ -487,6 +555,7 @@ struct Solver {
         ++check_seq;
         if (after_check) { after_check(); hook_seq = check_seq; }
         HIP_TRY(hipStreamSynchronize(stream));
+        ST_TRY(ipc_check_err("explicit check"));
         ev1_at_check = true;
         double s = 0.0;
         for (int i = 0; i < g2; ++i) s += hp[i];
@@ -1043,9 +1112,9 @@ struct Solver {
         // LDS-resident single-workgroup form when the matrix fits (classic recurrence: also fine after restarts)
         const bool pmode = pmode_early;
         // column-panel step (panel.h) where the gather operand is too large for the caches (fp64 sequences only)
-        pan = plan_panel(n, nnz, maxlen_hint, pan_allowed && precision == 0 && !pmode && !classic && pp.variant == kVec && !shard);   // (the row-partitioned solve shards the gather step)
+        pan = plan_panel(n, nnz, maxlen_hint, pan_allowed && precision == 0 && !pmode && !classic && pp.variant == kVec && !shard && !ipc);   // (the row-partitioned solve shards the gather step)
         // padded fixed-width form for short rows (pose graphs beyond the single-workgroup kernel): no row-pointer round trip
-        if (!pan.on && !pmode && !classic && !shard && precision == 0 && pp.variant == kVec && pp.width == 4 && pp.defer < 3 &&
+        if (!pan.on && !pmode && !classic && !shard && !ipc && precision == 0 && pp.variant == kVec && pp.width == 4 && pp.defer < 3 &&
             maxlen_hint >= 1 && maxlen_hint <= 16 && env_int("MACHIP_ELL", 1) != 0) {
             const int W = maxlen_hint <= 8 ? 8 : 16;
             if (!ell_col) { ST_TRY(dev_alloc(&ell_col, (size_t)n * 16)); ST_TRY(dev_alloc(&ell_val, (size_t)n * 16)); }
@@ -1116,7 +1185,7 @@ struct Solver {
         if (pmode) ST_TRY(pack_persist(A));
         while (!done && steps_total < max_steps) {
             // ---- (re)start a Krylov sequence from u ----
-            seq_sharded = false;
+            seq_sharded = false; seq_ipc = false;
             if (pmode) {
                 ++epoch;
                 k_persist_begin<<<g2, kBlock, 0, stream>>>(persist_view(), (int)epoch, begin_src);
@@ -1137,6 +1206,9 @@ struct Solver {
                 if (shard && pp.variant == kVec) {       // row-partitioned sequence: every rank starts from the same records
                     seq_sharded = true; seq_plan = pp;
                     ST_TRY(shard_broadcast_init());
+                } else if (ipc && pp.variant == kVec && pp.grid >= ipc->nranks) {
+                    // between processes every rank has just run k_pipe_init itself on its own copy of u: identical records
+                    seq_sharded = true; seq_ipc = true; seq_plan = pp;
                 }
             }
             const double seq_tol = f32_seq ? f32_switch : tol;     // what this sequence's residual estimate aims for
@@ -1228,6 +1300,7 @@ struct Solver {
                     ev_pool.push_back(p.ev);
                 } else {
                     ST_TRY(wait_flag(((unsigned long long)epoch << 32) | (unsigned long long)(unsigned int)p.jend));
+                    ST_TRY(ipc_check_err("Lanczos chunk"));
                     // the flag can overtake the records on their way to host memory: the beta slots of this chunk
                     // were poisoned before it was enqueued, wait until every one has landed
                     unsigned long budget = 5000000ul;   // ~20 ms in total: a genuine NaN (non-finite input) must not stall the solve

@@ -37,6 +37,24 @@ def attach(problem, dist, rank: int, nranks: int):
     return shard_bounds(problem.m, rank, nranks)
 
 
+def attach_ipc(problem, dist, rank: int, nranks: int, timeout_s: float = 10.0):
+    """Row-partition the eigen-solve of ``problem`` between the processes of the job (machip_comm_init_ipc): every rank
+    exports IPC handles of its exchange buffers, the group carries the blobs, every rank maps its peers' buffers.  Call
+    after ``attach`` when an RCCL communicator carries the gradient, or alone (ranks sharing one GPU: the gradient shards
+    then travel through the mapped buffers too).  ``detach_ipc`` before closing the problem."""
+    blob = problem.ipc_export()
+    blobs = dist.all_gather_object(blob)
+    problem.comm_init_ipc(rank, nranks, blobs, timeout_s)
+    dist.barrier()                      # everybody has mapped everybody before the first step is launched
+    return shard_bounds(problem.m, rank, nranks)
+
+
+def detach_ipc(problem, dist):
+    """Orderly exit: nobody unmaps / frees while a peer may still write."""
+    dist.barrier()
+    problem.comm_close_ipc()
+
+
 def default_key() -> str:
     ppid = os.getppid()
     start = "0"

@@ -1943,3 +1943,105 @@ def test_new_entry_points_reject_bad_arguments():
     assert abs(lam64[0] - g2["lam_init"]) <= LAM_RTOL * g2["lam_init"]
     for h in (P, Q, P2):
         h.close()
+
+
+# --------------------------------------------------------------------------------------------
+# Inter-process communicator with a row-partitioned eigen-solve (round 4: machip_comm_init_ipc)
+# --------------------------------------------------------------------------------------------
+IPC_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import numpy as np
+from mac_amd import _lib
+from mac_amd.dist import FileGroup, attach_ipc, detach_ipc
+from mac_amd.utils.fiedler import reference_start_block
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+wl, iters, die_at = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+if wl.startswith("golden:"):
+    from conftest import load_golden
+    g = load_golden(wl[7:])
+    n, k, x0 = int(g["n"]), int(g["k"]), g["x_init"]
+    P = _lib.Problem(n, g["fi"], g["fj"], g["fw"], g["ci"], g["cj"], g["cw"])
+else:
+    import bench
+    w = bench.make_workload(wl)
+    n, k, x0 = w["n"], w["k"], w["x0"]
+    P = _lib.Problem(n, w["fi"], w["fj"], w["fw"], w["ci"], w["cj"], w["cw"])
+P.set_start(reference_start_block(n)[:, 0].copy())
+dist = FileGroup(rank, world) if world > 1 else None
+if dist is not None:
+    attach_ipc(P, dist, rank, world, timeout_s=float(os.environ.get("IPC_TIMEOUT", "10")))
+P.set_x(x0)
+out = []
+try:
+    for it in range(iters):
+        if rank == 1 and it == die_at:
+            os._exit(17)                      # a rank dies mid-run: no goodbye, no abort flag
+        f, dual, gn = P.fw_step(k, it)
+        out.append((f.hex(), dual.hex(), gn.hex(), int(P.stats.lanczos_steps)))
+        P.fw_commit()
+    x = P.get_x()
+    print("RESULT", json.dumps({"rank": rank, "out": out, "xsum": float(x.sum()).hex(), "xdot": float(x @ np.arange(len(x))).hex(),
+                                "mode": int(_lib.load().machip_comm_mode(P._h))}), flush=True)
+    if dist is not None:
+        detach_ipc(P, dist)
+    P.close()
+    if dist is not None:
+        dist.close()
+except _lib.MachipError as e:
+    print("ERROR", json.dumps({"rank": rank, "status": e.status, "msg": str(e), "done": len(out)}), flush=True)
+    os._exit(3)
+'''
+
+
+def _run_ipc_job(world, wl, iters, die_at=-1, timeout=300, env_extra=None):
+    import json
+    import uuid
+    key = uuid.uuid4().hex
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MACHIP_RDZV_KEY=key, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.update(env_extra or {})
+        procs.append(subprocess.Popen([sys.executable, "-c", IPC_WORKER, wl, str(iters), str(die_at)], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    res = []
+    for p in procs:
+        try:
+            so, se = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        lines = [l for l in so.splitlines() if l.startswith(("RESULT", "ERROR"))]
+        res.append((p.returncode, lines[-1] if lines else "", se[-1500:]))
+    return [(rc, (ln.split(" ", 1)[0], json.loads(ln.split(" ", 1)[1])) if ln else None, se) for rc, ln, se in res]
+
+
+@pytest.mark.parametrize("world,wl,iters", [(2, "golden:er2000_solve", 5), (3, "golden:er2000_solve", 4), (2, "c2", 4)])
+def test_ipc_row_partitioned_eigensolve_between_processes_is_bit_identical(world, wl, iters):
+    """machip_comm_init_ipc: `world` PROCESSES on this one GPU (what bench.py --gpus N launches with MACHIP_SHARE_GPU=1), the
+    peers' record / partial-sum / vector / gradient buffers mapped through hipIpcOpenMemHandle, every rank launching its share
+    of each fused Lanczos step and ordering the steps by flag words in device memory -- no host in the loop, no RCCL (it refuses
+    two ranks on one device: the gradient shards travel through the mapped buffers too).  f / dual / ||g|| / step counts of
+    every iteration and the final x must equal the single-process run BIT FOR BIT on every rank."""
+    single = _run_ipc_job(1, wl, iters)[0]
+    assert single[0] == 0 and single[1][0] == "RESULT", single
+    multi = _run_ipc_job(world, wl, iters)
+    for rc, msg, se in multi:
+        assert rc == 0 and msg and msg[0] == "RESULT", (rc, msg, se)
+        assert msg[1]["out"] == single[1][1]["out"] and msg[1]["xsum"] == single[1][1]["xsum"] and msg[1]["xdot"] == single[1][1]["xdot"]
+        assert msg[1]["mode"] == 5, msg[1]["mode"]              # the last eigen-solve really ran row-partitioned between the processes
+
+
+def test_ipc_peers_of_a_dead_rank_return_an_error_within_the_time_limit():
+    """A rank that dies mid-solve (os._exit: no goodbye) must not hang its peers: their next device-side wait times out after
+    the communicator's limit (2 s here), later waits return at once, and the call comes back with MACHIP_RCCL_ERROR."""
+    import time
+    t0 = time.time()
+    res = _run_ipc_job(2, "golden:er2000_solve", 6, die_at=2, timeout=120, env_extra={"IPC_TIMEOUT": "2"})
+    el = time.time() - t0
+    assert res[1][0] == 17                                   # the rank that died
+    rc, msg, se = res[0]
+    assert rc == 3 and msg and msg[0] == "ERROR", (rc, msg, se)
+    assert msg[1]["status"] == _lib.RCCL_ERROR and msg[1]["done"] == 2 and "peer" in msg[1]["msg"]
+    assert el < 60.0, el
