@@ -530,9 +530,33 @@ def main():
     P.set_precision(args.precision)
     from mac_amd.utils.fiedler import reference_start_block
     P.set_start(reference_start_block(n)[:, 0].copy())
+    eig_mode = "single rank"
     if dist is not None and not replicas:
-        from mac_amd.dist import attach
-        attach(P, dist, rank, world)      # ncclCommInitRank inside libmachip; the file group only carries the id
+        from mac_amd.dist import attach, attach_ipc
+        share = os.environ.get("MACHIP_SHARE_GPU") == "1" and ndev < world       # protocol test: several ranks on one GPU
+        if not share:
+            attach(P, dist, rank, world)  # ncclCommInitRank inside libmachip; the file group only carries the id
+        eig_mode = "replicated on every rank"
+        # Default: on when the ranks share a GPU (protocol run), OFF on distinct devices -- measured on one GPU the device-ordered
+        # step costs +7.4 .. +8.8 us (two more launches per step and the flag round trip; profiles/r4_ipc_one_gpu.txt), which the
+        # 1/R share of the gathers does not buy back at configs[3] (predicted 0.7x of one GPU at R = 8, below); MACHIP_IPC_EIG=1
+        # turns it on anywhere.
+        ipc_default = "1" if share else "0"
+        if world > 1 and os.environ.get("MACHIP_IPC_EIG", ipc_default) != "0":
+            # row-partitioned eigen-solve between the processes (machip_comm_init_ipc): first contact is guarded -- any failure
+            # to map the peers' buffers leaves the replicated solve in place and is reported in the line
+            try:
+                attach_ipc(P, dist, rank, world, timeout_s=float(os.environ.get("MACHIP_IPC_TIMEOUT", "20")))
+                eig_mode = "row-partitioned between the processes, steps ordered by device-side flags (IPC-mapped buffers)"
+            except Exception as e:        # noqa: BLE001
+                oks = False
+                eig_mode = f"replicated on every rank (IPC attach failed on rank {rank}: {e})"
+            # all ranks must agree: if anyone failed, nobody may run the partitioned step
+            flags = dist.all_gather_object(eig_mode.startswith("row-partitioned"))
+            if not all(flags) and any(flags):
+                raise SystemExit("bench.py: IPC attach succeeded on some ranks only -- cannot continue")
+            if share and not all(flags):
+                raise SystemExit("bench.py: MACHIP_SHARE_GPU=1 needs the IPC communicator (RCCL refuses two ranks on one device): " + eig_mode)
 
     # ---- warmup (untimed) ----
     run_pass(P, k, args.warmup, w["x0"])
@@ -598,7 +622,7 @@ def main():
             par = (f"replicas x{world}: one independent problem per GPU (" +
                    ("city10000 / sphere2500 alternating" if args.config == "c5" else "budget sweep K_r = K (0.5 + r/(R-1))") + "), no collective")
         else:
-            par = f"candidate shard x{world} + RCCL all-gather of the gradient, eigen-solve replicated"
+            par = f"candidate shard x{world} + all-gather of the gradient ({'RCCL' if os.environ.get('MACHIP_SHARE_GPU') != '1' or ndev >= world else 'IPC peer writes: ranks share a GPU'}), eigen-solve {eig_mode}"
         out = {
             "metric": "frank_wolfe_iters_per_sec",
             "value": units / el,
@@ -636,7 +660,18 @@ def main():
             else:
                 pred = {2: 0.99, 4: 0.98, 8: 0.97}.get(world, 1.0 - 0.004 * world)
                 why = ("candidate shard: only the supergradient (0.4 % of an iteration) is divided, the all-gather of the 16 MB gradient costs more "
-                       "than it saves; the eigen-solve is replicated (the row-partitioned solve of DESIGN section 6 needs all ranks in one process)")
+                       "than it saves; the eigen-solve is replicated on every rank (MACHIP_IPC_EIG=1 row-partitions it between the processes)")
+                if eig_mode.startswith("row-partitioned"):
+                    # measured on one MI355X (profiles/r4_ipc_one_gpu.txt): gather step 13 us + 4.1 us per million entries, device-ordered
+                    # exchange +8 us per step (wait + publish launches, flag round trip), peer writes over xGMI ~3 us (unmeasured);
+                    # one GPU runs the column-panel step at 17.8 us
+                    nnz_m = float(np.mean([r[2] for r in rec])) / 1e6
+                    t1 = 17.8 if cfg == "c4" else 6.7
+                    tR = (13.0 if cfg == "c4" else 5.0) + 4.1 * nnz_m / world + 8.0 + 3.0
+                    pred = t1 / tR
+                    why = (f"row-partitioned eigen-solve: per step {tR:.1f} us predicted (fixed part of the gather step + 4.1 us x {nnz_m:.2f} M entries / {world} ranks "
+                           f"+ 8 us device-ordered exchange measured on one GPU + ~3 us of peer writes over xGMI, unmeasured) against {t1} us on one GPU: a single "
+                           "problem of this size does not get faster on more GPUs; replicas mode is what scales")
             out["predicted_vs_1gpu"] = {"factor": pred, "why": why}
     # ---- roofline of the dominant kernel: in-solve duration from the hipEvents that bracket the Krylov chunks
     #      on the handle's stream (machip_solve_stats.step_ms / steps_timed), summed over EVERY timed pass ----
@@ -719,6 +754,9 @@ def main():
         out["speedup_vs_cpu_strong"] = out["value"] / cs["value"]
     if rank == 0:
         print(json.dumps(out))
+    if dist is not None and eig_mode.startswith("row-partitioned"):
+        from mac_amd.dist import detach_ipc
+        detach_ipc(P, dist)
     P.close()
     if dist is not None:
         dist.close()

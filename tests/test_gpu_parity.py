@@ -2017,7 +2017,7 @@ def _run_ipc_job(world, wl, iters, die_at=-1, timeout=300, env_extra=None):
     return [(rc, (ln.split(" ", 1)[0], json.loads(ln.split(" ", 1)[1])) if ln else None, se) for rc, ln, se in res]
 
 
-@pytest.mark.parametrize("world,wl,iters", [(2, "golden:er2000_solve", 5), (3, "golden:er2000_solve", 4), (2, "c2", 4)])
+@pytest.mark.parametrize("world,wl,iters", [(2, "golden:er2000_solve", 5), (3, "golden:er2000_solve", 4), (2, "c2", 4), (2, "c4", 3)])
 def test_ipc_row_partitioned_eigensolve_between_processes_is_bit_identical(world, wl, iters):
     """machip_comm_init_ipc: `world` PROCESSES on this one GPU (what bench.py --gpus N launches with MACHIP_SHARE_GPU=1), the
     peers' record / partial-sum / vector / gradient buffers mapped through hipIpcOpenMemHandle, every rank launching its share
