@@ -464,13 +464,84 @@ def self_launch(args):
                     p.terminate()
             break
         time.sleep(0.2)
+    stalled = [r for r, p in enumerate(procs) if p.poll() is None]
     codes = [p.wait() for p in procs]
     rd.join(timeout=5)
+    if failed:
+        first = [r for r, c in enumerate(codes) if c not in (0, -15)]
+        sys.stderr.write(f"bench.py launcher: rank(s) {first} failed first (exit codes {codes}); rank(s) {stalled} were still running and were terminated\n")
     if not failed and not any(codes):
         sys.stdout.write((buf[0] if buf else b"").decode())
         sys.stdout.flush()
     else:
         raise SystemExit(f"rank exit codes {codes}")
+
+
+def collect_nccl_log(prefix, cap=40):
+    """Lines RCCL wrote at NCCL_DEBUG=WARN (one file per rank process), for the JSON line."""
+    import glob
+    lines = []
+    for f in sorted(glob.glob(prefix + "_*.log")):
+        try:
+            with open(f, errors="replace") as fh:
+                lines += [f"{os.path.basename(f)}: {l.rstrip()}" for l in fh if l.strip()]
+            os.remove(f)
+        except OSError:
+            pass
+    return lines[:cap]
+
+
+def dry_run(args, dist, rank, local_rank, world, ndev, nccl_log):
+    """`--gpus N --dry`: everything the first multi-GPU run touches for the first time, on a tiny problem, each step reported
+    instead of raised: visible devices, peer-access matrix (hipDeviceCanAccessPeer), RCCL communicator + first all-gather
+    (under libmachip's watchdog), IPC export / open of the peers' buffers and a row-partitioned eigen-solve, results equal on
+    every rank."""
+    from mac_amd import _lib
+    from mac_amd.dist import attach, attach_ipc, detach_ipc
+    from mac_amd.utils.fiedler import reference_start_block
+    lib = _lib.load()
+    dev = local_rank % max(1, ndev)
+    rep = {"rank": rank, "device": dev, "visible_devices": ndev, "peer_access_row": [int(lib.machip_peer_access(dev, b)) for b in range(ndev)],
+           "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+    w = er_workload(6000, 0.002, 1, "dry-run ER N=6000")     # (beyond the single-workgroup kernel: the fused, row-partitionable step runs)
+    P = _lib.Problem(w["n"], w["fi"], w["fj"], w["fw"], w["ci"], w["cj"], w["cw"], device=dev)
+    P.set_start(reference_start_block(w["n"])[:, 0].copy())
+    steps = {}
+    share = os.environ.get("MACHIP_SHARE_GPU") == "1" and ndev < world
+    if dist is not None and world > 1:
+        if not share:
+            try:
+                attach(P, dist, rank, world); steps["rccl_comm_init"] = "ok"
+            except Exception as e:     # noqa: BLE001
+                steps["rccl_comm_init"] = f"FAILED: {e}"
+        else:
+            steps["rccl_comm_init"] = "skipped (ranks share a GPU: RCCL refuses that)"
+        try:
+            attach_ipc(P, dist, rank, world, timeout_s=10.0); steps["ipc_exchange"] = "ok"
+        except Exception as e:         # noqa: BLE001
+            steps["ipc_exchange"] = f"FAILED: {e}"
+    P.set_x(w["x0"])
+    fs = []
+    try:
+        for it in range(2):
+            f, dual, gn = P.fw_step(w["k"], it)
+            fs.append(f.hex()); P.fw_commit()
+        steps["two_fw_iterations"] = "ok"
+        steps["comm_mode"] = int(lib.machip_comm_mode(P._h))
+    except Exception as e:             # noqa: BLE001
+        steps["two_fw_iterations"] = f"FAILED: {e}"
+    rep["steps"] = steps; rep["lambda2_hex"] = fs
+    reps = dist.all_gather_object(rep) if dist is not None else [rep]
+    if steps.get("ipc_exchange") == "ok" and all(r["steps"].get("two_fw_iterations") == "ok" for r in reps):
+        detach_ipc(P, dist)
+    if rank == 0:
+        same = len({tuple(r["lambda2_hex"]) for r in reps}) == 1
+        ok = same and all(v == "ok" or isinstance(v, int) or str(v).startswith("skipped") for r in reps for v in r["steps"].values())
+        print(json.dumps({"dry": True, "n_gpus": world, "ok": bool(ok), "results_equal_on_all_ranks": same, "ranks": reps,
+                          "errors": collect_nccl_log(nccl_log) if nccl_log else []}))
+    P.close()
+    if dist is not None:
+        dist.close()
 
 
 def main():
@@ -488,6 +559,8 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes (roofline.traffic = null)")
     ap.add_argument("--no-warm", action="store_true", help="skip the warm-start passes (use_cache=True: the reference's own micro-benchmark)")
     ap.add_argument("--no-same-node", action="store_true", help="configs[3]: skip the same-node reference-equivalent solve at N = 20 000 (~90 s of CPU)")
+    ap.add_argument("--dry", action="store_true", help="N > 1: first-contact check only -- device visibility, peer access matrix, RCCL communicator + "
+                    "one all-gather and the IPC buffer exchange on a tiny problem, no workload; prints one JSON line")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -499,6 +572,12 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    nccl_log = None
+    if world > 1:                      # RCCL's own warnings end up in the JSON line (`errors`), not on a terminal nobody reads
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
+        key = os.environ.get("MACHIP_RDZV_KEY") or os.environ.get("MASTER_PORT", "0")
+        nccl_log = os.path.join(tempfile.gettempdir(), f"machip_nccl_{key}")
+        os.environ.setdefault("NCCL_DEBUG_FILE", nccl_log + "_%h_%p.log")
     from mac_amd import _lib           # loads libmachip.so (HIP 7.2 runtime) before anything else
     _lib.load()
     _lib.require_device()
@@ -514,6 +593,8 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    if args.dry:
+        return dry_run(args, dist, rank, local_rank, world, ndev, nccl_log)
     if args.config == "c5" and world == 1:
         return bench_c5_batched(args)
     if args.config == "c5s" and world == 1:
@@ -753,6 +834,8 @@ def main():
             out["cpu_strong_parity_lambda2_rel"] = float(max(abs(a - r[0]) / abs(a) for a, r in zip(fts, rec)))
         out["speedup_vs_cpu_strong"] = out["value"] / cs["value"]
     if rank == 0:
+        if nccl_log:
+            out["errors"] = collect_nccl_log(nccl_log)
         print(json.dumps(out))
     if dist is not None and eig_mode.startswith("row-partitioned"):
         from mac_amd.dist import detach_ipc

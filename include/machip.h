@@ -174,6 +174,13 @@ int machip_comm_init_local(machip_problem** handles, int nranks);
  * to a single rank's.  Composes with machip_comm_init: with an RCCL communicator the gradient shards travel by ncclAllGather,
  * without one (ranks sharing a GPU) by peer writes through the mapped buffers.  machip_comm_close_ipc before machip_destroy
  * marks an orderly exit (a handle destroyed without it raises abort on its peers). */
+/* First-contact helpers (round 4).  machip_comm_init and the communicator's FIRST ncclAllGather run under a watchdog
+ * (MACHIP_RCCL_TIMEOUT_S, default 120 s): a peer that never arrives / a fabric that cannot carry the collective returns
+ * MACHIP_RCCL_ERROR naming the rank instead of hanging the job.  machip_selftest_watchdog exercises that watchdog with a
+ * sleeping stand-in (no GPU needed: MACHIP_OK when work_ms < limit_ms, MACHIP_RCCL_ERROR otherwise); machip_peer_access =
+ * hipDeviceCanAccessPeer (1 / 0, -1 on error), what `bench.py --gpus N --dry` prints as a matrix. */
+int machip_selftest_watchdog(int work_ms, int limit_ms);
+int machip_peer_access(int device_a, int device_b);
 int machip_ipc_blob_bytes(void);
 int machip_ipc_export(machip_problem* p, void* blob, int blob_bytes);
 int machip_comm_init_ipc(machip_problem* p, int rank, int nranks, const void* blobs, double timeout_s);

@@ -70,6 +70,8 @@ SIGNATURES = {
     "machip_comm_unique_id": (C.c_int, [C.c_void_p]),
     "machip_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "machip_comm_init_local": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "machip_selftest_watchdog": (C.c_int, [C.c_int, C.c_int]),
+    "machip_peer_access": (C.c_int, [C.c_int, C.c_int]),
     "machip_ipc_blob_bytes": (C.c_int, []),
     "machip_ipc_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "machip_comm_init_ipc": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_double]),

@@ -5,7 +5,10 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <chrono>
 #include <condition_variable>
+#include <functional>
+#include <future>
 #include <memory>
 #include <mutex>
 #include <numeric>
@@ -25,6 +28,20 @@ using namespace machip;
         if (r__ != ncclSuccess)                                                              \
             return fail(MACHIP_RCCL_ERROR, std::string(#expr) + ": " + ncclGetErrorString(r__)); \
     } while (0)
+
+// First-contact watchdog (round 4): a call into RCCL that may block for ever -- ncclCommInitRank with a peer that never
+// arrives, the first collective on a fabric that is not what was assumed -- runs on a helper thread; the caller waits with a
+// limit (MACHIP_RCCL_TIMEOUT_S, default 120) and turns a stall into MACHIP_RCCL_ERROR with the rank in the message instead of
+// a hung job.  (A helper that never returns is abandoned with its state: the process is about to report failure anyway.)
+static int run_with_watchdog(const std::function<int()>& fn, double limit_s, const std::string& what) {
+    auto state = std::make_shared<std::promise<int>>();
+    std::future<int> fut = state->get_future();
+    std::thread([state, fn] { int r = MACHIP_HIP_ERROR; try { r = fn(); } catch (...) {} state->set_value(r); }).detach();
+    if (fut.wait_for(std::chrono::duration<double>(limit_s)) != std::future_status::ready)
+        return fail(MACHIP_RCCL_ERROR, what + " did not return within " + std::to_string((int)limit_s) + " s (a peer rank is missing, or the fabric / bootstrap interface is not reachable; MACHIP_RCCL_TIMEOUT_S raises the limit)");
+    return fut.get();
+}
+static double rccl_timeout_s() { const int t = env_int("MACHIP_RCCL_TIMEOUT_S", 120); return t > 0 ? (double)t : 120.0; }
 
 // In-process communicator (machip_comm_init_local): the ranks are handles of ONE process driven by one host
 // thread each (one GPU per handle, or several handles on one GPU); the all-gather is peer-to-peer device copies
@@ -102,6 +119,7 @@ struct machip_problem {
     // multi-GPU
     ncclComm_t comm = nullptr;
     std::shared_ptr<LocalGroup> lgroup;
+    bool first_collective_pending = false;   // the communicator's first ncclAllGather is awaited with a time limit
     std::unique_ptr<IpcGroup> ipcg;      // inter-process communicator with a row-partitioned eigen-solve (machip_comm_init_ipc)
     int rank = 0, nranks = 1;
     // evaluation lanes (machip_eval_batch): lightweight copies that share the pattern and the candidate arrays
@@ -336,7 +354,31 @@ int compute_gradient(machip_problem* p, bool have_vec_now = false) {
         return MACHIP_OK;
     }
     if (p->nranks > 1) {
-        if (p->comm) NCCL_TRY(ncclAllGather(p->g + shard * p->rank, p->g, (size_t)shard, ncclDouble, p->comm, p->stream));
+        if (p->comm) {
+            NCCL_TRY(ncclAllGather(p->g + shard * p->rank, p->g, (size_t)shard, ncclDouble, p->comm, p->stream));
+            if (p->first_collective_pending) {
+                // the FIRST collective of a communicator is awaited with a limit: a fabric that cannot carry it must surface as an
+                // error naming the rank, not as a job that never ends (later collectives are not polled)
+                p->first_collective_pending = false;
+                const auto t0 = std::chrono::steady_clock::now();
+                const double lim = rccl_timeout_s();
+                for (;;) {
+                    const hipError_t q = hipStreamQuery(p->stream);
+                    if (q == hipSuccess) break;
+                    if (q != hipErrorNotReady) return fail(MACHIP_HIP_ERROR, std::string("first ncclAllGather: ") + hipGetErrorString(q));
+                    ncclResult_t ar = ncclSuccess;
+                    if (ncclCommGetAsyncError(p->comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress)
+                        return fail(MACHIP_RCCL_ERROR, std::string("first ncclAllGather failed asynchronously: ") + ncclGetErrorString(ar));
+                    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > lim) {
+                        (void)ncclCommAbort(p->comm);
+                        p->comm = nullptr;
+                        return fail(MACHIP_RCCL_ERROR, "first ncclAllGather of rank " + std::to_string(p->rank) + " of " + std::to_string(p->nranks) +
+                                    " did not complete within " + std::to_string((int)lim) + " s: communicator aborted");
+                    }
+                    std::this_thread::sleep_for(std::chrono::microseconds(200));
+                }
+            }
+        }
         else if (p->lgroup) { const int st = local_allgather(p, shard); if (st != MACHIP_OK) { p->lgroup->abort(); return st; } }
         else return fail(MACHIP_BAD_ARG, "nranks > 1 without a communicator");
     }
@@ -844,8 +886,21 @@ int machip_comm_init(machip_problem* p, int rank, int nranks, const void* id128)
     HIP_TRY(hipSetDevice(p->device));
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
-    NCCL_TRY(ncclCommInitRank(&p->comm, nranks, id, rank));
+    {
+        const int dev = p->device;
+        auto comm_out = std::make_shared<ncclComm_t>(nullptr);
+        auto err_out = std::make_shared<std::string>();
+        const int st = run_with_watchdog([=]() -> int {
+            if (hipSetDevice(dev) != hipSuccess) { *err_out = "hipSetDevice failed"; return MACHIP_HIP_ERROR; }
+            const ncclResult_t r = ncclCommInitRank(comm_out.get(), nranks, id, rank);
+            if (r != ncclSuccess) { *err_out = std::string("ncclCommInitRank: ") + ncclGetErrorString(r); return MACHIP_RCCL_ERROR; }
+            return MACHIP_OK;
+        }, rccl_timeout_s(), "ncclCommInitRank (rank " + std::to_string(rank) + " of " + std::to_string(nranks) + ")");
+        if (st != MACHIP_OK) return err_out->empty() ? st : fail((machip_status)st, *err_out);
+        p->comm = *comm_out;
+    }
     p->rank = rank; p->nranks = nranks;
+    p->first_collective_pending = true;
     long lo, hi, shard;
     shard_plan(p->m, nranks, rank, &lo, &hi, &shard);
     p->m_pad = shard * nranks;   // <= m + 63 < allocation slack
@@ -983,6 +1038,19 @@ int machip_comm_init_local(machip_problem** handles, int nranks) {
         p->rank = r; p->nranks = nranks; p->lgroup = G;
     }
     return MACHIP_OK;
+}
+
+int machip_selftest_watchdog(int work_ms, int limit_ms) {
+    // (test hook, no GPU needed: the watchdog around the RCCL first-contact calls, exercised with a sleeping stand-in)
+    return run_with_watchdog([=]() -> int { std::this_thread::sleep_for(std::chrono::milliseconds(work_ms)); return MACHIP_OK; },
+                             1e-3 * (double)limit_ms, "watchdog self-test (" + std::to_string(work_ms) + " ms of work)");
+}
+
+int machip_peer_access(int device_a, int device_b) {
+    int can = 0;
+    if (device_a == device_b) return 1;
+    if (hipDeviceCanAccessPeer(&can, device_a, device_b) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return can;
 }
 
 int machip_comm_mode(machip_problem* p) {

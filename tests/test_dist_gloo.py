@@ -113,3 +113,55 @@ def test_file_group_two_ranks():
     for rank, ok, mx, got in res:
         assert ok and mx == 11.0 and got == [("r", 0), ("r", 1)]
     assert not os.path.exists(os.path.join("/tmp", f"machip_rdzv_{key}"))
+
+
+class _FakeProblem:
+    """Stands in for mac_amd._lib.Problem on a machine without a GPU: records what attach_ipc / detach_ipc hand to the
+    C ABI (machip_ipc_export -> machip_comm_init_ipc -> machip_comm_close_ipc)."""
+
+    def __init__(self, rank, m):
+        self.rank, self.m, self.calls = rank, m, []
+
+    def ipc_export(self):
+        self.calls.append("export")
+        return bytes([self.rank]) * 16
+
+    def comm_init_ipc(self, rank, nranks, blobs, timeout_s):
+        self.calls.append(("init", rank, nranks, tuple(blobs), timeout_s))
+
+    def comm_close_ipc(self):
+        self.calls.append("close")
+
+
+def _ipc_proto_worker(rank, world, key, q):
+    sys.path.insert(0, ROOT)
+    from mac_amd.dist import FileGroup, attach_ipc, detach_ipc
+    g = FileGroup(rank, world, key=key)
+    P = _FakeProblem(rank, 1001)
+    lo, hi, shard = attach_ipc(P, g, rank, world, timeout_s=3.5)
+    detach_ipc(P, g)
+    g.close()
+    q.put((rank, P.calls, (lo, hi, shard)))
+
+
+def test_ipc_attach_protocol_three_ranks():
+    """mac_amd.dist.attach_ipc / detach_ipc over the torch-free file group with three processes: every rank exports once,
+    receives ALL blobs in rank order (its own included, at its own index), maps them with the limit it was given, gets the
+    shard bounds libmachip computes, and says goodbye only after a barrier.  (The product side of the same calls --
+    hipIpcOpenMemHandle, the device-ordered steps -- runs in tests/test_gpu_parity.py::test_ipc_* with real processes on a GPU.)"""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    key = f"ipc_{os.getpid()}"
+    world = 3
+    procs = [ctx.Process(target=_ipc_proto_worker, args=(r, world, key, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    blobs = tuple(bytes([r]) * 16 for r in range(world))
+    for rank, calls, bounds in res:
+        assert calls == ["export", ("init", rank, world, blobs, 3.5), "close"]
+        assert bounds == shard_bounds(1001, rank, world)

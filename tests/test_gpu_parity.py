@@ -2045,3 +2045,18 @@ def test_ipc_peers_of_a_dead_rank_return_an_error_within_the_time_limit():
     assert rc == 3 and msg and msg[0] == "ERROR", (rc, msg, se)
     assert msg[1]["status"] == _lib.RCCL_ERROR and msg[1]["done"] == 2 and "peer" in msg[1]["msg"]
     assert el < 60.0, el
+
+
+def test_bench_dry_run_checks_first_contact_on_one_gpu():
+    """`bench.py --gpus 2 --dry` (MACHIP_SHARE_GPU=1: both ranks on this GPU): device visibility, peer-access row, IPC
+    exchange and two Frank-Wolfe iterations of a tiny problem through the whole communicator stack, reported as one JSON line;
+    the eigen-solve of the last iteration really ran row-partitioned (comm_mode 5) and both ranks hold the same lambda_2 bits."""
+    import json
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--dry"], cwd=ROOT, capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, MACHIP_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr[-1500:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["dry"] and d["ok"] and d["results_equal_on_all_ranks"] and len(d["ranks"]) == 2
+    for rk in d["ranks"]:
+        assert rk["steps"]["ipc_exchange"] == "ok" and rk["steps"]["two_fw_iterations"] == "ok" and rk["steps"]["comm_mode"] == 5
+        assert rk["peer_access_row"][rk["device"]] == 1

@@ -257,3 +257,18 @@ def test_fiedler_csr_rejects_malformed_row_pointers_before_touching_the_matrix()
     with pytest.raises(AssertionError) as e:          # column out of range: also found on the host
         _lib.fiedler_csr(np.array([0, 2, 4], dtype=np.int32), np.array([0, 7, 0, 1], dtype=np.int32), np.ones(4), 2)
     assert "BAD_ARG" in str(e.value) and "column" in str(e.value)
+
+
+def test_rccl_first_contact_watchdog_turns_a_stall_into_an_error():
+    """The watchdog that guards ncclCommInitRank and a communicator's first ncclAllGather (machip.hip, run_with_watchdog),
+    exercised with a sleeping stand-in: work that finishes inside the limit returns OK, work that does not comes back as
+    MACHIP_RCCL_ERROR after the limit -- not after the work -- with a message that says what stalled."""
+    import time
+    lib = _lib.load()
+    assert lib.machip_selftest_watchdog(20, 2000) == _lib.OK
+    t0 = time.perf_counter()
+    st = lib.machip_selftest_watchdog(3000, 200)
+    el = time.perf_counter() - t0
+    assert st == _lib.RCCL_ERROR and el < 1.5, (st, el)
+    msg = _lib.last_error()
+    assert "did not return within" in msg and "peer rank is missing" in msg
