@@ -224,7 +224,9 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_fill(CsrView A, PanView P) 
 // ------------------------------------------------------------------------------------------
 #define PAN_MUL_ARGS(P, L, jrel) (((jrel) & 1) ? (L).Z1 : (L).Z0), (L).part, (L).st, (P).tptr, (P).thead, (P).n, (P).C, (P).NP, (P).TWW, (P), (L), (jrel)
 #define PAN_FIN_ARGS(P, L, jrel) (((jrel) & 1) ? (L).Z1 : (L).Z0), (P).coef, (P).ypart, (P).n, (P).NP, (P), (L), (jrel)
-template <int RPT>   // records per worker thread: the panel holds at most RPT * 960 columns
+// RAW (round 4, diagonally preconditioned LOBPCG on large graphs: precond.h / solver.h): the operand is a plain vector w (passed
+// through z_cur), read with 8-byte loads and copied into LDS as it is -- no records, no coefficients, no reduction prologue.
+template <int RPT, bool RAW = false>   // records per worker thread: the panel holds at most RPT * 960 columns
 __global__ __launch_bounds__(kPanThreads) void k_pan_mul(const Z2* __restrict__ z_cur, double* l_part, LanState* l_st,
                                                           const int* __restrict__ a_tptr, const unsigned short* __restrict__ a_thead,
                                                           int a_n, int a_C, int a_NP, int a_TWW, PanView A_, PipeView L_, int jrel) {
@@ -247,10 +249,12 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul(const Z2* __restrict__ 
     // panel's records and their tiles.  (One role per wave also keeps the two register-hungry phases -- 48 partial
     // loads in flight there, records + a wave's chunks here -- out of each other's allocation.)
     if (wv == 0) {
-        int jd;
-        const PipeCoef c = pipe_prologue_wave0(L, jrel, -1, scoef, &jd);
-        if (blockIdx.x == 0 && lane == 0) {
-            A.coef[0] = c.alpha; A.coef[1] = c.beta; A.coef[2] = c.mu; A.coef[3] = c.inv; A.coef[4] = (double)jd;
+        if (!RAW) {
+            int jd;
+            const PipeCoef c = pipe_prologue_wave0(L, jrel, -1, scoef, &jd);
+            if (blockIdx.x == 0 && lane == 0) {
+                A.coef[0] = c.alpha; A.coef[1] = c.beta; A.coef[2] = c.mu; A.coef[3] = c.inv; A.coef[4] = (double)jd;
+            }
         }
         PAN_CLK(tid == 0, 3);
         __syncthreads();
@@ -265,8 +269,14 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul(const Z2* __restrict__ 
     const Z2* __restrict__ Zc = z_cur + c0;
     // the panel's records, all requested at once (clamped index: unconditional loads stay batched, cf. the prologue)
     Z2 z[RPT];
+    if (RAW) {
+        const double* __restrict__ wc = reinterpret_cast<const double*>(z_cur) + c0;
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) z[i] = Zc[min(wt + kPanWorkThreads * i, Cp - 1)];
+        for (int i = 0; i < RPT; ++i) { z[i].v = wc[min(wt + kPanWorkThreads * i, Cp - 1)]; z[i].t = 0.0; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) z[i] = Zc[min(wt + kPanWorkThreads * i, Cp - 1)];
+    }
     // this wave's tiles: slot -> row, and the chunk (64 entries) at which each tile ends
     const int vt0 = ((b * A.NP + p) * kPanWork + ww) * A.TWW;
     int ro[kPanTW], cend[kPanTW];
@@ -297,11 +307,11 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul(const Z2* __restrict__ 
     __syncthreads();
     PAN_CLK(tid == 64, 4);
     {
-        const double alpha = scoef[0], mu = scoef[2], inv = scoef[3];
+        const double alpha = RAW ? 0.0 : scoef[0], mu = RAW ? 0.0 : scoef[2], inv = RAW ? 1.0 : scoef[3];
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             const int c = wt + kPanWorkThreads * i;
-            if (c < Cp) sv[c] = pan_vj(alpha, mu, inv, z[i].t, z[i].v);
+            if (c < Cp) sv[c] = RAW ? z[i].v : pan_vj(alpha, mu, inv, z[i].t, z[i].v);
         }
         for (int rl = wt; rl < R; rl += kPanWorkThreads) yblk[rl] = 0.0;      // rows of empty tiles
     }

@@ -19,6 +19,7 @@
 // The host only watches (theta, ||r||_1) records in pinned memory, as in the Lanczos path.
 #pragma once
 #include "kernels.h"
+#include "panel.h"
 
 namespace machip {
 
@@ -450,6 +451,26 @@ struct OpLob {
         }
     }
 };
+
+// Column-panel form of the product (panel.h, round 4: the diagonally preconditioned mode on large random graphs): k_pan_mul<RPT, RAW>
+// has left one partial product per (row, panel); this kernel adds them in panel order -- Lw[r] -- and takes the 15 inner products
+// exactly as the fused SpMV kernels do (OpLob::row / end).  256 threads per workgroup (OpLob's scratch), partials per workgroup.
+__global__ __launch_bounds__(kBlock) void k_pan_find(OpLob op, const double* __restrict__ ypart, int NP) {
+    op.begin(nullptr);
+    const int n = op.L.n;
+    for (int r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
+        double w = 0.0;
+        for (int p0 = 0; p0 < NP; p0 += 16) {     // sixteen panels in flight; added in panel order
+            double y[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) y[q] = ypart[(size_t)min(p0 + q, NP - 1) * n + r];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) w += (p0 + q < NP) ? y[q] : 0.0;
+        }
+        op.row(r, w);
+    }
+    op.end(nullptr);
+}
 
 // ---- 3x3 Rayleigh-Ritz on span{x, w - mean, p - mean} -------------------------------------------
 struct LobCoef { double z0, z1, z2, theta, mx, mw, mp; int bad; };

@@ -356,6 +356,21 @@ struct Solver {
         else k_pan_fin<256><<<pan.grid2, 256, 0, stream>>>(PAN_FIN_ARGS(panv, L, s));
     }
 
+    // y_p = L[block, panel p] w for a plain operand vector (k_pan_mul<RPT, RAW = true>): the diagonally preconditioned mode's product
+    void launch_pan_mul_raw(const double* w) {
+        const int g1 = pan.NB * pan.NP;
+        PipeView L{};        // (unused by the RAW instantiation: no records, no prologue)
+        L.n = n; L.part = part; L.st = st;
+        const Z2* wz = reinterpret_cast<const Z2*>(w);
+        switch (pan.RPT) {
+#define MACHIP_PAN_CASE(R) case R: k_pan_mul<R, true><<<g1, kPanThreads, 0, stream>>>(wz, L.part, L.st, panv.tptr, panv.thead, panv.n, panv.C, panv.NP, panv.TWW, panv, L, 0); break;
+            MACHIP_PAN_CASE(1) MACHIP_PAN_CASE(2) MACHIP_PAN_CASE(3) MACHIP_PAN_CASE(4) MACHIP_PAN_CASE(5) MACHIP_PAN_CASE(6)
+            MACHIP_PAN_CASE(7) MACHIP_PAN_CASE(8) MACHIP_PAN_CASE(9) MACHIP_PAN_CASE(10) MACHIP_PAN_CASE(11) MACHIP_PAN_CASE(12)
+#undef MACHIP_PAN_CASE
+            default: k_pan_mul<13, true><<<g1, kPanThreads, 0, stream>>>(wz, L.part, L.st, panv.tptr, panv.thead, panv.n, panv.C, panv.NP, panv.TWW, panv, L, 0); break;
+        }
+    }
+
     // ---- row-partitioned chunk: per step one launch per rank, ordered by events (ShardGroup) ----
     void shard_split(const SpmvPlan& pl) {
         const int R = (int)shard->rk.size();
@@ -634,6 +649,7 @@ struct Solver {
     // layout of the tridiagonal solver: up to n = 16 384 one workgroup, c = ceil(n/1024) unknowns per thread;
     // beyond, 4 unknowns per thread and as many 1024-thread workgroups as that takes
     bool lob_jacobi = false;   // the running preconditioned solve uses the diagonal preconditioner (natural layout, c = 1)
+    bool lob_pan = false;      // ... and its product runs in column-panel form
     int lob_c() const { return lob_jacobi ? 1 : n > kTriMaxN ? kTriBigC : (n + kTriThreads - 1) / kTriThreads; }
     int lob_stride() const {
         if (lob_jacobi) return n;
@@ -670,11 +686,14 @@ struct Solver {
         k_lob_tail<<<1, 64, 0, stream>>>(L, steps);
     }
     void lob_launch_chunk(const CsrView& AT, const SpmvPlan& pl, const LobView& L, int steps) {
-        if (lob_jacobi) {          // diagonal preconditioner: two launches per iteration
+        if (lob_jacobi) {          // diagonal preconditioner: two launches per iteration (three with the column-panel product)
             OpLob op;
             op.L = L;
             for (int s = 0; s < steps; ++s) {
-                launch_spmv(pl, stream, AT, L.wT, op);
+                if (lob_pan) {     // Lw = L w in column-panel form (panel.h: gathers served by LDS), then partial sums + inner products
+                    launch_pan_mul_raw(L.wT);
+                    k_pan_find<<<L.P_c, kBlock, 0, stream>>>(op, panv.ypart, panv.NP);
+                } else launch_spmv(pl, stream, AT, L.wT, op);
                 k_lob_update<true><<<L.P_a, kBlock, 0, stream>>>(L, s);
             }
             k_lob_tail<<<1, 64, 0, stream>>>(L, steps);
@@ -712,7 +731,7 @@ struct Solver {
     int lob_enqueue_chunk(const CsrView& A, const CsrView& AT, const SpmvPlan& pl, const LobView& L, int steps) {
         if (!use_graph || wb_active.s > 0) { lob_launch_chunk(AT, pl, L, steps); return MACHIP_OK; }   // (closure count is baked into the launches)
         if (graph_csr_key != (const void*)A.val) { drop_graphs(); graph_csr_key = (const void*)A.val; }
-        const auto key = std::make_tuple(1000 + pl.variant, pl.width, pl.grid, L.c + (n > kTriMaxN ? 100 : 0) + (lob_jacobi ? 1000 : 0), steps);
+        const auto key = std::make_tuple(1000 + pl.variant, pl.width, pl.grid, L.c + (n > kTriMaxN ? 100 : 0) + (lob_jacobi ? 1000 : 0) + (lob_pan ? 2000 + 10000 * pan.NP + 1000000 * pan.NB : 0), steps);
         auto it = graphs.find(key);
         if (it == graphs.end()) it = graphs.emplace(key, std::array<hipGraphExec_t, 2>{nullptr, nullptr}).first;
         hipGraphExec_t& ge = it->second[(size_t)(graph_flip++ & 1)];
@@ -816,9 +835,19 @@ struct Solver {
     int solve_lob(const CsrView& A, long nnz, double lnorm, double tol, int max_steps, int start_mode,
                   double* lam, double* res, long* iters, long* spmvs, long* restarts_out, bool jacobi = false) {
         lob_jacobi = jacobi;
+        lob_pan = false;
         ST_TRY(lob_alloc(jacobi ? 0 : nnz));
-        const SpmvPlan pl = plan_spmv(n, nnz, kAuto);
-        const LobView L = lview(pl);
+        // (explicit-check kernels may use the whole chip at large n, cf. solve_lanczos)
+        SpmvPlan pl = plan_spmv(n, nnz, kAuto, jacobi && n > 32768 ? kMaxGrid : 0);
+        if (jacobi) {
+            pan = plan_panel(n, nnz, maxlen_hint, pan_allowed && precision == 0 && !shard && !ipc);
+            if (pan.on) {
+                ST_TRY(ensure_panel(A, nnz, pan));
+                lob_pan = true;
+            }
+        }
+        LobView L = lview(pl);
+        if (lob_pan) L.P_c = std::min(256, vgrid());           // partial sums come from k_pan_find's workgroups
         const int g2 = vgrid();
         const bool debug = env_int("MACHIP_DEBUG", 0) != 0;
         const double scale = lnorm > 0 ? lnorm : 1.0;
