@@ -1134,6 +1134,7 @@ struct Solver {
         const int chunk_near = std::min(chunk0, std::max(2, env_int("MACHIP_CHUNK_NEAR", 8) & ~1));   // once the residual estimate is within 1e3 of the target
         if (max_steps & 1) ++max_steps;
         const double trigger_slack = 1.5;   // run the explicit check a little early rather than late
+        const double near_factor = 0.1 * env_int("MACHIP_NEAR_X10", 20);   // end game (no speculation, short chunks) from this many chunks of predicted steps to go
         std::deque<Pending> pend;
         bool done = false;
 
@@ -1263,7 +1264,7 @@ struct Solver {
                 // one chunk runs ahead of the host -- except in the end game (same threshold as the
                 // short chunks), where the chunk in flight is likely the last one and a speculative
                 // successor would only delay the explicit residual check queued behind it
-                const bool near = sched ? (to_go < 2.0 * chunk0 || (to_go >= 1e17 && est_latest < 1e3 * seq_tol * lnorm))
+                const bool near = sched ? (to_go < near_factor * chunk0 || (to_go >= 1e17 && est_latest < 1e3 * seq_tol * lnorm))
                                         : est_latest < 1e3 * seq_tol * lnorm;
                 const bool use_classic = classic && !pmode;
                 int depth = (use_classic || near) ? 1 : ((sched && to_go > 8.0 * chunk0) ? 3 : 2);
