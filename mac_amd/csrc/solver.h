@@ -753,7 +753,9 @@ struct Solver {
     // factorisation then costs tens of ms -- against seconds, or no convergence at all: fuzz seed 129, n = 36 874,
     // 3 900 active closures, lambda_2 / ||L|| = 1e-10: 200 000 iterations without converging -> 27 iterations, 36 ms).
     int wb_soft() const { return std::max(64, std::min(16384, env_int("MACHIP_WB_MAX", kWbMaxS))); }
-    int wb_hard() const { return std::max(wb_soft(), std::min(16384, env_int("MACHIP_WB_HARD", 16384))); }   // (11 600 closures on 30 000 nodes at lambda_2/||L|| = 3e-9: 0.30 s escalated against 0.75-0.9 s)
+    // (evaluation lanes: 4 096 -- an s x s inverse beyond that, 2 s^3 flops on the whole chip, starves the other lanes: city10000, nine
+    // budgets on four lanes, 423 it/s with escalations up to 16 384 closures against 669 with the cap; profiles/r4_exact_small.md)
+    int wb_hard() const { return std::max(wb_soft(), std::min(throughput_lane ? 4096 : 16384, env_int("MACHIP_WB_HARD", 16384))); }   // (11 600 closures on 30 000 nodes at lambda_2/||L|| = 3e-9: 0.30 s escalated against 0.75-0.9 s)
     int wb_limit_now = kWbMaxS;   // the tier this solve_lob call may use
     bool lob_escalate = false;    // set by solve_lob when it gives up early in favour of the exact preconditioner
     int wb_cap_s = 0;      // what the buffers below were sized for
@@ -1063,7 +1065,10 @@ struct Solver {
             HIP_TRY(hipEventRecord(ev0, stream));
             double lam = 0.0, res = 0.0;
             long iters = 0, spmvs = 0, rst = 0;
-            wb_limit_now = wb_soft();
+            // (evaluation lanes run many solves side by side: the exact mode's chip-wide kernels -- s column solves, the s x s inverse,
+            // an n x s product per application -- are kept to the cheap cases there, the tridiagonal preconditioner serves the rest and
+            // a crawling solve still escalates; city10000, 9 budgets on 4 lanes: 422 -> 664 it/s, profiles/r4_exact_small.md)
+            wb_limit_now = throughput_lane ? std::min(wb_soft(), env_int("MACHIP_WB_LANE_MAX", 256)) : wb_soft();
             int st = solve_lob(A, nnz, lnorm, tol, max_steps, start_mode, &lam, &res, &iters, &spmvs, &rst, want_jac);
             if (st == MACHIP_NOT_CONVERGED && lob_escalate) {
                 long it1 = iters, sp1 = spmvs;

@@ -7,7 +7,7 @@ tag=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-B="python $GRAFT_REPO_ROOT/bench.py $* --no-cpu --no-pmc --min-seconds 0"
+B="python $GRAFT_REPO_ROOT/bench.py $* --no-cpu --no-pmc --no-warm --min-seconds 0 --max-repeats 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- $B > $out/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -o f -- $B --no-roofline > $out/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -o w -- $B --no-roofline > $out/pmc_write.log 2>&1
