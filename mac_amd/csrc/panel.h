@@ -55,6 +55,7 @@ struct PanView {
     int NB;      // row blocks
     int NTB;     // 64-row tiles per row block (rows per block R = 64 NTB <= kPanRows)
     int TWW;     // tiles per worker wave = ceil(NTB / 15); a (block, panel) has 15 TWW physical tiles
+    int CELLS;   // row blocks a workgroup of k_pan_mul<.., MULTI> walks (1: the single-cell kernel)
     int* tptr;              // [tiles + 1] first entry of physical tile ((b*NP + p)*15 + w)*TWW + q  (sorted tile w + 15 q)
     unsigned short* thead;  // [tiles*64] row (relative to the block) held by each slot
     double* bval;           // panel-form values, zero-padded tiles
@@ -226,7 +227,10 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_fill(CsrView A, PanView P) 
 #define PAN_FIN_ARGS(P, L, jrel) (((jrel) & 1) ? (L).Z1 : (L).Z0), (P).coef, (P).ypart, (P).n, (P).NP, (P), (L), (jrel)
 // RAW (round 4, diagonally preconditioned LOBPCG on large graphs: precond.h / solver.h): the operand is a plain vector w (passed
 // through z_cur), read with 8-byte loads and copied into LDS as it is -- no records, no coefficients, no reduction prologue.
-template <int RPT, bool RAW = false>   // records per worker thread: the panel holds at most RPT * 960 columns
+// MULTI (round 4): a workgroup keeps its panel in LDS and walks A.CELLS row blocks (b = blockIdx / NP + cell * gridDim / NP) one
+// after the other -- more row blocks than one wave of workgroups has, without loading the operand again: lifts the n <= 145 000
+// limit of the single-cell form (plan_panel).  MULTI = false is the single-cell kernel of round 3, unchanged.
+template <int RPT, bool RAW = false, bool MULTI = false>   // records per worker thread: the panel holds at most RPT * 960 columns
 __global__ __launch_bounds__(kPanThreads) void k_pan_mul(const Z2* __restrict__ z_cur, double* l_part, LanState* l_st,
                                                           const int* __restrict__ a_tptr, const unsigned short* __restrict__ a_thead,
                                                           int a_n, int a_C, int a_NP, int a_TWW, PanView A_, PipeView L_, int jrel) {
@@ -240,7 +244,9 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul(const Z2* __restrict__ 
     __shared__ double scoef[8];
     static_assert((RPT * kPanWorkThreads + kPanRows + 8) * 8 <= 163840, "panel + row-block image exceed the LDS");
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x / A.NP, p = blockIdx.x - b * A.NP;
+    const int bg = blockIdx.x / A.NP, p = blockIdx.x - bg * A.NP;
+    const int ncell = MULTI ? A.CELLS : 1, nbg = MULTI ? (int)gridDim.x / A.NP : 0;
+    int b = bg;
     const int c0 = p * A.C;
     const int Cp = min(A.C, A.n - c0);           // >= 1 by construction of the plan
     const int R = 64 * A.NTB;
@@ -260,6 +266,7 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul(const Z2* __restrict__ 
         __syncthreads();
         __syncthreads();
         __syncthreads();
+        for (int cell = 1; cell < ncell; ++cell) { __syncthreads(); __syncthreads(); __syncthreads(); }
         return;
     }
     const int wt = tid - 64, ww = wv - 1;        // worker thread / worker wave
@@ -277,8 +284,11 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul(const Z2* __restrict__ 
 #pragma unroll
         for (int i = 0; i < RPT; ++i) z[i] = Zc[min(wt + kPanWorkThreads * i, Cp - 1)];
     }
+  for (int cell = 0; cell < ncell; ++cell) {
+    if (MULTI) b = bg + cell * nbg;
+    const bool live = !MULTI || b < A.NB;        // (the last cells of some workgroups have no row block)
     // this wave's tiles: slot -> row, and the chunk (64 entries) at which each tile ends
-    const int vt0 = ((b * A.NP + p) * kPanWork + ww) * A.TWW;
+    const int vt0 = ((min(b, A.NB - 1) * A.NP + p) * kPanWork + ww) * A.TWW;
     int ro[kPanTW], cend[kPanTW];
     int E0;
     {
@@ -291,7 +301,7 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul(const Z2* __restrict__ 
 #pragma unroll
         for (int q = 0; q < kPanTW; ++q) cend[q] = (tp[q + 1] - E0) >> 6;      // (tiles q >= TWW: same as the last real one)
     }
-    const int nch = cend[kPanTW - 1];
+    const int nch = live ? cend[kPanTW - 1] : 0;
     const double* __restrict__ bv = A.bval + E0 + lane;
     const unsigned short* __restrict__ bc = A.bcol + E0 + lane;
     double pv[kPanCH];
@@ -304,14 +314,16 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul(const Z2* __restrict__ 
 #ifdef PAN_CLOCKS
     if (wv == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PAN_CLK(tid == 64, 2); }   // records, tile table, the wave's chunks arrived (wave 1)
 #endif
-    __syncthreads();
+    __syncthreads();             // (cell 0: the coefficients are there; later cells: the previous cell's stores have read yblk)
     PAN_CLK(tid == 64, 4);
     {
-        const double alpha = RAW ? 0.0 : scoef[0], mu = RAW ? 0.0 : scoef[2], inv = RAW ? 1.0 : scoef[3];
+        if (cell == 0) {
+            const double alpha = RAW ? 0.0 : scoef[0], mu = RAW ? 0.0 : scoef[2], inv = RAW ? 1.0 : scoef[3];
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) {
-            const int c = wt + kPanWorkThreads * i;
-            if (c < Cp) sv[c] = RAW ? z[i].v : pan_vj(alpha, mu, inv, z[i].t, z[i].v);
+            for (int i = 0; i < RPT; ++i) {
+                const int c = wt + kPanWorkThreads * i;
+                if (c < Cp) sv[c] = RAW ? z[i].v : pan_vj(alpha, mu, inv, z[i].t, z[i].v);
+            }
         }
         for (int rl = wt; rl < R; rl += kPanWorkThreads) yblk[rl] = 0.0;      // rows of empty tiles
     }
@@ -359,9 +371,10 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul(const Z2* __restrict__ 
     // the row block's sums, un-sorted by the LDS image: coalesced stores
     for (int rl = wt; rl < R; rl += kPanWorkThreads) {
         const int row = b * R + rl;
-        if (row < A.n) A.ypart[(size_t)p * A.n + row] = yblk[rl];
+        if (live && row < A.n) A.ypart[(size_t)p * A.n + row] = yblk[rl];
     }
     PAN_CLK(tid == 64, 8); PAN_CLK(tid == 1023, 9);
+  }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -139,6 +139,7 @@ inline SpmvPlan plan_pipe(int n, long nnz, int maxlen) {
 struct PanPlan {
     bool on = false;
     int NP = 1, C = 1, NB = 1, NTB = 1, TWW = 1, RPT = 1;
+    int cells = 1;                   // row blocks per workgroup of k_pan_mul (> 1: the MULTI instantiation, grid = NP * ceil(NB / cells))
     int grid2 = 1, block2 = 256;     // launch shape of k_pan_fin
     bool fused = false;              // one launch per step (k_pan_step) instead of k_pan_mul + k_pan_fin (measured SLOWER: profiles/r4_c4_one_launch_step.md)
 };
@@ -176,10 +177,23 @@ inline PanPlan plan_panel(int n, long nnz, int maxlen, bool allowed) {
             if ((groups + b - 1) / b <= tmax) { np = c; nb = b; break; }
         }
         if (!np) {
-            if (mode < 0) return pp;             // no single-wave shape: not worth it (measured at n = 2e5 .. 4e5)
-            np = (n + cmax - 1) / cmax; nb = std::max(1, grid_cap() / np);   // forced: several waves of workgroups
+            // no single-wave shape (n > ~145 000).  Round 4: ONE wave of workgroups all the same, each keeping its panel in LDS and
+            // walking `cells` row blocks (k_pan_mul<.., MULTI>): panels of ~8 448 columns, as many row blocks as the 7 680-row image needs
+            const int maxcells = env_int("MACHIP_PANEL_MAXCELLS", 6);
+            for (int c = std::max(1, (n + 8447) / 8448); c >= 1 && c <= grid_cap(); --c) {
+                if ((n + c - 1) / c > cmax) break;
+                const int nbg = std::max(1, grid_cap() / c);
+                const int nb_min = (groups + tmax - 1) / tmax;
+                const int cl = (nb_min + nbg - 1) / nbg;
+                if (cl <= maxcells) { np = c; nb = nbg * cl; pp.cells = cl; break; }
+            }
+            if (!np) {
+                if (mode < 0) return pp;
+                np = (n + cmax - 1) / cmax; nb = std::max(1, grid_cap() / np);   // forced: several waves of workgroups
+            }
         }
     }
+    if (env_int("MACHIP_PANEL_CELLS", 0) > 0) pp.cells = env_int("MACHIP_PANEL_CELLS", 0);      // (tests: the multi-cell kernel on small graphs)
     if (np > 64) return pp;
     int C = (n + np - 1) / np;
     np = (n + C - 1) / C;                              // panels that actually hold columns
@@ -187,11 +201,16 @@ inline PanPlan plan_panel(int n, long nnz, int maxlen, bool allowed) {
     int ntb = (groups + nb - 1) / nb;                            // tiles per row block
     ntb = std::min(ntb, tmax);                                   // (the row block's LDS image holds 7 680 rows)
     nb = (groups + ntb - 1) / ntb;
+    pp.cells = std::max(1, std::min(pp.cells, nb));
+    // several cells per workgroup cost ~15 us each (a cell is a serial chain: tile table -> chunks -> sums -> stores): measured
+    // cross-over against the gather step at ~43 entries per row (tools/panel_size_probe.py, profiles/r4_panel_sizes.txt:
+    // n = 200 000: 54.8 vs 59.9 us at 43 / row, 51.4 vs 47.6 at 33; n = 300 000: 91 vs 118 at 49, 80 vs 78 at 33)
+    if (mode < 0 && pp.cells > 1 && mean < 0.1 * env_int("MACHIP_PANEL_MULTI_MIN_MEAN10", 430)) return PanPlan();
     pp.on = true; pp.NP = np; pp.C = C; pp.NB = nb; pp.NTB = ntb; pp.TWW = (ntb + kPanWork - 1) / kPanWork;
     pp.RPT = (C + kPanWorkThreads - 1) / kPanWorkThreads;
     // MACHIP_PANEL_FUSED=1: the one-launch form (k_pan_step; tickets for 256 row blocks, one partial-sum slot per slice).  Off by
     // default: 26.9 against 19.1 us per step at configs[3] -- the in-launch hand-off costs more than the launch it saves.
-    pp.fused = env_int("MACHIP_PANEL_FUSED", 0) != 0 && nb <= 256 && nb * np <= 256;
+    pp.fused = env_int("MACHIP_PANEL_FUSED", 0) != 0 && nb <= 256 && nb * np <= 256 && pp.cells == 1;
     pp.block2 = env_int("MACHIP_PANEL_B2", 512);
     if (pp.block2 != 256 && pp.block2 != 512 && pp.block2 != 1024) pp.block2 = 256;
     pp.grid2 = (int)std::max<long>(1, std::min<long>(env_int("MACHIP_PANEL_G2", grid_cap()), ((long)n + pp.block2 - 1) / pp.block2));

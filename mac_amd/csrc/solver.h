@@ -324,7 +324,7 @@ struct Solver {
         if (!panv.coef) ST_TRY(dev_alloc(&panv.coef, 8));
         if (!panv.tick) { ST_TRY(dev_alloc(&panv.tick, 256)); ST_TRY(dev_alloc(&panv.claim, 4096)); }     // (NB <= 256, NB NP <= 4096: plan_panel)
         panv.spin_ticks = env_int("MACHIP_PANEL_SPIN_US", 20) * 100;
-        panv.n = n; panv.NP = pn.NP; panv.C = pn.C; panv.NB = pn.NB; panv.NTB = pn.NTB; panv.TWW = pn.TWW;
+        panv.n = n; panv.NP = pn.NP; panv.C = pn.C; panv.NB = pn.NB; panv.NTB = pn.NTB; panv.TWW = pn.TWW; panv.CELLS = pn.cells;
         k_pan_rows<<<(n + kBlock - 1) / kBlock, kBlock, 0, stream>>>(A, panv);
         k_pan_count<<<pan_build_grid(pn.NB, pn.NP), kPanThreads, 0, stream>>>(A, panv);
         k_pan_scan<<<1, 1024, 0, stream>>>(panv);
@@ -344,7 +344,16 @@ struct Solver {
             }
             return;
         }
-        switch (pan.RPT) {
+        if (pan.cells > 1) {     // several row blocks per workgroup, the panel loaded once (k_pan_mul<.., MULTI>)
+            const int gm = pan.NP * ((pan.NB + pan.cells - 1) / pan.cells);
+            switch (pan.RPT) {
+#define MACHIP_PAN_CASE(R) case R: k_pan_mul<R, false, true><<<gm, kPanThreads, 0, stream>>>(PAN_MUL_ARGS(panv, L, s)); break;
+                MACHIP_PAN_CASE(1) MACHIP_PAN_CASE(2) MACHIP_PAN_CASE(3) MACHIP_PAN_CASE(4) MACHIP_PAN_CASE(5) MACHIP_PAN_CASE(6)
+                MACHIP_PAN_CASE(7) MACHIP_PAN_CASE(8) MACHIP_PAN_CASE(9) MACHIP_PAN_CASE(10) MACHIP_PAN_CASE(11) MACHIP_PAN_CASE(12)
+#undef MACHIP_PAN_CASE
+                default: k_pan_mul<13, false, true><<<gm, kPanThreads, 0, stream>>>(PAN_MUL_ARGS(panv, L, s)); break;
+            }
+        } else switch (pan.RPT) {
 #define MACHIP_PAN_CASE(R) case R: k_pan_mul<R><<<g1, kPanThreads, 0, stream>>>(PAN_MUL_ARGS(panv, L, s)); break;
             MACHIP_PAN_CASE(1) MACHIP_PAN_CASE(2) MACHIP_PAN_CASE(3) MACHIP_PAN_CASE(4) MACHIP_PAN_CASE(5) MACHIP_PAN_CASE(6)
             MACHIP_PAN_CASE(7) MACHIP_PAN_CASE(8) MACHIP_PAN_CASE(9) MACHIP_PAN_CASE(10) MACHIP_PAN_CASE(11) MACHIP_PAN_CASE(12)
@@ -1161,7 +1170,7 @@ struct Solver {
         if (pan.on) {
             ST_TRY(ensure_panel(A, nnz, pan));
             pp.variant = kPanel; pp.grid = pan.fused ? pan.NB * pan.NP : pan.grid2; pp.block = pan.fused ? kBlock : pan.block2;   // (grid = partial sums per quantity)
-            pp.width = pan.NP * 100 + pan.RPT; pp.unroll = pan.TWW; pp.defer = pan.NB + (pan.fused ? 1000 : 0);
+            pp.width = pan.NP * 100 + pan.RPT; pp.unroll = pan.TWW; pp.defer = pan.NB + (pan.fused ? 1000 : 0) + 10000 * pan.cells;
         }
         const PipeView L = pview(pp);
         const int pchunk0 = std::min(kPersistMaxSteps, std::max(2, env_int("MACHIP_PCHUNK", 64)));

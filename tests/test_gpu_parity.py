@@ -1028,6 +1028,9 @@ def test_full_size_config4_properties():
     {"MACHIP_PANEL": "1", "MACHIP_PANEL_NP": "3"}, {"MACHIP_PANEL": "1", "MACHIP_PANEL_NP": "1", "MACHIP_PANEL_NB": "2"},
     {"MACHIP_PANEL": "1", "MACHIP_PANEL_NP": "5", "MACHIP_PANEL_NB": "7", "MACHIP_PANEL_B2": "512", "MACHIP_PANEL_G2": "3"},
     {"MACHIP_PANEL": "1", "MACHIP_PANEL_NP": "7", "MACHIP_GRAPH": "0", "MACHIP_CHUNK": "6", "MACHIP_PANEL_B2": "1024"},
+    # ... several row blocks per workgroup, the panel loaded once (k_pan_mul<.., MULTI>; round 4): even split, ragged split (cells that have no row block)
+    {"MACHIP_PANEL": "1", "MACHIP_PANEL_NP": "3", "MACHIP_PANEL_NB": "6", "MACHIP_PANEL_CELLS": "2"},
+    {"MACHIP_PANEL": "1", "MACHIP_PANEL_NP": "5", "MACHIP_PANEL_NB": "7", "MACHIP_PANEL_CELLS": "3", "MACHIP_GRAPH": "0", "MACHIP_CHUNK": "6"},
     # ... and as ONE launch per step (k_pan_step: arrival tickets, slice claims); odd n -> padded pair stride, last-arriver sweep with no waiting
     {"MACHIP_PANEL": "1", "MACHIP_PANEL_FUSED": "1", "MACHIP_PANEL_NP": "3"},
     {"MACHIP_PANEL": "1", "MACHIP_PANEL_FUSED": "1", "MACHIP_PANEL_NP": "5", "MACHIP_PANEL_NB": "7", "MACHIP_PANEL_SPIN_US": "0"},
