@@ -2063,3 +2063,33 @@ def test_bench_dry_run_checks_first_contact_on_one_gpu():
     for rk in d["ranks"]:
         assert rk["steps"]["ipc_exchange"] == "ok" and rk["steps"]["two_fw_iterations"] == "ok" and rk["steps"]["comm_mode"] == 5
         assert rk["peer_access_row"][rk["device"]] == 1
+
+
+def test_exact_preconditioner_counts_fixed_off_chain_edges_as_closures():
+    """ADVICE r3 (solver.h wb_alloc): the Woodbury buffers are sized from the ACTIVE CANDIDATES, but every off-chain entry of L(x) is a
+    closure -- fixed edges off the chain included.  400 fixed closures + 40 candidates: the first extraction finds more closures than
+    the buffers hold (256), the buffers must grow and the exact preconditioner must run (a handful of iterations), not be skipped
+    silently for the tridiagonal one (hundreds on this weakly linked chain).  lambda_2 against SciPy's shift-invert Lanczos."""
+    import scipy.sparse.linalg as spla
+    n = 6000
+    rng = np.random.default_rng(11)
+    chain_i = np.arange(n - 1, dtype=np.int32)
+    cw_chain = 10.0 ** rng.uniform(0, 2.5, n - 1)
+    a = rng.integers(0, n, 400); b = np.clip(a + rng.integers(2, 3000, 400), 0, n - 1)
+    keep = b - a > 1
+    fa, fb = a[keep].astype(np.int32), b[keep].astype(np.int32)
+    fi = np.r_[chain_i, fa]; fj = np.r_[chain_i + 1, fb]; fw = np.r_[cw_chain, 10.0 ** rng.uniform(0, 2, len(fa))]
+    c1 = rng.integers(0, n - 50, 40).astype(np.int32); c2 = (c1 + rng.integers(2, 40, 40)).astype(np.int32)
+    cw = rng.uniform(1.0, 50.0, 40)
+    x = rng.uniform(0.3, 1.0, 40)
+    P = _lib.Problem(n, fi, fj, fw, c1, c2, cw)
+    P.set_x(x)
+    P.set_solver(2)
+    lam, v, _ = P.fiedler()
+    its = int(P.stats.lanczos_steps)
+    assert P.stats.residual < 1e-8 and its <= 40, its
+    L = oracle.mac_laplacian(oracle.laplacian_from_edges(fi, fj, fw, n), c1.astype(np.int64), c2.astype(np.int64), cw, x, n)
+    sh = 1e-6 * lam
+    w = np.sort(spla.eigsh((L + sh * sp.identity(n)).tocsc(), k=2, sigma=0, which="LM", tol=0, return_eigenvectors=False)) - sh
+    assert abs(lam - w[1]) <= 1e-7 * w[1], (lam, w[1])
+    P.close()
