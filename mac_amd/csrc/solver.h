@@ -681,16 +681,23 @@ struct Solver {
     void lob_launch_chunk_t(const CsrView& AT, const SpmvPlan& pl, const LobView& L, int steps) {
         OpLob op;
         op.L = L;
+        // Round 4: between two products the update of iteration s - 1, the tridiagonal solve of iteration s and g = U^T y run as ONE
+        // single-workgroup launch (k_lob_fused; the same arithmetic per unknown): T W S (F W S)^(steps - 1) U instead of (T W S U)^steps
+        const bool fuse = env_int("MACHIP_LOB_FUSE", 1) != 0 && CMAX <= 12;      // (beyond 12 unknowns per thread the fused kernel spills)
+        WbView W0 = wb_active;       // (s = 0 without the exact preconditioner: the fused kernel then skips g)
         for (int s = 0; s < steps; ++s) {
-            k_tri_solve<CMAX><<<1, kTriThreads, 0, stream>>>(L, s);
+            if (s == 0 || !fuse) {
+                k_tri_solve<CMAX><<<1, kTriThreads, 0, stream>>>(L, s);
+                if (wb_active.s > 0) k_wb_g<<<(wb_active.s + kBlock - 1) / kBlock, kBlock, 0, stream>>>(L, wb_active);
+            }
             if (wb_active.s > 0) {   // w <- y - Z C^-1 U^T y
                 const WbView& W = wb_active;
-                k_wb_g<<<(W.s + kBlock - 1) / kBlock, kBlock, 0, stream>>>(L, W);
                 k_wb_h<<<std::min(kMaxGrid, (W.s + 3) / 4), kBlock, 0, stream>>>(W);
                 k_wb_w<<<(int)std::min<size_t>(kMaxGrid, W.cap / 64), kWbwThreads, 0, stream>>>(L, W);
             }
             launch_spmv(pl, stream, AT, L.wT, op);
-            k_lob_update<false><<<L.P_a, kBlock, 0, stream>>>(L, s);
+            if (fuse && s + 1 < steps) k_lob_fused<CMAX><<<1, kTriThreads, 0, stream>>>(L, W0, s);
+            else k_lob_update<false><<<L.P_a, kBlock, 0, stream>>>(L, s);
         }
         k_lob_tail<<<1, 64, 0, stream>>>(L, steps);
     }

@@ -297,6 +297,123 @@ __global__ __launch_bounds__(256) void k_gj_step(const double* __restrict__ src,
             }
 }
 
+// ---- update + tridiagonal solve + g in ONE single-workgroup launch (round 4; n <= 16 384) ------------------------------------
+// Between two products L w the preconditioned iteration runs k_lob_update (Rayleigh-Ritz on the 15 sums, x / p / Lx / Lp / r),
+// k_tri_solve (y = T^-1 r, one workgroup) and k_wb_g (g = U^T y): three dependent launches of ~5-7 us each around ~1 us of work on
+// a pose graph.  Here thread t of one 1 024-thread workgroup does all of it for the CMAX unknowns it owns in the solver's
+// chunk layout: update (the residual stays in registers), the two sweeps of the LU solve with their scans, y into wT, then --
+// behind a barrier: the same CU wrote it -- the s differences g.  Same arithmetic per unknown as the three kernels; the
+// 1-norm of the residual is reduced by this one workgroup (partR slot 0, the other slots zeroed).
+template <int CMAX>
+__global__ __launch_bounds__(kTriThreads) void k_lob_fused(LobView L, WbView W, int jrel) {
+    __shared__ double sc[8];
+    __shared__ double sA[16], sB[16], sL[16];
+    __shared__ double s_pa[CMAX * kTriThreads];
+    const int t = threadIdx.x, n = L.n;
+    const int itn = L.st->it0 + jrel + 1;          // index of the iterate this launch produces
+    if (t >= 64 && t < 128) {                      // record of the iterate entering this launch (cf. k_lob_update)
+        double a = 0.0;
+        const double* pr = L.partR + (size_t)((itn - 1) & 1) * kMaxGrid;
+        for (int i = t - 64; i < L.P_a; i += 64) a += pr[i];
+        a = wave_total(a);
+        if (t == 64) {
+            L.hrec[4 * (size_t)(itn - 1)] = L.st->theta;
+            L.hrec[4 * (size_t)(itn - 1) + 1] = a;
+            L.hrec[4 * (size_t)(itn - 1) + 2] = lob_tag(L.st->epoch, itn - 1);
+        }
+    }
+    if (t < 64) {
+        double s[kLobNS];
+#pragma unroll
+        for (int q = 0; q < kLobNS; ++q) s[q] = 0.0;
+        for (int base = 0; base < L.P_c; base += 128) {    // (two columns of partials in flight: 1 024 threads leave 128 VGPRs per lane)
+            double v[kLobNS][2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int q = 0; q < kLobNS; ++q) v[q][c] = L.part[(size_t)q * kMaxGrid + base + t + 64 * c];   // < kMaxGrid
+#pragma unroll
+            for (int q = 0; q < kLobNS; ++q)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) s[q] += (base + t + 64 * c < L.P_c) ? v[q][c] : 0.0;
+        }
+        wave_total_n<kLobNS>(s);
+        if (t == 0) {
+            const LobCoef co = lob_rayleigh_ritz(s, L.n, L.st->havep0 != 0 || jrel > 0);
+            sc[0] = co.z0; sc[1] = co.z1; sc[2] = co.z2; sc[3] = co.theta; sc[4] = co.mx; sc[5] = co.mw; sc[6] = co.mp;
+            sc[7] = co.bad ? 1.0 : 0.0;
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        L.st->theta = sc[3];
+        if (sc[7] != 0.0) L.st->bad = 1;
+    }
+    const double z0 = sc[0], z1 = sc[1], z2 = sc[2], th = sc[3], mx = sc[4], mw = sc[5], mp = sc[6];
+    double rr[CMAX];
+    double l1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < CMAX; ++i) {
+        const int e = t * CMAX + i, k = i * kTriThreads + t;
+        rr[i] = 0.0;
+        if (e < n) {
+            const double w = L.wT[k] - mw;
+            const double pn = z1 * w + z2 * (L.p[e] - mp);
+            const double lpn = z1 * L.Lw[e] + z2 * L.Lp[e];
+            const double xn = z0 * (L.x[e] - mx) + pn;
+            const double lxn = z0 * L.Lx[e] + lpn;
+            L.p[e] = pn; L.Lp[e] = lpn; L.x[e] = xn; L.Lx[e] = lxn;
+            const double res = lxn - th * xn;
+            rr[i] = res;
+            L.rT[k] = res;
+            l1 += fabs(res);
+        }
+    }
+    {   // ||r||_1: wave totals, then 16 values
+        l1 = wave_total(l1);
+        if ((t & 63) == 0) sL[t >> 6] = l1;
+        __syncthreads();
+        if (t == 0) {
+            double a = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) a += sL[q];
+            L.partR[(size_t)(itn & 1) * kMaxGrid] = a;
+        }
+        if (t >= 1 && t < L.P_a) L.partR[(size_t)(itn & 1) * kMaxGrid + t] = 0.0;
+    }
+    // ---- y = T^-1 r (tri_solve_body with the right-hand side in registers) ----
+    double y[CMAX];
+    double run = 0.0, prod = 1.0;
+#pragma unroll
+    for (int i = 0; i < CMAX; ++i) {
+        const int k = i * kTriThreads + t;
+        const double l = L.tl[k];
+        run = rr[i] - l * run;
+        prod = -l * prod;
+        y[i] = run; s_pa[k] = prod;
+    }
+    const double carry = affine_carry_in<false>(prod, run, sA, sB);
+    double xr = 0.0, pb = 1.0;
+#pragma unroll
+    for (int i = CMAX - 1; i >= 0; --i) {
+        const int k = i * kTriThreads + t;
+        const double cu = L.tcu[k];
+        xr = (y[i] + s_pa[k] * carry) * L.tdinv[k] - cu * xr;
+        pb = -cu * pb;
+        y[i] = xr; s_pa[k] = pb;
+    }
+    const double carry2 = affine_carry_in<true>(pb, xr, sA, sB);
+#pragma unroll
+    for (int i = 0; i < CMAX; ++i) L.wT[i * kTriThreads + t] = y[i] + s_pa[i * kTriThreads + t] * carry2;
+    // ---- g = U^T y ----
+    if (W.s > 0) {
+        __threadfence_block();
+        __syncthreads();
+        for (int a = t; a < W.s; a += kTriThreads)
+            W.g[a] = L.wT[tri_perm(W.ui[a], L.c, L.stride)] - L.wT[tri_perm(W.uj[a], L.c, L.stride)];
+    }
+}
+
 // ---- application: w <- y - Z C^-1 U^T y with y = T^-1 r already in wT ----
 __global__ __launch_bounds__(kBlock) void k_wb_g(LobView L, WbView W) {
     for (int a = blockIdx.x * kBlock + threadIdx.x; a < W.s; a += gridDim.x * kBlock)
