@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MACHIP_ABI_VERSION 3
+#define MACHIP_ABI_VERSION 4   /* 4: inter-process communicator (machip_ipc_*), first-contact helpers */
 
 typedef enum machip_status {
     MACHIP_OK = 0,
