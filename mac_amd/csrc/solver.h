@@ -693,7 +693,7 @@ struct Solver {
             if (wb_active.s > 0) {   // w <- y - Z C^-1 U^T y
                 const WbView& W = wb_active;
                 k_wb_h<<<std::min(kMaxGrid, (W.s + 3) / 4), kBlock, 0, stream>>>(W);
-                k_wb_w<<<(int)std::min<size_t>(kMaxGrid, W.cap / 64), kWbwThreads, 0, stream>>>(L, W);
+                k_wb_w<<<(int)std::min<size_t>(kMaxGrid, W.cap / kWbwRows), kWbwThreads, 0, stream>>>(L, W);
             }
             launch_spmv(pl, stream, AT, L.wT, op);
             if (fuse && s + 1 < steps) k_lob_fused<CMAX><<<1, kTriThreads, 0, stream>>>(L, W0, s);
@@ -727,7 +727,7 @@ struct Solver {
                     const WbView& W = wb_active;
                     k_wb_g<<<(W.s + kBlock - 1) / kBlock, kBlock, 0, stream>>>(L, W);
                     k_wb_h<<<std::min(kMaxGrid, (W.s + 3) / 4), kBlock, 0, stream>>>(W);
-                    k_wb_w<<<(int)std::min<size_t>(kMaxGrid, W.cap / 64), kWbwThreads, 0, stream>>>(L, W);
+                    k_wb_w<<<(int)std::min<size_t>(kMaxGrid, W.cap / kWbwRows), kWbwThreads, 0, stream>>>(L, W);
                 }
                 launch_spmv(pl, stream, AT, L.wT, op);
                 k_lob_update<false><<<L.P_a, kBlock, 0, stream>>>(L, s);

@@ -225,17 +225,26 @@ __global__ __launch_bounds__(256) void k_gj_step(const double* __restrict__ src,
                 double ip = __builtin_amdgcn_rcp(piv);     // hardware reciprocal + two Newton steps (no IEEE division on the chain)
                 ip = ip * __builtin_fma(-piv, ip, 2.0);
                 ip = ip * __builtin_fma(-piv, ip, 2.0);
+                // generic update for all 16 entries, then the pivot row / column / element by their owners (pj is a compile-time
+                // index: static registers, lane predicates only -- the per-entry compare-and-select form was 40 % more instructions)
+                double sc[4], nc[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sc[j] = rp[j] * ip;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) nc[i] = -cp[i] * ip;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const bool rp_ = 4 * br + i == p, cp_ = 4 * bc + j == p;
-                        const double sc = rp[j] * ip;
-                        double v = __builtin_fma(-cp[i], sc, m[i][j]);
-                        if (rp_) v = cp_ ? ip : sc;
-                        else if (cp_) v = -cp[i] * ip;
-                        m[i][j] = v;
-                    }
+                    for (int j = 0; j < 4; ++j) m[i][j] = __builtin_fma(-cp[i], sc[j], m[i][j]);
+                if (bc == pb) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) m[i][pj] = nc[i];
+                }
+                if (br == pb) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) m[pj][j] = sc[j];
+                    if (bc == pb) m[pj][pj] = ip;
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();          // (everybody has read row / column p before the next pivot's owners overwrite them)
             }
@@ -430,34 +439,35 @@ __global__ __launch_bounds__(kBlock) void k_wb_h(WbView W) {      // h = Cinv g:
         if (lane == 0) W.h[a] = acc;
     }
 }
-// w <- y - Z h: the n x s product by 64-row tiles, the s columns dealt to the 16 waves of a workgroup (8 column loads in
-// flight per lane), wave sums added in wave order through LDS -- deterministic.  (Rounds 1-3: one thread per row walking all s
-// columns, 8 workgroups in all: 33 us per application at s = 645 on intel, a fifth of the whole preconditioned solve.)
+// w <- y - Z h: the n x s product.  A workgroup owns 16 rows (a 128-byte segment of every column of Z), its 1 024 threads are
+// 16 rows x 64 column groups: thread (r, c) walks the columns c, c + 64, ... (8 loads in flight), the 64 group sums of a row are
+// added in group order through LDS -- deterministic.  cap / 16 workgroups (128 on intel: rounds 1-3 ran one thread per row, 8
+// workgroups, 33 us per application at s = 645; the first round-4 form, 64-row tiles x 16 waves = 32 workgroups, 8.9 us).
 constexpr int kWbwThreads = 1024;
+constexpr int kWbwRows = 16;
 __global__ __launch_bounds__(kWbwThreads) void k_wb_w(LobView L, WbView W) {
-    __shared__ double sred[kWbwThreads / 64][64];
+    __shared__ double sred[kWbwThreads / kWbwRows][kWbwRows + 1];
     const size_t cap = W.cap;
-    const int s = W.s, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    constexpr int NW = kWbwThreads / 64;
-    const int per = (s + NW - 1) / NW, b0 = wv * per, b1 = min(s, b0 + per);
-    for (size_t k0 = (size_t)blockIdx.x * 64; k0 < cap; k0 += (size_t)gridDim.x * 64) {
-        const size_t k = k0 + lane;          // (cap is a multiple of 1024)
+    const int s = W.s, r = threadIdx.x & (kWbwRows - 1), cg = threadIdx.x / kWbwRows;
+    constexpr int NG = kWbwThreads / kWbwRows;      // 64 column groups
+    for (size_t k0 = (size_t)blockIdx.x * kWbwRows; k0 < cap; k0 += (size_t)gridDim.x * kWbwRows) {
+        const size_t k = k0 + r;             // (cap is a multiple of 1024)
         double acc = 0.0;
-        int b = b0;
-        for (; b + 7 < b1; b += 8) {
+        int b = cg;
+        for (; b + 7 * NG < s; b += 8 * NG) {
             double z[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) z[q] = W.Zt[k + (size_t)(b + q) * cap];
+            for (int q = 0; q < 8; ++q) z[q] = W.Zt[k + (size_t)(b + q * NG) * cap];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc = __builtin_fma(z[q], W.h[b + q], acc);
+            for (int q = 0; q < 8; ++q) acc = __builtin_fma(z[q], W.h[b + q * NG], acc);
         }
-        for (; b < b1; ++b) acc = __builtin_fma(W.Zt[k + (size_t)b * cap], W.h[b], acc);
-        sred[wv][lane] = acc;
+        for (; b < s; b += NG) acc = __builtin_fma(W.Zt[k + (size_t)b * cap], W.h[b], acc);
+        sred[cg][r] = acc;
         __syncthreads();
-        if (wv == 0) {
+        if (cg == 0) {
             double t = 0.0;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) t += sred[w][lane];
+            for (int g = 0; g < NG; ++g) t += sred[g][r];
             L.wT[k] -= t;
         }
         __syncthreads();
