@@ -55,7 +55,7 @@ struct PanView {
     int NB;      // row blocks
     int NTB;     // 64-row tiles per row block (rows per block R = 64 NTB <= kPanRows)
     int TWW;     // tiles per worker wave = ceil(NTB / 15); a (block, panel) has 15 TWW physical tiles
-    int CELLS;   // row blocks a workgroup of k_pan_mul<.., MULTI> walks (1: the single-cell kernel)
+    int CELLS;   // row blocks a workgroup of k_pan_mul_multi walks (1: the single-cell kernel k_pan_mul)
     int* tptr;              // [tiles + 1] first entry of physical tile ((b*NP + p)*15 + w)*TWW + q  (sorted tile w + 15 q)
     unsigned short* thead;  // [tiles*64] row (relative to the block) held by each slot
     double* bval;           // panel-form values, zero-padded tiles
@@ -227,10 +227,7 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_fill(CsrView A, PanView P) 
 #define PAN_FIN_ARGS(P, L, jrel) (((jrel) & 1) ? (L).Z1 : (L).Z0), (P).coef, (P).ypart, (P).n, (P).NP, (P), (L), (jrel)
 // RAW (round 4, diagonally preconditioned LOBPCG on large graphs: precond.h / solver.h): the operand is a plain vector w (passed
 // through z_cur), read with 8-byte loads and copied into LDS as it is -- no records, no coefficients, no reduction prologue.
-// MULTI (round 4): a workgroup keeps its panel in LDS and walks A.CELLS row blocks (b = blockIdx / NP + cell * gridDim / NP) one
-// after the other -- more row blocks than one wave of workgroups has, without loading the operand again: lifts the n <= 145 000
-// limit of the single-cell form (plan_panel).  MULTI = false is the single-cell kernel of round 3, unchanged.
-template <int RPT, bool RAW = false, bool MULTI = false>   // records per worker thread: the panel holds at most RPT * 960 columns
+template <int RPT, bool RAW = false>   // records per worker thread: the panel holds at most RPT * 960 columns
 __global__ __launch_bounds__(kPanThreads) void k_pan_mul(const Z2* __restrict__ z_cur, double* l_part, LanState* l_st,
                                                           const int* __restrict__ a_tptr, const unsigned short* __restrict__ a_thead,
                                                           int a_n, int a_C, int a_NP, int a_TWW, PanView A_, PipeView L_, int jrel) {
@@ -244,9 +241,7 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul(const Z2* __restrict__ 
     __shared__ double scoef[8];
     static_assert((RPT * kPanWorkThreads + kPanRows + 8) * 8 <= 163840, "panel + row-block image exceed the LDS");
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bg = blockIdx.x / A.NP, p = blockIdx.x - bg * A.NP;
-    const int ncell = MULTI ? A.CELLS : 1, nbg = MULTI ? (int)gridDim.x / A.NP : 0;
-    int b = bg;
+    const int b = blockIdx.x / A.NP, p = blockIdx.x - b * A.NP;
     const int c0 = p * A.C;
     const int Cp = min(A.C, A.n - c0);           // >= 1 by construction of the plan
     const int R = 64 * A.NTB;
@@ -266,7 +261,6 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul(const Z2* __restrict__ 
         __syncthreads();
         __syncthreads();
         __syncthreads();
-        for (int cell = 1; cell < ncell; ++cell) { __syncthreads(); __syncthreads(); __syncthreads(); }
         return;
     }
     const int wt = tid - 64, ww = wv - 1;        // worker thread / worker wave
@@ -284,11 +278,8 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul(const Z2* __restrict__ 
 #pragma unroll
         for (int i = 0; i < RPT; ++i) z[i] = Zc[min(wt + kPanWorkThreads * i, Cp - 1)];
     }
-  for (int cell = 0; cell < ncell; ++cell) {
-    if (MULTI) b = bg + cell * nbg;
-    const bool live = !MULTI || b < A.NB;        // (the last cells of some workgroups have no row block)
     // this wave's tiles: slot -> row, and the chunk (64 entries) at which each tile ends
-    const int vt0 = ((min(b, A.NB - 1) * A.NP + p) * kPanWork + ww) * A.TWW;
+    const int vt0 = ((b * A.NP + p) * kPanWork + ww) * A.TWW;
     int ro[kPanTW], cend[kPanTW];
     int E0;
     {
@@ -301,7 +292,7 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul(const Z2* __restrict__ 
 #pragma unroll
         for (int q = 0; q < kPanTW; ++q) cend[q] = (tp[q + 1] - E0) >> 6;      // (tiles q >= TWW: same as the last real one)
     }
-    const int nch = live ? cend[kPanTW - 1] : 0;
+    const int nch = cend[kPanTW - 1];
     const double* __restrict__ bv = A.bval + E0 + lane;
     const unsigned short* __restrict__ bc = A.bcol + E0 + lane;
     double pv[kPanCH];
@@ -314,16 +305,14 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul(const Z2* __restrict__ 
 #ifdef PAN_CLOCKS
     if (wv == 1) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PAN_CLK(tid == 64, 2); }   // records, tile table, the wave's chunks arrived (wave 1)
 #endif
-    __syncthreads();             // (cell 0: the coefficients are there; later cells: the previous cell's stores have read yblk)
+    __syncthreads();
     PAN_CLK(tid == 64, 4);
     {
-        if (cell == 0) {
-            const double alpha = RAW ? 0.0 : scoef[0], mu = RAW ? 0.0 : scoef[2], inv = RAW ? 1.0 : scoef[3];
+        const double alpha = RAW ? 0.0 : scoef[0], mu = RAW ? 0.0 : scoef[2], inv = RAW ? 1.0 : scoef[3];
 #pragma unroll
-            for (int i = 0; i < RPT; ++i) {
-                const int c = wt + kPanWorkThreads * i;
-                if (c < Cp) sv[c] = RAW ? z[i].v : pan_vj(alpha, mu, inv, z[i].t, z[i].v);
-            }
+        for (int i = 0; i < RPT; ++i) {
+            const int c = wt + kPanWorkThreads * i;
+            if (c < Cp) sv[c] = RAW ? z[i].v : pan_vj(alpha, mu, inv, z[i].t, z[i].v);
         }
         for (int rl = wt; rl < R; rl += kPanWorkThreads) yblk[rl] = 0.0;      // rows of empty tiles
     }
@@ -371,10 +360,151 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul(const Z2* __restrict__ 
     // the row block's sums, un-sorted by the LDS image: coalesced stores
     for (int rl = wt; rl < R; rl += kPanWorkThreads) {
         const int row = b * R + rl;
-        if (live && row < A.n) A.ypart[(size_t)p * A.n + row] = yblk[rl];
+        if (row < A.n) A.ypart[(size_t)p * A.n + row] = yblk[rl];
     }
     PAN_CLK(tid == 64, 8); PAN_CLK(tid == 1023, 9);
-  }
+}
+
+
+// Several row blocks per workgroup (round 4): the workgroup keeps its panel in LDS and walks A.CELLS row blocks
+// (b = blockIdx / NP + cell * gridDim / NP) -- more row blocks than one wave of workgroups has, without loading the operand again:
+// lifts the n <= 145 000 limit of the single-cell kernel (plan_panel).  A cell is a serial chain (tile table -> chunk loads ->
+// row sums -> stores); here the NEXT cell's tile table is requested before the current cell's sums and its chunks right behind
+// them, in flight across the barrier and the stores -- the barriers order LDS traffic only (lds_barrier: s_waitcnt lgkmcnt(0) +
+// s_barrier; a __syncthreads would wait for those loads).  Same per-row arithmetic and order as k_pan_mul.
+__device__ __forceinline__ void pan_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+constexpr int kPanCHM = 14;        // chunks per round in the multi-cell kernel (the prefetched tile table needs the registers)
+template <int RPT>
+__global__ __launch_bounds__(kPanThreads) void k_pan_mul_multi(const Z2* __restrict__ z_cur, double* l_part, LanState* l_st,
+                                                                const int* __restrict__ a_tptr, const unsigned short* __restrict__ a_thead,
+                                                                int a_n, int a_C, int a_NP, int a_TWW, PanView A_, PipeView L_, int jrel) {
+    PanView A = A_;
+    A.tptr = const_cast<int*>(a_tptr); A.thead = const_cast<unsigned short*>(a_thead); A.n = a_n; A.C = a_C; A.NP = a_NP; A.TWW = a_TWW;
+    PipeView L = L_;
+    L.part = l_part; L.st = l_st;
+    __shared__ double sv[RPT * kPanWorkThreads];
+    __shared__ double yblk[kPanRows];
+    __shared__ double scoef[8];
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bg = blockIdx.x / A.NP, p = blockIdx.x - bg * A.NP;
+    const int ncell = A.CELLS, nbg = (int)gridDim.x / A.NP;
+    const int c0 = p * A.C;
+    const int Cp = min(A.C, A.n - c0);
+    const int R = 64 * A.NTB;
+    if (wv == 0) {
+        int jd;
+        const PipeCoef c = pipe_prologue_wave0(L, jrel, -1, scoef, &jd);
+        if (blockIdx.x == 0 && lane == 0) {
+            A.coef[0] = c.alpha; A.coef[1] = c.beta; A.coef[2] = c.mu; A.coef[3] = c.inv; A.coef[4] = (double)jd;
+        }
+        for (int cell = 0; cell < ncell; ++cell) { pan_lds_barrier(); pan_lds_barrier(); pan_lds_barrier(); }
+        return;
+    }
+    const int wt = tid - 64, ww = wv - 1;
+    const Z2* __restrict__ Zc = z_cur + c0;
+    Z2 z[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) z[i] = Zc[min(wt + kPanWorkThreads * i, Cp - 1)];
+    // tile table of a cell: tile ends (uniform) and slot -> row of this wave's tiles
+    int tp[kPanTW + 1], ro[kPanTW];
+    {
+        const int vt0 = ((min(bg, A.NB - 1) * A.NP + p) * kPanWork + ww) * A.TWW;
+#pragma unroll
+        for (int q = 0; q <= kPanTW; ++q) tp[q] = __builtin_amdgcn_readfirstlane(A.tptr[vt0 + min(q, A.TWW)]);
+#pragma unroll
+        for (int q = 0; q < kPanTW; ++q) ro[q] = A.thead[(size_t)(vt0 + min(q, A.TWW - 1)) * 64 + lane];
+    }
+    int cend[kPanTW];
+    int E0 = tp[0];
+#pragma unroll
+    for (int q = 0; q < kPanTW; ++q) cend[q] = (tp[q + 1] - E0) >> 6;
+    int nch = bg < A.NB ? cend[kPanTW - 1] : 0;
+    double pv[kPanCHM];
+    int pk[kPanCHM];
+#pragma unroll
+    for (int c = 0; c < kPanCHM; ++c) { pv[c] = 0.0; pk[c] = 0; }
+#pragma unroll
+    for (int c = 0; c < kPanCHM; ++c)
+        if (c < nch) { pv[c] = A.bval[E0 + lane + c * 64]; pk[c] = A.bcol[E0 + lane + c * 64]; }
+    pan_lds_barrier();           // the coefficients are there
+    {                            // (before the loop: the records' registers are free from here on)
+        const double alpha = scoef[0], mu = scoef[2], inv = scoef[3];
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int c = wt + kPanWorkThreads * i;
+            if (c < Cp) sv[c] = pan_vj(alpha, mu, inv, z[i].t, z[i].v);
+        }
+    }
+    for (int cell = 0; cell < ncell; ++cell) {
+        const int b = bg + cell * nbg;
+        const bool live = b < A.NB;                  // (the last cells of some workgroups have no row block)
+        const double* __restrict__ bv = A.bval + E0 + lane;
+        const unsigned short* __restrict__ bc = A.bcol + E0 + lane;
+        if (cell) pan_lds_barrier();                 // the previous cell's stores have read yblk
+        for (int rl = wt; rl < R; rl += kPanWorkThreads) yblk[rl] = 0.0;
+        pan_lds_barrier();
+        // the next cell's tile table: in flight while this cell's rows are summed
+        const int bn = bg + (cell + 1) * nbg;
+        const bool more = cell + 1 < ncell;
+        int tpn[kPanTW + 1], ron[kPanTW];
+        {
+            const int vtn = ((min(more ? bn : b, A.NB - 1) * A.NP + p) * kPanWork + ww) * A.TWW;
+#pragma unroll
+            for (int q = 0; q <= kPanTW; ++q) tpn[q] = A.tptr[vtn + min(q, A.TWW)];
+#pragma unroll
+            for (int q = 0; q < kPanTW; ++q) ron[q] = A.thead[(size_t)(vtn + min(q, A.TWW - 1)) * 64 + lane];
+        }
+        double acc = 0.0;
+        for (int cb = 0; cb < nch; cb += kPanCHM) {
+#pragma clang fp contract(off)      // (two roundings at every chunk position: see k_pan_mul)
+            if (cb) {
+#pragma unroll
+                for (int c = 0; c < kPanCHM; ++c)
+                    if (cb + c < nch) { pv[c] = bv[(cb + c) * 64]; pk[c] = bc[(cb + c) * 64]; }
+            }
+#pragma unroll
+            for (int c = 0; c < kPanCHM; ++c) pv[c] *= sv[min(pk[c], Cp - 1)];
+            unsigned endmask = 0;
+#pragma unroll
+            for (int q = 0; q < kPanTW; ++q) {
+                const int prev = q ? cend[q - 1] : 0, last = cend[q] - 1 - cb;
+                if (q < A.TWW && cend[q] > prev && last >= 0 && last < kPanCHM) endmask |= 1u << last;
+            }
+#pragma unroll
+            for (int c = 0; c < kPanCHM; ++c) {
+                if (cb + c < nch) {
+                    acc += pv[c];
+                    if (endmask & (1u << c)) {
+#pragma unroll
+                        for (int q = 0; q < kPanTW; ++q)
+                            if (cb + c + 1 == cend[q] && (q == 0 ? cend[0] > 0 : cend[q] > cend[q - 1])) yblk[ro[q]] = acc;
+                        acc = 0.0;
+                    }
+                }
+            }
+        }
+        // the next cell's chunks: requested now, in flight across the barrier and this cell's stores
+        if (more) {
+#pragma unroll
+            for (int q = 0; q <= kPanTW; ++q) tp[q] = __builtin_amdgcn_readfirstlane(tpn[q]);
+#pragma unroll
+            for (int q = 0; q < kPanTW; ++q) ro[q] = ron[q];
+            E0 = tp[0];
+#pragma unroll
+            for (int q = 0; q < kPanTW; ++q) cend[q] = (tp[q + 1] - E0) >> 6;
+            nch = bn < A.NB ? cend[kPanTW - 1] : 0;
+#pragma unroll
+            for (int c = 0; c < kPanCHM; ++c) { pv[c] = 0.0; pk[c] = 0; }
+#pragma unroll
+            for (int c = 0; c < kPanCHM; ++c)
+                if (c < nch) { pv[c] = A.bval[E0 + lane + c * 64]; pk[c] = A.bcol[E0 + lane + c * 64]; }
+        }
+        pan_lds_barrier();
+        for (int rl = wt; rl < R; rl += kPanWorkThreads) {
+            const int row = b * R + rl;
+            if (live && row < A.n) A.ypart[(size_t)p * A.n + row] = yblk[rl];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------

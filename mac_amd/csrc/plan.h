@@ -139,7 +139,7 @@ inline SpmvPlan plan_pipe(int n, long nnz, int maxlen) {
 struct PanPlan {
     bool on = false;
     int NP = 1, C = 1, NB = 1, NTB = 1, TWW = 1, RPT = 1;
-    int cells = 1;                   // row blocks per workgroup of k_pan_mul (> 1: the MULTI instantiation, grid = NP * ceil(NB / cells))
+    int cells = 1;                   // row blocks per workgroup (> 1: k_pan_mul_multi, grid = NP * ceil(NB / cells))
     int grid2 = 1, block2 = 256;     // launch shape of k_pan_fin
     bool fused = false;              // one launch per step (k_pan_step) instead of k_pan_mul + k_pan_fin (measured SLOWER: profiles/r4_c4_one_launch_step.md)
 };
@@ -178,8 +178,8 @@ inline PanPlan plan_panel(int n, long nnz, int maxlen, bool allowed) {
         }
         if (!np) {
             // no single-wave shape (n > ~145 000).  Round 4: ONE wave of workgroups all the same, each keeping its panel in LDS and
-            // walking `cells` row blocks (k_pan_mul<.., MULTI>): panels of ~8 448 columns, as many row blocks as the 7 680-row image needs
-            const int maxcells = env_int("MACHIP_PANEL_MAXCELLS", 6);
+            // walking `cells` row blocks (k_pan_mul_multi): panels of ~8 448 columns, as many row blocks as the 7 680-row image needs
+            const int maxcells = env_int("MACHIP_PANEL_MAXCELLS", 12);
             for (int c = std::max(1, (n + 8447) / 8448); c >= 1 && c <= grid_cap(); --c) {
                 if ((n + c - 1) / c > cmax) break;
                 const int nbg = std::max(1, grid_cap() / c);
@@ -202,10 +202,11 @@ inline PanPlan plan_panel(int n, long nnz, int maxlen, bool allowed) {
     ntb = std::min(ntb, tmax);                                   // (the row block's LDS image holds 7 680 rows)
     nb = (groups + ntb - 1) / ntb;
     pp.cells = std::max(1, std::min(pp.cells, nb));
-    // several cells per workgroup cost ~15 us each (a cell is a serial chain: tile table -> chunks -> sums -> stores): measured
-    // cross-over against the gather step at ~43 entries per row (tools/panel_size_probe.py, profiles/r4_panel_sizes.txt:
-    // n = 200 000: 54.8 vs 59.9 us at 43 / row, 51.4 vs 47.6 at 33; n = 300 000: 91 vs 118 at 49, 80 vs 78 at 33)
-    if (mode < 0 && pp.cells > 1 && mean < 0.1 * env_int("MACHIP_PANEL_MULTI_MIN_MEAN10", 430)) return PanPlan();
+    // several cells per workgroup (k_pan_mul_multi: the next cell's tile table and chunks are in flight behind the current cell's
+    // sums): measured against the gather step (tools/panel_size_probe.py, profiles/r4_panel_sizes.txt) -- per step a tie at ~29
+    // entries per row for n = 150 000, ahead from there (n = 200 000: 41.1 vs 43.7 us at 29 / row, 43.8 vs 50.9 at 36; n = 400 000:
+    // 119 vs 132 at 34, 129 vs 200 at 49); with the panel build (0.3-0.5 ms per solve) the whole solve wins from ~33 entries per row
+    if (mode < 0 && pp.cells > 1 && mean < 0.1 * env_int("MACHIP_PANEL_MULTI_MIN_MEAN10", 330)) return PanPlan();
     pp.on = true; pp.NP = np; pp.C = C; pp.NB = nb; pp.NTB = ntb; pp.TWW = (ntb + kPanWork - 1) / kPanWork;
     pp.RPT = (C + kPanWorkThreads - 1) / kPanWorkThreads;
     // MACHIP_PANEL_FUSED=1: the one-launch form (k_pan_step; tickets for 256 row blocks, one partial-sum slot per slice).  Off by

@@ -344,14 +344,14 @@ struct Solver {
             }
             return;
         }
-        if (pan.cells > 1) {     // several row blocks per workgroup, the panel loaded once (k_pan_mul<.., MULTI>)
+        if (pan.cells > 1) {     // several row blocks per workgroup, the panel loaded once (k_pan_mul_multi)
             const int gm = pan.NP * ((pan.NB + pan.cells - 1) / pan.cells);
             switch (pan.RPT) {
-#define MACHIP_PAN_CASE(R) case R: k_pan_mul<R, false, true><<<gm, kPanThreads, 0, stream>>>(PAN_MUL_ARGS(panv, L, s)); break;
+#define MACHIP_PAN_CASE(R) case R: k_pan_mul_multi<R><<<gm, kPanThreads, 0, stream>>>(PAN_MUL_ARGS(panv, L, s)); break;
                 MACHIP_PAN_CASE(1) MACHIP_PAN_CASE(2) MACHIP_PAN_CASE(3) MACHIP_PAN_CASE(4) MACHIP_PAN_CASE(5) MACHIP_PAN_CASE(6)
                 MACHIP_PAN_CASE(7) MACHIP_PAN_CASE(8) MACHIP_PAN_CASE(9) MACHIP_PAN_CASE(10) MACHIP_PAN_CASE(11) MACHIP_PAN_CASE(12)
 #undef MACHIP_PAN_CASE
-                default: k_pan_mul<13, false, true><<<gm, kPanThreads, 0, stream>>>(PAN_MUL_ARGS(panv, L, s)); break;
+                default: k_pan_mul_multi<13><<<gm, kPanThreads, 0, stream>>>(PAN_MUL_ARGS(panv, L, s)); break;
             }
         } else switch (pan.RPT) {
 #define MACHIP_PAN_CASE(R) case R: k_pan_mul<R><<<g1, kPanThreads, 0, stream>>>(PAN_MUL_ARGS(panv, L, s)); break;
