@@ -683,7 +683,9 @@ struct Solver {
         op.L = L;
         // Round 4: between two products the update of iteration s - 1, the tridiagonal solve of iteration s and g = U^T y run as ONE
         // single-workgroup launch (k_lob_fused; the same arithmetic per unknown): T W S (F W S)^(steps - 1) U instead of (T W S U)^steps
-        const bool fuse = env_int("MACHIP_LOB_FUSE", 1) != 0 && CMAX <= 12;      // (beyond 12 unknowns per thread the fused kernel spills)
+        // (small graphs only: with more unknowns per thread the one workgroup's strided reads of six vectors cost more than the two
+        // launches saved -- city10000, C = 10, in the configs[4] sweep: 870 it/s fused against 1 223)
+        const bool fuse = env_int("MACHIP_LOB_FUSE", 1) != 0 && CMAX <= 4;
         WbView W0 = wb_active;       // (s = 0 without the exact preconditioner: the fused kernel then skips g)
         for (int s = 0; s < steps; ++s) {
             if (s == 0 || !fuse) {
