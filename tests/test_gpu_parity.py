@@ -2036,6 +2036,21 @@ def test_ipc_row_partitioned_eigensolve_between_processes_is_bit_identical(world
         assert msg[1]["mode"] == 5, msg[1]["mode"]              # the last eigen-solve really ran row-partitioned between the processes
 
 
+@pytest.mark.parametrize("wl,env", [("golden:er2000_solve", {"MACHIP_VCAP": "80"}), ("golden:g2o_kitti_05", {}), ("golden:g2o_city10000", {}),
+                                    ("golden:er2000_solve", {"MACHIP_GRAPH": "0", "MACHIP_CHUNK": "6"})])
+def test_ipc_communicator_with_restarts_and_unpartitioned_solver_modes(wl, env):
+    """The inter-process communicator when the eigen-solve is NOT one plain partitioned sequence: a basis so small that the
+    sequence restarts (the restart continues in the classic two-kernel form, replicated on every rank), a pose graph whose solves
+    run in the preconditioned mode (replicated; only the gradient is exchanged), city10000 (padded fixed-width step: replicated;
+    then partitioned gather steps after a restart), eager launches with odd chunk lengths.  Two processes on one GPU, bit-identical
+    to one process run with the same settings."""
+    single = _run_ipc_job(1, wl, 3, env_extra=env)[0]
+    assert single[0] == 0 and single[1][0] == "RESULT", single
+    for rc, msg, se in _run_ipc_job(2, wl, 3, env_extra=env):
+        assert rc == 0 and msg and msg[0] == "RESULT", (rc, msg, se)
+        assert msg[1]["out"] == single[1][1]["out"] and msg[1]["xsum"] == single[1][1]["xsum"] and msg[1]["xdot"] == single[1][1]["xdot"]
+
+
 def test_ipc_peers_of_a_dead_rank_return_an_error_within_the_time_limit():
     """A rank that dies mid-solve (os._exit: no goodbye) must not hang its peers: their next device-side wait times out after
     the communicator's limit (2 s here), later waits return at once, and the call comes back with MACHIP_RCCL_ERROR."""
