@@ -65,6 +65,7 @@ struct PanView {
     unsigned int* tick;     // [NB] one-launch step (k_pan_step): arrivals of a row block's NP workgroups, monotonic over a sequence
     unsigned int* claim;    // [NB * NP] ... and which step's share (row block b, rows of slice p) has been taken
     int spin_ticks;         // ... how long (100 MHz ticks) a workgroup waits for its row block before leaving its share to the last arriver
+    int* ovf;               // set by k_pan_rows when a row has more than kPanMaxLen entries inside ONE panel (the build would clamp it)
     int* tcount;            // [tiles] entries (with padding) per tile (assembly scratch)
     int* ps;                // [(NP+1)][n] first off-diagonal entry of row r at or behind panel p (assembly scratch)
 #ifdef PAN_CLOCKS
@@ -99,12 +100,15 @@ __global__ __launch_bounds__(kBlock) void k_pan_rows(CsrView A, PanView P) {
     if (r >= A.n) return;
     int e = A.rowptr[r] + 1;               // (the diagonal sits first and is counted with its own panel)
     const int end = A.rowptr[r + 1];
+    bool over = false;
     for (int p = 0; p < P.NP; ++p) {
         P.ps[(size_t)p * A.n + r] = e;
-        const int hi = (p + 1) * P.C;
+        const int hi = (p + 1) * P.C, e0 = e;
         while (e < end && A.col[e] < hi) ++e;
+        over |= e - e0 + (r / P.C == p ? 1 : 0) > kPanMaxLen;
     }
     P.ps[(size_t)P.NP * A.n + r] = end;
+    if (over) *P.ovf = 1;                  // (a hub row concentrated in one panel: the solver falls back to the gather step)
 }
 
 constexpr int kPanRT = (kPanRows + kPanThreads - 1) / kPanThreads;   // rows per thread (8)

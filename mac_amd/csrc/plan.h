@@ -141,6 +141,7 @@ struct PanPlan {
     int NP = 1, C = 1, NB = 1, NTB = 1, TWW = 1, RPT = 1;
     int cells = 1;                   // row blocks per workgroup (> 1: k_pan_mul_multi, grid = NP * ceil(NB / cells))
     int grid2 = 1, block2 = 256;     // launch shape of k_pan_fin
+    bool verify = false;             // a row is longer than 127 entries: the build must confirm that no (row, panel) count exceeds 127
     bool fused = false;              // one launch per step (k_pan_step) instead of k_pan_mul + k_pan_fin (measured SLOWER: profiles/r4_c4_one_launch_step.md)
 };
 inline PanPlan plan_panel(int n, long nnz, int maxlen, bool allowed) {
@@ -152,7 +153,11 @@ inline PanPlan plan_panel(int n, long nnz, int maxlen, bool allowed) {
     // for the panel step's fixed costs (two launches, NB x 16 n bytes of panel loads, 2 x NP x 8 n bytes of partials) to
     // pay: measured cross-over on MI355X at n = 1e5 (tools/sweep_panel.py, profiles/r3_c4_panel.md): ~17 entries per row
     // (gather step 18.7 us and rising 4 us per million entries, panel step 18.3 us and rising 0.9 us per million)
-    if (maxlen > kPanMaxLen) return pp;               // the build kernels' length histograms stop at 127
+    // The build kernels' length histograms describe at most 127 entries of a row INSIDE ONE PANEL.  A row of up to 127 entries fits
+    // whatever its columns are; a longer (hub) row fits when its entries spread over the panels -- k_pan_rows checks every (row, panel)
+    // count and raises a flag, the solver then drops the panel form for this matrix (verify).  Rows beyond 64 x 127 entries: gather step.
+    if (maxlen > 64 * kPanMaxLen) return pp;
+    pp.verify = maxlen > kPanMaxLen;
     // (other sizes, tools/panel_size_probe.py: n = 66 000 .. 145 000 with a single wave of workgroups -- a tie at 23-26 entries
     // per row, 1.3-1.5x at 43-46; beyond n = 1e5 the build's 0.25 ms per solve moves the break-even to ~26)
     const int min_mean10 = env_int("MACHIP_PANEL_MIN_MEAN10", n <= 105000 ? 170 : 260);

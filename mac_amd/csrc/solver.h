@@ -199,7 +199,7 @@ struct Solver {
                         lx_ys, lx_pas, lx_as, lx_bs, lx_maps, lx_ba, lx_bd, lx_bu, wb_ui, wb_uj, wb_counts, wb_uc, wb_g, wb_h, wb_Zt, wb_Cm, wb_Cm2, wb_pas, wb_maps,
                         lx_colT, lx_bad, lx_st, valf};
         {
-            void* pb[] = {panv.tptr, panv.thead, panv.bval, panv.bcol, panv.ypart, panv.coef, panv.tcount, panv.ps, panv.tick, panv.claim};
+            void* pb[] = {panv.tptr, panv.thead, panv.bval, panv.bcol, panv.ypart, panv.coef, panv.tcount, panv.ps, panv.tick, panv.claim, panv.ovf};
             for (void* q : pb) if (q) (void)hipFree(q);
             void* pk[] = {ppack.band, ppack.cc, ppack.crow, ppack.ccol, ppack.cval, ell_col, ell_val};
             for (void* q : pk) if (q) (void)hipFree(q);
@@ -323,6 +323,8 @@ struct Solver {
         }
         if (!panv.coef) ST_TRY(dev_alloc(&panv.coef, 8));
         if (!panv.tick) { ST_TRY(dev_alloc(&panv.tick, 256)); ST_TRY(dev_alloc(&panv.claim, 4096)); }     // (NB <= 256, NB NP <= 4096: plan_panel)
+        if (!panv.ovf) ST_TRY(dev_alloc(&panv.ovf, 1));
+        HIP_TRY(hipMemsetAsync(panv.ovf, 0, sizeof(int), stream));
         panv.spin_ticks = env_int("MACHIP_PANEL_SPIN_US", 20) * 100;
         panv.n = n; panv.NP = pn.NP; panv.C = pn.C; panv.NB = pn.NB; panv.NTB = pn.NTB; panv.TWW = pn.TWW; panv.CELLS = pn.cells;
         k_pan_rows<<<(n + kBlock - 1) / kBlock, kBlock, 0, stream>>>(A, panv);
@@ -861,7 +863,7 @@ struct Solver {
         SpmvPlan pl = plan_spmv(n, nnz, kAuto, jacobi && n > 32768 ? kMaxGrid : 0);
         if (jacobi) {
             pan = plan_panel(n, nnz, maxlen_hint, pan_allowed && precision == 0 && !shard && !ipc);
-            if (pan.on) {
+            if (pan.on && !pan.verify) {
                 ST_TRY(ensure_panel(A, nnz, pan));
                 lob_pan = true;
             }
@@ -1178,6 +1180,14 @@ struct Solver {
         }
         if (pan.on) {
             ST_TRY(ensure_panel(A, nnz, pan));
+            if (pan.verify) {        // hub rows: is every (row, panel) count within what the tiles describe?  (one sync, hub matrices only)
+                int over = 0;
+                HIP_TRY(hipMemcpyAsync(&over, panv.ovf, sizeof(int), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+                if (over) pan.on = false;            // a hub row concentrated in one panel: the gather step serves this matrix
+            }
+        }
+        if (pan.on) {
             pp.variant = kPanel; pp.grid = pan.fused ? pan.NB * pan.NP : pan.grid2; pp.block = pan.fused ? kBlock : pan.block2;   // (grid = partial sums per quantity)
             pp.width = pan.NP * 100 + pan.RPT; pp.unroll = pan.TWW; pp.defer = pan.NB + (pan.fused ? 1000 : 0) + 10000 * pan.cells;
         }

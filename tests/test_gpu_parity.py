@@ -1103,18 +1103,19 @@ def test_padded_fixed_width_step_is_bit_identical_to_the_csr_step(hub):
 def test_panel_step_multi_round_windows_hub_rows_and_odd_sizes():
     """Corners of the column-panel step (panel.h) the bench matrices do not reach: (a) dense rows -- a worker wave's tiles
     hold more chunks than its registers (kPanCH = 20), so the multi-round path runs; (b) n not a multiple of 64 nor of the
-    panel width, last row block mostly empty; (c) a hub row right at the 127-entry limit (panel step still on) and one beyond
-    it (plan_panel must fall back to the gather step).  lambda_2 of the panel step equals the gather step's to 1e-12 and
-    SciPy's to 1e-8; the vectors agree."""
+    panel width, last row block mostly empty; (c) a hub row right at the 127-entry limit, one beyond it whose entries spread over the
+    panels (every (row, panel) count stays within 127: the panel step serves it) and one whose 200 closures sit inside ONE panel
+    (k_pan_rows raises its flag and the solver falls back to the gather step: the forced-panel solve is then bit-identical to the
+    gather solve).  lambda_2 of the panel step equals the gather step's to 1e-12 and SciPy's to 1e-8; the vectors agree."""
     import scipy.sparse.linalg as spla
     rng = np.random.default_rng(11)
-    for n, deg, hub in ((70001, 64, 0), (66003, 20, 126), (66003, 20, 140)):
+    for n, deg, hub, packed in ((70001, 64, 0, False), (66003, 20, 126, False), (66003, 20, 140, False), (66003, 20, 200, True)):
         m0 = n * deg // 2
         a = rng.integers(0, n, m0); b = rng.integers(0, n, m0)
         keep = (a != b) & (np.abs(a - b) != 1)
         lo, hi = np.minimum(a[keep], b[keep]), np.maximum(a[keep], b[keep])
         if hub:          # a hub: node 7 joined to `hub` further nodes (its row: chain 2 + diagonal + closures)
-            extra = rng.choice(np.arange(100, n), hub, replace=False)
+            extra = rng.choice(np.arange(100, 6000 if packed else n), hub, replace=False)     # (forced shape: panels of 8 256 columns)
             lo = np.concatenate([lo, np.full(hub, 7)]); hi = np.concatenate([hi, extra])
         key = np.unique(lo.astype(np.int64) * n + hi)
         ci, cj = (key // n).astype(np.int32), (key % n).astype(np.int32)
@@ -1142,6 +1143,15 @@ def test_panel_step_multi_round_windows_hub_rows_and_odd_sizes():
             else:
                 os.environ["MACHIP_PANEL"] = old
         assert abs(res["1"][0] - res["0"][0]) <= 1e-12 * res["0"][0], (n, deg, hub, res["0"][0], res["1"][0])
+        out8 = (C.c_int * 8)()
+        nnz_l = n + 2 * (n - 1 + m)
+        os.environ["MACHIP_PANEL"] = "1"
+        try:
+            assert _lib.load().machip_panel_plan(n, nnz_l, hub + 3 if hub else 127, out8) == 0 and out8[0] == 1   # (the plan admits all four)
+        finally:
+            os.environ.pop("MACHIP_PANEL", None) if old is None else os.environ.__setitem__("MACHIP_PANEL", old)
+        same = res["1"][0] == res["0"][0] and res["1"][2] == res["0"][2] and np.array_equal(res["1"][1], res["0"][1])
+        assert same == packed, (n, deg, hub, packed, res["0"][0], res["1"][0], res["0"][2], res["1"][2])
         assert np.abs(sign_align(res["1"][1], res["0"][1]) - res["0"][1]).max() <= 1e-7
         ip, ix, da = P.laplacian_csr()
         L = sp.csr_matrix((da, ix, ip), shape=(n, n))

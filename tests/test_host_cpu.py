@@ -184,14 +184,15 @@ def test_panel_plan_covers_every_row_and_column_within_the_kernel_limits():
     """Shape arithmetic of the column-panel Lanczos step (solver.h plan_panel, exported as machip_panel_plan; host only):
     the panels cover every column, the row blocks every row, a panel fits the LDS next to the row block's image
     (RPT <= 13 records per worker thread), a worker wave owns at most 8 tiles, and the automatic rule turns the step on
-    only for large, dense-enough matrices with rows the build kernels can describe."""
+    only for large, dense-enough matrices with rows the build kernels can describe (a hub row of up to 64 x 127 entries is
+    admitted subject to the build's per-panel check, test_gpu_parity's hub cases)."""
     import ctypes as C
     lib = _lib.load()
     out = (C.c_int * 8)()
     old = {k: os.environ.pop(k, None) for k in ("MACHIP_PANEL", "MACHIP_PANEL_NP", "MACHIP_PANEL_NB")}
     try:
         # automatic rule (BASELINE configs[3]: on for the dense iterates only)
-        for n, nnz, maxlen, want in ((100000, 700344, 30, 0), (100000, 1747218, 40, 1), (100000, 4044528, 70, 1), (100000, 4044528, 200, 0),
+        for n, nnz, maxlen, want in ((100000, 700344, 30, 0), (100000, 1747218, 40, 1), (100000, 4044528, 70, 1), (100000, 4044528, 200, 1), (100000, 4044528, 9000, 0),
                                      (10000, 956618, 120, 0), (1728, 5496, 9, 0), (65536, 65536 * 20, 60, 1), (500000, 500000 * 30, 60, 0)):
             assert lib.machip_panel_plan(n, nnz, maxlen, out) == _lib.OK
             assert out[0] == want, (n, nnz, maxlen, list(out))
