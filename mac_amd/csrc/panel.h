@@ -584,8 +584,23 @@ __device__ __forceinline__ pan_d2 pan_load_wt2(const double* p) {
     return r;
 }
 
+// XCD-LOCAL variants (k_pan_step<RPT, true>: all NP workgroups of a row block run on ONE XCD and share its L2): plain 16-byte
+// stores (the L1 writes through, `s_waitcnt vmcnt(0)` = acknowledged by the L2), loads that bypass this CU's L1 (`sc0`), tickets and
+// claims as L2-local atomics (no `sc1`: they execute in the XCD's L2 and never travel to the fabric).
+__device__ __forceinline__ pan_d2 pan_load_l2(const double* p) {
+    pan_d2 r;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0" : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+__device__ __forceinline__ unsigned pan_poll_l2(unsigned* p) {      // returning add of 0, executed by the L2 (an atomic LOAD of workgroup scope may hit the L1)
+    unsigned r, z = 0u;
+    asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p), "v"(z) : "memory");
+    return r;
+}
+__device__ __forceinline__ int pan_xcc_id() { return (int)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15; }      // HW_REG_XCC_ID[3:0]
+
 #define PAN_STEP_ARGS(P, L, jrel) (((jrel) & 1) ? (L).Z1 : (L).Z0), (L).part, (L).st, (P).tptr, (P).thead, (P).n, (P).C, (P).NP, (P).TWW, (P), (L), (jrel)
-template <int RPT>
+template <int RPT, bool LOCAL = false>
 __global__ __launch_bounds__(kPanThreads) void k_pan_step(const Z2* __restrict__ z_cur, double* l_part, LanState* l_st,
                                                            const int* __restrict__ a_tptr, const unsigned short* __restrict__ a_thead,
                                                            int a_n, int a_C, int a_NP, int a_TWW, PanView A_, PipeView L_, int jrel) {
@@ -600,11 +615,19 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_step(const Z2* __restrict__
     static_assert((RPT * kPanWorkThreads + kPanRows + 8) * 8 + 16 <= 163840, "panel + row-block image exceed the LDS");
     static_assert(kNP * kPanWaves * 64 <= kPanRows, "slice epilogue scratch must fit the row-block image");
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x / A.NP, p = blockIdx.x - b * A.NP;
+    int b, p;
+    if (LOCAL) {        // workgroup w runs on XCD w mod 8: XCD x serves the row blocks x bpx .. x bpx + bpx - 1 (bpx NP <= 32 CUs)
+        const int bpx = (A.NB + 7) >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        b = xcd * bpx + slot / A.NP; p = slot % A.NP;
+        if (slot >= bpx * A.NP || b >= A.NB) return;
+    } else { b = blockIdx.x / A.NP; p = blockIdx.x - b * A.NP; }
     const int c0 = p * A.C;
     const int Cp = min(A.C, A.n - c0);
     const int R = 64 * A.NTB;
     PAN_CLK(tid == 0, 0); PAN_CLK(tid == 64, 1);
+#ifdef PAN_CLOCKS
+    if (tid == 0) A.clk[blockIdx.x * 16 + 12] = pan_xcc_id();
+#endif
     if (wv == 0) {      // wave 0: step j-1's reductions (the coefficients everyone waits for)
         int jd;
         (void)pipe_prologue_wave0(L, jrel, -1, scoef, &jd);
@@ -691,7 +714,10 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_step(const Z2* __restrict__
             const size_t ys = (size_t)((A.n + 1) & ~1);            // plane stride (even: 16-byte aligned pairs)
             for (int rl = 2 * wt; rl < R; rl += 2 * kPanWorkThreads) {
                 const int row = b * R + rl;
-                if (row < A.n) pan_store_wt2(A.ypart + (size_t)p * ys + row, yblk[rl], yblk[rl + 1]);     // (R is even; a pair may run one past n: the plane is padded)
+                if (row < A.n) {      // (R is even; a pair may run one past n: the plane is padded)
+                    if (LOCAL) { pan_d2 v2; v2.x = yblk[rl]; v2.y = yblk[rl + 1]; *reinterpret_cast<pan_d2*>(A.ypart + (size_t)p * ys + row) = v2; }
+                    else pan_store_wt2(A.ypart + (size_t)p * ys + row, yblk[rl], yblk[rl + 1]);
+                }
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -701,12 +727,13 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_step(const Z2* __restrict__
     const int j = (int)scoef[4];
     const unsigned target = (unsigned)(j + 1) * (unsigned)A.NP;
     if (tid == 0) {
-        const unsigned old = __hip_atomic_fetch_add(A.tick + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned old = LOCAL ? __hip_atomic_fetch_add(A.tick + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                                   : __hip_atomic_fetch_add(A.tick + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned state = old + 1 == target ? 2u : 0u;       // 2: last arriver of the row block
         if (!state && A.spin_ticks > 0) {
             const long long t0 = wall_clock64();
             do {
-                if (__hip_atomic_load(A.tick + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { state = 1u; break; }
+                if ((LOCAL ? pan_poll_l2(A.tick + b) : __hip_atomic_load(A.tick + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= target) { state = 1u; break; }
                 __builtin_amdgcn_s_sleep(8);
             } while (wall_clock64() - t0 < (long long)A.spin_ticks);
         }
@@ -728,8 +755,10 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_step(const Z2* __restrict__
         const int sl = (p + k) % NP;
         if (tid == 0) {
             unsigned expect = (unsigned)j;
-            sflag[1] = __hip_atomic_compare_exchange_strong(A.claim + (size_t)b * NP + sl, &expect, (unsigned)(j + 1), __ATOMIC_RELAXED,
-                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
+            sflag[1] = (LOCAL ? __hip_atomic_compare_exchange_strong(A.claim + (size_t)b * NP + sl, &expect, (unsigned)(j + 1), __ATOMIC_RELAXED,
+                                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                              : __hip_atomic_compare_exchange_strong(A.claim + (size_t)b * NP + sl, &expect, (unsigned)(j + 1), __ATOMIC_RELAXED,
+                                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ? 1u : 0u;
         }
         __syncthreads();
         const bool mine = sflag[1] != 0u;
@@ -746,7 +775,7 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_step(const Z2* __restrict__
             for (int p0 = 0; p0 < NP; p0 += 12) {     // twelve panels in flight; added in panel order
                 pan_d2 y[12];
 #pragma unroll
-                for (int q = 0; q < 12; ++q) y[q] = pan_load_wt2(A.ypart + (size_t)min(p0 + q, NP - 1) * ys + r);
+                for (int q = 0; q < 12; ++q) y[q] = LOCAL ? pan_load_l2(A.ypart + (size_t)min(p0 + q, NP - 1) * ys + r) : pan_load_wt2(A.ypart + (size_t)min(p0 + q, NP - 1) * ys + r);
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]), "+v"(y[6]), "+v"(y[7]),
                              "+v"(y[8]), "+v"(y[9]), "+v"(y[10]), "+v"(y[11]) :: "memory");      // (ties the values to the wait)
 #pragma unroll

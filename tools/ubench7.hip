@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <vector>
 #include "../mac_amd/csrc/panel.h"
@@ -17,7 +18,8 @@ using namespace machip;
 static int FUSED = 1;
 template <int RPT>
 void step(PanView& P, PipeView& L, hipStream_t s, int j) {
-    if (FUSED) k_pan_step<RPT><<<P.NB * P.NP, kPanThreads, 0, s>>>(PAN_STEP_ARGS(P, L, j));
+    if (FUSED == 2) k_pan_step<RPT, true><<<8 * ((P.NB + 7) / 8) * P.NP, kPanThreads, 0, s>>>(PAN_STEP_ARGS(P, L, j));     // a row block's workgroups on one XCD
+    else if (FUSED) k_pan_step<RPT><<<P.NB * P.NP, kPanThreads, 0, s>>>(PAN_STEP_ARGS(P, L, j));
     else { k_pan_mul<RPT><<<P.NB * P.NP, kPanThreads, 0, s>>>(PAN_MUL_ARGS(P, L, j)); k_pan_fin<512><<<196, 512, 0, s>>>(PAN_FIN_ARGS(P, L, j)); }
 }
 template <int RPT>
@@ -36,13 +38,21 @@ void run(PanView P, PipeView L, hipStream_t s, long nnz, std::vector<double>& u0
     CK(hipEventRecord(e2, s)); CK(hipEventSynchronize(e2));
     float ms, ms2; CK(hipEventElapsedTime(&ms, e0, e1)); CK(hipEventElapsedTime(&ms2, e1, e2));
     CK(hipGetLastError());
-    std::vector<long long> c((size_t)g1 * 16);
-    CK(hipMemcpy(c.data(), P.clk, c.size() * 8, hipMemcpyDeviceToHost));
+    const int gl = FUSED == 2 ? 8 * ((P.NB + 7) / 8) * P.NP : g1;
+    {   // cross-variant check: the records after the last step, bit for bit
+        std::vector<Z2> z((size_t)P.n);
+        CK(hipMemcpy(z.data(), ((8 + steps) & 1) ? L.Z1 : L.Z0, (size_t)P.n * sizeof(Z2), hipMemcpyDeviceToHost));
+        unsigned long long h = 1469598103934665603ull;
+        for (int i = 0; i < P.n; ++i) { unsigned long long a, b2; memcpy(&a, &z[i].t, 8); memcpy(&b2, &z[i].v, 8); h = (h ^ a) * 1099511628211ull; h = (h ^ b2) * 1099511628211ull; }
+        printf("   records after %d steps: hash %016llx  z[12345] = {%.17g, %.17g}\n", 8 + steps, h, z[12345].t, z[12345].v);
+    }
+    std::vector<long long> c((size_t)kMaxGrid * 16);
+    CK(hipMemcpy(c.data(), P.clk, (size_t)gl * 16 * 8, hipMemcpyDeviceToHost));
     long long t0 = c[0];
-    for (int b = 0; b < g1; ++b) t0 = std::min(t0, c[(size_t)b * 16]);
+    for (int b = 0; b < gl; ++b) if (c[(size_t)b * 16]) t0 = std::min(t0, c[(size_t)b * 16]);
     auto stat = [&](int i, const char* what) {
         double mn = 1e30, mx = 0, av = 0;
-        for (int b = 0; b < g1; ++b) { const double v = (c[(size_t)b * 16 + i] - t0) * 0.01; mn = std::min(mn, v); mx = std::max(mx, v); av += v; }
+        for (int b = 0; b < gl; ++b) { if (!c[(size_t)b * 16]) continue; const double v = (c[(size_t)b * 16 + i] - t0) * 0.01; mn = std::min(mn, v); mx = std::max(mx, v); av += v; }
         printf("      %-52s min %6.2f  mean %6.2f  max %6.2f us\n", what, mn, av / g1, mx);
     };
     (void)ms2;
@@ -52,12 +62,17 @@ void run(PanView P, PipeView L, hipStream_t s, long nnz, std::vector<double>& u0
     stat(7, "tiles accumulated (wave 1)");
     if (FUSED) { stat(8, "partials stored and drained (wave 1)"); stat(9, "ticket / wait over"); stat(10, "slices finished (wave 1)"); stat(11, "last wave done"); }
     else { stat(8, "wave 1 done"); stat(9, "wave 15 done"); }
-    {   // who is late?  completion (slot 9) by XCD (blockIdx mod 8), by panel and by row block
+    if (FUSED != 2) {   // who is late?  completion (slot 9) by XCD (blockIdx mod 8), by panel and by row block
         double bx[8] = {0}, bp[64] = {0}, bb[256] = {0}; int nx[8] = {0}, np_[64] = {0}, nb_[256] = {0};
         for (int b = 0; b < g1; ++b) { const double v = (c[(size_t)b * 16 + (FUSED ? 11 : 9)] - t0) * 0.01; bx[b % 8] += v; nx[b % 8]++; bp[b % P.NP] += v; np_[b % P.NP]++; bb[b / P.NP] += v; nb_[b / P.NP]++; }
         printf("      done by XCD:  "); for (int i = 0; i < 8; ++i) printf(" %5.2f", bx[i] / std::max(1, nx[i])); printf("\n");
         printf("      done by panel:"); for (int i = 0; i < P.NP; ++i) printf(" %5.2f", bp[i] / std::max(1, np_[i])); printf("\n");
         printf("      done by block:"); for (int i = 0; i < P.NB; ++i) printf(" %5.2f", bb[i] / std::max(1, nb_[i])); printf("\n");
+    }
+    if (FUSED) {   // hardware XCC id of every workgroup: do the workgroups w = x (mod 8) share one?
+        int bad = 0; long long first[8];
+        for (int w = 0; w < gl; ++w) { const long long x = c[(size_t)w * 16 + 12]; if (w < 8) first[w] = x; else if (x != first[w & 7]) ++bad; }
+        printf("      XCC id of workgroups 0..7:"); for (int w = 0; w < 8; ++w) printf(" %lld", first[w]); printf("   workgroups off their residue class: %d of %d\n", bad, gl);
     }
     CK(hipFree(u0));
 }
@@ -100,7 +115,7 @@ int main(int argc, char** argv) {
         const size_t ecap = (size_t)nnz + (size_t)P.NB * P.NP * 64 * 128 + kPanSlack;
         CK(hipMalloc(&P.tptr, (NT + 1) * 4)); CK(hipMalloc(&P.tcount, NT * 4)); CK(hipMalloc(&P.thead, NT * 64 * 2));
         CK(hipMalloc(&P.bval, ecap * 8)); CK(hipMalloc(&P.bcol, ecap * 2)); CK(hipMalloc(&P.ypart, (size_t)P.NP * (n + 2) * 8)); CK(hipMalloc(&P.ps, (size_t)(P.NP + 1) * n * 4));
-        CK(hipMalloc(&P.tick, 4 * 256)); CK(hipMalloc(&P.claim, 4 * 4096)); P.spin_ticks = spin_us * 100;
+        CK(hipMalloc(&P.ovf, 4)); CK(hipMemset(P.ovf, 0, 4)); P.CELLS = 1; CK(hipMalloc(&P.tick, 4 * 256)); CK(hipMalloc(&P.claim, 4 * 4096)); P.spin_ticks = spin_us * 100;
         CK(hipMalloc(&P.coef, 64)); CK(hipMalloc(&P.clk, 16 * 8 * kMaxGrid)); CK(hipMemset(P.clk, 0, 16 * 8 * kMaxGrid));
         hipEvent_t a0, a1; CK(hipEventCreate(&a0)); CK(hipEventCreate(&a1));
         CK(hipEventRecord(a0, s));
