@@ -117,6 +117,7 @@ struct Solver {
     size_t wb_Zt_cap = 0, wb_pas_cap = 0;
     double *wb_pas = nullptr, *wb_maps = nullptr;   // batched multi-workgroup column solves (n > 16 384)
     double* wb_Cm2 = nullptr;    // second buffer of the blocked Gauss-Jordan inversion (ping-pong)
+    double* wb_piv = nullptr;    // 2 x (32 x 32): look-ahead inverse of the next pivot block (k_gj_step)
     WbView wb_active{};          // s > 0 while the running solve uses it
     double *lx_part = nullptr, *lx_partR = nullptr;
     int *lx_colT = nullptr, *lx_bad = nullptr;
@@ -136,6 +137,12 @@ struct Solver {
     long chain_edges = 0;       // how many of them
     long support_hint = -1;     // active candidate edges of the matrix about to be solved (-1 = unknown)
     long hist_lan_steps = -1, hist_lob_iters = -1;   // steps / iterations of the last solve in each mode
+    long hist_exact_iters = -1;                       // ... of the last solve the exact chain + closures preconditioner served
+    // Lanczos -> exact hand-over (solve(): chain-like graphs beyond the single-workgroup sizes with at most wb_soft() closures): the
+    // Lanczos loop gives up when its own forecast of the remaining steps costs more than 1.3x the exact mode's estimate, twice in a row
+    static constexpr int kSwitchToExact = 1000;       // internal status of solve_lanczos, never leaves solve()
+    double switch_est_us = 0.0;                       // > 0: the hand-over is allowed, the exact mode's estimated cost
+    double switch_to_go = 0.0;                        // forecast at the hand-over (history for the next solve)
     static constexpr int kLobCap = 100000;
     // column-panel step (panel.h): the panel form of the matrix being solved, rebuilt per solve from its CSR
     bool seq_sharded = false;      // the running Krylov sequence is row-partitioned (its basis is spread over the ranks)
@@ -196,7 +203,7 @@ struct Solver {
         void* ptrs[] = {u, V, tri, part, Z0, Z1, st, st2, y_raw, w2, yvec, ypart, sdev,
                         part_c, part_a2, part_r, scratch3, rq_dev, start, wc, ctri, part_u, part_a, stc,
                         lx_x, lx_Lx, lx_p, lx_Lp, lx_Lw, lx_rT, lx_wT, lx_tl, lx_tdinv, lx_tcu, lx_part, lx_partR,
-                        lx_ys, lx_pas, lx_as, lx_bs, lx_maps, lx_ba, lx_bd, lx_bu, wb_ui, wb_uj, wb_counts, wb_uc, wb_g, wb_h, wb_Zt, wb_Cm, wb_Cm2, wb_pas, wb_maps,
+                        lx_ys, lx_pas, lx_as, lx_bs, lx_maps, lx_ba, lx_bd, lx_bu, wb_ui, wb_uj, wb_counts, wb_uc, wb_g, wb_h, wb_Zt, wb_Cm, wb_Cm2, wb_piv, wb_pas, wb_maps,
                         lx_colT, lx_bad, lx_st, valf};
         {
             void* pb[] = {panv.tptr, panv.thead, panv.bval, panv.bcol, panv.ypart, panv.coef, panv.tcount, panv.ps, panv.tick, panv.claim, panv.ovf};
@@ -838,8 +845,14 @@ struct Solver {
         HIP_TRY(hipMemsetAsync(info, 0, sizeof(int), stream));
         const int tiles = W.ld / kGjT;
         double *src = wb_Cm, *dst = wb_Cm2;
-        for (int kb = 0; kb < W.ld; kb += kGjB) {
-            k_gj_step<0><<<dim3(tiles, tiles), 256, 0, stream>>>(src, dst, W.ld, kb, info);
+        // (from MACHIP_GJ_LOOK_MIN = 1 024 rows on, look-ahead: the workgroup holding the next pivot block inverts it for the next launch;
+        // below that all tiles run in one round of workgroups and the redundant inversion is off nobody's critical path)
+        const bool look = W.ld >= env_int("MACHIP_GJ_LOOK_MIN", 1024);
+        if (look && !wb_piv) ST_TRY(dev_alloc(&wb_piv, (size_t)2 * kGjB * kGjB));
+        for (int kb = 0, k = 0; kb < W.ld; kb += kGjB, ++k) {
+            if (look) k_gj_step<0><<<dim3(tiles, tiles), 256, 0, stream>>>(src, dst, W.ld, kb, info, k ? wb_piv + (size_t)(k & 1) * kGjB * kGjB : nullptr,
+                                                                        wb_piv + (size_t)((k + 1) & 1) * kGjB * kGjB);
+            else k_gj_step<0><<<dim3(tiles, tiles), 256, 0, stream>>>(src, dst, W.ld, kb, info);
             std::swap(src, dst);
         }
         HIP_TRY(hipGetLastError());
@@ -1076,13 +1089,51 @@ struct Solver {
         const bool exact_small = small && !throughput_lane && precision == 0 && support_hint >= 0 && support_hint <= env_int("MACHIP_LOB_SMALL_S", 700) &&
                                  support_hint <= wb_soft() && env_int("MACHIP_WOODBURY", 1) != 0 &&
                                  (hist_lan_steps <= 0 || cost_lob < 0.4 * (double)hist_lan_steps);
+        // Beyond the single-workgroup sizes (n <= 16 384: the one-workgroup tridiagonal kernels the figures below were measured with)
+        // the same choice needs a Lanczos history: with the look-ahead inverse (woodbury.h: 1.7 ms at 2 137 closures) the exact mode
+        // solves city10000's second iterate (2 137 closures, lambda_2 = 0.0012) in 2.5 ms where 3 488 Lanczos steps take 14.3 ms.
+        // Cost model in us, from counts only: set-up 120 + 4e-6 n s + 1.1e-5 s^2 (column solves, capacitance), inverse
+        // (ld / 32) x (13 + 3.5e-6 ld^2), per iteration 45 + 1.2e-6 n s + 2.5e-6 s^2 (n x s and s x s products); a Lanczos step
+        // 4.2 + 2e-6 nnz (tools/city_exact_probe.py, tools/ubench_gj.hip; profiles/r4_exact_big.md).
+        bool exact_big = false;
+        if (!small && n <= kTriMaxN && !throughput_lane && precision == 0 && support_hint > 0 && support_hint <= wb_soft() && hist_lan_steps > 0 &&
+            env_int("MACHIP_WOODBURY", 1) != 0 && env_int("MACHIP_EXACT_BIG", 1) != 0) {
+            const double sd = (double)support_hint, nd = (double)n, ldw = (double)((support_hint + kGjT - 1) / kGjT * kGjT);
+            const double its = hist_exact_iters > 0 ? (double)hist_exact_iters : 14.0;
+            const double est_exact = 120.0 + 4e-6 * nd * sd + 1.1e-5 * sd * sd + (ldw / kGjB) * (13.0 + 3.5e-6 * ldw * ldw) +
+                                     its * (45.0 + 1.2e-6 * nd * sd + 2.5e-6 * sd * sd);
+            exact_big = est_exact < 0.8 * (double)hist_lan_steps * (4.2 + 2e-6 * (double)nnz);
+        }
         const bool want = chain_dominated &&
-                          (mode == 2 || (mode == 0 && chain_like && support_hint >= 0 && ((sparse && !slow_lob) || stiff || exact_small)));
+                          (mode == 2 || (mode == 0 && chain_like && support_hint >= 0 && ((sparse && !slow_lob) || stiff || exact_small || exact_big)));
         last_was_lob = false;
         final_check_seq = -2;
         const bool want_jac = mode == 3 && n > 256;
-        if ((eligible && want) || want_jac) {
-            HIP_TRY(hipEventRecord(ev0, stream));
+        // No history (or one that spoke for Lanczos): start with Lanczos, but let it hand over to the exact mode once ITS OWN forecast
+        // says the rest of the solve costs more than that (city10000's first iterate: forecast > 1 000 steps from step 128 on -> 0.7 ms
+        // of Lanczos + 3.0 ms exact instead of 7.3 ms).  Forecasts come from device results that are bit-reproducible: so is the choice.
+        bool after_switch = false;
+        long pre_steps = 0;
+        if (!((eligible && want) || want_jac) && mode == 0 && eligible && chain_dominated && chain_like && !small && n <= kTriMaxN && !throughput_lane &&
+            precision == 0 && forced_variant == 0 && support_hint > 0 && support_hint <= wb_soft() &&      // (sharded / inter-process solves too: every rank
+            // holds the same tridiagonal records, takes the same decision at the same step, and runs the exact mode replicated)
+            env_int("MACHIP_WOODBURY", 1) != 0 && env_int("MACHIP_EXACT_BIG", 1) != 0 && env_int("MACHIP_EXACT_SWITCH", 1) != 0) {
+            const double sd = (double)support_hint, nd = (double)n, ldw = (double)((support_hint + kGjT - 1) / kGjT * kGjT);
+            const double its = hist_exact_iters > 0 ? (double)hist_exact_iters : 14.0;
+            switch_est_us = 120.0 + 4e-6 * nd * sd + 1.1e-5 * sd * sd + (ldw / kGjB) * (13.0 + 3.5e-6 * ldw * ldw) +
+                            its * (45.0 + 1.2e-6 * nd * sd + 2.5e-6 * sd * sd);
+            const int st = solve_lanczos(A, nnz, lnorm, tol, max_steps, start_mode, forced_variant, lambda2, stats);
+            switch_est_us = 0.0;
+            if (st != kSwitchToExact) {
+                if (st == MACHIP_OK) hist_lan_steps = last_steps - (long)(0.35 * (double)last_steps_lowp);
+                return st;
+            }
+            after_switch = true;
+            pre_steps = last_steps;
+            hist_lan_steps = last_steps + (long)std::min(switch_to_go, 1e6);     // (what the solve would have taken, by its own forecast)
+        }
+        if ((eligible && want) || want_jac || after_switch) {
+            if (!after_switch) HIP_TRY(hipEventRecord(ev0, stream));      // (after a hand-over ev0 still marks the start of the Lanczos part)
             double lam = 0.0, res = 0.0;
             long iters = 0, spmvs = 0, rst = 0;
             // (evaluation lanes run many solves side by side: the exact mode's chip-wide kernels -- s column solves, the s x s inverse,
@@ -1103,11 +1154,12 @@ struct Solver {
                 HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
                 have_prev = true; last_was_lob = true; last_steps = iters; J_last = 0;
                 hist_lob_iters = iters;
+                if (wb_active.s > 0) hist_exact_iters = iters;
                 *lambda2 = lam;
                 if (stats) {
-                    stats->lanczos_steps = iters; stats->spmv_total = spmvs; stats->vec_passes = iters * 16;
+                    stats->lanczos_steps = iters + pre_steps; stats->spmv_total = spmvs + pre_steps; stats->vec_passes = iters * 16 + pre_steps * 7;
                     stats->restarts = rst; stats->nnz = nnz; stats->residual = res; stats->lnorm = lnorm; stats->gpu_ms = ms;
-                    stats->step_ms = ms; stats->steps_timed = iters; stats->steps_lowp = 0;
+                    stats->step_ms = ms; stats->steps_timed = iters + pre_steps; stats->steps_lowp = 0;
                 }
                 if (lam < 1e-12 * (lnorm > 0 ? lnorm : 1.0))
                     return fail(MACHIP_DISCONNECTED, "lambda_2 ~ 0: the graph is not connected");
@@ -1137,6 +1189,7 @@ struct Solver {
         double step_ms_acc = 0.0;   // stream time of the Krylov chunks alone (step kernels + one tail kernel per chunk)
         long steps_timed_acc = 0;
         int status = MACHIP_NOT_CONVERGED;
+        bool switch_out = false;           // handed over to the exact mode (solve(): switch_est_us)
         double lam = 0.0, res = 0.0;
         const double tiny_l = (lnorm > 0 ? lnorm : 1.0);
         if (n < 2) { *lambda2 = 0.0; return fail(MACHIP_BAD_ARG, "graph with a single node has no Fiedler pair"); }
@@ -1287,6 +1340,7 @@ struct Solver {
             // thousands of steps within 1e3 of the target; random graphs a few dozen)
             std::deque<std::pair<int, double>> hist;
             double to_go = 1e18;
+            int switch_votes = 0;
             const bool sched = env_int("MACHIP_SCHED", 1) != 0;
             const double ltarget = std::log(std::max(seq_tol * tiny_l, 1e-300));
             const int jcap = (int)std::min<size_t>(vcap - 2, (size_t)std::max(2, n - 1) + 8) & ~1;
@@ -1428,6 +1482,13 @@ struct Solver {
                 }
                 const bool at_cap = (J >= jcap) || (steps_total >= max_steps && pend.empty());
                 const bool trig = broke || est < trigger_slack * seq_tol * lnorm;
+                if (switch_est_us > 0.0 && restarts == 0 && !f32_seq && cheb.deg == 0 && !broke && !trig && !at_cap && J >= 128 && to_go < 1e17 &&
+                    to_go * (4.2 + 2e-6 * (double)nnz) > 1.3 * switch_est_us) {
+                    if (++switch_votes >= 2) {
+                        if (debug) fprintf(stderr, "[machip]    J=%d: forecast %.0f steps to go -- handing over to the exact chain + closures mode (estimate %.0f us)\n", J, to_go, switch_est_us);
+                        switch_to_go = to_go; switch_out = true; break;
+                    }
+                } else switch_votes = 0;
 
                 if (debug) fprintf(stderr, "[machip] %s J=%d Jeff=%d theta=%.15g est=%.3e to_go=%.0f broke=%d pend=%zu passes=%d\n", pmode ? "persist" : (classic ? "classic" : "pipe"), J, Jeff, sm.theta, lnorm > 0 ? est / lnorm : est, std::min(to_go, 1e9), (int)broke, pend.size(), sm.passes);
                 bool handover = false;
@@ -1474,6 +1535,7 @@ struct Solver {
             pend.clear();
             last_seq_f32 = f32_seq;
             last_seq_sharded = seq_sharded;
+            if (switch_out) break;
             if (converged) { done = true; break; }
             if (steps_total >= max_steps) break;
             // restart from the best Ritz vector found so far (it sits normalised in yvec)
@@ -1489,6 +1551,10 @@ struct Solver {
             ++restarts;
             classic = true;   // refine with the accurate form (see enqueue_classic)
             if (restarts > 64) break;
+        }
+        if (switch_out) {        // (no Ritz vector was formed: have_prev keeps its value; the caller continues with the exact mode)
+            last_steps = steps_total; last_steps_lowp = steps_lowp;
+            return kSwitchToExact;
         }
         have_prev = true;
         last_steps = steps_total;

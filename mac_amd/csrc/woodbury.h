@@ -17,7 +17,7 @@
 
 namespace machip {
 
-constexpr int kWbMaxS = 2048;     // closures beyond this: the dense factorisation (7 ms at 2 048) costs more than it saves
+constexpr int kWbMaxS = 3072;     // closures beyond this: the dense inverse (1.7 ms at 2 137, 4.5 ms at 3 072, 9.2 ms at 4 096) costs more than it saves
 
 struct WbView {
     int s;                 // active closures (upper off-band entries of L)
@@ -139,14 +139,79 @@ constexpr int kGjB = 32;
 constexpr int kGjT = 64;
 typedef double gj_d4 __attribute__((ext_vector_type(4)));
 
+// P = A_KK^-1 by ONE wave: scalar Gauss-Jordan, the 32 x 32 block in registers (lane (br, bc) keeps the 4 x 4 sub-block (4 br.., 4 bc..)).
+// Per pivot p only row p and column p travel: their owners park them in LDS (rowp[32], colp[32]), every lane reads the 4 + 4 entries
+// its sub-block needs (a wave's LDS traffic is ordered: no barrier), 16 multiply-adds per lane.  (First build: all 256 threads on an LDS
+// copy, one barrier per pivot -- 0.53 us per pivot, 17 of the kernel's 28 us.)  Returns 1 on a non-positive pivot.
+__device__ __forceinline__ int gj_invert_block(double (&m)[4][4], double* rowp, double* colp, int br, int bc) {
+    int bad = 0;
+    for (int pb = 0; pb < kGjB / 4; ++pb) {
+#pragma unroll
+        for (int pj = 0; pj < 4; ++pj) {
+            const int p = 4 * pb + pj;
+            if (br == pb) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rowp[4 * bc + j] = m[pj][j];
+            }
+            if (bc == pb) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) colp[4 * br + i] = m[i][pj];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const double piv = rowp[p];
+            double rp[4], cp[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rp[j] = rowp[4 * bc + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cp[i] = colp[4 * br + i];
+            if (!(piv > 0.0) || !(piv < 1e300)) bad = 1;
+            double ip = __builtin_amdgcn_rcp(piv);     // hardware reciprocal + two Newton steps (no IEEE division on the chain)
+            ip = ip * __builtin_fma(-piv, ip, 2.0);
+            ip = ip * __builtin_fma(-piv, ip, 2.0);
+            // generic update for all 16 entries, then the pivot row / column / element by their owners (pj is a compile-time
+            // index: static registers, lane predicates only -- the per-entry compare-and-select form was 40 % more instructions)
+            double sc[4], nc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sc[j] = rp[j] * ip;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) nc[i] = -cp[i] * ip;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m[i][j] = __builtin_fma(-cp[i], sc[j], m[i][j]);
+            if (bc == pb) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) m[i][pj] = nc[i];
+            }
+            if (br == pb) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m[pj][j] = sc[j];
+                if (bc == pb) m[pj][pj] = ip;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();          // (everybody has read row / column p before the next pivot's owners overwrite them)
+        }
+    }
+    return bad;
+}
+
 template <int VAR = 0>     // (VAR != 0: timing builds of tools/ubench_gj.hip -- 1: no pivot-block inversion, 2: nor the products)
-__global__ __launch_bounds__(256) void k_gj_step(const double* __restrict__ src, double* __restrict__ dst, int ld, int kb, int* bad) {
+__global__ __launch_bounds__(256) void k_gj_step(const double* __restrict__ src, double* __restrict__ dst, int ld, int kb, int* bad,
+                                                 const double* __restrict__ pin = nullptr, double* __restrict__ pout = nullptr) {
     __shared__ double sP[2][kGjB][kGjB + 1];
     __shared__ double sA[kGjT][kGjB + 1];      // A_iK: rows of the tile x pivot columns
     __shared__ double sT[kGjT][kGjB + 1];      // -(A_iK P); rows inside the pivot block: P
     __shared__ double sB[kGjB][kGjT + 1];      // A_Kj: pivot rows x columns of the tile; columns inside the pivot block: identity
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int r0 = blockIdx.y * kGjT, c0 = blockIdx.x * kGjT;
+    // Look-ahead (large matrices, solver.h): with `pin` the inverse of THIS step's pivot block comes from the previous launch -- the
+    // workgroup whose tile holds the NEXT pivot block inverts it once its tile is updated and leaves it in `pout` --, so only one
+    // workgroup per step runs the ~7 us scalar inversion instead of all of them in front of their products (1 156 workgroups at
+    // s = 2 137: 40 -> ~20 us per step).  That workgroup is dispatched first: the tile grid is rotated so that (0, 0) is its tile.
+    const int tiles = gridDim.x, tnext = pout ? min((kb + kGjB) / kGjT, tiles - 1) : 0;
+    const int ty = (blockIdx.y + tnext) % tiles, tx = (blockIdx.x + tnext) % tiles;
+    const int r0 = ty * kGjT, c0 = tx * kGjT;
     const int li = lane & 15, lk = lane >> 4;
     // wave 0 inverts the pivot block (below); waves 1-3 stage A_iK and A_Kj in LDS meanwhile
     const int br = lane >> 3, bc = lane & 7;         // wave 0: lane (br, bc) keeps the 4 x 4 sub-block (4 br.., 4 bc..) of A_KK in registers
@@ -155,7 +220,7 @@ __global__ __launch_bounds__(256) void k_gj_step(const double* __restrict__ src,
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) m[i][j] = src[(size_t)(kb + 4 * br + i) * ld + kb + 4 * bc + j];
+            for (int j = 0; j < 4; ++j) m[i][j] = pin ? pin[(4 * br + i) * kGjB + 4 * bc + j] : src[(size_t)(kb + 4 * br + i) * ld + kb + 4 * bc + j];
     } else {
         // all 22 loads of a thread in flight at once (unconditional, clamped index; a loop with a run-time trip count is
         // compiled into one load -> wait -> LDS store round trip per element: 11 dependent cold misses, 7 of the first
@@ -197,70 +262,15 @@ __global__ __launch_bounds__(256) void k_gj_step(const double* __restrict__ src,
     // their owners park them in LDS, every lane reads the 4 + 4 entries its sub-block needs (a wave's LDS traffic is ordered:
     // no barrier), 16 multiply-adds per lane. ----
     int isbad = 0;
-    if (wv == 0 && !VAR) {
-        double* rowp = &sP[1][0][0];                   // [32] row p, then [32] column p (scratch: sP[1] is otherwise unused)
-        double* colp = rowp + kGjB;
-        for (int pb = 0; pb < kGjB / 4; ++pb) {
-#pragma unroll
-            for (int pj = 0; pj < 4; ++pj) {
-                const int p = 4 * pb + pj;
-                if (br == pb) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) rowp[4 * bc + j] = m[pj][j];
-                }
-                if (bc == pb) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) colp[4 * br + i] = m[i][pj];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const double piv = rowp[p];
-                double rp[4], cp[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) rp[j] = rowp[4 * bc + j];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) cp[i] = colp[4 * br + i];
-                if (!(piv > 0.0) || !(piv < 1e300)) isbad = 1;
-                double ip = __builtin_amdgcn_rcp(piv);     // hardware reciprocal + two Newton steps (no IEEE division on the chain)
-                ip = ip * __builtin_fma(-piv, ip, 2.0);
-                ip = ip * __builtin_fma(-piv, ip, 2.0);
-                // generic update for all 16 entries, then the pivot row / column / element by their owners (pj is a compile-time
-                // index: static registers, lane predicates only -- the per-entry compare-and-select form was 40 % more instructions)
-                double sc[4], nc[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) sc[j] = rp[j] * ip;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) nc[i] = -cp[i] * ip;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) m[i][j] = __builtin_fma(-cp[i], sc[j], m[i][j]);
-                if (bc == pb) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) m[i][pj] = nc[i];
-                }
-                if (br == pb) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) m[pj][j] = sc[j];
-                    if (bc == pb) m[pj][pj] = ip;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();          // (everybody has read row / column p before the next pivot's owners overwrite them)
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) sP[0][4 * br + i][4 * bc + j] = m[i][j];
-    } else if (wv == 0) {
+    if (wv == 0 && !VAR && !pin) isbad = gj_invert_block(m, &sP[1][0][0], &sP[1][0][0] + kGjB, br, bc);     // (scratch: sP[1] is otherwise unused)
+    if (wv == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) sP[0][4 * br + i][4 * bc + j] = m[i][j];
     }
     __syncthreads();
-    if (isbad && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) *bad = 1;
+    if (isbad && tid == 0) *bad = 1;          // (every workgroup that inverted the block saw the same pivots)
     // ---- sT = -(A_iK P): wave w owns rows 16 w .. 16 w + 15, both 16-column halves ----
     if (VAR < 2) {
         gj_d4 t[2];
@@ -304,6 +314,33 @@ __global__ __launch_bounds__(256) void k_gj_step(const double* __restrict__ src,
                 const int row = r0 + 32 * wr + 16 * bi + lk + 4 * q, col = c0 + 32 * wc + 16 * bj + li;
                 dst[(size_t)row * ld + col] = acc[bi][bj][q];
             }
+    // ---- look-ahead: the next pivot block sits in this tile (quadrant (o, o)): its owner wave parks it in LDS, wave 0 inverts it ----
+    const int kn = kb + kGjB;
+    if (pout && kn < ld && r0 == (kn / kGjT) * kGjT && c0 == r0) {       // (uniform per workgroup)
+        const int o = kn - r0;                       // 0 or 32
+        double (*stage)[kGjB + 1] = sA;              // (A_iK is consumed: the products are done -- barrier below orders the reuse)
+        __syncthreads();
+        if (wr == o / 32 && wc == o / 32) {
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) stage[16 * bi + lk + 4 * q][16 * bj + li] = acc[bi][bj][q];
+        }
+        __syncthreads();
+        if (wv == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m[i][j] = stage[4 * br + i][4 * bc + j];
+            if (gj_invert_block(m, &sP[1][0][0], &sP[1][0][0] + kGjB, br, bc) && lane == 0) *bad = 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pout[(4 * br + i) * kGjB + 4 * bc + j] = m[i][j];
+        }
+    }
 }
 
 // ---- update + tridiagonal solve + g in ONE single-workgroup launch (round 4; n <= 16 384) ------------------------------------

@@ -245,22 +245,67 @@ def test_preconditioned_mode_fallbacks_and_errors():
     P.close()
 
 
+def test_lanczos_hands_over_to_the_exact_mode_on_its_own_forecast():
+    """Chain of 9 000 nodes + 1 800 short closures (20 % of n: denser than the static rule for the preconditioned mode admits, no history
+    on a fresh handle): the automatic mode starts with Lanczos, whose convergence forecast says thousands of steps to go, and hands
+    over to the exact chain + closures mode (solver.h, switch_est_us) -- far fewer steps than the forced Lanczos solve, the same
+    lambda_2 (1e-8) and vector, SciPy's shift-invert value; a second solve starts in the exact mode.  A warm start from the converged
+    vector stays with Lanczos (its forecast is short)."""
+    import scipy.sparse.linalg as spla
+    n, s_ = 9000, 1800
+    rng = np.random.default_rng(21)
+    fi = np.arange(n - 1, dtype=np.int32)
+    ci = rng.choice(n - 60, s_, replace=False).astype(np.int32); cj = (ci + rng.integers(2, 50, s_)).astype(np.int32)
+    P = _lib.Problem(n, fi, fi + 1, np.full(n - 1, 40.0), ci, cj, np.full(s_, 15.0))
+    P.set_start(reference_start_block(n)[:, 0].copy())
+    P.set_x(np.ones(s_))
+    P.set_solver(1); lam_l, v_l, _ = P.fiedler(); st_l = int(P.stats.lanczos_steps)
+    P.close()
+    P = _lib.Problem(n, fi, fi + 1, np.full(n - 1, 40.0), ci, cj, np.full(s_, 15.0))
+    P.set_start(reference_start_block(n)[:, 0].copy())
+    P.set_x(np.ones(s_))
+    P.set_solver(0)
+    lam_a, v_a, _ = P.fiedler(); st_a = int(P.stats.lanczos_steps)
+    lam_b, v_b, _ = P.fiedler(); st_b = int(P.stats.lanczos_steps)
+    assert st_l > 2000 and 128 < st_a < st_l // 3 and st_b <= 40, (st_l, st_a, st_b)
+    assert abs(lam_a - lam_l) <= LAM_RTOL * lam_l and abs(lam_b - lam_l) <= LAM_RTOL * lam_l and P.stats.residual < 1e-8
+    assert np.abs(sign_align(v_a, v_l) - v_l).max() < 1e-5
+    ip, ix, da = P.laplacian_csr()
+    L = sp.csr_matrix((da, ix, ip), shape=(n, n))
+    w = spla.eigsh(L + 1e-9 * sp.identity(n), k=2, sigma=0, which="LM", return_eigenvectors=False)
+    assert abs(np.sort(w)[1] - 1e-9 - lam_a) <= 1e-7 * lam_a
+    P.close()
+
+
 def test_auto_mode_learns_a_stiff_problem_from_step_counts():
-    """city10000 with the first 20 % of the closures selected is stiff (~10^4 Lanczos steps) although its
-    closure density is above the static threshold: the automatic mode sees that from the first solve's step
-    count and runs the preconditioned mode from then on (deterministic: counts, not timings)."""
+    """city10000 with the first 20 % of the closures selected is stiff (~10^4 Lanczos steps) although its closure density is above
+    the static threshold.  (a) Round-3 rule (MACHIP_EXACT_BIG=0): the automatic mode sees that from the first solve's step count and
+    runs the preconditioned mode from then on.  (b) Round 4: the first solve itself hands over -- the Lanczos loop's own forecast of
+    the steps to go exceeds the exact chain + closures mode's estimated cost (2 137 closures) twice in a row --, later solves start
+    in the exact mode.  Deterministic either way: counts and bit-reproducible forecasts, never timings."""
     g = load_golden("g2o_city10000")
-    P = problem_of(g)
     m = len(g["cw"])
     x = np.zeros(m); x[: m // 5] = 1.0
-    P.set_x(x)
-    P.set_solver(0)
-    lam1, _, _ = P.fiedler(); s1 = int(P.stats.lanczos_steps)
-    lam2, _, _ = P.fiedler(); s2 = int(P.stats.lanczos_steps)
-    lam3, _, _ = P.fiedler(); s3 = int(P.stats.lanczos_steps)
-    assert s1 > 2500 and s2 * 6 < s1 and s3 == s2
-    assert abs(lam1 - lam2) <= LAM_RTOL * lam1 and lam2 == lam3
-    P.close()
+    lams = []
+    for big in ("0", "1"):
+        os.environ["MACHIP_EXACT_BIG"] = big
+        try:
+            P = problem_of(g)
+            P.set_x(x)
+            P.set_solver(0)
+            lam1, _, _ = P.fiedler(); s1 = int(P.stats.lanczos_steps)
+            lam2, _, _ = P.fiedler(); s2 = int(P.stats.lanczos_steps)
+            lam3, _, _ = P.fiedler(); s3 = int(P.stats.lanczos_steps)
+            P.close()
+        finally:
+            os.environ.pop("MACHIP_EXACT_BIG", None)
+        if big == "0":
+            assert s1 > 2500 and s2 * 6 < s1 and s3 == s2, (s1, s2, s3)
+        else:
+            assert 128 < s1 < 1500 and s2 <= 40 and s3 == s2, (s1, s2, s3)      # (Lanczos steps before the hand-over + exact iterations)
+        assert abs(lam1 - lam2) <= LAM_RTOL * lam1 and lam2 == lam3
+        lams.append(lam1)
+    assert abs(lams[0] - lams[1]) <= LAM_RTOL * lams[0]
 
 
 @pytest.mark.parametrize("seed", range(8))

@@ -28,7 +28,7 @@ static float time_var(double* d0, double* d1, int ld, int* bad, hipStream_t st) 
 }
 int main() {
     hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    for (int s : {43, 157, 400, 645, 800, 1600, 2400, 4096}) {
+    for (int s : {43, 157, 400, 645, 800, 1100, 1600, 2137, 2400, 4096}) {
         const int ld = (s + kGjT - 1) / kGjT * kGjT;
         std::mt19937_64 rng(s);
         std::uniform_real_distribution<double> U(-1.0, 1.0), E(-2.0, 6.0);
@@ -89,6 +89,28 @@ int main() {
                 if (memcmp(again.data(), Ci.data(), sizeof(double) * ld * ld)) ++diff;
             }
             printf("          40 repeats: %d differ from the first run bit for bit\n", diff);
+        }
+        {   // look-ahead form (the workgroup holding the next pivot block inverts it for the next launch): same bits? time?
+            double* piv; CK(hipMalloc(&piv, sizeof(double) * 2 * kGjB * kGjB));
+            std::vector<double> again((size_t)ld * ld);
+            float lbest = 1e9f; int diff = 0;
+            for (int rep = 0; rep < 6; ++rep) {
+                CK(hipMemcpy(d0, C.data(), sizeof(double) * ld * ld, hipMemcpyHostToDevice));
+                CK(hipEventRecord(e0, st));
+                double *src = d0, *dst = d1;
+                for (int kb = 0, k = 0; kb < ld; kb += kGjB, ++k) {
+                    k_gj_step<0><<<dim3(ld / kGjT, ld / kGjT), 256, 0, st>>>(src, dst, ld, kb, bad, k ? piv + (size_t)(k & 1) * kGjB * kGjB : nullptr, piv + (size_t)((k + 1) & 1) * kGjB * kGjB);
+                    std::swap(src, dst);
+                }
+                CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep) lbest = std::min(lbest, ms);
+                CK(hipMemcpy(again.data(), src, sizeof(double) * ld * ld, hipMemcpyDeviceToHost));
+                if (memcmp(again.data(), Ci.data(), sizeof(double) * ld * ld)) ++diff;
+            }
+            CK(hipGetLastError());
+            printf("          look-ahead pivot inversion: inverse %8.3f ms (%.2f us per launch), %d of 6 runs differ from the plain form bit for bit\n", lbest, 1e3 * lbest / (ld / kGjB), diff);
+            CK(hipFree(piv));
         }
         printf("          per launch: full %.2f us | without the pivot-block inversion %.2f us | loads + stores only %.2f us\n", 1e3 * best / (ld / kGjB),
                1e3 * time_var<1>(d0, d1, ld, bad, st) / (ld / kGjB), 1e3 * time_var<2>(d0, d1, ld, bad, st) / (ld / kGjB));
