@@ -265,6 +265,7 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul(const Z2* __restrict__ 
         __syncthreads();
         __syncthreads();
         __syncthreads();
+        if (RAW) { __syncthreads(); __syncthreads(); }      // (the workers' reduction of w^T L w)
         return;
     }
     const int wt = tid - 64, ww = wv - 1;        // worker thread / worker wave
@@ -362,9 +363,29 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul(const Z2* __restrict__ 
     PAN_CLK(tid == 64, 7);
     __syncthreads();
     // the row block's sums, un-sorted by the LDS image: coalesced stores
+    double wdot = 0.0;
     for (int rl = wt; rl < R; rl += kPanWorkThreads) {
         const int row = b * R + rl;
-        if (row < A.n) A.ypart[(size_t)p * A.n + row] = yblk[rl];
+        if (row < A.n) {
+            A.ypart[(size_t)p * A.n + row] = yblk[rl];
+            if (RAW) wdot = __builtin_fma(reinterpret_cast<const double*>(z_cur)[row], yblk[rl], wdot);
+        }
+    }
+    if (RAW) {
+        // w^T (L w) of this (row block, panel) cell -- the ONE inner product of the preconditioned iteration that needs the new
+        // product (precond.h, k_lob_update_pan: every other sum comes from the previous update by the symmetry of L); slot
+        // blockIdx of l_part, summed in slot order by that kernel's prologue.  Fixed order: worker waves 1..15.
+        wdot = wave_total(wdot);
+        if (lane == 0 && ww < 8) scoef[ww] = wdot;     // (scoef is idle in the RAW instantiation; 15 waves -> two rounds of 8 slots)
+        __syncthreads();
+        if (lane == 0 && ww >= 8) scoef[ww - 8] += wdot;
+        __syncthreads();
+        if (tid == 64) {
+            double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a += scoef[k];
+            l_part[blockIdx.x] = a;
+        }
     }
     PAN_CLK(tid == 64, 8); PAN_CLK(tid == 1023, 9);
 }

@@ -682,6 +682,125 @@ __global__ __launch_bounds__(kBlock) void k_lob_update(LobView L, int jrel) {
     if (threadIdx.x == 0) L.partR[(size_t)(itn & 1) * kMaxGrid + blockIdx.x] = l1;
 }
 
+// ---- column-panel product, TWO launches per iteration (round 4, late) ---------------------------------------------------------
+// k_pan_mul<RPT, RAW> leaves the partial products per (row, panel) and w^T L w per cell; this kernel is k_pan_find + k_lob_update<JAC>
+// in one: prologue (15 sums -> Rayleigh-Ritz), then per row  Lw = sum of the partials in panel order,  the update of x / p / Lx / Lp,
+// the residual, w' = r / diag -- and the sums of the NEXT iteration from the values just stored: by the symmetry of L
+//     x'^T L w' = w'^T (L x'),   p'^T L w' = w'^T (L p'),
+// so only w'^T L w' has to wait for the next product (it comes with it).  The sums are double-buffered by the parity of the iterate
+// (a fast workgroup writes the next sums while a slow one still reads the current ones).  Same Rayleigh-Ritz, same update arithmetic
+// as k_lob_update<true>; the inner products differ from k_pan_find's by roundings (other association), not by definition.
+//   sums: 0 xx 1 xw 2 xp 3 ww 4 wp 5 pp | 6 xLx 7 xLw 8 xLp 9 wLw 10 wLp 11 pLp | 12 Sx 13 Sw 14 Sp
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_lob_update_pan(LobView L, const double* __restrict__ ypart, int NP, const double* __restrict__ partW, int P_w, int jrel, int par) {
+    __shared__ double sc[8];
+    __shared__ double red[BLOCK / 64][kLobNS + 1];
+    // par = parity of the iterate this launch produces (itn = it0 + jrel + 1; the host knows it0's parity when it enqueues the chunk:
+    // the partial sums can be requested without waiting for the state word)
+    const int P_u = (int)gridDim.x;
+    const double* __restrict__ pin = L.part + (size_t)(par ^ 1) * (kLobNS * kMaxGrid);
+    double* __restrict__ pout = L.part + (size_t)par * (kLobNS * kMaxGrid);
+    const int n = L.n;
+    // The first row of every thread is requested BEFORE the prologue's barrier (the grid is sized for one or two rows per thread): the
+    // partial products and the six vectors travel while wave 0 reduces the sums and runs the Rayleigh-Ritz step.
+    constexpr int PB = 16;
+    const int r0 = blockIdx.x * BLOCK + threadIdx.x, rc = min(r0, n - 1);
+    double y0[PB];
+#pragma unroll
+    for (int q = 0; q < PB; ++q) y0[q] = ypart[(size_t)min(q, NP - 1) * n + rc];
+    double f_w = L.wT[rc], f_p = L.p[rc], f_lp = L.Lp[rc], f_x = L.x[rc], f_lx = L.Lx[rc], f_d = L.tdinv[rc];
+    if (blockIdx.x == 0 && threadIdx.x >= 64 && threadIdx.x < 128) {      // record of the iterate entering this launch (cf. k_lob_update)
+        const int itn = L.st->it0 + jrel + 1;
+        double a = 0.0;
+        const double* pr = L.partR + (size_t)(par ^ 1) * kMaxGrid;
+        for (int i = threadIdx.x - 64; i < P_u; i += 64) a += pr[i];
+        a = wave_total(a);
+        if (threadIdx.x == 64) {
+            L.hrec[4 * (size_t)(itn - 1)] = L.st->theta;
+            L.hrec[4 * (size_t)(itn - 1) + 1] = a;
+            L.hrec[4 * (size_t)(itn - 1) + 2] = lob_tag(L.st->epoch, itn - 1);
+        }
+    }
+    if (threadIdx.x < 64) {
+        double s[kLobNS];
+#pragma unroll
+        for (int q = 0; q < kLobNS; ++q) s[q] = 0.0;
+        for (int base = 0; base < max(P_u, P_w); base += 256) {      // (both grids hold at most 256 workgroups by plan: one round)
+            double v[kLobNS][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int q = 0; q < kLobNS; ++q) {
+                    const int i = min(base + (int)threadIdx.x + 64 * c, kMaxGrid - 1);
+                    v[q][c] = q == 9 ? partW[i] : pin[(size_t)q * kMaxGrid + i];
+                }
+#pragma unroll
+            for (int q = 0; q < kLobNS; ++q)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s[q] += (base + (int)threadIdx.x + 64 * c < (q == 9 ? P_w : P_u)) ? v[q][c] : 0.0;
+        }
+        wave_total_n<kLobNS>(s);
+        if (threadIdx.x == 0) {
+            const LobCoef co = lob_rayleigh_ritz(s, L.n, L.st->havep0 != 0 || jrel > 0);
+            sc[0] = co.z0; sc[1] = co.z1; sc[2] = co.z2; sc[3] = co.theta; sc[4] = co.mx; sc[5] = co.mw; sc[6] = co.mp;
+            sc[7] = co.bad ? 1.0 : 0.0;
+        }
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        L.st->theta = sc[3];
+        if (sc[7] != 0.0) L.st->bad = 1;
+    }
+    const double z0 = sc[0], z1 = sc[1], z2 = sc[2], th = sc[3], mx = sc[4], mw = sc[5], mp = sc[6];
+    double a[kLobNS + 1];
+#pragma unroll
+    for (int q = 0; q <= kLobNS; ++q) a[q] = 0.0;
+    for (int r = r0; r < n; r += gridDim.x * BLOCK) {
+        double lw = 0.0;
+        if (r != r0) {
+#pragma unroll
+            for (int q = 0; q < PB; ++q) y0[q] = ypart[(size_t)min(q, NP - 1) * n + r];
+            f_w = L.wT[r]; f_p = L.p[r]; f_lp = L.Lp[r]; f_x = L.x[r]; f_lx = L.Lx[r]; f_d = L.tdinv[r];
+        }
+#pragma unroll
+        for (int q = 0; q < PB; ++q) lw += (q < NP) ? y0[q] : 0.0;      // added in panel order (k_pan_fin's loop)
+        for (int p0 = PB; p0 < NP; p0 += PB) {
+            double y[PB];
+#pragma unroll
+            for (int q = 0; q < PB; ++q) y[q] = ypart[(size_t)min(p0 + q, NP - 1) * n + r];
+#pragma unroll
+            for (int q = 0; q < PB; ++q) lw += (p0 + q < NP) ? y[q] : 0.0;
+        }
+        const double w = f_w - mw;
+        const double pn = z1 * w + z2 * (f_p - mp);
+        const double lpn = z1 * lw + z2 * f_lp;
+        const double xn = z0 * (f_x - mx) + pn;
+        const double lxn = z0 * f_lx + lpn;
+        L.p[r] = pn; L.Lp[r] = lpn; L.x[r] = xn; L.Lx[r] = lxn;
+        const double res = lxn - th * xn;
+        const double wn = res * f_d;
+        L.wT[r] = wn;
+        a[0] += xn * xn; a[1] += xn * wn; a[2] += xn * pn; a[3] += wn * wn; a[4] += wn * pn; a[5] += pn * pn;
+        a[6] += xn * lxn; a[7] += wn * lxn; a[8] += xn * lpn; a[10] += wn * lpn; a[11] += pn * lpn;
+        a[12] += xn; a[13] += wn; a[14] += pn;
+        a[kLobNS] += fabs(res);
+    }
+    const int wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q <= kLobNS; ++q) {
+        const double tq = wave_total(a[q]);
+        if ((threadIdx.x & 63) == 0) red[wv][q] = tq;
+    }
+    __syncthreads();
+    if (threadIdx.x <= kLobNS) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < BLOCK / 64; ++k) t += red[k][threadIdx.x];
+        if (threadIdx.x < kLobNS) pout[(size_t)threadIdx.x * kMaxGrid + blockIdx.x] = t;
+        else L.partR[(size_t)par * kMaxGrid + blockIdx.x] = t;
+    }
+}
+
 // 1 / diag(L) in natural order (Jacobi preconditioner; any CSR: the row is searched for its diagonal entry)
 __global__ __launch_bounds__(kBlock) void k_jac_dinv(CsrView A, double* __restrict__ dinv, int* bad) {
     for (int r = blockIdx.x * kBlock + threadIdx.x; r < A.n; r += gridDim.x * kBlock) {
@@ -693,18 +812,38 @@ __global__ __launch_bounds__(kBlock) void k_jac_dinv(CsrView A, double* __restri
 }
 
 // First residual of a (re)started recurrence: x = yvec (unit, mean free), Lx = w2 = L yvec.
-template <bool JAC = false>
+template <bool JAC = false, bool SUMS = false>     // SUMS: also the inner products k_lob_update_pan expects from its predecessor (p = 0)
 __global__ __launch_bounds__(kBlock) void k_lob_start(LobView L, const double* __restrict__ xin, const double* __restrict__ lxin,
                                                       const double* __restrict__ rq, int it0, unsigned int epoch) {
     __shared__ double sm[4];
     const double th = *rq;
     double l1 = 0.0;
+    double a[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};      // xx xw ww xLx xLw Sx Sw
     for (int r = blockIdx.x * kBlock + threadIdx.x; r < L.n; r += gridDim.x * kBlock) {
         const double x = xin[r], lx = lxin[r];
         L.x[r] = x; L.Lx[r] = lx; L.p[r] = 0.0; L.Lp[r] = 0.0;
         const double res = lx - th * x;
         if (JAC) L.wT[r] = res * L.tdinv[r]; else L.rT[tri_perm(r, L.c, L.stride)] = res;
+        if (JAC && SUMS) {
+            const double wn = res * L.tdinv[r];
+            a[0] += x * x; a[1] += x * wn; a[2] += wn * wn; a[3] += x * lx; a[4] += wn * lx; a[5] += x; a[6] += wn;
+        }
         l1 += fabs(res);
+    }
+    if (JAC && SUMS) {
+        double* __restrict__ pout = L.part + (size_t)(it0 & 1) * (kLobNS * kMaxGrid);
+        constexpr int slot[7] = {0, 1, 3, 6, 7, 12, 13};
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const double t = block_sum(a[q], sm);
+            __syncthreads();
+            if (threadIdx.x == 0) pout[(size_t)slot[q] * kMaxGrid + blockIdx.x] = t;
+        }
+        if (threadIdx.x == 0) {
+            constexpr int zero[7] = {2, 4, 5, 8, 10, 11, 14};
+#pragma unroll
+            for (int q = 0; q < 7; ++q) pout[(size_t)zero[q] * kMaxGrid + blockIdx.x] = 0.0;
+        }
     }
     l1 = block_sum(l1, sm);
     if (threadIdx.x == 0) {

@@ -378,7 +378,7 @@ struct Solver {
     void launch_pan_mul_raw(const double* w) {
         const int g1 = pan.NB * pan.NP;
         PipeView L{};        // (unused by the RAW instantiation: no records, no prologue)
-        L.n = n; L.part = part; L.st = st;
+        L.n = n; L.part = lx_part + (size_t)2 * kLobNS * kMaxGrid; L.st = st;      // (part: w^T L w per (row block, panel) cell)
         const Z2* wz = reinterpret_cast<const Z2*>(w);
         switch (pan.RPT) {
 #define MACHIP_PAN_CASE(R) case R: k_pan_mul<R, true><<<g1, kPanThreads, 0, stream>>>(wz, L.part, L.st, panv.tptr, panv.thead, panv.n, panv.C, panv.NP, panv.TWW, panv, L, 0); break;
@@ -650,7 +650,7 @@ struct Solver {
                 ST_TRY(dev_alloc(&lx_as, fcap)); ST_TRY(dev_alloc(&lx_bs, fcap));
                 ST_TRY(dev_alloc(&lx_maps, 4 * (size_t)kMaxGrid));   // one map per workgroup and direction
             }
-            ST_TRY(dev_alloc(&lx_part, (size_t)kLobNS * kMaxGrid)); ST_TRY(dev_alloc(&lx_partR, 2 * kMaxGrid));
+            ST_TRY(dev_alloc(&lx_part, (size_t)(2 * kLobNS + 1) * kMaxGrid)); ST_TRY(dev_alloc(&lx_partR, 2 * kMaxGrid));     // (two parities of the 15 sums + w^T L w per panel cell: k_lob_update_pan)
             ST_TRY(dev_alloc(&lx_bad, 1)); ST_TRY(dev_alloc(&lx_st, 1));
             HIP_TRY(hipHostMalloc((void**)&h_lrec, sizeof(double) * 4 * (size_t)(kLobCap + kLobMaxChunk + 4), hipHostMallocMapped));
             memset(h_lrec, 0, sizeof(double) * 4 * (size_t)(kLobCap + kLobMaxChunk + 4));
@@ -668,6 +668,8 @@ struct Solver {
     // beyond, 4 unknowns per thread and as many 1024-thread workgroups as that takes
     bool lob_jacobi = false;   // the running preconditioned solve uses the diagonal preconditioner (natural layout, c = 1)
     bool lob_pan = false;      // ... and its product runs in column-panel form
+    int lob_par0 = 0;          // parity of the iterate count at the start of the chunk being enqueued
+    bool lob_pan2 = false;     // ... with two launches per iteration (k_lob_update_pan; MACHIP_LOB_PAN2=0: k_pan_find + k_lob_update)
     int lob_c() const { return lob_jacobi ? 1 : n > kTriMaxN ? kTriBigC : (n + kTriThreads - 1) / kTriThreads; }
     int lob_stride() const {
         if (lob_jacobi) return n;
@@ -717,6 +719,14 @@ struct Solver {
             OpLob op;
             op.L = L;
             for (int s = 0; s < steps; ++s) {
+                if (lob_pan && lob_pan2) {     // two launches per iteration: product (+ w^T L w per cell), then sums + Rayleigh-Ritz + update + next sums
+                    launch_pan_mul_raw(L.wT);
+                    const double* pw = lx_part + (size_t)2 * kLobNS * kMaxGrid;
+                    if (pan.block2 == 512) k_lob_update_pan<512><<<pan.grid2, 512, 0, stream>>>(L, panv.ypart, panv.NP, pw, pan.NB * pan.NP, s, (lob_par0 + s + 1) & 1);
+                    else if (pan.block2 == 1024) k_lob_update_pan<1024><<<pan.grid2, 1024, 0, stream>>>(L, panv.ypart, panv.NP, pw, pan.NB * pan.NP, s, (lob_par0 + s + 1) & 1);
+                    else k_lob_update_pan<256><<<pan.grid2, 256, 0, stream>>>(L, panv.ypart, panv.NP, pw, pan.NB * pan.NP, s, (lob_par0 + s + 1) & 1);
+                    continue;
+                }
                 if (lob_pan) {     // Lw = L w in column-panel form (panel.h: gathers served by LDS), then partial sums + inner products
                     launch_pan_mul_raw(L.wT);
                     k_pan_find<<<L.P_c, kBlock, 0, stream>>>(op, panv.ypart, panv.NP);
@@ -758,7 +768,7 @@ struct Solver {
     int lob_enqueue_chunk(const CsrView& A, const CsrView& AT, const SpmvPlan& pl, const LobView& L, int steps) {
         if (!use_graph || wb_active.s > 0) { lob_launch_chunk(AT, pl, L, steps); return MACHIP_OK; }   // (closure count is baked into the launches)
         if (graph_csr_key != (const void*)A.val) { drop_graphs(); graph_csr_key = (const void*)A.val; }
-        const auto key = std::make_tuple(1000 + pl.variant, pl.width, pl.grid, L.c + (n > kTriMaxN ? 100 : 0) + (lob_jacobi ? 1000 : 0) + (lob_pan ? 2000 + 10000 * pan.NP + 1000000 * pan.NB : 0), steps);
+        const auto key = std::make_tuple(1000 + pl.variant, pl.width, pl.grid, L.c + (n > kTriMaxN ? 100 : 0) + (lob_jacobi ? 1000 : 0) + (lob_pan ? 2000 + 10000 * pan.NP + 1000000 * pan.NB : 0) + (lob_pan2 ? 500 + 250 * lob_par0 : 0), steps);
         auto it = graphs.find(key);
         if (it == graphs.end()) it = graphs.emplace(key, std::array<hipGraphExec_t, 2>{nullptr, nullptr}).first;
         hipGraphExec_t& ge = it->second[(size_t)(graph_flip++ & 1)];
@@ -876,13 +886,16 @@ struct Solver {
         SpmvPlan pl = plan_spmv(n, nnz, kAuto, jacobi && n > 32768 ? kMaxGrid : 0);
         if (jacobi) {
             pan = plan_panel(n, nnz, maxlen_hint, pan_allowed && precision == 0 && !shard && !ipc);
+            lob_pan = false; lob_pan2 = false;
             if (pan.on && !pan.verify) {
                 ST_TRY(ensure_panel(A, nnz, pan));
                 lob_pan = true;
+                lob_pan2 = env_int("MACHIP_LOB_PAN2", 1) != 0 && pan.NB * pan.NP <= 256 && pan.grid2 <= 256 && pan.cells == 1;
             }
         }
         LobView L = lview(pl);
         if (lob_pan) L.P_c = std::min(256, vgrid());           // partial sums come from k_pan_find's workgroups
+        if (lob_pan && lob_pan2) L.P_a = pan.grid2;            // ... ||r||_1 partials from k_lob_update_pan's (and k_lob_start's) pan.grid2 workgroups
         const int g2 = vgrid();
         const bool debug = env_int("MACHIP_DEBUG", 0) != 0;
         const double scale = lnorm > 0 ? lnorm : 1.0;
@@ -970,7 +983,8 @@ struct Solver {
         int best_it = 0;
         while (true) {
             ++epoch;
-            if (jacobi) k_lob_start<true><<<g2, kBlock, 0, stream>>>(L, yvec, w2, rq_dev, it_enq, epoch);
+            if (jacobi && lob_pan && lob_pan2) k_lob_start<true, true><<<pan.grid2, kBlock, 0, stream>>>(L, yvec, w2, rq_dev, it_enq, epoch);     // (same grid as k_lob_update_pan: its prologue counts gridDim partials)
+            else if (jacobi) k_lob_start<true><<<g2, kBlock, 0, stream>>>(L, yvec, w2, rq_dev, it_enq, epoch);
             else k_lob_start<false><<<g2, kBlock, 0, stream>>>(L, yvec, w2, rq_dev, it_enq, epoch);
             std::deque<int> pend;
             std::deque<std::pair<int, double>> hist;
@@ -985,6 +999,7 @@ struct Solver {
                     ramp = std::min(chunk0, ramp * 2);
                     if (near) chunk = std::min(chunk, std::max(2, (int)(0.75 * to_go) + 1));
                     chunk = std::min(chunk, cap - it_enq);
+                    lob_par0 = it_enq & 1;      // (parity of the chunk's first iterate: baked into k_lob_update_pan's launches and the graph key)
                     ST_TRY(lob_enqueue_chunk(A, AT, pl, L, chunk));
                     it_enq += chunk;
                     *spmvs += chunk;

@@ -607,7 +607,7 @@ def test_teacher_forced_config2_all_twenty_reference_iterates(precision):
     P.close()
 
 
-@pytest.mark.parametrize("form", ["auto", "panel", "panel_one_launch", "gather"])
+@pytest.mark.parametrize("form", ["auto", "panel", "panel_one_launch", "gather", "lobpcg_panel"])
 def test_teacher_forced_config4_all_twenty_iterates(form):
     """BASELINE.json configs[3] (ER N = 100k, 2M candidates): lambda_2 on ALL 20 iterates of the reference's loop with
     ARPACK (tol 1e-13, residual <= 2e-13) standing in for the sparse LU that does not finish at this size
@@ -615,7 +615,9 @@ def test_teacher_forced_config4_all_twenty_iterates(form):
     MAC.laplacian / solve_subset_box_lp / update, SciPy eigsh).  These are the iterates the bench runs: nnz 0.7 M .. 4.0 M,
     the dense ones (6-19) are where the column-panel step spends its steps.  Forms: the automatic choice (gather step on
     the sparse iterates, panel step on the dense ones), the panel step forced onto every iterate as two launches
-    (k_pan_mul + k_pan_fin) and as one (k_pan_step, arrival tickets), the gather step forced onto every iterate."""
+    (k_pan_mul + k_pan_fin) and as one (k_pan_step, arrival tickets), the gather step forced onto every iterate; the experimental
+    diagonally preconditioned LOBPCG with the column-panel product, two launches per iteration (k_pan_mul<.., RAW> with w^T L w per
+    cell + k_lob_update_pan: the other fourteen inner products from the previous update by the symmetry of L)."""
     import bench
     w = bench.make_workload("c4")
     gv = load_golden("er100k_arpack")
@@ -627,8 +629,9 @@ def test_teacher_forced_config4_all_twenty_iterates(form):
     bits = gv["ref_s_bits"]
     vert = lambda i: np.unpackbits(bits[i])[:m].astype(np.float64)    # noqa: E731
     env = {"auto": {}, "panel": {"MACHIP_PANEL": "1", "MACHIP_PANEL_FUSED": "0"},
-           "panel_one_launch": {"MACHIP_PANEL": "1", "MACHIP_PANEL_FUSED": "1"}, "gather": {"MACHIP_PANEL": "0"}}[form]
-    old = {kk: os.environ.get(kk) for kk in ("MACHIP_PANEL", "MACHIP_PANEL_FUSED")}
+           "panel_one_launch": {"MACHIP_PANEL": "1", "MACHIP_PANEL_FUSED": "1"}, "gather": {"MACHIP_PANEL": "0"},
+           "lobpcg_panel": {"MACHIP_SOLVER": "jacobi", "MACHIP_PANEL": "1"}}[form]
+    old = {kk: os.environ.get(kk) for kk in ("MACHIP_PANEL", "MACHIP_PANEL_FUSED", "MACHIP_SOLVER")}
     try:
         os.environ.update(env)
         _teacher_forced(P, k, w["x0"], vert, gv["lam_traj"])
@@ -1082,6 +1085,11 @@ def test_full_size_config4_properties():
     {"MACHIP_PANEL": "1", "MACHIP_PANEL_FUSED": "1", "MACHIP_PANEL_NP": "7", "MACHIP_GRAPH": "0", "MACHIP_CHUNK": "6"},
     # diagonally preconditioned LOBPCG (experimental mode, round 4: fewer iterations than Lanczos steps, slower per iteration)
     {"MACHIP_SOLVER": "jacobi"},
+    # ... with the column-panel product: two launches per iteration (k_lob_update_pan; odd chunk lengths: the parity of the sums' double
+    # buffer changes from chunk to chunk), and the three-launch form it replaced
+    {"MACHIP_SOLVER": "jacobi", "MACHIP_PANEL": "1", "MACHIP_PANEL_NP": "3"},
+    {"MACHIP_SOLVER": "jacobi", "MACHIP_PANEL": "1", "MACHIP_PANEL_NP": "5", "MACHIP_PANEL_NB": "7", "MACHIP_PANEL_B2": "256", "MACHIP_PANEL_G2": "3", "MACHIP_GRAPH": "0"},
+    {"MACHIP_SOLVER": "jacobi", "MACHIP_PANEL": "1", "MACHIP_PANEL_NP": "3", "MACHIP_LOB_PAN2": "0"},
 ])
 def test_solver_variants_agree(env):
     """Every launch shape / row mapping of the fused step kernel, eager vs graph launches, odd chunk
