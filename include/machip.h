@@ -175,7 +175,7 @@ int machip_comm_init_local(machip_problem** handles, int nranks);
  * without one (ranks sharing a GPU) by peer writes through the mapped buffers.  machip_comm_close_ipc before machip_destroy
  * marks an orderly exit (a handle destroyed without it raises abort on its peers). */
 /* First-contact helpers (round 4).  machip_comm_init and the communicator's FIRST ncclAllGather run under a watchdog
- * (MACHIP_RCCL_TIMEOUT_S, default 120 s): a peer that never arrives / a fabric that cannot carry the collective returns
+ * (MACHIP_RCCL_TIMEOUT_S, default 600 s): a peer that never arrives / a fabric that cannot carry the collective returns
  * MACHIP_RCCL_ERROR naming the rank instead of hanging the job.  machip_selftest_watchdog exercises that watchdog with a
  * sleeping stand-in (no GPU needed: MACHIP_OK when work_ms < limit_ms, MACHIP_RCCL_ERROR otherwise); machip_peer_access =
  * hipDeviceCanAccessPeer (1 / 0, -1 on error), what `bench.py --gpus N --dry` prints as a matrix. */
@@ -221,7 +221,10 @@ int machip_eval_batch(machip_problem* p, int B, const double* X, double tol, int
  * evaluation lanes (own x / gradient / CSR / eigen-solver state / stream, sharing pattern and candidate arrays; up to
  * MACHIP_LANES run concurrently, one host thread each, each stream on a hardware queue of its own).  Every problem starts
  * from a clean solver state and the handle's start vector: its results are bit-identical to a fresh handle running
- * machip_fw_step / machip_fw_commit in a loop, whatever lane takes it -- as long as no single Krylov sequence outgrows the
+ * machip_fw_step / machip_fw_commit in a loop IN THE SAME SOLVER MODE (machip_set_solver(1), the Lanczos path, on both: under
+ * the automatic mode a standalone handle may take the exact chain + closures mode -- small pose graphs up to 700 closures, larger
+ * ones on a long forecast -- which a lane keeps to 256 closures so as not to starve the other lanes; the two then agree to the
+ * solver tolerance, not bit for bit), whatever lane takes it -- as long as no single Krylov sequence outgrows the
  * lane's basis (a lane holds MACHIP_LANE_VBUDGET_MB = 1/8 of the handle's basis budget: 6 710 columns against 10 010 at
  * n = 1e4, 671 against 5 368 at n = 1e5); a longer sequence restarts earlier on a lane than on the handle and then agrees
  * with it to the solver tolerance, not bit for bit.

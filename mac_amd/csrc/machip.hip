@@ -31,7 +31,7 @@ using namespace machip;
 
 // First-contact watchdog (round 4): a call into RCCL that may block for ever -- ncclCommInitRank with a peer that never
 // arrives, the first collective on a fabric that is not what was assumed -- runs on a helper thread; the caller waits with a
-// limit (MACHIP_RCCL_TIMEOUT_S, default 120) and turns a stall into MACHIP_RCCL_ERROR with the rank in the message instead of
+// limit (MACHIP_RCCL_TIMEOUT_S, default 600) and turns a stall into MACHIP_RCCL_ERROR with the rank in the message instead of
 // a hung job.  (A helper that never returns is abandoned with its state: the process is about to report failure anyway.)
 static int run_with_watchdog(const std::function<int()>& fn, double limit_s, const std::string& what) {
     auto state = std::make_shared<std::promise<int>>();
@@ -41,7 +41,7 @@ static int run_with_watchdog(const std::function<int()>& fn, double limit_s, con
         return fail(MACHIP_RCCL_ERROR, what + " did not return within " + std::to_string((int)limit_s) + " s (a peer rank is missing, or the fabric / bootstrap interface is not reachable; MACHIP_RCCL_TIMEOUT_S raises the limit)");
     return fut.get();
 }
-static double rccl_timeout_s() { const int t = env_int("MACHIP_RCCL_TIMEOUT_S", 120); return t > 0 ? (double)t : 120.0; }
+static double rccl_timeout_s() { const int t = env_int("MACHIP_RCCL_TIMEOUT_S", 600); return t > 0 ? (double)t : 600.0; }
 
 // In-process communicator (machip_comm_init_local): the ranks are handles of ONE process driven by one host
 // thread each (one GPU per handle, or several handles on one GPU); the all-gather is peer-to-peer device copies

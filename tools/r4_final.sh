@@ -14,6 +14,7 @@ bash tools/profile_round.sh r4_c2 --config c2 --warmup 0 > $out/prof_c2.log 2>&1
 bash tools/profile_round.sh r4_c3 --config c3 --warmup 0 > $out/prof_c3.log 2>&1
 # condense on the box (the raw traces exceed what gpurun copies back): summaries -> $out, raw CSVs dropped
 mkdir -p profiles_box; for t in r4_c4 r4_c2 r4_c3; do python tools/summarize_profile.py $t > $out/summarize_$t.log 2>&1; f=$(find gpurun_out/$t/trace -name "t_kernel_stats.csv" | head -1); cp "$f" $out/${t}_kernel_stats.csv; cp profiles/${t}_summary.md profiles/${t}_summary.json $out/; rm -rf gpurun_out/$t; done
+timeout 600 python tools/g2o_first_budget.py tests/golden/data/*.g2o > $out/r4_first_budget.txt 2>&1
 for g in intel sphere2500 city10000; do timeout 300 python tools/sweep_probe.py $g 16 20 2>&1 | tail -6; done > $out/r4_sweep.txt
 for f in $out/r4_bench_*.json; do python - $f <<'PY'
 import json, sys
