@@ -69,6 +69,13 @@ void run(PanView P, PipeView L, hipStream_t s, long nnz, std::vector<double>& u0
         printf("      done by panel:"); for (int i = 0; i < P.NP; ++i) printf(" %5.2f", bp[i] / std::max(1, np_[i])); printf("\n");
         printf("      done by block:"); for (int i = 0; i < P.NB; ++i) printf(" %5.2f", bb[i] / std::max(1, nb_[i])); printf("\n");
     }
+    {   // are the SAME workgroups late every time?  the 16 slowest (block index: time) of this run's last step
+        std::vector<std::pair<double, int>> v;
+        for (int b = 0; b < gl; ++b) if (c[(size_t)b * 16]) v.push_back({(c[(size_t)b * 16 + (FUSED ? 11 : 9)] - t0) * 0.01, b});
+        std::sort(v.begin(), v.end()); std::reverse(v.begin(), v.end());
+        printf("      slowest:"); for (int i = 0; i < 16 && i < (int)v.size(); ++i) printf(" %d:%.1f", v[i].second, v[i].first); printf("\n");
+        printf("      fastest:"); for (int i = 0; i < 8 && i < (int)v.size(); ++i) printf(" %d:%.1f", v[v.size() - 1 - i].second, v[v.size() - 1 - i].first); printf("\n");
+    }
     if (FUSED) {   // hardware XCC id of every workgroup: do the workgroups w = x (mod 8) share one?
         int bad = 0; long long first[8];
         for (int w = 0; w < gl; ++w) { const long long x = c[(size_t)w * 16 + 12]; if (w < 8) first[w] = x; else if (x != first[w & 7]) ++bad; }
