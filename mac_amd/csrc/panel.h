@@ -66,6 +66,9 @@ struct PanView {
     unsigned int* claim;    // [NB * NP] ... and which step's share (row block b, rows of slice p) has been taken
     int spin_ticks;         // ... how long (100 MHz ticks) a workgroup waits for its row block before leaving its share to the last arriver
     int* ovf;               // set by k_pan_rows when a row has more than kPanMaxLen entries inside ONE panel (the build would clamp it)
+    int band;               // 1: the tridiagonal band (diagonal, columns r - 1 and r + 1) is kept OUT of the panel form -- bd holds it, k_pan_fin adds it
+    double* bd;             // [3][n] band values: diagonal, column r - 1, column r + 1 (0 where absent)
+    int* bpk;               // [n] (CSR index of the row's first off-diagonal band entry) << 2 | how many there are (0..2): the hole k_pan_fill skips
     int* tcount;            // [tiles] entries (with padding) per tile (assembly scratch)
     int* ps;                // [(NP+1)][n] first off-diagonal entry of row r at or behind panel p (assembly scratch)
 #ifdef PAN_CLOCKS
@@ -101,23 +104,47 @@ __global__ __launch_bounds__(kBlock) void k_pan_rows(CsrView A, PanView P) {
     int e = A.rowptr[r] + 1;               // (the diagonal sits first and is counted with its own panel)
     const int end = A.rowptr[r + 1];
     bool over = false;
+    int hb = end, hn = 0;                  // band mode: the (at most two, adjacent) entries of columns r - 1, r + 1
+    double vl = 0.0, vu = 0.0;
     for (int p = 0; p < P.NP; ++p) {
         P.ps[(size_t)p * A.n + r] = e;
         const int hi = (p + 1) * P.C, e0 = e;
-        while (e < end && A.col[e] < hi) ++e;
-        over |= e - e0 + (r / P.C == p ? 1 : 0) > kPanMaxLen;
+        int inband = 0;
+        while (e < end && A.col[e] < hi) {
+            const int c = A.col[e];
+            if (P.band && (c == r - 1 || c == r + 1)) {
+                if (!hn) hb = e;
+                ++hn; ++inband;
+                if (c == r - 1) vl = A.val[e]; else vu = A.val[e];
+            }
+            ++e;
+        }
+        over |= e - e0 - inband + ((!P.band && r / P.C == p) ? 1 : 0) > kPanMaxLen;
     }
     P.ps[(size_t)P.NP * A.n + r] = end;
+    if (P.band) {
+        P.bpk[r] = (hb << 2) | hn;
+        P.bd[r] = A.val[A.rowptr[r]]; P.bd[(size_t)A.n + r] = vl; P.bd[2 * (size_t)A.n + r] = vu;
+    }
     if (over) *P.ovf = 1;                  // (a hub row concentrated in one panel: the solver falls back to the gather step)
 }
 
 constexpr int kPanRT = (kPanRows + kPanThreads - 1) / kPanThreads;   // rows per thread (8)
 
 // entries of row r inside panel p (diagonal included when r lies in the panel); *start = first off-diagonal one
-__device__ __forceinline__ int pan_row_count(const PanView& P, int n, int r, int p, int* start) {
-    const int st = P.ps[(size_t)p * n + r];
+// Band mode: neither the diagonal nor the entries of columns r - 1 / r + 1 count; *hole / *hlen = the CSR range of those inside
+// [start, end of the panel's run) that the copy has to skip (hlen = 0: none).
+__device__ __forceinline__ int pan_row_count(const PanView& P, int n, int r, int p, int* start, int* hole = nullptr, int* hlen = nullptr) {
+    const int st = P.ps[(size_t)p * n + r], en = P.ps[(size_t)(p + 1) * n + r];
     *start = st;
-    return min(P.ps[(size_t)(p + 1) * n + r] - st + (r / P.C == p ? 1 : 0), kPanMaxLen);
+    if (P.band) {
+        const int pk = P.bpk[r], hb = pk >> 2, hn = pk & 3;
+        const int h0 = max(st, hb), h1 = min(en, hb + hn), hl = max(0, h1 - h0);
+        if (hole) { *hole = h0; *hlen = hl; }
+        return min(en - st - hl, kPanMaxLen);
+    }
+    if (hole) { *hole = 0; *hlen = 0; }
+    return min(en - st + (r / P.C == p ? 1 : 0), kPanMaxLen);
 }
 
 // Build kernels: workgroup id -> (row block b, panel p) such that the NP workgroups of one row block have the same id % 8,
@@ -209,14 +236,15 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_fill(CsrView A, PanView P) 
         const int base = P.tptr[vt], tm = (P.tptr[vt + 1] - base) >> 6;
         if (tm == 0) continue;
         const int r = b * R + P.thead[vt * 64 + (s & 63)];
-        int st = 0, c = 0;
-        if (r < A.n) c = pan_row_count(P, A.n, r, p, &st);
-        const int shift = (r < A.n && r / P.C == p) ? 1 : 0;      // entry 0 is the diagonal
+        int st = 0, c = 0, hole = 0, hlen = 0;
+        if (r < A.n) c = pan_row_count(P, A.n, r, p, &st, &hole, &hlen);
+        const int shift = (!P.band && r < A.n && r / P.C == p) ? 1 : 0;      // entry 0 is the diagonal
         const int dg = shift ? A.rowptr[r] : 0;
         for (int i = 0; i < tm; ++i) {
             const int dst = base + 64 * i + (s & 63);
             if (i < c) {
-                const int src = (shift && i == 0) ? dg : st + i - shift;
+                int src = (shift && i == 0) ? dg : st + i - shift;
+                if (hlen && src >= hole) src += hlen;             // (band mode: skip columns r - 1 / r + 1)
                 P.bval[dst] = A.val[src];
                 P.bcol[dst] = (unsigned short)(A.col[src] - c0);
             } else { P.bval[dst] = 0.0; P.bcol[dst] = 0; }
@@ -561,6 +589,12 @@ __global__ __launch_bounds__(BLOCK) void k_pan_fin(const Z2* __restrict__ z_cur,
         }
         Z2 o;
         o.v = pan_vj(alpha, mu, inv, z.t, z.v);
+        if (A.band) {       // the tridiagonal band, kept out of the panel form (it sat in the diagonal cells only: 2.2x the entries of any other cell)
+            const Z2 zl = Zc[max(r - 1, 0)], zu = Zc[min(r + 1, n - 1)];
+            w = __builtin_fma(A.bd[r], o.v, w);
+            w = __builtin_fma(A.bd[(size_t)n + r], pan_vj(alpha, mu, inv, zl.t, zl.v), w);
+            w = __builtin_fma(A.bd[2 * (size_t)n + r], pan_vj(alpha, mu, inv, zu.t, zu.v), w);
+        }
         o.t = __builtin_fma(-beta, z.v, w);         // Paige's intermediate for the next step (explicit fma: k_pan_step rounds alike)
         vj[r] = o.v;
         Zn[r] = o;

@@ -141,6 +141,7 @@ struct PanPlan {
     int NP = 1, C = 1, NB = 1, NTB = 1, TWW = 1, RPT = 1;
     int cells = 1;                   // row blocks per workgroup (> 1: k_pan_mul_multi, grid = NP * ceil(NB / cells))
     int grid2 = 1, block2 = 256;     // launch shape of k_pan_fin
+    bool band = false;               // diagonal + columns r -/+ 1 kept out of the tiles and added by k_pan_fin (evens out the diagonal cells)
     bool verify = false;             // a row is longer than 127 entries: the build must confirm that no (row, panel) count exceeds 127
     bool fused = false;              // one launch per step (k_pan_step) instead of k_pan_mul + k_pan_fin (measured SLOWER: profiles/r4_c4_one_launch_step.md)
 };
@@ -217,6 +218,7 @@ inline PanPlan plan_panel(int n, long nnz, int maxlen, bool allowed) {
     // MACHIP_PANEL_FUSED=1: the one-launch form (k_pan_step; tickets for 256 row blocks, one partial-sum slot per slice).  Off by
     // default: 26.9 against 19.1 us per step at configs[3] -- the in-launch hand-off costs more than the launch it saves.
     pp.fused = env_int("MACHIP_PANEL_FUSED", 0) != 0 && nb <= 256 && nb * np <= 256 && pp.cells == 1;
+    pp.band = env_int("MACHIP_PANEL_BAND", 1) != 0 && !pp.fused && nnz < (1l << 29);     // (k_pan_step and the LOBPCG kernels finish rows without the band terms)
     pp.block2 = env_int("MACHIP_PANEL_B2", 512);
     if (pp.block2 != 256 && pp.block2 != 512 && pp.block2 != 1024) pp.block2 = 256;
     pp.grid2 = (int)std::max<long>(1, std::min<long>(env_int("MACHIP_PANEL_G2", grid_cap()), ((long)n + pp.block2 - 1) / pp.block2));

@@ -154,7 +154,7 @@ struct Solver {
     bool pan_allowed = false;   // the CSR is one this library assembled (diagonal first, other columns ascending)
     PanPlan pan;
     PanView panv{};
-    size_t pan_cap = 0, pan_nt_cap = 0, pan_y_cap = 0;
+    size_t pan_cap = 0, pan_nt_cap = 0, pan_y_cap = 0, pan_band_cap = 0;
 
     // budget_mb > 0: HBM budget of the Krylov basis V for this instance (evaluation lanes take a share each)
     int init(int n_, hipStream_t s, int budget_mb = 0) {
@@ -206,7 +206,7 @@ struct Solver {
                         lx_ys, lx_pas, lx_as, lx_bs, lx_maps, lx_ba, lx_bd, lx_bu, wb_ui, wb_uj, wb_counts, wb_uc, wb_g, wb_h, wb_Zt, wb_Cm, wb_Cm2, wb_piv, wb_pas, wb_maps,
                         lx_colT, lx_bad, lx_st, valf};
         {
-            void* pb[] = {panv.tptr, panv.thead, panv.bval, panv.bcol, panv.ypart, panv.coef, panv.tcount, panv.ps, panv.tick, panv.claim, panv.ovf};
+            void* pb[] = {panv.tptr, panv.thead, panv.bval, panv.bcol, panv.ypart, panv.coef, panv.tcount, panv.ps, panv.tick, panv.claim, panv.ovf, panv.bd, panv.bpk};
             for (void* q : pb) if (q) (void)hipFree(q);
             void* pk[] = {ppack.band, ppack.cc, ppack.crow, ppack.ccol, ppack.cval, ell_col, ell_val};
             for (void* q : pk) if (q) (void)hipFree(q);
@@ -304,7 +304,7 @@ struct Solver {
 
     // ---- column-panel step (panel.h) ---------------------------------------------------------------
     // (Re)build the panel form of A on the stream: buffers grow on demand (cached chunk graphs carry their addresses).
-    int ensure_panel(const CsrView& A, long nnz, const PanPlan& pn) {
+    int ensure_panel(const CsrView& A, long nnz, const PanPlan& pn, bool band = false) {
         const size_t NT = (size_t)pn.NB * pn.NP * kPanWork * pn.TWW;
         bool dropped = false;
         auto regrow = [&](auto** ptr, size_t count) -> int {
@@ -331,6 +331,12 @@ struct Solver {
         if (!panv.coef) ST_TRY(dev_alloc(&panv.coef, 8));
         if (!panv.tick) { ST_TRY(dev_alloc(&panv.tick, 256)); ST_TRY(dev_alloc(&panv.claim, 4096)); }     // (NB <= 256, NB NP <= 4096: plan_panel)
         if (!panv.ovf) ST_TRY(dev_alloc(&panv.ovf, 1));
+        // band mode (Lanczos form, two launches): diagonal and chain neighbours stay out of the tiles -- k_pan_fin adds them
+        panv.band = band ? 1 : 0;
+        if (band && (size_t)n > pan_band_cap) {
+            ST_TRY(regrow(&panv.bd, 3 * (size_t)n)); ST_TRY(regrow(&panv.bpk, (size_t)n));
+            pan_band_cap = (size_t)n;
+        }
         HIP_TRY(hipMemsetAsync(panv.ovf, 0, sizeof(int), stream));
         panv.spin_ticks = env_int("MACHIP_PANEL_SPIN_US", 20) * 100;
         panv.n = n; panv.NP = pn.NP; panv.C = pn.C; panv.NB = pn.NB; panv.NTB = pn.NTB; panv.TWW = pn.TWW; panv.CELLS = pn.cells;
@@ -1247,7 +1253,7 @@ struct Solver {
             pp.variant = kEll; pp.unroll = W / 4;
         }
         if (pan.on) {
-            ST_TRY(ensure_panel(A, nnz, pan));
+            ST_TRY(ensure_panel(A, nnz, pan, pan.band));
             if (pan.verify) {        // hub rows: is every (row, panel) count within what the tiles describe?  (one sync, hub matrices only)
                 int over = 0;
                 HIP_TRY(hipMemcpyAsync(&over, panv.ovf, sizeof(int), hipMemcpyDeviceToHost, stream));

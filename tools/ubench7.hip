@@ -15,7 +15,7 @@ namespace machip { thread_local std::string g_err; }
 using namespace machip;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
-static int FUSED = 1;
+static int FUSED = 1, BAND = 0;
 template <int RPT>
 void step(PanView& P, PipeView& L, hipStream_t s, int j) {
     if (FUSED == 2) k_pan_step<RPT, true><<<8 * ((P.NB + 7) / 8) * P.NP, kPanThreads, 0, s>>>(PAN_STEP_ARGS(P, L, j));     // a row block's workgroups on one XCD
@@ -89,6 +89,7 @@ int main(int argc, char** argv) {
     const int NPa = argc > 1 ? atoi(argv[1]) : 12, NBa = argc > 2 ? atoi(argv[2]) : 21;
     FUSED = argc > 3 ? atoi(argv[3]) : 1;
     const int spin_us = argc > 4 ? atoi(argv[4]) : 20;
+    BAND = argc > 5 ? atoi(argv[5]) : 0;      // two-launch form only: band kept out of the tiles (k_pan_fin adds it)
     for (double deg : {26.0, 40.0}) {
         const int n = 100000;
         std::mt19937_64 rng(7);
@@ -122,7 +123,7 @@ int main(int argc, char** argv) {
         const size_t ecap = (size_t)nnz + (size_t)P.NB * P.NP * 64 * 128 + kPanSlack;
         CK(hipMalloc(&P.tptr, (NT + 1) * 4)); CK(hipMalloc(&P.tcount, NT * 4)); CK(hipMalloc(&P.thead, NT * 64 * 2));
         CK(hipMalloc(&P.bval, ecap * 8)); CK(hipMalloc(&P.bcol, ecap * 2)); CK(hipMalloc(&P.ypart, (size_t)P.NP * (n + 2) * 8)); CK(hipMalloc(&P.ps, (size_t)(P.NP + 1) * n * 4));
-        CK(hipMalloc(&P.ovf, 4)); CK(hipMemset(P.ovf, 0, 4)); P.CELLS = 1; CK(hipMalloc(&P.tick, 4 * 256)); CK(hipMalloc(&P.claim, 4 * 4096)); P.spin_ticks = spin_us * 100;
+        CK(hipMalloc(&P.ovf, 4)); CK(hipMemset(P.ovf, 0, 4)); P.CELLS = 1; P.band = BAND; CK(hipMalloc(&P.bd, 3 * (size_t)n * 8)); CK(hipMalloc(&P.bpk, (size_t)n * 4)); CK(hipMalloc(&P.tick, 4 * 256)); CK(hipMalloc(&P.claim, 4 * 4096)); P.spin_ticks = spin_us * 100;
         CK(hipMalloc(&P.coef, 64)); CK(hipMalloc(&P.clk, 16 * 8 * kMaxGrid)); CK(hipMemset(P.clk, 0, 16 * 8 * kMaxGrid));
         hipEvent_t a0, a1; CK(hipEventCreate(&a0)); CK(hipEventCreate(&a1));
         CK(hipEventRecord(a0, s));
