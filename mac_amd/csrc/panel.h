@@ -840,9 +840,16 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_step(const Z2* __restrict__
             for (int h = 0; h < 2; ++h) {
                 if (h && !two) break;
                 const Z2 z = h ? z1 : z0;
-                const double w = h ? w1 : w0;
+                double w = h ? w1 : w0;
                 Z2 o;
                 o.v = pan_vj(alpha, mu, inv, z.t, z.v);
+                if (A.band) {       // (the band terms exactly as k_pan_fin adds them)
+                    const int rr = r + h;
+                    const Z2 zl = Zr[max(rr - 1, 0)], zu = Zr[min(rr + 1, n - 1)];
+                    w = __builtin_fma(A.bd[rr], o.v, w);
+                    w = __builtin_fma(A.bd[(size_t)n + rr], pan_vj(alpha, mu, inv, zl.t, zl.v), w);
+                    w = __builtin_fma(A.bd[2 * (size_t)n + rr], pan_vj(alpha, mu, inv, zu.t, zu.v), w);
+                }
                 o.t = __builtin_fma(-beta, z.v, w);      // Paige's intermediate for the next step
                 vj[r + h] = o.v;
                 Zn[r + h] = o;

@@ -218,7 +218,7 @@ inline PanPlan plan_panel(int n, long nnz, int maxlen, bool allowed) {
     // MACHIP_PANEL_FUSED=1: the one-launch form (k_pan_step; tickets for 256 row blocks, one partial-sum slot per slice).  Off by
     // default: 26.9 against 19.1 us per step at configs[3] -- the in-launch hand-off costs more than the launch it saves.
     pp.fused = env_int("MACHIP_PANEL_FUSED", 0) != 0 && nb <= 256 && nb * np <= 256 && pp.cells == 1;
-    pp.band = env_int("MACHIP_PANEL_BAND", 1) != 0 && !pp.fused && nnz < (1l << 29);     // (k_pan_step and the LOBPCG kernels finish rows without the band terms)
+    pp.band = env_int("MACHIP_PANEL_BAND", 1) != 0 && nnz < (1l << 29);     // (the LOBPCG kernels finish rows without the band terms: solver.h passes band = false there)
     pp.block2 = env_int("MACHIP_PANEL_B2", 512);
     if (pp.block2 != 256 && pp.block2 != 512 && pp.block2 != 1024) pp.block2 = 256;
     pp.grid2 = (int)std::max<long>(1, std::min<long>(env_int("MACHIP_PANEL_G2", grid_cap()), ((long)n + pp.block2 - 1) / pp.block2));
