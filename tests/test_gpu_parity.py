@@ -1216,6 +1216,55 @@ def test_panel_step_multi_round_windows_hub_rows_and_odd_sizes():
         P.close()
 
 
+def test_panel_band_split_when_band_entries_are_missing_or_weightless():
+    """Band split of the column-panel step (panel.h, PanView::band: diagonal and columns r -/+ 1 stay out of the tiles, k_pan_fin adds
+    them) on graphs WITHOUT a complete chain: the fixed edges are a random spanning tree (most rows have no neighbour at r -/+ 1, some have
+    one, a few both; rows 0 and n - 1 have one-sided bands), candidates include pairs (r, r + 1) so that a band entry can come from a
+    candidate and be zero-weighted by x.  lambda_2 / vector of the band-split form = the round-3 layout (MACHIP_PANEL_BAND=0) = the
+    gather step to 1e-12, SciPy to 1e-8; several panels and row blocks, n not a multiple of anything."""
+    import scipy.sparse.linalg as spla
+    rng = np.random.default_rng(23)
+    n = 7001
+    par = np.array([rng.integers(max(0, i - 40), i) for i in range(1, n)])          # tree: node i hangs on an earlier node nearby
+    fi = np.minimum(par, np.arange(1, n)).astype(np.int32); fj = np.maximum(par, np.arange(1, n)).astype(np.int32)
+    fw = 0.5 + rng.random(n - 1)
+    m0 = 40000
+    a = rng.integers(0, n, m0); b = rng.integers(0, n, m0)
+    a[:500] = rng.integers(0, n - 1, 500); b[:500] = a[:500] + 1                     # band entries that come from candidates
+    keep = a != b
+    key = np.unique(np.minimum(a, b)[keep].astype(np.int64) * n + np.maximum(a, b)[keep])
+    ci, cj = (key // n).astype(np.int32), (key % n).astype(np.int32)
+    m = len(ci)
+    cw = 0.5 + rng.random(m)
+    x = rng.random(m); x[rng.random(m) < 0.4] = 0.0
+    P = _lib.Problem(n, fi, fj, fw, ci, cj, cw)
+    P.set_start(reference_start_block(n)[:, 0].copy())
+    P.set_x(x)
+    res = {}
+    keys = ("MACHIP_PANEL", "MACHIP_PANEL_BAND", "MACHIP_PANEL_NP", "MACHIP_PANEL_NB")
+    old = {k_: os.environ.get(k_) for k_ in keys}
+    try:
+        for tag, env in (("gather", {"MACHIP_PANEL": "0"}), ("band", {"MACHIP_PANEL": "1", "MACHIP_PANEL_NP": "5", "MACHIP_PANEL_NB": "3"}),
+                         ("tiles", {"MACHIP_PANEL": "1", "MACHIP_PANEL_NP": "5", "MACHIP_PANEL_NB": "3", "MACHIP_PANEL_BAND": "0"})):
+            for k_ in keys:
+                os.environ.pop(k_, None)
+            os.environ.update(env)
+            lam, v, _ = P.fiedler(tol=1e-10)
+            res[tag] = (lam, v)
+    finally:
+        for k_, v_ in old.items():
+            os.environ.pop(k_, None) if v_ is None else os.environ.__setitem__(k_, v_)
+    for tag in ("band", "tiles"):
+        assert abs(res[tag][0] - res["gather"][0]) <= 1e-12 * res["gather"][0], (tag, res[tag][0], res["gather"][0])
+        assert np.abs(sign_align(res[tag][1], res["gather"][1]) - res["gather"][1]).max() <= 1e-7
+    assert not np.array_equal(res["band"][1], res["gather"][1])                       # (the panel form really ran: other roundings)
+    ip, ix, da = P.laplacian_csr()
+    L = sp.csr_matrix((da, ix, ip), shape=(n, n))
+    w = spla.eigsh(L, k=2, which="SA", tol=1e-10, ncv=64, v0=np.ones(n) + 0.01 * rng.random(n), return_eigenvectors=False)
+    assert abs(np.sort(w)[1] - res["band"][0]) <= 1e-8 * res["band"][0]
+    P.close()
+
+
 @pytest.mark.parametrize("nm", ["intel", "sphere2500"])
 def test_chebyshev_filtered_single_workgroup_recurrence_matches_goldens(nm):
     """MACHIP_CHEB_DEG=8: the single-workgroup Lanczos kernel run on C = -T_8(M(L)) after a short plain sequence (persist.h,
