@@ -55,6 +55,18 @@ dom = dict(kernel="one Lanczos step: k_pipe_vec (gather form) or k_pan_mul + k_p
            panel_steps=sum(r["calls"] for r in heads if r["kernel"].startswith("k_pan")),
            gather_avg_us=sum(r["avg_us"] * r["calls"] for r in parts if not r["kernel"].startswith("k_pan")) / max(1, sum(r["calls"] for r in heads if not r["kernel"].startswith("k_pan"))),
            panel_avg_us=sum(r["avg_us"] * r["calls"] for r in parts if r["kernel"].startswith("k_pan")) / max(1, sum(r["calls"] for r in heads if r["kernel"].startswith("k_pan"))))
+if calls == 0:
+    # no Lanczos step in the trace (intel: every solve runs in the exact chain + closures mode): the unit is one
+    # preconditioned iteration = everything between two k_lob_update / k_lob_fused launches (tridiagonal solve, g / h / w of the
+    # Woodbury correction, the product, the update); the inverse (k_gj_step) and the set-up kernels are listed in the table
+    it_parts = [r for r in rows if r["kernel"].startswith(("k_lob_update", "k_lob_fused", "k_tri_solve", "k_wb_g", "k_wb_h", "k_wb_w", "k_spmv"))]
+    its = sum(r["calls"] for r in rows if r["kernel"].startswith(("k_lob_update", "k_lob_fused")))
+    dom = dict(kernel="one preconditioned (exact chain + closures) iteration: k_tri_solve / k_lob_fused + k_wb_g / k_wb_h / k_wb_w + product + update",
+               calls=its, avg_us=sum(r["avg_us"] * r["calls"] for r in it_parts) / max(1, its),
+               hbm_bytes_per_launch=sum(r["hbm_bytes_per_launch"] * r["calls"] for r in it_parts) / max(1, its),
+               gather_steps=0, panel_steps=0, gather_avg_us=0.0, panel_avg_us=0.0,
+               inverse_launches=sum(r["calls"] for r in rows if r["kernel"].startswith("k_gj_step")),
+               inverse_avg_us=sum(r["avg_us"] * r["calls"] for r in rows if r["kernel"].startswith("k_gj_step")) / max(1, sum(r["calls"] for r in rows if r["kernel"].startswith("k_gj_step"))))
 js = dict(tag=tag, bench=bench_line, dominant=dom, kernels=rows)
 json.dump(js, open(out_js, "w"), indent=1)
 with open(out_md, "w") as fh:
@@ -62,10 +74,16 @@ with open(out_md, "w") as fh:
              "(FETCH_SIZE, WRITE_SIZE); raw CSVs were in `gpurun_out/" + tag + "/` (scratch).\n\n")
     if bench_line:
         fh.write("bench line of the traced run (profiler attached, so slower than the un-profiled number):\n\n```\n" + json.dumps(bench_line) + "\n```\n\n")
-    fh.write(f"Dominant work: **{dom['kernel']}**, {dom['calls']} steps ({dom['gather_steps']} gather-form at {dom['gather_avg_us']:.2f} us, "
-             f"{dom['panel_steps']} panel-form at {dom['panel_avg_us']:.2f} us = k_pan_mul + k_pan_fin), kernel time per step {dom['avg_us']:.2f} us, "
-             f"HBM traffic per step (2*FETCH+WRITE) {dom['hbm_bytes_per_launch']/1e6:.2f} MB.\n\n")
-    if bench_line and bench_line.get("roofline"):
+    if "inverse_launches" in dom:
+        fh.write(f"Dominant work: **{dom['kernel']}**, {dom['calls']} iterations, kernel time per iteration {dom['avg_us']:.2f} us, HBM traffic per "
+                 f"iteration (2*FETCH+WRITE) {dom['hbm_bytes_per_launch']/1e6:.3f} MB; the s x s inverse: {dom['inverse_launches']} launches of k_gj_step at "
+                 f"{dom['inverse_avg_us']:.2f} us.  No Lanczos step ran in this trace, so the bench line's roofline object (defined per Lanczos step) has "
+                 f"nothing to be cross-checked against: the working set lives in L2 / LDS and the solve is a latency chain (DESIGN section 5).\n\n")
+    else:
+        fh.write(f"Dominant work: **{dom['kernel']}**, {dom['calls']} steps ({dom['gather_steps']} gather-form at {dom['gather_avg_us']:.2f} us, "
+                 f"{dom['panel_steps']} panel-form at {dom['panel_avg_us']:.2f} us = k_pan_mul + k_pan_fin), kernel time per step {dom['avg_us']:.2f} us, "
+                 f"HBM traffic per step (2*FETCH+WRITE) {dom['hbm_bytes_per_launch']/1e6:.2f} MB.\n\n")
+    if bench_line and bench_line.get("roofline") and dom["calls"] > 0 and "inverse_launches" not in dom:
         r = bench_line["roofline"]
         frac_trace = r["algorithmic_bytes_per_launch"] / (dom["avg_us"] * 1e-6) / 1e9 / r["peak"]
         fh.write(f"Cross-check of the bench line's roofline object: in-solve step time (hipEvents around the Krylov chunks, "
