@@ -114,7 +114,9 @@ inline SpmvPlan plan_pipe(int n, long nnz, int maxlen) {
     } else {
         g = mean < 16.0 ? 4 : (mean < 24.0 ? 8 : 16);
         if (g == 8 && maxlen > 8 * mean && maxlen > 128) g = 16;
-        unr = g == 4 ? (maxlen > 48 ? 2 : 1) : 2;
+        // (round 4: FOUR chains while the mean stays below 12 -- a Frank-Wolfe vertex gives 4 % of the rows 40-65 entries, a 4-lane group
+        // walks them in 16 rounds while its wave idles along, profiles/r4_hub_rows_pmc.txt: configs[3] iterates 1-2 14.1 -> 13.1 / 13.5 us)
+        unr = g == 4 ? (maxlen > 48 ? (mean < 12.0 ? 4 : 2) : 1) : 2;
         // at most grid_cap() workgroups (each re-reads every workgroup's partials): grow the workgroup instead of
         // the grid (wave 0 of every workgroup only runs the prologue: BLOCK - 64 threads own rows)
         blk = 256;
