@@ -61,6 +61,7 @@ struct LanView {
 // weight_graph_lap_from_edges, mac/utils/graphs.py:58-98)
 // ------------------------------------------------------------------------------------------
 // Pass 1: active entries per row (+1 for the diagonal) and one total per workgroup.
+constexpr int kAsmGrid = 4096;     // most workgroups of the assembly kernels (stride of their per-workgroup result arrays)
 constexpr long long kAsmInactive = 0x7ff8dead00000001ll;   // a NaN payload no arithmetic produces: "slot not active"
 // (round 3: the value of every slot -- x_k w_k, the fixed weight, or the marker above for an inactive slot -- is parked in slot order
 // here, so that the fill pass streams it instead of gathering x[k] a second time: the pattern walk used to fetch ~10x the
@@ -108,11 +109,11 @@ __global__ __launch_bounds__(kBlock) void k_asm_count(PatternView P, const doubl
     __syncthreads();
     if (threadIdx.x == 0) {
         blk_sum[blockIdx.x] = tot;
-        blk_sum[kMaxGrid + blockIdx.x] = stot;                                   // active candidates
+        blk_sum[kAsmGrid + blockIdx.x] = stot;                                   // active candidates
         const int longest = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
-        blk_sum[2 * kMaxGrid + blockIdx.x] = longest;                            // longest row
+        blk_sum[2 * kAsmGrid + blockIdx.x] = longest;                            // longest row
         if (hsum) {     // the host's copy, written straight into mapped pinned memory (no copy kernel behind the launch)
-            hsum[blockIdx.x] = tot; hsum[kMaxGrid + blockIdx.x] = stot; hsum[2 * kMaxGrid + blockIdx.x] = longest;
+            hsum[blockIdx.x] = tot; hsum[kAsmGrid + blockIdx.x] = stot; hsum[2 * kAsmGrid + blockIdx.x] = longest;
         }
     }
 }
@@ -120,6 +121,20 @@ __global__ __launch_bounds__(kBlock) void k_asm_count(PatternView P, const doubl
 // Pass 2: workgroup base = sum of the preceding workgroup totals; exclusive scan of the row
 // counts in LDS; each G-lane group compacts the active slots of its rows (ballot + popcount,
 // order preserved => columns stay sorted) behind the diagonal entry.
+// Round 5: the fill pass also leaves what the column-panel form (panel.h) needs of every row -- where its entries of each column
+// panel start (`ps`), its tridiagonal band (`bd`, `bpk`) -- while the row's columns are in registers anyway: k_pan_rows (one thread
+// walking one row, 36 us per Frank-Wolfe iteration at configs[3]) no longer runs on matrices this library assembles.  The panel
+// shape is a function of n alone, so the table is written before the host knows whether the panel step will run (NP = 0: no table).
+struct PanSpec {
+    int NP = 0;             // column panels (0: nothing to write)
+    int C = 1;              // columns per panel
+    int band = 0;           // columns r - 1 / r + 1 are kept out of the tiles
+    int* ps = nullptr;      // [n][NP + 1] first off-diagonal entry of row r at or behind panel p
+    double* bd = nullptr;   // [3][n] diagonal, column r - 1, column r + 1
+    int* bpk = nullptr;     // [n] (CSR index of the row's first off-diagonal band entry) << 3 | how many there are
+    int* ovf = nullptr;     // raised when a row holds more than 7 band entries (duplicates of a chain pair): the gather step serves the matrix
+};
+
 template <int G>
 __global__ __launch_bounds__(kBlock) void k_asm_fill(PatternView P, const double* __restrict__ sval,
                                                      int rows_per_block,
@@ -127,7 +142,7 @@ __global__ __launch_bounds__(kBlock) void k_asm_fill(PatternView P, const double
                                                      const int* __restrict__ blk_sum,
                                                      int* __restrict__ rowptr, int* __restrict__ col,
                                                      double* __restrict__ val,
-                                                     double* __restrict__ blk_lnorm) {
+                                                     double* __restrict__ blk_lnorm, PanSpec S = PanSpec()) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     int* s_off = reinterpret_cast<int*>(smem_raw);                    // rows_per_block + 1
     __shared__ int sm_i[4];
@@ -144,23 +159,24 @@ __global__ __launch_bounds__(kBlock) void k_asm_fill(PatternView P, const double
     for (int b = tid; b < (int)blockIdx.x; b += kBlock) acc += blk_sum[b];
     const int base = block_sum_i(acc, sm_i);
 
-    // exclusive scan of cnt[r0..r1) -> s_off[0..nr]
+    // exclusive scan of cnt[r0..r1) -> s_off[0..nr]: per-thread runs of `per` rows, wave scans, four wave totals
+    // (round 5: thread 0 used to walk the 256 per-thread sums in LDS one after the other -- a 12 us chain at the head of every workgroup)
     const int per = (nr + kBlock - 1) / kBlock;
     int csum = 0;
     for (int i = 0; i < per; ++i) {
         const int idx = tid * per + i;
         if (idx < nr) csum += cnt[r0 + idx];
     }
-    s_chunk[tid] = csum;
-    __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        for (int t = 0; t < kBlock; ++t) { const int c = s_chunk[t]; s_chunk[t] = run; run += c; }
-        s_off[nr] = run;
-    }
-    __syncthreads();
     {
-        int run = s_chunk[tid];
+        const int ln = tid & 63, wv = tid >> 6;
+        int x = csum;
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, kWave); if (ln >= o) x += y; }
+        if (ln == 63) s_chunk[wv] = x;
+        __syncthreads();
+        int before = 0;
+        for (int q = 0; q < wv; ++q) before += s_chunk[q];
+        int run = before + x - csum;          // exclusive prefix of this thread's rows
+        if (tid == kBlock - 1) s_off[nr] = before + x;
         for (int i = 0; i < per; ++i) {
             const int idx = tid * per + i;
             if (idx < nr) { s_off[idx] = run; run += cnt[r0 + idx]; }
@@ -174,6 +190,10 @@ __global__ __launch_bounds__(kBlock) void k_asm_fill(PatternView P, const double
         const int out = base + s_off[r - r0];
         int pos = out + 1;
         double dsum = 0.0, asum = 0.0;
+        int lastpid = 0;                        // panel of the row's last active entry so far (group-uniform)
+        int hb = 0x7fffffff, hn = 0;            // band entries (columns r - 1, r + 1): first position, how many
+        double vl = 0.0, vu = 0.0;
+        const int gbase = ((tid & 63) / G) * G; // first lane of this group inside its wave
         for (int p0 = b; p0 < e; p0 += G) {
             const int p = p0 + lane;
             const bool in = p < e;
@@ -183,15 +203,48 @@ __global__ __launch_bounds__(kBlock) void k_asm_fill(PatternView P, const double
             const unsigned long long bal = __ballot(act);
             unsigned long long gm;
             if (G == 64) gm = bal;
-            else gm = (bal >> (((tid & 63) / G) * G)) & ((1ull << (G & 63)) - 1ull);
-            const int before = __popcll(gm & ((1ull << lane) - 1ull));
-            if (act) { col[pos + before] = P.pcol[p]; val[pos + before] = -v; }
+            else gm = (bal >> gbase) & ((1ull << (G & 63)) - 1ull);
+            const unsigned long long below = gm & ((1ull << lane) - 1ull);
+            const int before = __popcll(below);
+            const int c = act ? P.pcol[p] : 0;
+            if (act) { col[pos + before] = c; val[pos + before] = -v; }
+            if (S.NP) {
+                // entry at position q of panel pid, its predecessor in the row of panel ppid: the panels (ppid, pid] start at q
+                const int pid = act ? c / S.C : 0;
+                const int src = below ? 63 - __builtin_clzll(below) : 0;
+                const int got = __shfl(pid, gbase + src, kWave);
+                const int ppid = below ? got : lastpid;
+                if (act) {
+                    const int q = pos + before;
+                    for (int pp = ppid + 1; pp <= pid; ++pp) S.ps[(size_t)r * (S.NP + 1) + pp] = q;
+                    if (S.band && (c == r - 1 || c == r + 1)) {
+                        hb = q; hn = 1;
+                        if (c == r - 1) vl = -v; else vu = -v;
+                    }
+                }
+                if (gm) lastpid = __shfl(pid, gbase + 63 - __builtin_clzll(gm), kWave);
+            }
             pos += __popcll(gm);
             dsum += v;
             asum += fabs(v);
         }
         dsum = group_sum<G>(dsum);
         asum = group_sum<G>(asum);
+        if (S.NP) {
+            if (lane == 0) S.ps[(size_t)r * (S.NP + 1)] = out + 1;
+            for (int pp = lastpid + 1 + lane; pp <= S.NP; pp += G) S.ps[(size_t)r * (S.NP + 1) + pp] = pos;      // panels behind the last entry
+            if (S.band) {
+                hn = group_sum_i<G>(hn);
+                vl = group_sum<G>(vl); vu = group_sum<G>(vu);          // (one lane holds each value, the others add exact zeros)
+#pragma unroll
+                for (int o = G / 2; o > 0; o >>= 1) hb = min(hb, __shfl_xor(hb, o, kWave));
+                if (lane == 0) {
+                    S.bpk[r] = ((hn ? hb : pos) << 3) | min(hn, 7);
+                    if (hn > 7) *S.ovf = 1;
+                    S.bd[r] = dsum; S.bd[(size_t)P.n + r] = vl; S.bd[2 * (size_t)P.n + r] = vu;
+                }
+            }
+        }
         if (lane == 0) {
             rowptr[r] = out;
             col[out] = r;
@@ -1037,22 +1090,6 @@ __global__ __launch_bounds__(kBlock) void k_resid_l1(const double* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-// Supergradient  g_k = (w_k (v_i - v_j)) (v_i - v_j)   (mac/solvers/mac.py:117-124; same
-// operation order, no fused multiply-add, so it is bit-exact with the reference given v)
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_grad(const int* __restrict__ ci, const int* __restrict__ cj,
-                                                 const double* __restrict__ cw, const double* __restrict__ v,
-                                                 long lo, long hi, double* __restrict__ g, PeerVecs all = PeerVecs()) {
-#pragma clang fp contract(off)   // plain operators under 'contract off': every op rounds once
-    for (long k = lo + (long)blockIdx.x * kBlock + threadIdx.x; k < hi; k += (long)gridDim.x * kBlock) {
-        const double d = v[ci[k]] - v[cj[k]];
-        const double t = cw[k] * d;
-        if (all.n) { for (int q = 0; q < all.n; ++q) all.v[q][k] = t * d; }   // (IPC communicator: the shard goes into every rank's gradient)
-        else g[k] = t * d;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // Top-k LP oracle (solve_subset_box_lp, mac/optimization/constraints.py:12-22): radix select
 // of the k-th largest g on order-preserving 64-bit keys, 6 digit passes (11,11,11,11,11,9 bits),
 // LDS histograms flushed with integer atomics; the last workgroup to finish a pass scans the
@@ -1074,21 +1111,131 @@ __device__ __forceinline__ unsigned long long f64_key(double d) {
 }
 
 constexpr int kBins = 2048;
+constexpr int kSelRep = 16;        // replicas of the first digit's histogram when k_grad<true> counts it (hist + 6 kBins ...)
 
 __device__ __forceinline__ int sel_shift(int pass) { return pass < 5 ? 53 - 11 * pass : 0; }
 __device__ __forceinline__ int sel_bits(int pass) { return pass < 5 ? 11 : 9; }
 
-__global__ __launch_bounds__(kBlock) void k_sel_pass(const double* __restrict__ g, long m, int pass,
-                                                     unsigned int* __restrict__ hist /*[6][kBins]*/,
-                                                     SelState* st) {
+// ------------------------------------------------------------------------------------------
+// Supergradient  g_k = (w_k (v_i - v_j)) (v_i - v_j)   (mac/solvers/mac.py:117-124; same
+// operation order, no fused multiply-add, so it is bit-exact with the reference given v)
+// HIST (round 5): the first digit pass of the top-K select rides along -- g_k is in a register here, its top 11 key bits go
+// into an LDS histogram that is flushed into hist[0 .. kBins) (zeroed by k_sel_init in front of this launch): one 8 m-byte
+// pass over g and one launch less per Frank-Wolfe iteration.  Single rank only (a sharded gradient sees its own range).
+// ------------------------------------------------------------------------------------------
+template <bool HIST>
+__global__ __launch_bounds__(kBlock) void k_grad(const int* __restrict__ ci, const int* __restrict__ cj,
+                                                 const double* __restrict__ cw, const double* __restrict__ v,
+                                                 long lo, long hi, double* __restrict__ g, PeerVecs all = PeerVecs(),
+                                                 unsigned int* __restrict__ hist0 = nullptr) {
+#pragma clang fp contract(off)   // plain operators under 'contract off': every op rounds once
+    __shared__ unsigned int lh[HIST ? kBins : 1];
+    if (HIST) {
+        for (int i = threadIdx.x; i < kBins; i += kBlock) lh[i] = 0;
+        __syncthreads();
+    }
+    unsigned int cur = 0xffffffffu, run = 0;
+    for (long k = lo + (long)blockIdx.x * kBlock + threadIdx.x; k < hi; k += (long)gridDim.x * kBlock) {
+        const double d = v[ci[k]] - v[cj[k]];
+        const double t = cw[k] * d;
+        const double gk = t * d;
+        if (all.n) { for (int q = 0; q < all.n; ++q) all.v[q][k] = gk; }   // (IPC communicator: the shard goes into every rank's gradient)
+        else g[k] = gk;
+        if (HIST) {
+            const unsigned int bin = (unsigned int)(f64_key(gk) >> sel_shift(0));
+            if (bin == cur) ++run;
+            else { if (run) atomicAdd(&lh[cur], run); cur = bin; run = 1; }
+        }
+    }
+    if (HIST) {
+        if (run) atomicAdd(&lh[cur], run);
+        __syncthreads();
+        // (performed before the next launch reads them: the kernel boundary orders.  kSelRep replicas of the histogram: a gradient's
+        // first digit lands in two or three bins, and 4 096 workgroups adding to the same words serialise at the memory side --
+        // 33 us of a 54 us launch when first measured)
+        unsigned int* hr = hist0 + (size_t)(blockIdx.x % kSelRep) * kBins;
+        for (int i = threadIdx.x; i < kBins; i += kBlock)
+            if (lh[i]) atomicAdd(&hr[i], lh[i]);
+    }
+}
+
+// The scan that closes a digit pass (one workgroup of BLOCK threads): walk the bins from the top until the cumulative count reaches
+// the rank still to find, publish (prefix, remaining rank) for the next pass -- or the finished threshold.
+template <int BLOCK, class LoadBin>
+__device__ __forceinline__ void sel_close_pass(LoadBin load_bin, int pass, unsigned long long prefix, SelState* st,
+                                               unsigned int* s_w /* BLOCK / 64 words of LDS */) {
+    const int tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+    const int sh = sel_shift(pass), nb = sel_bits(pass);
+    const long long kk = pass ? st->kk : st->k;
+    const int nbins = 1 << nb;
+    constexpr int per = kBins / BLOCK;   // bins per thread, thread 0 owns the TOP bins
+    unsigned int c[per];
+    unsigned int tsum = 0;
+#pragma unroll
+    for (int q = 0; q < per; ++q) {
+        const int bin = nbins - 1 - (tid * per + q);
+        c[q] = bin >= 0 ? load_bin(bin) : 0u;
+        tsum += c[q];
+    }
+    unsigned int x = tsum;                               // inclusive scan over the BLOCK per-thread sums (counts fit 32 bits)
+    for (int o = 1; o < 64; o <<= 1) { const unsigned int y = __shfl_up(x, o, kWave); if (ln >= o) x += y; }
+    __syncthreads();
+    if (ln == 63) s_w[wv] = x;
+    __syncthreads();
+    for (int q = 0; q < wv; ++q) x += s_w[q];
+    const long long pre = (long long)x;
+    if (pre >= kk && pre - (long long)tsum < kk) {      // exactly one thread owns the kk-th key
+        long long rem = kk - (pre - (long long)tsum);
+        int q = 0;
+        for (; q < per; ++q) {
+            if ((long long)c[q] >= rem) break;
+            rem -= c[q];
+        }
+        const int bin = nbins - 1 - (tid * per + q);
+        st->kk = rem;
+        st->prefix = (prefix << nb) | (unsigned long long)bin;
+        if (pass == 5) {
+            st->T = (prefix << nb) | (unsigned long long)bin;
+            st->cnt_eq = (long long)c[q];
+        } else if ((long long)c[q] == rem) {   // the whole bucket is selected: T = its lowest key, every "tie" counts
+            st->T = ((prefix << nb) | (unsigned long long)bin) << sh;
+            st->cnt_eq = rem;
+            st->ticket[7] = 1u;
+        }
+    }
+}
+
+// Closes digit pass 0 when its histogram came from somewhere else (k_grad<true>: the supergradient kernel counts the first digit).
+__global__ __launch_bounds__(1024) void k_sel_close0(unsigned int* __restrict__ hist, SelState* st) {
+    __shared__ unsigned int s_w[1024 / 64];
+    if (st->k <= 0) return;
+    const unsigned int* rep = hist + 6 * kBins;                 // kSelRep replicas filled by k_grad<true> (complete: kernel boundary)
+    sel_close_pass<1024>([rep](int bin) {
+        unsigned int v[kSelRep];
+#pragma unroll
+        for (int r = 0; r < kSelRep; ++r) v[r] = rep[(size_t)r * kBins + bin];       // (plain loads, all in flight: written by the previous launch)
+        unsigned int a = 0;
+#pragma unroll
+        for (int r = 0; r < kSelRep; ++r) a += v[r];
+        return a; }, 0, 0ull, st, s_w);
+}
+
+// U keys per thread and round, their loads issued together: with one key per round a thread's 30 keys at 2 M candidates
+// were 30 dependent memory round trips (21 us for a 16 MB pass; round 3: U = 4).  Round 5: what a pass over a dense digit costs
+// is the FLUSH -- every workgroup adds its ~2 000 non-empty bins to the global histogram with returning device-scope atomics,
+// 512 workgroups = a million atomics = 17 us -- so the workgroups are few and large (BLOCK = 1 024 threads on one LDS histogram).
+template <int U, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_sel_pass(const double* __restrict__ g, long m, int pass,
+                                                    unsigned int* __restrict__ hist /*[6][kBins]*/,
+                                                    SelState* st) {
     __shared__ unsigned int lh[kBins];
     __shared__ unsigned int s_last;
-    __shared__ unsigned int s_scan[kBlock];
+    __shared__ unsigned int s_w[BLOCK / 64];
     const int tid = threadIdx.x;
     // an earlier pass found a bucket that is needed completely: the remaining digits cannot change the
     // selected set (ticket[7] is that pass's "done" mark; typical after 3 of the 6 passes on a gradient)
     if (pass && st->ticket[7]) return;
-    for (int i = tid; i < kBins; i += kBlock) lh[i] = 0;
+    for (int i = tid; i < kBins; i += BLOCK) lh[i] = 0;
     __syncthreads();
     const int sh = sel_shift(pass), nb = sel_bits(pass);
     const unsigned long long prefix = pass ? st->prefix : 0ull;
@@ -1096,16 +1243,13 @@ __global__ __launch_bounds__(kBlock) void k_sel_pass(const double* __restrict__ 
     // the high digits of a gradient vector fall into a handful of bins: count runs of equal
     // digits in registers and touch the LDS histogram once per run, not once per key
     unsigned int cur = 0xffffffffu, run = 0;
-    // four keys per thread and round, their loads issued together: with one key per round a thread's 30 keys at 2 M candidates
-    // were 30 dependent memory round trips (21 us for a 16 MB pass; round 3)
-    constexpr int U = 4;
-    for (long i0 = (long)blockIdx.x * (kBlock * U) + tid; i0 < m; i0 += (long)gridDim.x * (kBlock * U)) {
+    for (long i0 = (long)blockIdx.x * (BLOCK * U) + tid; i0 < m; i0 += (long)gridDim.x * (BLOCK * U)) {
         double gv[U];
 #pragma unroll
-        for (int q = 0; q < U; ++q) { const long i = i0 + (long)q * kBlock; gv[q] = g[i < m ? i : m - 1]; }
+        for (int q = 0; q < U; ++q) { const long i = i0 + (long)q * BLOCK; gv[q] = g[i < m ? i : m - 1]; }
 #pragma unroll
         for (int q = 0; q < U; ++q) {
-            if (i0 + (long)q * kBlock >= m) continue;
+            if (i0 + (long)q * BLOCK >= m) continue;
             const unsigned long long key = f64_key(gv[q]);
             const bool match = pass == 0 || (key >> (sh + nb)) == prefix;
             if (match) {
@@ -1130,7 +1274,7 @@ __global__ __launch_bounds__(kBlock) void k_sel_pass(const double* __restrict__ 
     // the last workgroup occasionally read a bin before every add had landed, and the selection came
     // out a few elements too large.  Found by tools/round_check.py.)
     unsigned int seen = 0;
-    for (int i = tid; i < kBins; i += kBlock)
+    for (int i = tid; i < kBins; i += BLOCK)
         if (lh[i]) seen |= __hip_atomic_fetch_add(&gh[i], lh[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("" ::"v"(seen));
     __syncthreads();
@@ -1139,45 +1283,7 @@ __global__ __launch_bounds__(kBlock) void k_sel_pass(const double* __restrict__ 
     __syncthreads();
     if (!s_last) return;
     // last workgroup: walk the bins from the top until the cumulative count reaches kk
-    const long long kk = pass ? st->kk : st->k;
-    const int nbins = 1 << nb;
-    const int per = kBins / kBlock;   // 8 bins per thread, thread 0 owns the TOP bins
-    unsigned int c[kBins / kBlock];
-    unsigned int tsum = 0;
-    for (int q = 0; q < per; ++q) {
-        const int bin = nbins - 1 - (tid * per + q);
-        c[q] = bin >= 0 ? __hip_atomic_load(&gh[bin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        tsum += c[q];
-    }
-    s_scan[tid] = tsum;
-    __syncthreads();
-    // inclusive prefix over the 256 per-thread sums (Hillis-Steele in LDS; counts fit 32 bits)
-    for (int off = 1; off < kBlock; off <<= 1) {
-        const unsigned int add = tid >= off ? s_scan[tid - off] : 0u;
-        __syncthreads();
-        s_scan[tid] += add;
-        __syncthreads();
-    }
-    const long long pre = (long long)s_scan[tid];
-    if (pre >= kk && pre - (long long)tsum < kk) {      // exactly one thread owns the kk-th key
-        long long rem = kk - (pre - (long long)tsum);
-        int q = 0;
-        for (; q < per; ++q) {
-            if ((long long)c[q] >= rem) break;
-            rem -= c[q];
-        }
-        const int bin = nbins - 1 - (tid * per + q);
-        st->kk = rem;
-        st->prefix = (prefix << nb) | (unsigned long long)bin;
-        if (pass == 5) {
-            st->T = (prefix << nb) | (unsigned long long)bin;
-            st->cnt_eq = (long long)c[q];
-        } else if ((long long)c[q] == rem) {   // the whole bucket is selected: T = its lowest key, every "tie" counts
-            st->T = ((prefix << nb) | (unsigned long long)bin) << sh;
-            st->cnt_eq = rem;
-            st->ticket[7] = 1u;
-        }
-    }
+    sel_close_pass<BLOCK>([gh](int bin) { return __hip_atomic_load(&gh[bin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }, pass, prefix, st, s_w);
 }
 
 // Ties at the k-th value: select the lowest indices.  One workgroup; exits at once in the

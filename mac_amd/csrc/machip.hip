@@ -106,6 +106,7 @@ struct machip_problem {
     int maxlen = 0;           // longest row of the assembled L(x)
     double lnorm = 0.0;
     bool assembled = false, have_vec = false, csr_only = false;
+    bool band_dups_ok = true;    // no row holds more than 7 slots of columns r - 1 / r + 1 (the panel form packs that count in 3 bits)
     // select / FW scalars
     unsigned int* hist = nullptr;
     SelState* sel = nullptr;
@@ -216,6 +217,11 @@ int build_pattern(machip_problem* p, int64_t nf, const int32_t* fi, const int32_
             }
         }
         if (pcol.size() > 2000000000ull) return fail(MACHIP_BAD_ARG, "pattern exceeds int32 indexing");
+        {
+            int band_slots = 0;
+            for (size_t q = (size_t)prow[(size_t)r]; q < pcol.size(); ++q) band_slots += (pcol[q] == r - 1 || pcol[q] == r + 1);
+            if (band_slots > 7) p->band_dups_ok = false;
+        }
         prow[(size_t)r + 1] = (int)pcol.size();
     }
     p->P = (long)pcol.size();
@@ -233,7 +239,9 @@ int build_pattern(machip_problem* p, int64_t nf, const int32_t* fi, const int32_
     while (G < 64 && G < mean * 0.75) G <<= 1;
     p->asm_G = env_int("MACHIP_ASM_G", G);
     const int gpb = kBlock / p->asm_G;
-    long nblk = std::min<long>(kMaxGrid, ((long)n + gpb - 1) / gpb);
+    // (round 5: up to 4 096 workgroups -- with 1 024 a G-lane group walked 13 rows one after the other at configs[3], each a chain of
+    // dependent loads: prow -> pk -> x[pk]; the pass was latency-bound at a quarter of the chip's memory-level parallelism)
+    long nblk = std::min<long>(std::min(kAsmGrid, std::max(1, env_int("MACHIP_ASM_MAXGRID", kAsmGrid))), ((long)n + gpb - 1) / gpb);
     if (nblk < 1) nblk = 1;
     long rpb = ((long)n + nblk - 1) / nblk;
     rpb = (rpb + gpb - 1) / gpb * gpb;
@@ -247,22 +255,25 @@ int build_pattern(machip_problem* p, int64_t nf, const int32_t* fi, const int32_
 }
 
 template <int G>
-void launch_asm(machip_problem* p) {
+void launch_asm(machip_problem* p, const PanSpec& S) {
     const PatternView P = p->pattern();
     k_asm_count<G><<<p->asm_grid, kBlock, 0, p->stream>>>(P, p->x, p->tol_sel, p->asm_rpb, p->cnt, p->blk_sum, p->sval, p->d_hint);
     const size_t lds = sizeof(int) * ((size_t)p->asm_rpb + 1);
     k_asm_fill<G><<<p->asm_grid, kBlock, lds, p->stream>>>(P, p->sval, p->asm_rpb, p->cnt, p->blk_sum,
-                                                           p->rowptr, p->col, p->val, p->d_hdbl);   // (row-sum maxima: host only)
+                                                           p->rowptr, p->col, p->val, p->d_hdbl, S);   // (row-sum maxima: host only)
 }
 
 int assemble(machip_problem* p) {
     if (p->csr_only) return fail(MACHIP_BAD_ARG, "handle wraps a caller CSR; nothing to assemble");
+    // the fill pass writes the column-panel form's per-row tables on the side where that form can run at this n (solver.h)
+    PanSpec S;
+    ST_TRY(p->sol.pan_spec_prepare(&S));
     switch (p->asm_G) {
-        case 4: launch_asm<4>(p); break;
-        case 8: launch_asm<8>(p); break;
-        case 16: launch_asm<16>(p); break;
-        case 32: launch_asm<32>(p); break;
-        default: launch_asm<64>(p); break;
+        case 4: launch_asm<4>(p, S); break;
+        case 8: launch_asm<8>(p, S); break;
+        case 16: launch_asm<16>(p, S); break;
+        case 32: launch_asm<32>(p, S); break;
+        default: launch_asm<64>(p, S); break;
     }
     HIP_TRY(hipGetLastError());       // a refused launch must not leave stale row offsets behind a MACHIP_OK
     const int gb = p->asm_grid;
@@ -271,7 +282,7 @@ int assemble(machip_problem* p) {
     int maxlen = 0;
     double ln = 0.0;
     for (int b = 0; b < gb; ++b) {
-        nnz += p->h_int[b]; supp += p->h_int[kMaxGrid + b]; maxlen = std::max(maxlen, p->h_int[2 * kMaxGrid + b]);
+        nnz += p->h_int[b]; supp += p->h_int[kAsmGrid + b]; maxlen = std::max(maxlen, p->h_int[2 * kAsmGrid + b]);
         ln = std::max(ln, p->h_dbl[b]);
     }
     p->nnz = nnz; p->support = supp; p->lnorm = ln; p->maxlen = maxlen;
@@ -281,15 +292,16 @@ int assemble(machip_problem* p) {
 
 int alloc_common(machip_problem* p, int vbudget_mb = 0) {
     ST_TRY(p->sol.init(p->n, p->stream, vbudget_mb));
-    HIP_TRY(hipHostMalloc((void**)&p->h_int, sizeof(int) * 3 * kMaxGrid, hipHostMallocMapped));
-    HIP_TRY(hipHostMalloc((void**)&p->h_dbl, sizeof(double) * 4 * kMaxGrid, hipHostMallocMapped));
+    HIP_TRY(hipHostMalloc((void**)&p->h_int, sizeof(int) * 3 * kAsmGrid, hipHostMallocMapped));
+    HIP_TRY(hipHostMalloc((void**)&p->h_dbl, sizeof(double) * std::max(4 * kMaxGrid, kAsmGrid), hipHostMallocMapped));
     HIP_TRY(hipHostGetDevicePointer((void**)&p->d_hint, p->h_int, 0));
     HIP_TRY(hipHostGetDevicePointer((void**)&p->d_hdbl, p->h_dbl, 0));
     return MACHIP_OK;
 }
 
 // k-th largest of keys[0..m): threshold, remaining rank and tie rule into *st.
-int select_on(machip_problem* p, const double* keys, long k, SelState* st, int prefer_high) {
+// hist0_done: the first digit's histogram has been counted by the producer of the keys (k_grad<true>) behind a k_sel_init.
+int select_on(machip_problem* p, const double* keys, long k, SelState* st, int prefer_high, bool hist0_done = false) {
     const long m = p->m;
     if (k < 0) k = 0;
     if (k > m) k = m;
@@ -298,19 +310,24 @@ int select_on(machip_problem* p, const double* keys, long k, SelState* st, int p
         HIP_TRY(hipGetLastError());
         return MACHIP_OK;
     }
-    k_sel_init<<<1, 1024, 0, p->stream>>>(st, (long long)k, p->hist, 6 * kBins);
+    if (!hist0_done) k_sel_init<<<1, 1024, 0, p->stream>>>(st, (long long)k, p->hist, 6 * kBins);
     if (k > 0) {
-        // <= 256 workgroups: every arrival is one serialized device-scope atomic on the ticket word
-        const int grid = (int)std::min<long>(256, (m + kBlock * 4 - 1) / (kBlock * 4));
-        for (int pass = 0; pass < 6; ++pass)
-            k_sel_pass<<<std::max(grid, 1), kBlock, 0, p->stream>>>(keys, m, pass, p->hist, st);
+        // few, large workgroups: a dense digit costs one returning device-scope atomic per non-empty bin and workgroup (kernels.h)
+        const int B = env_int("MACHIP_SEL_BLOCK", 1024) == 256 ? 256 : 1024;
+        const int U = B == 256 ? 8 : 4;
+        const int grid = (int)std::max<long>(1, std::min<long>(env_int("MACHIP_SEL_GRID", B == 256 ? 256 : 128), (m + (long)B * U - 1) / ((long)B * U)));
+        if (hist0_done) k_sel_close0<<<1, 1024, 0, p->stream>>>(p->hist, st);
+        for (int pass = hist0_done ? 1 : 0; pass < 6; ++pass) {
+            if (B == 256) k_sel_pass<8, 256><<<grid, 256, 0, p->stream>>>(keys, m, pass, p->hist, st);
+            else k_sel_pass<4, 1024><<<grid, 1024, 0, p->stream>>>(keys, m, pass, p->hist, st);
+        }
     }
     k_sel_ties<<<1, 1024, 0, p->stream>>>(keys, m, st, prefer_high);
     HIP_TRY(hipGetLastError());
     return MACHIP_OK;
 }
 
-int select_topk(machip_problem* p, long k) { return select_on(p, p->g, k, p->sel, 0); }
+int select_topk(machip_problem* p, long k, bool hist0_done = false) { return select_on(p, p->g, k, p->sel, 0, hist0_done); }
 
 // Contiguous candidate ranges: shard = ceil(m / R); rank r owns [r shard, (r+1) shard) clipped to m;
 // the gathered vector is padded to R shard entries.  The ONE place this arithmetic lives (machip_shard_plan exports it).
@@ -334,7 +351,9 @@ int local_allgather(machip_problem* p, long shard) {
     return MACHIP_OK;
 }
 
-int compute_gradient(machip_problem* p, bool have_vec_now = false) {
+// fuse_k >= 0 (single rank, long candidate lists): the first digit pass of the top-fuse_k select that follows is counted by the
+// gradient kernel itself (k_grad<true>; *fused tells the caller so)
+int compute_gradient(machip_problem* p, bool have_vec_now = false, long fuse_k = -1, bool* fused = nullptr) {
     if (!p->have_vec && !have_vec_now) return fail(MACHIP_BAD_ARG, "no Fiedler vector on the device: call machip_fiedler first");
     const long m = p->m;
     long lo = 0, hi = m, shard = m;
@@ -344,7 +363,12 @@ int compute_gradient(machip_problem* p, bool have_vec_now = false) {
         const int grid = (int)std::min<long>(kMaxGrid * 4, (hi - lo + kBlock - 1) / kBlock);
         PeerVecs all;
         if (ipc_gather) { all.n = p->ipcg->nranks; for (int q = 0; q < all.n; ++q) all.v[q] = p->ipcg->g[q]; }
-        k_grad<<<grid, kBlock, 0, p->stream>>>(p->ci, p->cj, p->cw, p->sol.yvec, lo, hi, p->g, all);
+        const bool fuse = fuse_k > 0 && p->nranks <= 1 && m > kSelSmallMax && env_int("MACHIP_SEL_FUSE", 1) != 0;
+        if (fused) *fused = fuse;
+        if (fuse) {
+            k_sel_init<<<1, 1024, 0, p->stream>>>(p->sel, (long long)std::min(fuse_k, m), p->hist, (6 + kSelRep) * kBins);
+            k_grad<true><<<grid, kBlock, 0, p->stream>>>(p->ci, p->cj, p->cw, p->sol.yvec, lo, hi, p->g, all, p->hist + 6 * kBins);
+        } else k_grad<false><<<grid, kBlock, 0, p->stream>>>(p->ci, p->cj, p->cw, p->sol.yvec, lo, hi, p->g, all);
         HIP_TRY(hipGetLastError());
     }
     if (ipc_gather) {
@@ -397,7 +421,6 @@ int run_fiedler(machip_problem* p, double tol, int max_steps, const double* x0, 
     machip_solve_stats local;
     memset(&local, 0, sizeof(local));
     p->sol.maxlen_hint = p->maxlen;
-    p->sol.pan_allowed = !p->csr_only;     // panel.h walks rows as this library assembles them (diagonal first)
     p->sol.support_hint = (p->csr_only && !p->sol.chain_like) ? -1 : p->support;
     const int st = p->sol.solve(p->csr(), p->nnz, p->lnorm, tol, max_steps, (x0 == nullptr && warm_start) ? 1 : 0,
                                 kAuto, lambda2, &local);
@@ -496,12 +519,14 @@ int machip_create(int device, int64_t n, int64_t n_fixed, const int32_t* fi, con
         HIP_TRY(hipMemset(p->x, 0, sizeof(double) * mp));
         HIP_TRY(hipMemset(p->g, 0, sizeof(double) * mp));
         const size_t cap = (size_t)p->P + (size_t)n + 8;
-        ST_TRY(dev_alloc(&p->cnt, (size_t)n + 1)); ST_TRY(dev_alloc(&p->blk_sum, 3 * kMaxGrid));
+        ST_TRY(dev_alloc(&p->cnt, (size_t)n + 1)); ST_TRY(dev_alloc(&p->blk_sum, 3 * kAsmGrid));
         ST_TRY(dev_alloc(&p->rowptr, (size_t)n + 1)); ST_TRY(dev_alloc(&p->col, cap)); ST_TRY(dev_alloc(&p->val, cap));
-        ST_TRY(dev_alloc(&p->blk_lnorm, kMaxGrid)); ST_TRY(dev_alloc(&p->sval, (size_t)p->P + 8));
-        ST_TRY(dev_alloc(&p->hist, 6 * kBins)); ST_TRY(dev_alloc(&p->sel, 2)); ST_TRY(dev_alloc(&p->part_fw, 2 * kMaxGrid));
+        ST_TRY(dev_alloc(&p->blk_lnorm, kAsmGrid)); ST_TRY(dev_alloc(&p->sval, (size_t)p->P + 8));
+        ST_TRY(dev_alloc(&p->hist, (6 + kSelRep) * kBins)); ST_TRY(dev_alloc(&p->sel, 2)); ST_TRY(dev_alloc(&p->part_fw, 2 * kMaxGrid));
         ST_TRY(alloc_common(p));
         p->sol.csr_cap = cap;
+        p->sol.pat = p->pattern();
+        p->sol.pan_allowed = p->band_dups_ok;     // panel.h walks rows as this library assembles them (diagonal first)
         // pose-graph shape: do the fixed edges contain (nearly) the whole chain (i, i+1)?  Decides
         // whether the preconditioned eigen-solver mode is considered (solver.h, precond.h).
         {
@@ -662,8 +687,9 @@ int machip_fw_step(machip_problem* p, int64_t k, int iter, double tol, int max_s
     // gradient -> top-K -> bookkeeping, on the vector in yvec
     int epi_status = MACHIP_OK;
     auto epilogue = [&](bool speculative) {
-        int st = compute_gradient(p, speculative);
-        if (st == MACHIP_OK) st = select_topk(p, (long)k);
+        bool fused = false;
+        int st = compute_gradient(p, speculative, (long)k, &fused);
+        if (st == MACHIP_OK) st = select_topk(p, (long)k, fused);
         if (st == MACHIP_OK) {
             k_fw_final<<<grid, kBlock, 0, p->stream>>>(p->g, p->x, p->m, p->sel, gamma, p->x_next, nullptr, p->d_hdbl);   // partials: host only
             if (hipGetLastError() != hipSuccess) st = fail(MACHIP_HIP_ERROR, "k_fw_final launch failed");
@@ -1088,14 +1114,16 @@ int make_lane(machip_problem* p, machip_problem** out) {
         ST_TRY(create_lane_stream(q->device, &q->stream));
         ST_TRY(dev_alloc(&q->x, (size_t)q->m + 64));
         const size_t cap = (size_t)q->P + (size_t)q->n + 8;
-        ST_TRY(dev_alloc(&q->cnt, (size_t)q->n + 1)); ST_TRY(dev_alloc(&q->blk_sum, 3 * kMaxGrid));
+        ST_TRY(dev_alloc(&q->cnt, (size_t)q->n + 1)); ST_TRY(dev_alloc(&q->blk_sum, 3 * kAsmGrid));
         ST_TRY(dev_alloc(&q->rowptr, (size_t)q->n + 1)); ST_TRY(dev_alloc(&q->col, cap)); ST_TRY(dev_alloc(&q->val, cap));
-        ST_TRY(dev_alloc(&q->blk_lnorm, kMaxGrid)); ST_TRY(dev_alloc(&q->sval, (size_t)q->P + 8));
+        ST_TRY(dev_alloc(&q->blk_lnorm, kAsmGrid)); ST_TRY(dev_alloc(&q->sval, (size_t)q->P + 8));
         // every lane keeps its own Krylov basis: a share of the handle's budget each (MACHIP_LANE_VBUDGET_MB, default
         // MACHIP_VBUDGET_MB / 8 = 512 MB: 16 lanes together hold twice what the handle itself holds; a sequence longer than
         // the lane's share restarts earlier than it would on the handle -- include/machip.h states the guarantee accordingly)
         ST_TRY(alloc_common(q, std::max(16, env_int("MACHIP_LANE_VBUDGET_MB", std::max(16, env_int("MACHIP_VBUDGET_MB", 4096) / 8)))));
         q->sol.csr_cap = cap;
+        q->sol.pat = q->pattern();
+        q->sol.pan_allowed = p->sol.pan_allowed;
         q->sol.chain_like = p->sol.chain_like; q->sol.chain_edges = p->sol.chain_edges;
         return MACHIP_OK;
     };
@@ -1113,7 +1141,7 @@ int ensure_lane_fw(machip_problem* q) {
     if (!q->x_next) ST_TRY(dev_alloc(&q->x_next, mp));
     if (!q->g) ST_TRY(dev_alloc(&q->g, mp));
     if (!q->s) ST_TRY(dev_alloc(&q->s, mp));
-    if (!q->hist) ST_TRY(dev_alloc(&q->hist, 6 * kBins));
+    if (!q->hist) ST_TRY(dev_alloc(&q->hist, (6 + kSelRep) * kBins));
     if (!q->sel) ST_TRY(dev_alloc(&q->sel, 2));
     if (!q->part_fw) ST_TRY(dev_alloc(&q->part_fw, 2 * kMaxGrid));
     HIP_TRY(hipMemsetAsync(q->g, 0, sizeof(double) * mp, q->stream));     // (never the legacy stream: another lane's thread may be capturing a graph)

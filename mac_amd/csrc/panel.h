@@ -56,7 +56,8 @@ struct PanView {
     int NTB;     // 64-row tiles per row block (rows per block R = 64 NTB <= kPanRows)
     int TWW;     // tiles per worker wave = ceil(NTB / 15); a (block, panel) has 15 TWW physical tiles
     int CELLS;   // row blocks a workgroup of k_pan_mul_multi walks (1: the single-cell kernel k_pan_mul)
-    int* tptr;              // [tiles + 1] first entry of physical tile ((b*NP + p)*15 + w)*TWW + q  (sorted tile w + 15 q)
+    int* tptr;              // [cells (15 TWW + 1)] first entry of physical tile (w TWW + q) of cell b NP + p (sorted tile w + 15 q); a cell's last entry = end of its data
+    int* cbase;             // [cells + 1] first entry of every cell's static range of bval / bcol (k_pan_cellcap)
     unsigned short* thead;  // [tiles*64] row (relative to the block) held by each slot
     double* bval;           // panel-form values, zero-padded tiles
     unsigned short* bcol;   // column minus the panel's first column
@@ -68,9 +69,8 @@ struct PanView {
     int* ovf;               // set by k_pan_rows when a row has more than kPanMaxLen entries inside ONE panel (the build would clamp it)
     int band;               // 1: the tridiagonal band (diagonal, columns r - 1 and r + 1) is kept OUT of the panel form -- bd holds it, k_pan_fin adds it
     double* bd;             // [3][n] band values: diagonal, column r - 1, column r + 1 (0 where absent)
-    int* bpk;               // [n] (CSR index of the row's first off-diagonal band entry) << 2 | how many there are (0..2): the hole k_pan_fill skips
-    int* tcount;            // [tiles] entries (with padding) per tile (assembly scratch)
-    int* ps;                // [(NP+1)][n] first off-diagonal entry of row r at or behind panel p (assembly scratch)
+    int* bpk;               // [n] (CSR index of the row's first off-diagonal band entry) << 3 | how many there are (0..7): the hole the build skips
+    int* ps;                // [n][NP+1] first off-diagonal entry of row r at or behind panel p (assembly scratch)
 #ifdef PAN_CLOCKS
     long long* clk;         // tools/ubench6.hip: 16 wall-clock stamps (100 MHz) per workgroup
 #endif
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kBlock) void k_pan_rows(CsrView A, PanView P) {
     int hb = end, hn = 0;                  // band mode: the (at most two, adjacent) entries of columns r - 1, r + 1
     double vl = 0.0, vu = 0.0;
     for (int p = 0; p < P.NP; ++p) {
-        P.ps[(size_t)p * A.n + r] = e;
+        P.ps[(size_t)r * (P.NP + 1) + p] = e;
         const int hi = (p + 1) * P.C, e0 = e;
         int inband = 0;
         while (e < end && A.col[e] < hi) {
@@ -115,15 +115,16 @@ __global__ __launch_bounds__(kBlock) void k_pan_rows(CsrView A, PanView P) {
             if (P.band && (c == r - 1 || c == r + 1)) {
                 if (!hn) hb = e;
                 ++hn; ++inband;
-                if (c == r - 1) vl = A.val[e]; else vu = A.val[e];
+                if (c == r - 1) vl += A.val[e]; else vu += A.val[e];      // (+=: a candidate may duplicate a chain pair)
             }
             ++e;
         }
         over |= e - e0 - inband + ((!P.band && r / P.C == p) ? 1 : 0) > kPanMaxLen;
     }
-    P.ps[(size_t)P.NP * A.n + r] = end;
+    P.ps[(size_t)r * (P.NP + 1) + P.NP] = end;
     if (P.band) {
-        P.bpk[r] = (hb << 2) | hn;
+        P.bpk[r] = (hb << 3) | min(hn, 7);
+        over |= hn > 7;
         P.bd[r] = A.val[A.rowptr[r]]; P.bd[(size_t)A.n + r] = vl; P.bd[2 * (size_t)A.n + r] = vu;
     }
     if (over) *P.ovf = 1;                  // (a hub row concentrated in one panel: the solver falls back to the gather step)
@@ -135,10 +136,10 @@ constexpr int kPanRT = (kPanRows + kPanThreads - 1) / kPanThreads;   // rows per
 // Band mode: neither the diagonal nor the entries of columns r - 1 / r + 1 count; *hole / *hlen = the CSR range of those inside
 // [start, end of the panel's run) that the copy has to skip (hlen = 0: none).
 __device__ __forceinline__ int pan_row_count(const PanView& P, int n, int r, int p, int* start, int* hole = nullptr, int* hlen = nullptr) {
-    const int st = P.ps[(size_t)p * n + r], en = P.ps[(size_t)(p + 1) * n + r];
+    const int st = P.ps[(size_t)r * (P.NP + 1) + p], en = P.ps[(size_t)r * (P.NP + 1) + p + 1];
     *start = st;
     if (P.band) {
-        const int pk = P.bpk[r], hb = pk >> 2, hn = pk & 3;
+        const int pk = P.bpk[r], hb = pk >> 3, hn = pk & 7;
         const int h0 = max(st, hb), h1 = min(en, hb + hn), hl = max(0, h1 - h0);
         if (hole) { *hole = h0; *hlen = hl; }
         return min(en - st - hl, kPanMaxLen);
@@ -147,108 +148,184 @@ __device__ __forceinline__ int pan_row_count(const PanView& P, int n, int r, int
     return min(en - st + (r / P.C == p ? 1 : 0), kPanMaxLen);
 }
 
-// Build kernels: workgroup id -> (row block b, panel p) such that the NP workgroups of one row block have the same id % 8,
-// i.e. run on ONE XCD (workgroups are dealt round-robin to the 8 XCDs): they read the same CSR rows -- a row's run inside a
-// panel is ~2.5 entries, so every 128-byte line is wanted by several panels -- and with b = id / NP each line was fetched into
-// eight different L2s (k_pan_fill: 338 MB fetched per launch for a 36 MB matrix).  Launch with pan_build_grid() workgroups.
-__host__ __device__ inline int pan_build_grid(int NB, int NP) { return ((NB + 7) / 8) * 8 * NP; }
+// Build kernel: workgroup id -> (row block b, panel p).  Workgroups are dealt round-robin to the 8 XCDs, and the NP cells of one
+// row block read the same CSR rows -- a row's run inside a panel is ~2.5 entries, so every 128-byte line is wanted by several
+// panels: with b = id / NP each line was fetched into eight different L2s (338 MB fetched per launch for a 36 MB matrix, round 3).
+// XCD x therefore takes the cells [x per, (x + 1) per) in row-block-major order, per = ceil(cells / 8): whole row blocks almost
+// everywhere, and no XCD more than its share (round 5: the build keeps a 150 KB LDS image -- one workgroup per CU -- and the
+// round-3 mapping, row block b on XCD b mod 8, gave five XCDs 36 cells for 32 CUs: two waves of workgroups, twice the time).
+__host__ __device__ inline int pan_build_grid(int NB, int NP) { return ((NB * NP + 7) / 8) * 8; }
 __device__ __forceinline__ bool pan_build_bp(int id, int NB, int NP, int* b, int* p) {
-    const int rest = id >> 3;
-    *p = rest % NP;
-    *b = (rest / NP) * 8 + (id & 7);
-    return *b < NB;
+    const int per = (NB * NP + 7) >> 3;
+    const int cell = (id & 7) * per + (id >> 3);
+    *b = cell / NP;
+    *p = cell - *b * NP;
+    return cell < NB * NP && (id >> 3) < per;
 }
 
-// Pass 1, one workgroup per (row block, panel): sort the block's rows by length (counting sort; ties in arrival order
-// -- a row's sum does not depend on the slot it lands in, PROVIDED the multiply-accumulate of k_pan_mul rounds the same
-// way at every chunk position: see the contraction note there -- so the tie order never shows in a result) and record
-// slot -> row and the tile sizes.
-__global__ __launch_bounds__(kPanThreads) void k_pan_count(CsrView A, PanView P) {
+// Static capacity of the cells (round 5): the entries a (row block, panel) cell can ever hold are the slots of the UNION PATTERN
+// inside it, so every cell owns a fixed range of the value / column arrays -- [cbase[cell], cbase[cell + 1]) -- and the build
+// needs no scan over the tiles of the whole matrix (k_pan_scan, one workgroup, 20 us per Frank-Wolfe iteration, is gone; count
+// and fill are one launch).  Counted once per handle and panel shape; cellcnt[cell] = pattern slots of the cell.
+__global__ __launch_bounds__(kBlock) void k_pan_cellcap(PatternView Pt, int R, int C, int NP, int* __restrict__ cellcnt) {
+    const int r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= Pt.n) return;
+    const int b = r / R;
+    int run = 0, cur = -1;
+    for (int e = Pt.prow[r]; e < Pt.prow[r + 1]; ++e) {
+        const int p = Pt.pcol[e] / C;
+        if (p != cur) { if (run) atomicAdd(&cellcnt[b * NP + cur], run); cur = p; run = 0; }
+        ++run;
+    }
+    if (run) atomicAdd(&cellcnt[b * NP + cur], run);
+}
+
+// The panel form of one cell in ONE launch (round 5; was k_pan_count + k_pan_scan + k_pan_fill): sort the block's rows by
+// their number of entries in the panel (counting sort in LDS; ties in arrival order -- a row's sum does not depend on the slot
+// it lands in, PROVIDED the multiply-accumulate of k_pan_mul rounds the same way at every chunk position: see the contraction
+// note there), cut them into 64-row tiles, and copy every row's entries into the slot it was dealt, zero-padded to the tile's
+// height.  The copy goes THROUGH LDS: a thread reads ITS rows' short runs (batched: the first four entries of all eight rows
+// are in flight together) and drops them at their final offsets of an LDS image of the cell (zeroed first: the padding), and the
+// image is then streamed out with perfectly coalesced stores -- written straight from the row-owning threads, a tile row's 512
+// bytes came from 64 different waves, one 8-byte request each (117 us per launch at configs[3]; the first build of this kernel).
+// An image holds kPanStage entries; a larger cell takes several rounds (ranges of the cell's entries, whatever tile they belong to).
+// Tile table: tptr[cell (NTP + 1) + physical tile], the cell's last entry = end of its data (cells are not adjacent in memory).
+constexpr int kPanStage = 15360;       // entries of the LDS image (120 KB of values + 30 KB of columns: one workgroup per CU)
+__global__ __launch_bounds__(kPanThreads) void k_pan_build(CsrView A, PanView P) {
+    __shared__ double sval[kPanStage];
+    __shared__ __attribute__((aligned(16))) unsigned short scol[kPanStage];
     __shared__ int hist[kPanMaxLen + 1], start[kPanMaxLen + 1], fill[kPanMaxLen + 1];
+    __shared__ int toff[kPanWork * kPanTW + 1];
+    static_assert(kPanStage * 10 + 3 * (kPanMaxLen + 1) * 4 + (kPanWork * kPanTW + 1) * 4 + 256 <= 163840, "the LDS image of a cell must fit one CU");
     int b, p;
     if (!pan_build_bp((int)blockIdx.x, P.NB, P.NP, &b, &p)) return;
     const int tid = threadIdx.x;
     const int R = 64 * P.NTB, NTP = kPanWork * P.TWW;
+    const int cell = b * P.NP + p;
+    const int c0 = p * P.C;
     if (tid <= kPanMaxLen) { hist[tid] = 0; fill[tid] = 0; }
     __syncthreads();
-    int c[kPanRT];
+    int c[kPanRT], st[kPanRT], hole[kPanRT], hlen[kPanRT];
 #pragma unroll
     for (int j = 0; j < kPanRT; ++j) {
         const int rl = tid + kPanThreads * j, r = b * R + rl;
-        int st;
-        c[j] = (rl < R && r < A.n) ? pan_row_count(P, A.n, r, p, &st) : 0;
-        if (rl < R) atomicAdd(&hist[c[j]], 1);
+        st[j] = 0; hole[j] = 0; hlen[j] = 0;
+        c[j] = (rl < R && r < A.n) ? pan_row_count(P, A.n, r, p, &st[j], &hole[j], &hlen[j]) : 0;
     }
-    __syncthreads();
-    if (tid == 0) { int run = 0; for (int Lc = kPanMaxLen; Lc >= 0; --Lc) { start[Lc] = run; run += hist[Lc]; } }
-    __syncthreads();
-    const size_t vtb = (size_t)(b * P.NP + p) * NTP;
 #pragma unroll
-    for (int j = 0; j < kPanRT; ++j) {
-        const int rl = tid + kPanThreads * j;
-        if (rl < R) {
-            const int slot = start[c[j]] + atomicAdd(&fill[c[j]], 1);
-            const int ts = slot >> 6, w = ts % kPanWork, q = ts / kPanWork;
-            P.thead[(vtb + (size_t)(w * P.TWW + q)) * 64 + (slot & 63)] = (unsigned short)rl;
-        }
+    for (int j = 0; j < kPanRT; ++j)
+        if (tid + kPanThreads * j < R) atomicAdd(&hist[c[j]], 1);
+    __syncthreads();
+    // (the scans below are wave scans / binary searches: as loops of one thread over LDS they were ~15 us of this launch)
+    static_assert(kPanMaxLen + 1 == 128, "two length bins per lane of one wave");
+    if (tid < 64) {           // start[L] = rows longer than L (descending sort: the longest rows take the first slots)
+        const int a = hist[kPanMaxLen - 2 * tid], b2 = hist[kPanMaxLen - 1 - 2 * tid];
+        int x = a + b2;
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, kWave); if (tid >= o) x += y; }
+        start[kPanMaxLen - 2 * tid] = x - a - b2;
+        start[kPanMaxLen - 1 - 2 * tid] = x - b2;
     }
+    __syncthreads();
     if (tid < NTP) {          // physical tile tid = (w, q) holds sorted tile ts = w + 15 q: its longest row comes first
         const int w = tid / P.TWW, q = tid - w * P.TWW, ts = w + kPanWork * q;
         int tm = 0;
-        if (ts < P.NTB) { const int s0 = ts * 64; for (int Lc = kPanMaxLen; Lc > 0; --Lc) if (s0 >= start[Lc] && s0 < start[Lc] + hist[Lc]) tm = Lc; }
-        P.tcount[vtb + tid] = 64 * tm;
-    }
-}
-
-// Pass 2: exclusive scan of the tile sizes (one workgroup; a few ten thousand values).
-__global__ __launch_bounds__(1024) void k_pan_scan(PanView P) {
-    __shared__ int s_part[1024];
-    const int NT = P.NB * P.NP * kPanWork * P.TWW;
-    const int per = (NT + 1023) / 1024;
-    const int tid = threadIdx.x;
-    const int lo = tid * per, hi = min(NT, lo + per);
-    int s = 0;
-    for (int i = lo; i < hi; ++i) s += P.tcount[i];
-    s_part[tid] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int add = tid >= off ? s_part[tid - off] : 0;
-        __syncthreads();
-        s_part[tid] += add;
-        __syncthreads();
-    }
-    int run = s_part[tid] - s;
-    for (int i = lo; i < hi; ++i) { P.tptr[i] = run; run += P.tcount[i]; }
-    if (tid == 1023) P.tptr[NT] = s_part[1023];
-}
-
-// Pass 3, one workgroup per (row block, panel): every slot copies its row's entries of the panel, zero-padded to the
-// tile's height (writes coalesced along the lanes).
-__global__ __launch_bounds__(kPanThreads) void k_pan_fill(CsrView A, PanView P) {
-    int b, p;
-    if (!pan_build_bp((int)blockIdx.x, P.NB, P.NP, &b, &p)) return;
-    const int tid = threadIdx.x;
-    const int R = 64 * P.NTB, NTP = kPanWork * P.TWW;
-    const int c0 = p * P.C;
-    const size_t vtb = (size_t)(b * P.NP + p) * NTP;
-    for (int s = tid; s < NTP * 64; s += kPanThreads) {
-        const size_t vt = vtb + (size_t)(s >> 6);
-        const int base = P.tptr[vt], tm = (P.tptr[vt + 1] - base) >> 6;
-        if (tm == 0) continue;
-        const int r = b * R + P.thead[vt * 64 + (s & 63)];
-        int st = 0, c = 0, hole = 0, hlen = 0;
-        if (r < A.n) c = pan_row_count(P, A.n, r, p, &st, &hole, &hlen);
-        const int shift = (!P.band && r < A.n && r / P.C == p) ? 1 : 0;      // entry 0 is the diagonal
-        const int dg = shift ? A.rowptr[r] : 0;
-        for (int i = 0; i < tm; ++i) {
-            const int dst = base + 64 * i + (s & 63);
-            if (i < c) {
-                int src = (shift && i == 0) ? dg : st + i - shift;
-                if (hlen && src >= hole) src += hlen;             // (band mode: skip columns r - 1 / r + 1)
-                P.bval[dst] = A.val[src];
-                P.bcol[dst] = (unsigned short)(A.col[src] - c0);
-            } else { P.bval[dst] = 0.0; P.bcol[dst] = 0; }
+        if (ts < P.NTB) {     // length of the row in sorted slot 64 ts = the largest L with more than 64 ts rows of length >= L
+            const int s0 = ts * 64;
+            int lo = 0, hi = kPanMaxLen;         // invariant: rows(>= lo) > s0 (lo = 0: all R rows)
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (start[mid] + hist[mid] > s0) lo = mid; else hi = mid - 1; }
+            tm = lo;
         }
+        toff[tid + 1] = 64 * tm;
+    }
+    __syncthreads();
+    if (tid < 64) {           // prefix of the tile sizes (two tiles per lane: NTP <= 120), then the staging rounds
+        const int t0 = 2 * tid, t1 = 2 * tid + 1;
+        const int a = t0 < NTP ? toff[t0 + 1] : 0, b2 = t1 < NTP ? toff[t1 + 1] : 0;
+        int x = a + b2;
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, kWave); if (tid >= o) x += y; }
+        const int base = P.cbase[cell];
+        if (t0 < NTP) toff[t0 + 1] = base + x - b2;
+        if (t1 < NTP) toff[t1 + 1] = base + x;
+        if (tid == 0) toff[0] = base;
+    }
+    __syncthreads();
+    if (tid <= NTP) P.tptr[(size_t)cell * (NTP + 1) + tid] = toff[tid];
+    const size_t vtb = (size_t)cell * NTP;
+    int dst0[kPanRT];
+#pragma unroll
+    for (int j = 0; j < kPanRT; ++j) {
+        const int rl = tid + kPanThreads * j;
+        dst0[j] = 0x3fffffff;
+        if (rl < R) {
+            const int slot = start[c[j]] + atomicAdd(&fill[c[j]], 1);
+            const int ts = slot >> 6, w = ts % kPanWork, q = ts / kPanWork, ph = w * P.TWW + q;
+            P.thead[(vtb + (size_t)ph) * 64 + (slot & 63)] = (unsigned short)rl;
+            dst0[j] = toff[ph] + (slot & 63);
+        }
+    }
+    const int cend = toff[NTP];
+    for (int rb = toff[0]; rb < cend; rb += kPanStage) {
+        const int ext = min(kPanStage, cend - rb);
+        for (int e = tid; e < ext; e += kPanThreads) { sval[e] = 0.0; scol[e] = 0; }
+        __syncthreads();
+        // entry i of a row's run inside the panel -> its CSR index (non-band form: entry 0 of a diagonal cell's row is the
+        // diagonal; band form: the run skips the hole of columns r - 1 / r + 1); it sits at dst0 + 64 i of the cell.  Lanes with
+        // nothing to fetch load entry 0 of the matrix (one line for everybody): unconditional loads stay batched.
+#pragma unroll
+        for (int j0 = 0; j0 < kPanRT; j0 += 4) {
+            // the entries [lo, hi) of each row that fall into this round, and the longest such range among the wave's rows: the
+            // batches below run that often for everybody (a loop per row over ITS run length is one dependent round trip per
+            // entry for the whole wave: 70 of the first build's 117 us)
+            int lo[4], hi[4], cm = 0;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = j0 + jj;
+                lo[jj] = rb > dst0[j] ? (rb - dst0[j] + 63) >> 6 : 0;
+                const int t = rb + ext - dst0[j];
+                hi[jj] = t > 0 ? min(c[j], (t + 63) >> 6) : 0;
+                cm = max(cm, hi[jj] - lo[jj]);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cm = max(cm, __shfl_xor(cm, o, kWave));
+            for (int i0 = 0; i0 < cm; i0 += 4) {
+                double v[4][4];
+                int cc[4][4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int j = j0 + jj;
+                    const int r = b * R + tid + kPanThreads * j;
+                    const bool mine = lo[jj] + i0 < hi[jj];
+                    const int shift = (!P.band && c[j] > 0 && r / P.C == p) ? 1 : 0;
+                    const int dg = (shift && mine && lo[jj] + i0 == 0) ? A.rowptr[min(r, A.n - 1)] : 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int ii = min(lo[jj] + i0 + i, max(c[j] - 1, 0));
+                        int src = (shift && ii == 0) ? dg : st[j] + ii - shift;
+                        if (hlen[j] && src >= hole[j]) src += hlen[j];
+                        if (!mine) src = 0;
+                        v[jj][i] = A.val[src]; cc[jj][i] = A.col[src];
+                    }
+                }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int j = j0 + jj;
+                    const int d0 = dst0[j] - rb;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int e = lo[jj] + i0 + i;
+                        if (e < hi[jj]) { sval[d0 + 64 * e] = v[jj][i]; scol[d0 + 64 * e] = (unsigned short)(cc[jj][i] - c0); }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < ext; e += kPanThreads) P.bval[rb + e] = sval[e];
+        {   // columns: four 2-byte entries per 8-byte store (cell ranges start on 64-entry boundaries)
+            const unsigned long long* s4 = reinterpret_cast<const unsigned long long*>(scol);
+            unsigned long long* d4 = reinterpret_cast<unsigned long long*>(P.bcol + rb);
+            for (int e = tid; e < (ext >> 2); e += kPanThreads) d4[e] = s4[e];
+        }
+        __syncthreads();
     }
 }
 
@@ -318,7 +395,7 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul(const Z2* __restrict__ 
     {
         int tp[kPanTW + 1];
 #pragma unroll
-        for (int q = 0; q <= kPanTW; ++q) tp[q] = __builtin_amdgcn_readfirstlane(A.tptr[vt0 + min(q, A.TWW)]);
+        for (int q = 0; q <= kPanTW; ++q) tp[q] = __builtin_amdgcn_readfirstlane(A.tptr[vt0 + (b * A.NP + p) + min(q, A.TWW)]);      // (tile table: NTP + 1 entries per cell)
 #pragma unroll
         for (int q = 0; q < kPanTW; ++q) ro[q] = A.thead[(size_t)(vt0 + min(q, A.TWW - 1)) * 64 + lane];
         E0 = tp[0];
@@ -463,7 +540,7 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul_multi(const Z2* __restr
     {
         const int vt0 = ((min(bg, A.NB - 1) * A.NP + p) * kPanWork + ww) * A.TWW;
 #pragma unroll
-        for (int q = 0; q <= kPanTW; ++q) tp[q] = __builtin_amdgcn_readfirstlane(A.tptr[vt0 + min(q, A.TWW)]);
+        for (int q = 0; q <= kPanTW; ++q) tp[q] = __builtin_amdgcn_readfirstlane(A.tptr[vt0 + (min(bg, A.NB - 1) * A.NP + p) + min(q, A.TWW)]);
 #pragma unroll
         for (int q = 0; q < kPanTW; ++q) ro[q] = A.thead[(size_t)(vt0 + min(q, A.TWW - 1)) * 64 + lane];
     }
@@ -503,7 +580,7 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul_multi(const Z2* __restr
         {
             const int vtn = ((min(more ? bn : b, A.NB - 1) * A.NP + p) * kPanWork + ww) * A.TWW;
 #pragma unroll
-            for (int q = 0; q <= kPanTW; ++q) tpn[q] = A.tptr[vtn + min(q, A.TWW)];
+            for (int q = 0; q <= kPanTW; ++q) tpn[q] = A.tptr[vtn + (min(more ? bn : b, A.NB - 1) * A.NP + p) + min(q, A.TWW)];
 #pragma unroll
             for (int q = 0; q < kPanTW; ++q) ron[q] = A.thead[(size_t)(vtn + min(q, A.TWW - 1)) * 64 + lane];
         }
@@ -702,7 +779,7 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_step(const Z2* __restrict__
         {
             int tp[kPanTW + 1];
 #pragma unroll
-            for (int q = 0; q <= kPanTW; ++q) tp[q] = __builtin_amdgcn_readfirstlane(A.tptr[vt0 + min(q, A.TWW)]);
+            for (int q = 0; q <= kPanTW; ++q) tp[q] = __builtin_amdgcn_readfirstlane(A.tptr[vt0 + (b * A.NP + p) + min(q, A.TWW)]);      // (tile table: NTP + 1 entries per cell)
 #pragma unroll
             for (int q = 0; q < kPanTW; ++q) ro[q] = A.thead[(size_t)(vt0 + min(q, A.TWW - 1)) * 64 + lane];
             E0 = tp[0];

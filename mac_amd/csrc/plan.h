@@ -147,7 +147,9 @@ struct PanPlan {
     bool verify = false;             // a row is longer than 127 entries: the build must confirm that no (row, panel) count exceeds 127
     bool fused = false;              // one launch per step (k_pan_step) instead of k_pan_mul + k_pan_fin (measured SLOWER: profiles/r4_c4_one_launch_step.md)
 };
-inline PanPlan plan_panel(int n, long nnz, int maxlen, bool allowed) {
+// nnz_cap: the most entries the handle's L(x) can ever hold (decides the band form once per handle); shape_only: the shape the
+// automatic mode WOULD take for this n, whatever nnz is (the assembly writes the per-row tables before nnz is known, kernels.h PanSpec)
+inline PanPlan plan_panel(int n, long nnz, int maxlen, bool allowed, long nnz_cap = -1, bool shape_only = false) {
     PanPlan pp;
     const int mode = env_int("MACHIP_PANEL", -1);     // -1 auto, 0 off, 1 forced (tests: small graphs with several panels)
     if (!allowed || mode == 0 || n < 128) return pp;
@@ -164,7 +166,7 @@ inline PanPlan plan_panel(int n, long nnz, int maxlen, bool allowed) {
     // (other sizes, tools/panel_size_probe.py: n = 66 000 .. 145 000 with a single wave of workgroups -- a tie at 23-26 entries
     // per row, 1.3-1.5x at 43-46; beyond n = 1e5 the build's 0.25 ms per solve moves the break-even to ~26)
     const int min_mean10 = env_int("MACHIP_PANEL_MIN_MEAN10", n <= 105000 ? 170 : 260);
-    if (mode < 0 && !(n >= env_int("MACHIP_PANEL_MIN_N", 65536) && mean >= 0.1 * min_mean10)) return pp;
+    if (mode < 0 && !(n >= env_int("MACHIP_PANEL_MIN_N", 65536) && (shape_only || mean >= 0.1 * min_mean10))) return pp;
     // Shape: NP panels x NB row blocks with NB * NP <= 256 workgroups -- ONE wave of workgroups, one per CU (a second wave
     // doubles the kernel: n = 131 072 with 16 x 18 = 288 workgroups ran 30.5 us per step against 24.9 for the gather step) --,
     // panels of at most 13 x 960 columns (LDS next to the row block's image), row blocks of at most 120 tiles (that image).
@@ -214,13 +216,13 @@ inline PanPlan plan_panel(int n, long nnz, int maxlen, bool allowed) {
     // sums): measured against the gather step (tools/panel_size_probe.py, profiles/r4_panel_sizes.txt) -- per step a tie at ~29
     // entries per row for n = 150 000, ahead from there (n = 200 000: 41.1 vs 43.7 us at 29 / row, 43.8 vs 50.9 at 36; n = 400 000:
     // 119 vs 132 at 34, 129 vs 200 at 49); with the panel build (0.3-0.5 ms per solve) the whole solve wins from ~33 entries per row
-    if (mode < 0 && pp.cells > 1 && mean < 0.1 * env_int("MACHIP_PANEL_MULTI_MIN_MEAN10", 330)) return PanPlan();
+    if (mode < 0 && !shape_only && pp.cells > 1 && mean < 0.1 * env_int("MACHIP_PANEL_MULTI_MIN_MEAN10", 330)) return PanPlan();
     pp.on = true; pp.NP = np; pp.C = C; pp.NB = nb; pp.NTB = ntb; pp.TWW = (ntb + kPanWork - 1) / kPanWork;
     pp.RPT = (C + kPanWorkThreads - 1) / kPanWorkThreads;
     // MACHIP_PANEL_FUSED=1: the one-launch form (k_pan_step; tickets for 256 row blocks, one partial-sum slot per slice).  Off by
     // default: 26.9 against 19.1 us per step at configs[3] -- the in-launch hand-off costs more than the launch it saves.
     pp.fused = env_int("MACHIP_PANEL_FUSED", 0) != 0 && nb <= 256 && nb * np <= 256 && pp.cells == 1;
-    pp.band = env_int("MACHIP_PANEL_BAND", 1) != 0 && nnz < (1l << 29);     // (the LOBPCG kernels finish rows without the band terms: solver.h passes band = false there)
+    pp.band = env_int("MACHIP_PANEL_BAND", 1) != 0 && (nnz_cap >= 0 ? nnz_cap : nnz) < (1l << 28);     // (CSR positions are packed with 3 count bits; the LOBPCG kernels finish rows without the band terms: solver.h passes band = false there)
     pp.block2 = env_int("MACHIP_PANEL_B2", 512);
     if (pp.block2 != 256 && pp.block2 != 512 && pp.block2 != 1024) pp.block2 = 256;
     pp.grid2 = (int)std::max<long>(1, std::min<long>(env_int("MACHIP_PANEL_G2", grid_cap()), ((long)n + pp.block2 - 1) / pp.block2));
