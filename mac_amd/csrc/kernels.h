@@ -60,17 +60,26 @@ struct LanView {
 // Laplacian assembly  (reference: MAC.laplacian, mac/solvers/mac.py:74-89, and
 // weight_graph_lap_from_edges, mac/utils/graphs.py:58-98)
 // ------------------------------------------------------------------------------------------
-// Pass 1: active entries per row (+1 for the diagonal) and one total per workgroup.
 constexpr int kAsmGrid = 4096;     // most workgroups of the assembly kernels (stride of their per-workgroup result arrays)
-constexpr long long kAsmInactive = 0x7ff8dead00000001ll;   // a NaN payload no arithmetic produces: "slot not active"
-// (round 3: the value of every slot -- x_k w_k, the fixed weight, or the marker above for an inactive slot -- is parked in slot order
-// here, so that the fill pass streams it instead of gathering x[k] a second time: the pattern walk used to fetch ~10x the
-// algorithmic bytes, two random 8-byte gathers per slot being most of it.)
+// Which candidates are in the support: bit k of `bits` = (x_k > tol) (mac.py:85).  Written by whoever writes x -- k_fw_final for
+// the next iterate (for free: one ballot per wave), k_x_bits for an x that came from the host -- and read by both assembly passes
+// instead of x itself (2 M candidates = 250 KB: every gather is an L2 hit).  (Rounds 1-4 gathered x[pk] for every slot of the
+// pattern in the count pass and parked x_k w_k per slot for the fill pass: 4.2 M scattered 8-byte gathers and 68 MB of parked
+// values per Frank-Wolfe iteration at configs[3], whatever the support was.)
+__global__ __launch_bounds__(kBlock) void k_x_bits(const double* __restrict__ x, long m, double tol, unsigned long long* __restrict__ bits) {
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < m; i += (long)gridDim.x * kBlock) {
+        const unsigned long long bal = __ballot(x[i] > tol);      // (a wave covers 64 consecutive, 64-aligned candidates)
+        if ((threadIdx.x & 63) == 0) bits[i >> 6] = bal;
+    }
+}
+__device__ __forceinline__ bool x_bit(const unsigned int* __restrict__ bits32, int k) { return (bits32[k >> 5] >> (k & 31)) & 1u; }
+
+// Pass 1: active entries per row (+1 for the diagonal) and one total per workgroup.
 template <int G>
-__global__ __launch_bounds__(kBlock) void k_asm_count(PatternView P, const double* __restrict__ x,
-                                                      double tol, int rows_per_block,
+__global__ __launch_bounds__(kBlock) void k_asm_count(PatternView P, const unsigned int* __restrict__ xbits,
+                                                      int rows_per_block,
                                                       int* __restrict__ cnt, int* __restrict__ blk_sum,
-                                                      double* __restrict__ sval, int* __restrict__ hsum = nullptr) {
+                                                      int* __restrict__ hsum = nullptr) {
     __shared__ int sm[4];
     constexpr int GPB = kBlock / G;
     const int lane = threadIdx.x % G, g = threadIdx.x / G;
@@ -83,13 +92,9 @@ __global__ __launch_bounds__(kBlock) void k_asm_count(PatternView P, const doubl
         for (int p = b + lane; p < e; p += G) {
             const int k = P.pk[p];
             const bool cand = k >= 0;
-            const double wgt = P.pw[p];
-            double v = wgt;
-            bool act = true;
-            if (cand) { const double xk = x[k]; act = xk > tol; v = xk * wgt; }
-            sval[p] = act ? v : __longlong_as_double(kAsmInactive);
+            const bool act = cand ? x_bit(xbits, k) : true;
             c += act;
-            sc += (cand && act && P.pcol[p] > r);   // each candidate counted once (upper slot)
+            sc += (cand && act);          // every candidate owns two slots (row i and row j): the support is half of this
         }
         c = group_sum_i<G>(c);
         sc = group_sum_i<G>(sc);
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(kBlock) void k_asm_count(PatternView P, const doubl
     __syncthreads();
     if (threadIdx.x == 0) {
         blk_sum[blockIdx.x] = tot;
-        blk_sum[kAsmGrid + blockIdx.x] = stot;                                   // active candidates
+        blk_sum[kAsmGrid + blockIdx.x] = stot;                                   // active candidate slots (2 per candidate)
         const int longest = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
         blk_sum[2 * kAsmGrid + blockIdx.x] = longest;                            // longest row
         if (hsum) {     // the host's copy, written straight into mapped pinned memory (no copy kernel behind the launch)
@@ -136,7 +141,7 @@ struct PanSpec {
 };
 
 template <int G>
-__global__ __launch_bounds__(kBlock) void k_asm_fill(PatternView P, const double* __restrict__ sval,
+__global__ __launch_bounds__(kBlock) void k_asm_fill(PatternView P, const unsigned int* __restrict__ xbits, const double* __restrict__ x,
                                                      int rows_per_block,
                                                      const int* __restrict__ cnt,
                                                      const int* __restrict__ blk_sum,
@@ -197,9 +202,13 @@ __global__ __launch_bounds__(kBlock) void k_asm_fill(PatternView P, const double
         for (int p0 = b; p0 < e; p0 += G) {
             const int p = p0 + lane;
             const bool in = p < e;
-            const double sv = in ? sval[p] : __longlong_as_double(kAsmInactive);
-            const bool act = __double_as_longlong(sv) != kAsmInactive;     // (a NaN that arithmetic produced stays an active entry)
-            const double v = act ? sv : 0.0;
+            const int kc = in ? P.pk[p] : -1;
+            // (x_k, the support bit and the weight are requested together: behind one another they were three dependent round trips
+            // per 32 slots -- 88 us per launch at configs[3])
+            const double wgt = in ? P.pw[p] : 0.0;
+            const double xk = kc >= 0 ? x[kc] : 1.0;
+            const bool act = in && (kc < 0 || x_bit(xbits, kc));
+            const double v = act ? xk * wgt : 0.0;     // x_k w_k exactly as mac.py:86 forms it (fixed slots: 1.0 x the weight)
             const unsigned long long bal = __ballot(act);
             unsigned long long gm;
             if (G == 64) gm = bal;
@@ -1416,7 +1425,8 @@ __global__ __launch_bounds__(1024) void k_sel_small(const double* __restrict__ g
 __global__ __launch_bounds__(kBlock) void k_fw_final(const double* __restrict__ g, const double* __restrict__ x,
                                                      long m, const SelState* __restrict__ st, double gamma,
                                                      double* __restrict__ x_next, double* __restrict__ s_out,
-                                                     double* __restrict__ part /*[2][kMaxGrid]*/) {
+                                                     double* __restrict__ part /*[2][kMaxGrid]*/,
+                                                     double tol = 0.0, unsigned long long* __restrict__ xbits_next = nullptr) {
 #pragma clang fp contract(off)   // x + gamma*(s - x) must round twice, like NumPy (no fma)
     __shared__ double sm[4];
     const unsigned long long T = st->T;
@@ -1435,7 +1445,12 @@ __global__ __launch_bounds__(kBlock) void k_fw_final(const double* __restrict__ 
             q += gi * gi;
             if (x_next) {
                 const double step = gamma * diff;   // two roundings (contract off above)
-                x_next[i] = xi + step;
+                const double xn = xi + step;
+                x_next[i] = xn;
+                if (xbits_next) {                   // support bitmap of the next iterate (k_x_bits' rule; a wave = 64 aligned candidates)
+                    const unsigned long long bal = __ballot(xn > tol);
+                    if ((threadIdx.x & 63) == 0) xbits_next[i >> 6] = bal;
+                }
             }
         }
     }

@@ -101,7 +101,9 @@ struct machip_problem {
     double *x = nullptr, *x_next = nullptr, *g = nullptr, *s = nullptr, *scratch_m = nullptr;
     // assembled CSR (device)
     int *cnt = nullptr, *blk_sum = nullptr, *rowptr = nullptr, *col = nullptr;
-    double *val = nullptr, *blk_lnorm = nullptr, *sval = nullptr;   // sval: per-slot values of the running assembly
+    double *val = nullptr, *blk_lnorm = nullptr;
+    unsigned long long *xb = nullptr, *xb_next = nullptr;     // support bitmaps of x / x_next (kernels.h k_x_bits)
+    bool xb_valid = false, xb_next_valid = false;
     long nnz = 0, support = 0;
     int maxlen = 0;           // longest row of the assembled L(x)
     double lnorm = 0.0;
@@ -257,9 +259,10 @@ int build_pattern(machip_problem* p, int64_t nf, const int32_t* fi, const int32_
 template <int G>
 void launch_asm(machip_problem* p, const PanSpec& S) {
     const PatternView P = p->pattern();
-    k_asm_count<G><<<p->asm_grid, kBlock, 0, p->stream>>>(P, p->x, p->tol_sel, p->asm_rpb, p->cnt, p->blk_sum, p->sval, p->d_hint);
+    const unsigned int* xb32 = reinterpret_cast<const unsigned int*>(p->xb);
+    k_asm_count<G><<<p->asm_grid, kBlock, 0, p->stream>>>(P, xb32, p->asm_rpb, p->cnt, p->blk_sum, p->d_hint);
     const size_t lds = sizeof(int) * ((size_t)p->asm_rpb + 1);
-    k_asm_fill<G><<<p->asm_grid, kBlock, lds, p->stream>>>(P, p->sval, p->asm_rpb, p->cnt, p->blk_sum,
+    k_asm_fill<G><<<p->asm_grid, kBlock, lds, p->stream>>>(P, xb32, p->x, p->asm_rpb, p->cnt, p->blk_sum,
                                                            p->rowptr, p->col, p->val, p->d_hdbl, S);   // (row-sum maxima: host only)
 }
 
@@ -268,6 +271,11 @@ int assemble(machip_problem* p) {
     // the fill pass writes the column-panel form's per-row tables on the side where that form can run at this n (solver.h)
     PanSpec S;
     ST_TRY(p->sol.pan_spec_prepare(&S));
+    if (!p->xb_valid) {     // x came from the host (or a copy): the support bitmap is taken here; k_fw_final leaves the next iterate's
+        const int grid = std::max(1, (int)std::min<long>(kMaxGrid, (p->m + kBlock - 1) / kBlock));
+        k_x_bits<<<grid, kBlock, 0, p->stream>>>(p->x, p->m, p->tol_sel, p->xb);
+        p->xb_valid = true;
+    }
     switch (p->asm_G) {
         case 4: launch_asm<4>(p, S); break;
         case 8: launch_asm<8>(p, S); break;
@@ -285,7 +293,7 @@ int assemble(machip_problem* p) {
         nnz += p->h_int[b]; supp += p->h_int[kAsmGrid + b]; maxlen = std::max(maxlen, p->h_int[2 * kAsmGrid + b]);
         ln = std::max(ln, p->h_dbl[b]);
     }
-    p->nnz = nnz; p->support = supp; p->lnorm = ln; p->maxlen = maxlen;
+    p->nnz = nnz; p->support = supp / 2; p->lnorm = ln; p->maxlen = maxlen;     // (two pattern slots per active candidate)
     p->assembled = true;
     return MACHIP_OK;
 }
@@ -521,7 +529,8 @@ int machip_create(int device, int64_t n, int64_t n_fixed, const int32_t* fi, con
         const size_t cap = (size_t)p->P + (size_t)n + 8;
         ST_TRY(dev_alloc(&p->cnt, (size_t)n + 1)); ST_TRY(dev_alloc(&p->blk_sum, 3 * kAsmGrid));
         ST_TRY(dev_alloc(&p->rowptr, (size_t)n + 1)); ST_TRY(dev_alloc(&p->col, cap)); ST_TRY(dev_alloc(&p->val, cap));
-        ST_TRY(dev_alloc(&p->blk_lnorm, kAsmGrid)); ST_TRY(dev_alloc(&p->sval, (size_t)p->P + 8));
+        ST_TRY(dev_alloc(&p->blk_lnorm, kAsmGrid));
+        ST_TRY(dev_alloc(&p->xb, (size_t)m / 64 + 2)); ST_TRY(dev_alloc(&p->xb_next, (size_t)m / 64 + 2));
         ST_TRY(dev_alloc(&p->hist, (6 + kSelRep) * kBins)); ST_TRY(dev_alloc(&p->sel, 2)); ST_TRY(dev_alloc(&p->part_fw, 2 * kMaxGrid));
         ST_TRY(alloc_common(p));
         p->sol.csr_cap = cap;
@@ -568,7 +577,7 @@ void machip_destroy(machip_problem* p) {
     }
     p->sol.destroy();
     void* ptrs[] = {p->prow, p->pcol, p->pk, p->pw, p->ci, p->cj, p->cw, p->x, p->x_next, p->g, p->s, p->scratch_m, p->cnt,
-                    p->blk_sum, p->rowptr, p->col, p->val, p->blk_lnorm, p->sval, p->hist, p->sel, p->part_fw};
+                    p->blk_sum, p->rowptr, p->col, p->val, p->blk_lnorm, p->xb, p->xb_next, p->hist, p->sel, p->part_fw};
     for (void* q : ptrs) if (q) (void)hipFree(q);
     if (p->h_int) (void)hipHostFree(p->h_int);
     if (p->h_dbl) (void)hipHostFree(p->h_dbl);
@@ -581,7 +590,7 @@ int machip_set_x(machip_problem* p, const double* x) {
     HIP_TRY(hipSetDevice(p->device));
     HIP_TRY(hipMemcpyAsync(p->x, x, sizeof(double) * (size_t)p->m, hipMemcpyHostToDevice, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
-    p->assembled = false;
+    p->assembled = false; p->xb_valid = false;
     return MACHIP_OK;
 }
 
@@ -691,7 +700,8 @@ int machip_fw_step(machip_problem* p, int64_t k, int iter, double tol, int max_s
         int st = compute_gradient(p, speculative, (long)k, &fused);
         if (st == MACHIP_OK) st = select_topk(p, (long)k, fused);
         if (st == MACHIP_OK) {
-            k_fw_final<<<grid, kBlock, 0, p->stream>>>(p->g, p->x, p->m, p->sel, gamma, p->x_next, nullptr, p->d_hdbl);   // partials: host only
+            k_fw_final<<<grid, kBlock, 0, p->stream>>>(p->g, p->x, p->m, p->sel, gamma, p->x_next, nullptr, p->d_hdbl, p->tol_sel, p->xb_next);   // partials: host only
+            p->xb_next_valid = true;
             if (hipGetLastError() != hipSuccess) st = fail(MACHIP_HIP_ERROR, "k_fw_final launch failed");
         }
         epi_status = st;
@@ -761,6 +771,8 @@ int machip_round_nearest(machip_problem* p, int64_t k, int decimals, double* rou
 int machip_fw_commit(machip_problem* p) {
     if (!p || p->csr_only) return fail(MACHIP_BAD_ARG, "bad handle");
     std::swap(p->x, p->x_next);
+    std::swap(p->xb, p->xb_next);
+    p->xb_valid = p->xb_next_valid; p->xb_next_valid = false;
     p->assembled = false;
     return MACHIP_OK;
 }
@@ -1116,7 +1128,8 @@ int make_lane(machip_problem* p, machip_problem** out) {
         const size_t cap = (size_t)q->P + (size_t)q->n + 8;
         ST_TRY(dev_alloc(&q->cnt, (size_t)q->n + 1)); ST_TRY(dev_alloc(&q->blk_sum, 3 * kAsmGrid));
         ST_TRY(dev_alloc(&q->rowptr, (size_t)q->n + 1)); ST_TRY(dev_alloc(&q->col, cap)); ST_TRY(dev_alloc(&q->val, cap));
-        ST_TRY(dev_alloc(&q->blk_lnorm, kAsmGrid)); ST_TRY(dev_alloc(&q->sval, (size_t)q->P + 8));
+        ST_TRY(dev_alloc(&q->blk_lnorm, kAsmGrid));
+        ST_TRY(dev_alloc(&q->xb, (size_t)q->m / 64 + 2)); ST_TRY(dev_alloc(&q->xb_next, (size_t)q->m / 64 + 2));
         // every lane keeps its own Krylov basis: a share of the handle's budget each (MACHIP_LANE_VBUDGET_MB, default
         // MACHIP_VBUDGET_MB / 8 = 512 MB: 16 lanes together hold twice what the handle itself holds; a sequence longer than
         // the lane's share restarts earlier than it would on the handle -- include/machip.h states the guarantee accordingly)
@@ -1206,7 +1219,7 @@ int machip_eval_batch(machip_problem* p, int B, const double* X, double tol, int
                 hipStreamSynchronize(q->stream) != hipSuccess) {
                 st = fail(MACHIP_HIP_ERROR, "machip_eval_batch: copy of x failed");
             } else {
-                q->assembled = false;
+                q->assembled = false; q->xb_valid = false;
                 st = assemble(q);
                 // clean solver state per entry (no step-count history from whatever this lane solved before: the automatic
                 // mode choice reads it): an entry's result does not depend on the lane that takes it or on its place in the batch
