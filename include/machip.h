@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MACHIP_ABI_VERSION 4   /* 4: inter-process communicator (machip_ipc_*), first-contact helpers */
+#define MACHIP_ABI_VERSION 5   /* 5: per-handle option table (machip_set_option), machip_comm_drop_ipc; 4: inter-process communicator */
 
 typedef enum machip_status {
     MACHIP_OK = 0,
@@ -185,6 +185,10 @@ int machip_ipc_blob_bytes(void);
 int machip_ipc_export(machip_problem* p, void* blob, int blob_bytes);
 int machip_comm_init_ipc(machip_problem* p, int rank, int nranks, const void* blobs, double timeout_s);
 int machip_comm_close_ipc(machip_problem* p);
+/* Leave the inter-process communicator again (mappings closed, flag words freed, rank 0 of 1): the way back to a replicated
+ * solve when the attach succeeded here but failed on a peer (mac_amd.dist.attach_ipc).  Collective in spirit: call it on
+ * every rank, behind a barrier, before anybody launches another step. */
+int machip_comm_drop_ipc(machip_problem* p);
 /* With 2..8 handles the in-process communicator also ROW-PARTITIONS THE EIGEN-SOLVE (MACHIP_SHARD_EIG=0 turns that off):
  * inside machip_fw_step rank 0's solver drives every rank's stream; per Lanczos step each rank launches its share of
  * the step's workgroups on its own copy of L(x) and of the gather operand and writes the records / partial sums it
@@ -253,6 +257,21 @@ int machip_set_solver(machip_problem* p, int mode);
  *     pair therefore obeys the same stop rule and the same 1e-8 parity bound as mode 0. */
 int machip_set_precision(machip_problem* p, int precision);
 
+/* Per-handle option table (round 5; replaces the MACHIP_* environment knobs of rounds 1-4).  The reference's only selector is
+ * one string, `fiedler_method` (mac/utils/fiedler.py:38-42 -> machip_set_solver above); everything else this library can
+ * vary -- launch shapes, thresholds of the automatic mode, test hooks that force a code path onto a small graph -- is an entry
+ * of the handle's table, named as listed by machip_option_name(i) (mac_amd/csrc/options.h): e.g. "panel" (-1 automatic, 0 off,
+ * 1 forced), "chunk", "lanes", "woodbury".  value = MACHIP_OPTION_AUTO restores the measured default.
+ * p == NULL edits the PROCESS defaults: what handles created afterwards (and the handle machip_fiedler_csr keeps) start
+ * from.  Those defaults are initialised from the environment once, when the library is first used (MACHIP_<NAME>, developer
+ * use: sweeps under tools/); nothing reads the environment after that.  Options consumed when a handle is created
+ * ("asm_g", "vbudget_mb", "vcap", ...) must be set as process defaults before machip_create.  An evaluation lane runs on its
+ * owner's table.  Unknown name -> MACHIP_BAD_ARG.  Not thread-safe against a running call on the same handle. */
+#define MACHIP_OPTION_AUTO INT64_MIN
+int machip_set_option(machip_problem* p, const char* name, int64_t value);
+int machip_get_option(machip_problem* p, const char* name, int64_t* value);   /* MACHIP_OPTION_AUTO when not set */
+const char* machip_option_name(int i);    /* i = 0, 1, ...; NULL past the last one */
+
 int machip_synchronize(machip_problem* p);
 
 /* Measurement helpers (no counterpart in the reference; bench.py and the CPU tests use them).
@@ -266,8 +285,8 @@ int machip_synchronize(machip_problem* p);
 int machip_membench(int device, int64_t bytes, int reps, double* read_gbs, double* triad_gbs);
 /* Host only, no GPU: the shape the column-panel Lanczos step (mac_amd/csrc/panel.h) would use for a matrix of n rows, nnz
  * entries and longest row maxlen -- out8 = {on, NP panels, C columns per panel, NB row blocks, NTB 64-row tiles per block,
- * TWW tiles per worker wave, RPT records per worker thread, workgroups of k_pan_fin} -- under the current environment
- * (MACHIP_PANEL etc.).  For CPU tests of the shape arithmetic (coverage of all rows / columns, LDS and register limits). */
+ * TWW tiles per worker wave, RPT records per worker thread, workgroups of k_pan_fin} -- under the process-default options
+ * ("panel" etc.).  For CPU tests of the shape arithmetic (coverage of all rows / columns, LDS and register limits). */
 int machip_panel_plan(int64_t n, int64_t nnz, int maxlen, int* out8);
 /* machip_fiedler_csr keeps one CSR-only handle (stream, device buffers, chunk graphs) between calls and reuses it when
  * device and n match and the matrix fits -- every solve still starts from a clean solver state.  This frees it (the

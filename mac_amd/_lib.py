@@ -82,6 +82,10 @@ SIGNATURES = {
     "machip_fw_sweep": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), _f64p, C.c_int, C.c_double, C.c_double, C.c_double,
                                   C.c_int, C.c_int, C.c_int, _f64p, _f64p, _f64p, _f64p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "machip_set_solver": (C.c_int, [C.c_void_p, C.c_int]),
+    "machip_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "machip_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
+    "machip_option_name": (C.c_char_p, [C.c_int]),
+    "machip_comm_drop_ipc": (C.c_int, [C.c_void_p]),
     "machip_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "machip_synchronize": (C.c_int, [C.c_void_p]),
     "machip_membench": (C.c_int, [C.c_int, C.c_int64, C.c_int, _f64p, _f64p]),
@@ -108,6 +112,48 @@ def load():
     import atexit
     atexit.register(lib.machip_release_cache)     # the handle machip_fiedler_csr keeps between calls
     return lib
+
+
+OPTION_AUTO = -(1 << 63)      # MACHIP_OPTION_AUTO: "the measured default"
+
+
+def option_names():
+    """Names of the option table (mac_amd/csrc/options.h)."""
+    lib, out, i = load(), [], 0
+    while True:
+        nm = lib.machip_option_name(i)
+        if nm is None:
+            return out
+        out.append(nm.decode())
+        i += 1
+
+
+def set_default_option(name, value=None):
+    """Process default of an option: what handles created AFTERWARDS start from (value None = automatic).  The options a
+    handle consumes at creation ("asm_g", "vbudget_mb", "vcap", "lane_queues" ...) can only be set this way."""
+    check(load().machip_set_option(None, name.encode(), OPTION_AUTO if value is None else int(value)))
+
+
+class default_options:
+    """Context manager: process defaults for the handles created inside the block, restored afterwards (tests)."""
+
+    def __init__(self, **opts):
+        self.opts = opts
+
+    def __enter__(self):
+        lib = load()
+        self.old = {}
+        for k, v in self.opts.items():
+            cur = C.c_int64(0)
+            check(lib.machip_get_option(None, k.encode(), C.byref(cur)))
+            self.old[k] = cur.value
+            set_default_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            check(load().machip_set_option(None, k.encode(), v))
+        return False
 
 
 def membench(nbytes=1 << 30, reps=10, device=0):
@@ -290,6 +336,23 @@ class Problem:
 
     def comm_close_ipc(self):
         check(self._lib.machip_comm_close_ipc(self._h))
+
+    def comm_drop_ipc(self):
+        """Leave the inter-process communicator again (back to a single-rank handle)."""
+        check(self._lib.machip_comm_drop_ipc(self._h))
+
+    def set_option(self, name, value=None):
+        """Entry `name` of this handle's option table (mac_amd/csrc/options.h; value None = the measured default)."""
+        check(self._lib.machip_set_option(self._h, name.encode(), OPTION_AUTO if value is None else int(value)))
+
+    def set_options(self, **opts):
+        for k, v in opts.items():
+            self.set_option(k, v)
+
+    def get_option(self, name):
+        v = C.c_int64(0)
+        check(self._lib.machip_get_option(self._h, name.encode(), C.byref(v)))
+        return None if v.value == OPTION_AUTO else v.value
 
     def set_solver(self, mode):
         """0 = automatic, 1 = Lanczos, 2 = preconditioned (LOBPCG + tridiagonal chain solve)."""

@@ -41,7 +41,7 @@ static int run_with_watchdog(const std::function<int()>& fn, double limit_s, con
         return fail(MACHIP_RCCL_ERROR, what + " did not return within " + std::to_string((int)limit_s) + " s (a peer rank is missing, or the fabric / bootstrap interface is not reachable; MACHIP_RCCL_TIMEOUT_S raises the limit)");
     return fut.get();
 }
-static double rccl_timeout_s() { const int t = env_int("MACHIP_RCCL_TIMEOUT_S", 600); return t > 0 ? (double)t : 600.0; }
+static double rccl_timeout_s() { const Options& opt = default_options(); const int t = OPT(rccl_timeout_s, 600); return t > 0 ? (double)t : 600.0; }
 
 // In-process communicator (machip_comm_init_local): the ranks are handles of ONE process driven by one host
 // thread each (one GPU per handle, or several handles on one GPU); the all-gather is peer-to-peer device copies
@@ -142,9 +142,8 @@ struct machip_problem {
 // ineffective once HIP was initialised.  Round 4: a lane's stream is created WITH A CU MASK (all CUs enabled): the runtime
 // gives a CU-masked stream a hardware queue of its own (the mask is a property of the queue) instead of one from the shared
 // pool -- per stream, no environment, no effect on anybody else.  MACHIP_LANE_QUEUES=shared takes plain streams.
-static int create_lane_stream(int device, hipStream_t* out) {
-    const char* mode = getenv("MACHIP_LANE_QUEUES");
-    if (!(mode && !strcmp(mode, "shared"))) {
+static int create_lane_stream(const Options& opt, int device, hipStream_t* out) {
+    if (OPT(lane_queues, 0) == 0) {      // 0: CU-masked stream with a hardware queue of its own; 1: plain stream on the shared pool
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
             const int words = (prop.multiProcessorCount + 31) / 32;
@@ -171,6 +170,7 @@ struct Slot {
 
 int build_pattern(machip_problem* p, int64_t nf, const int32_t* fi, const int32_t* fj, const double* fw,
                   int64_t m, const int32_t* ci, const int32_t* cj, const double* cw) {
+    const Options& opt = p->sol.opt;
     const int n = p->n;
     std::vector<long> deg((size_t)n + 1, 0);
     auto chk = [&](int a, int b) { return a >= 0 && a < n && b >= 0 && b < n; };
@@ -229,21 +229,24 @@ int build_pattern(machip_problem* p, int64_t nf, const int32_t* fi, const int32_
     p->P = (long)pcol.size();
     ST_TRY(dev_alloc(&p->prow, (size_t)n + 1));
     ST_TRY(dev_alloc(&p->pcol, (size_t)p->P)); ST_TRY(dev_alloc(&p->pk, (size_t)p->P)); ST_TRY(dev_alloc(&p->pw, (size_t)p->P));
-    HIP_TRY(hipMemcpy(p->prow, prow.data(), sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice));
+    // (every copy of this library names the handle's own stream: the legacy stream would serialise with -- and, while a lane
+    // captures a chunk graph, fail against -- every blocking stream of the process; the lanes' CU-masked streams are blocking)
+    HIP_TRY(hipMemcpyAsync(p->prow, prow.data(), sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice, p->stream));
     if (p->P) {
-        HIP_TRY(hipMemcpy(p->pcol, pcol.data(), sizeof(int) * (size_t)p->P, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(p->pk, pk.data(), sizeof(int) * (size_t)p->P, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(p->pw, pw.data(), sizeof(double) * (size_t)p->P, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpyAsync(p->pcol, pcol.data(), sizeof(int) * (size_t)p->P, hipMemcpyHostToDevice, p->stream));
+        HIP_TRY(hipMemcpyAsync(p->pk, pk.data(), sizeof(int) * (size_t)p->P, hipMemcpyHostToDevice, p->stream));
+        HIP_TRY(hipMemcpyAsync(p->pw, pw.data(), sizeof(double) * (size_t)p->P, hipMemcpyHostToDevice, p->stream));
     }
+    HIP_TRY(hipStreamSynchronize(p->stream));      // (the host vectors go out of scope)
     // assembly launch shape: G lanes per row ~ half the mean pattern degree
     const double mean = n ? (double)p->P / n : 1.0;
     int G = 4;
     while (G < 64 && G < mean * 0.75) G <<= 1;
-    p->asm_G = env_int("MACHIP_ASM_G", G);
+    p->asm_G = OPT(asm_g, G);
     const int gpb = kBlock / p->asm_G;
     // (round 5: up to 4 096 workgroups -- with 1 024 a G-lane group walked 13 rows one after the other at configs[3], each a chain of
     // dependent loads: prow -> pk -> x[pk]; the pass was latency-bound at a quarter of the chip's memory-level parallelism)
-    long nblk = std::min<long>(std::min(kAsmGrid, std::max(1, env_int("MACHIP_ASM_MAXGRID", kAsmGrid))), ((long)n + gpb - 1) / gpb);
+    long nblk = std::min<long>(std::min(kAsmGrid, std::max(1, OPT(asm_maxgrid, kAsmGrid))), ((long)n + gpb - 1) / gpb);
     if (nblk < 1) nblk = 1;
     long rpb = ((long)n + nblk - 1) / nblk;
     rpb = (rpb + gpb - 1) / gpb * gpb;
@@ -310,10 +313,11 @@ int alloc_common(machip_problem* p, int vbudget_mb = 0) {
 // k-th largest of keys[0..m): threshold, remaining rank and tie rule into *st.
 // hist0_done: the first digit's histogram has been counted by the producer of the keys (k_grad<true>) behind a k_sel_init.
 int select_on(machip_problem* p, const double* keys, long k, SelState* st, int prefer_high, bool hist0_done = false) {
+    const Options& opt = p->sol.opt;
     const long m = p->m;
     if (k < 0) k = 0;
     if (k > m) k = m;
-    if (m <= kSelSmallMax && env_int("MACHIP_SEL_SMALL", 1)) {      // short key vectors: the whole select in one launch
+    if (m <= kSelSmallMax && OPT(sel_small, 1)) {      // short key vectors: the whole select in one launch
         k_sel_small<<<1, 1024, 0, p->stream>>>(keys, m, (long long)k, st, prefer_high);
         HIP_TRY(hipGetLastError());
         return MACHIP_OK;
@@ -321,14 +325,11 @@ int select_on(machip_problem* p, const double* keys, long k, SelState* st, int p
     if (!hist0_done) k_sel_init<<<1, 1024, 0, p->stream>>>(st, (long long)k, p->hist, 6 * kBins);
     if (k > 0) {
         // few, large workgroups: a dense digit costs one returning device-scope atomic per non-empty bin and workgroup (kernels.h)
-        const int B = env_int("MACHIP_SEL_BLOCK", 1024) == 256 ? 256 : 1024;
-        const int U = B == 256 ? 8 : 4;
-        const int grid = (int)std::max<long>(1, std::min<long>(env_int("MACHIP_SEL_GRID", B == 256 ? 256 : 128), (m + (long)B * U - 1) / ((long)B * U)));
+        // (measured at configs[3], 16 MB of keys: 512 x 256 threads 17 us per dense pass, 128 x 1 024 threads 10 us)
+        constexpr int B = 1024, U = 4;
+        const int grid = (int)std::max<long>(1, std::min<long>(128, (m + (long)B * U - 1) / ((long)B * U)));
         if (hist0_done) k_sel_close0<<<1, 1024, 0, p->stream>>>(p->hist, st);
-        for (int pass = hist0_done ? 1 : 0; pass < 6; ++pass) {
-            if (B == 256) k_sel_pass<8, 256><<<grid, 256, 0, p->stream>>>(keys, m, pass, p->hist, st);
-            else k_sel_pass<4, 1024><<<grid, 1024, 0, p->stream>>>(keys, m, pass, p->hist, st);
-        }
+        for (int pass = hist0_done ? 1 : 0; pass < 6; ++pass) k_sel_pass<U, B><<<grid, B, 0, p->stream>>>(keys, m, pass, p->hist, st);
     }
     k_sel_ties<<<1, 1024, 0, p->stream>>>(keys, m, st, prefer_high);
     HIP_TRY(hipGetLastError());
@@ -362,16 +363,25 @@ int local_allgather(machip_problem* p, long shard) {
 // fuse_k >= 0 (single rank, long candidate lists): the first digit pass of the top-fuse_k select that follows is counted by the
 // gradient kernel itself (k_grad<true>; *fused tells the caller so)
 int compute_gradient(machip_problem* p, bool have_vec_now = false, long fuse_k = -1, bool* fused = nullptr) {
+    const Options& opt = p->sol.opt;
     if (!p->have_vec && !have_vec_now) return fail(MACHIP_BAD_ARG, "no Fiedler vector on the device: call machip_fiedler first");
     const long m = p->m;
     long lo = 0, hi = m, shard = m;
     if (p->nranks > 1) shard_plan(m, p->nranks, p->rank, &lo, &hi, &shard);
     const bool ipc_gather = p->nranks > 1 && !p->comm && p->ipcg;     // no RCCL communicator (ranks sharing a GPU): shards by peer writes
+    // IPC gather: my shard is written into every peer's gradient -- not before every peer is done with its gradient of the
+    // previous call.  Channel 3 is that handshake: "I have arrived here" (everything this stream did with g before is complete),
+    // then wait until every peer has arrived too.  Without an eigen-solve that is partitioned between the ranks nothing else
+    // orders a fast rank against a slow one (round-4 advisor finding).
+    if (ipc_gather) {
+        k_ipc_publish<<<1, 64, 0, p->stream>>>(p->ipcg->view, 3);
+        k_ipc_wait<<<1, 64, 0, p->stream>>>(p->ipcg->view, 3);
+    }
     if (hi > lo) {
         const int grid = (int)std::min<long>(kMaxGrid * 4, (hi - lo + kBlock - 1) / kBlock);
         PeerVecs all;
         if (ipc_gather) { all.n = p->ipcg->nranks; for (int q = 0; q < all.n; ++q) all.v[q] = p->ipcg->g[q]; }
-        const bool fuse = fuse_k > 0 && p->nranks <= 1 && m > kSelSmallMax && env_int("MACHIP_SEL_FUSE", 1) != 0;
+        const bool fuse = fuse_k > 0 && p->nranks <= 1 && m > kSelSmallMax && OPT(sel_fuse, 1) != 0;
         if (fused) *fused = fuse;
         if (fuse) {
             k_sel_init<<<1, 1024, 0, p->stream>>>(p->sel, (long long)std::min(fuse_k, m), p->hist, (6 + kSelRep) * kBins);
@@ -520,12 +530,13 @@ int machip_create(int device, int64_t n, int64_t n_fixed, const int32_t* fi, con
         ST_TRY(dev_alloc(&p->ci, mp)); ST_TRY(dev_alloc(&p->cj, mp)); ST_TRY(dev_alloc(&p->cw, mp));
         ST_TRY(dev_alloc(&p->x, mp)); ST_TRY(dev_alloc(&p->x_next, mp)); ST_TRY(dev_alloc(&p->g, mp)); ST_TRY(dev_alloc(&p->s, mp));
         if (m) {
-            HIP_TRY(hipMemcpy(p->ci, ci, sizeof(int) * (size_t)m, hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(p->cj, cj, sizeof(int) * (size_t)m, hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(p->cw, cw, sizeof(double) * (size_t)m, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpyAsync(p->ci, ci, sizeof(int) * (size_t)m, hipMemcpyHostToDevice, p->stream));
+            HIP_TRY(hipMemcpyAsync(p->cj, cj, sizeof(int) * (size_t)m, hipMemcpyHostToDevice, p->stream));
+            HIP_TRY(hipMemcpyAsync(p->cw, cw, sizeof(double) * (size_t)m, hipMemcpyHostToDevice, p->stream));
         }
-        HIP_TRY(hipMemset(p->x, 0, sizeof(double) * mp));
-        HIP_TRY(hipMemset(p->g, 0, sizeof(double) * mp));
+        HIP_TRY(hipMemsetAsync(p->x, 0, sizeof(double) * mp, p->stream));
+        HIP_TRY(hipMemsetAsync(p->g, 0, sizeof(double) * mp, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));      // (the caller's arrays are borrowed for the duration of the call only)
         const size_t cap = (size_t)p->P + (size_t)n + 8;
         ST_TRY(dev_alloc(&p->cnt, (size_t)n + 1)); ST_TRY(dev_alloc(&p->blk_sum, 3 * kAsmGrid));
         ST_TRY(dev_alloc(&p->rowptr, (size_t)n + 1)); ST_TRY(dev_alloc(&p->col, cap)); ST_TRY(dev_alloc(&p->val, cap));
@@ -570,10 +581,7 @@ void machip_destroy(machip_problem* p) {
         IpcGroup& G = *p->ipcg;
         if (!G.clean_exit) { k_ipc_abort<<<1, 64, 0, p->stream>>>(G.view); (void)hipStreamSynchronize(p->stream); }   // peers' waits end with an error, not a time-out
         p->sol.ipc = nullptr;
-        for (void* q : G.opened) (void)hipIpcCloseMemHandle(q);
-        if (G.flags_mem) (void)hipFree(G.flags_mem);
-        if (G.h_err) (void)hipHostFree(G.h_err);
-        p->ipcg.reset();
+        p->ipcg.reset();                   // (~IpcGroup closes the mappings and frees the flag / error words)
     }
     p->sol.destroy();
     void* ptrs[] = {p->prow, p->pcol, p->pk, p->pw, p->ci, p->cj, p->cw, p->x, p->x_next, p->g, p->s, p->scratch_m, p->cnt,
@@ -716,7 +724,7 @@ int machip_fw_step(machip_problem* p, int64_t k, int iter, double tol, int max_s
         if (st != MACHIP_OK) { guard.ok = soft(st); return st; }
     } else {
         // single rank: the epilogue rides behind the solve's explicit check (solver.h, after_check) -- no exchange step in it
-        const bool spec = p->nranks <= 1 && env_int("MACHIP_SPEC_EPILOGUE", 1) != 0;
+        const bool spec = p->nranks <= 1 && p->sol.opt.get(kOpt_spec_epilogue, 1) != 0;
         if (spec) p->sol.after_check = [&] { epilogue(true); };
         const int st = run_fiedler(p, tol, max_steps, nullptr, warm_start, &lam, stats);
         p->sol.after_check = nullptr;
@@ -828,11 +836,12 @@ int machip_fiedler_csr(int device, int64_t n, const int32_t* indptr, const int32
             ST_TRY(alloc_common(p));
             p->sol.csr_cap = cap;
         }
-        HIP_TRY(hipMemcpy(p->rowptr, indptr, sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpyAsync(p->rowptr, indptr, sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice, p->stream));
         if (nnz) {
-            HIP_TRY(hipMemcpy(p->col, indices, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(p->val, data, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpyAsync(p->col, indices, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice, p->stream));
+            HIP_TRY(hipMemcpyAsync(p->val, data, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, p->stream));
         }
+        HIP_TRY(hipStreamSynchronize(p->stream));
         p->nnz = nnz; p->lnorm = lnorm; p->maxlen = maxlen_csr; p->assembled = true; p->have_vec = false;
         // clean solver state: nothing learnt from, or left over by, an earlier matrix
         Solver& S = p->sol;
@@ -868,7 +877,7 @@ int machip_spmv(machip_problem* p, const double* v, double* y, int variant) {
     HIP_TRY(hipSetDevice(p->device));
     if (!p->assembled) ST_TRY(assemble(p));
     HIP_TRY(hipMemcpyAsync(p->sol.y_raw, v, sizeof(double) * (size_t)p->n, hipMemcpyHostToDevice, p->stream));
-    const SpmvPlan pl = plan_spmv(p->n, p->nnz, variant);
+    const SpmvPlan pl = plan_spmv(p->sol.opt, p->n, p->nnz, variant);
     OpPlain op{p->sol.w2};
     launch_spmv(pl, p->stream, p->csr(), p->sol.y_raw, op);
     HIP_TRY(hipMemcpyAsync(y, p->sol.w2, sizeof(double) * (size_t)p->n, hipMemcpyDeviceToHost, p->stream));
@@ -881,7 +890,7 @@ int machip_profile_spmv(machip_problem* p, int reps, double* avg_us, double* byt
     HIP_TRY(hipSetDevice(p->device));
     if (!p->assembled) ST_TRY(assemble(p));
     Solver& S = p->sol;
-    const SpmvPlan pl = plan_pipe(p->n, p->nnz, p->maxlen);
+    const SpmvPlan pl = plan_pipe(p->sol.opt, p->n, p->nnz, p->maxlen);
     // The dominant kernel of the path: one fused Lanczos step (k_pipe_*).  Re-launching step 1 of
     // a scratch sequence is idempotent (same Z read, same Z/V column written), so `reps`
     // back-to-back launches time exactly the kernel the solve runs, on the same L(x).
@@ -1005,6 +1014,9 @@ int machip_comm_init_ipc(machip_problem* p, int rank, int nranks, const void* bl
         G.opened.push_back(*out);
         return MACHIP_OK;
     };
+    // (a failure below leaves a half-mapped group behind: it is dropped -- mappings closed by ~IpcGroup -- and a retry starts from
+    // machip_ipc_export again)
+    struct Rollback { machip_problem* p; bool ok = false; ~Rollback() { if (!ok) p->ipcg.reset(); } } rollback{p};
     for (int q = 0; q < nranks; ++q) {
         if (q == rank) {
             G.Z0[q] = p->sol.Z0; G.Z1[q] = p->sol.Z1; G.part[q] = p->sol.part; G.yraw[q] = p->sol.y_raw; G.g[q] = p->g;
@@ -1029,7 +1041,8 @@ int machip_comm_init_ipc(machip_problem* p, int rank, int nranks, const void* bl
     long lo, hi, shard;
     shard_plan(p->m, nranks, rank, &lo, &hi, &shard);
     p->m_pad = shard * nranks;
-    if (env_int("MACHIP_SHARD_EIG", 1) != 0) p->sol.ipc = &G;      // (0: the eigen-solve stays replicated, only the gradient is exchanged)
+    if (p->sol.opt.get(kOpt_shard_eig, 1) != 0) p->sol.ipc = &G;      // (0: the eigen-solve stays replicated, only the gradient is exchanged)
+    rollback.ok = true;
     return MACHIP_OK;
 }
 
@@ -1050,7 +1063,7 @@ int machip_comm_init_local(machip_problem** handles, int nranks) {
     G->nranks = nranks;
     for (int r = 0; r < nranks; ++r) G->g.push_back(handles[r]->g);
     // row-partitioned eigen-solve (MACHIP_SHARD_EIG=0: every rank runs the whole solve itself, as in round 2)
-    G->shard_eig = nranks > 1 && nranks <= kMaxPeers && env_int("MACHIP_SHARD_EIG", 1) != 0;
+    G->shard_eig = nranks > 1 && nranks <= kMaxPeers && handles[0]->sol.opt.get(kOpt_shard_eig, 1) != 0;
     if (G->shard_eig) {
         G->sg.rk.resize((size_t)nranks);
         for (int r = 0; r < nranks; ++r) {
@@ -1101,7 +1114,7 @@ int machip_comm_mode(machip_problem* p) {
 
 int machip_panel_plan(int64_t n, int64_t nnz, int maxlen, int* out8) {
     if (n < 1 || n > 2000000000ll || nnz < 0 || !out8) return fail(MACHIP_BAD_ARG, "machip_panel_plan: bad argument");
-    const PanPlan pp = plan_panel((int)n, (long)nnz, maxlen, true);
+    const PanPlan pp = plan_panel(default_options(), (int)n, (long)nnz, maxlen, true);
     out8[0] = pp.on ? 1 : 0; out8[1] = pp.NP; out8[2] = pp.C; out8[3] = pp.NB; out8[4] = pp.NTB; out8[5] = pp.TWW; out8[6] = pp.RPT; out8[7] = pp.grid2;
     return MACHIP_OK;
 }
@@ -1123,7 +1136,7 @@ int make_lane(machip_problem* p, machip_problem** out) {
     q->asm_G = p->asm_G; q->asm_rpb = p->asm_rpb; q->asm_grid = p->asm_grid;
     q->ci = p->ci; q->cj = p->cj; q->cw = p->cw;
     auto body = [&]() -> int {
-        ST_TRY(create_lane_stream(q->device, &q->stream));
+        ST_TRY(create_lane_stream(p->sol.opt, q->device, &q->stream));
         ST_TRY(dev_alloc(&q->x, (size_t)q->m + 64));
         const size_t cap = (size_t)q->P + (size_t)q->n + 8;
         ST_TRY(dev_alloc(&q->cnt, (size_t)q->n + 1)); ST_TRY(dev_alloc(&q->blk_sum, 3 * kAsmGrid));
@@ -1133,7 +1146,9 @@ int make_lane(machip_problem* p, machip_problem** out) {
         // every lane keeps its own Krylov basis: a share of the handle's budget each (MACHIP_LANE_VBUDGET_MB, default
         // MACHIP_VBUDGET_MB / 8 = 512 MB: 16 lanes together hold twice what the handle itself holds; a sequence longer than
         // the lane's share restarts earlier than it would on the handle -- include/machip.h states the guarantee accordingly)
-        ST_TRY(alloc_common(q, std::max(16, env_int("MACHIP_LANE_VBUDGET_MB", std::max(16, env_int("MACHIP_VBUDGET_MB", 4096) / 8)))));
+        const Options& opt = p->sol.opt;
+        q->sol.opt = opt;                     // a lane runs on its owner's options
+        ST_TRY(alloc_common(q, std::max(16, OPT(lane_vbudget_mb, std::max(16, OPT(vbudget_mb, 4096) / 8)))));
         q->sol.csr_cap = cap;
         q->sol.pat = q->pattern();
         q->sol.pan_allowed = p->sol.pan_allowed;
@@ -1169,7 +1184,8 @@ int prepare_lanes(machip_problem* p, int B, bool fw, int* nl_out) {
     // see create_lane_stream at the top of this file), 4 where the solves launch chip-filling step kernels -- more than
     // four hardware queues of those at once collapse (city10000 sweep: 647 it/s with 4 lanes, 277 with 8, 240 with 12).
     const bool small = p->sol.chain_like && persist_fits(p->n, std::max(0l, (long)p->P - 2 * p->sol.chain_edges));   // (P: off-diagonal slots of the union pattern)
-    int nl = std::max(1, std::min(B, std::min(16, env_int("MACHIP_LANES", small ? 16 : 4))));
+    const Options& opt = p->sol.opt;
+    int nl = std::max(1, std::min(B, std::min(16, OPT(lanes, small ? 16 : 4))));
     while ((int)p->lanes.size() < nl) {
         machip_problem* q = nullptr;
         const int st = make_lane(p, &q);
@@ -1187,9 +1203,11 @@ int prepare_lanes(machip_problem* p, int B, bool fw, int* nl_out) {
     for (int l = 0; l < nl; ++l) {
         machip_problem* q = p->lanes[(size_t)l];
         q->sol.solver_mode = p->sol.solver_mode; q->sol.precision = p->sol.precision;
+        q->sol.opt = p->sol.opt;
         q->sol.throughput_lane = true;
         if (p->sol.have_start && q->seen_start_version != p->start_version) {     // per lane: a batch may use fewer lanes than exist
-            HIP_TRY(hipMemcpy(q->sol.start, p->sol.start, sizeof(double) * (size_t)p->n, hipMemcpyDeviceToDevice));
+            HIP_TRY(hipMemcpyAsync(q->sol.start, p->sol.start, sizeof(double) * (size_t)p->n, hipMemcpyDeviceToDevice, q->stream));
+            HIP_TRY(hipStreamSynchronize(q->stream));
             q->sol.have_start = true;
             q->seen_start_version = p->start_version;
         }
@@ -1296,6 +1314,36 @@ int machip_fw_sweep(machip_problem* p, int B, const int64_t* ks, const double* X
     return MACHIP_OK;
 }
 
+int machip_set_option(machip_problem* p, const char* name, int64_t value) {
+    const int id = option_id(name);
+    if (id < 0) return fail(MACHIP_BAD_ARG, std::string("machip_set_option: unknown option '") + (name ? name : "(null)") + "'");
+    const long v = value == INT64_MIN ? kOptAuto : (long)value;
+    if (!p) { default_options().v[id] = v; return MACHIP_OK; }
+    p->sol.opt.v[id] = v;
+    for (machip_problem* q : p->lanes) q->sol.opt.v[id] = v;
+    return MACHIP_OK;
+}
+
+int machip_get_option(machip_problem* p, const char* name, int64_t* value) {
+    const int id = option_id(name);
+    if (id < 0 || !value) return fail(MACHIP_BAD_ARG, "machip_get_option: unknown option or NULL output");
+    const long v = p ? p->sol.opt.v[id] : default_options().v[id];
+    *value = v == kOptAuto ? INT64_MIN : (int64_t)v;
+    return MACHIP_OK;
+}
+
+const char* machip_option_name(int i) { return (i >= 0 && i < kNumOpts) ? option_names()[i] : nullptr; }
+
+int machip_comm_drop_ipc(machip_problem* p) {
+    if (!p || !p->ipcg) return fail(MACHIP_BAD_ARG, "machip_comm_drop_ipc: no inter-process communicator");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    p->sol.ipc = nullptr;
+    p->ipcg.reset();
+    p->rank = 0; p->nranks = 1; p->m_pad = p->m;
+    return MACHIP_OK;
+}
+
 int machip_set_solver(machip_problem* p, int mode) {
     if (!p || mode < 0 || mode > 2) return fail(MACHIP_BAD_ARG, "machip_set_solver: mode must be 0 (auto), 1 (Lanczos) or 2 (preconditioned)");
     p->sol.solver_mode = mode;
@@ -1323,22 +1371,24 @@ int machip_membench(int device, int64_t bytes, int reps, double* read_gbs, doubl
     double2 *a = nullptr, *b = nullptr, *c = nullptr;
     double* out = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t ms_ = nullptr;
     auto body = [&]() -> int {
+        HIP_TRY(hipStreamCreateWithFlags(&ms_, hipStreamNonBlocking));      // (never the legacy stream)
         ST_TRY(dev_alloc(&a, (size_t)cnt2)); ST_TRY(dev_alloc(&b, (size_t)cnt2)); ST_TRY(dev_alloc(&c, (size_t)cnt2)); ST_TRY(dev_alloc(&out, 8));
-        HIP_TRY(hipMemset(a, 0, (size_t)cnt2 * 16)); HIP_TRY(hipMemset(b, 0, (size_t)cnt2 * 16)); HIP_TRY(hipMemset(c, 0, (size_t)cnt2 * 16));
+        HIP_TRY(hipMemsetAsync(a, 0, (size_t)cnt2 * 16, ms_)); HIP_TRY(hipMemsetAsync(b, 0, (size_t)cnt2 * 16, ms_)); HIP_TRY(hipMemsetAsync(c, 0, (size_t)cnt2 * 16, ms_));
         HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
         const int grid = 256 * 16;           // 16 workgroups of 256 threads per CU
         float ms = 0.f;
-        k_mb_read<<<grid, kBlock>>>(a, cnt2, out);
-        HIP_TRY(hipEventRecord(e0, nullptr));
-        for (int r = 0; r < reps; ++r) k_mb_read<<<grid, kBlock>>>(r & 1 ? b : a, cnt2, out);
-        HIP_TRY(hipEventRecord(e1, nullptr)); HIP_TRY(hipEventSynchronize(e1));
+        k_mb_read<<<grid, kBlock, 0, ms_>>>(a, cnt2, out);
+        HIP_TRY(hipEventRecord(e0, ms_));
+        for (int r = 0; r < reps; ++r) k_mb_read<<<grid, kBlock, 0, ms_>>>(r & 1 ? b : a, cnt2, out);
+        HIP_TRY(hipEventRecord(e1, ms_)); HIP_TRY(hipEventSynchronize(e1));
         HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
         *read_gbs = (double)cnt2 * 16.0 * reps / (ms * 1e-3) / 1e9;
-        k_mb_triad<<<grid, kBlock>>>(a, b, c, 3.0, cnt2);
-        HIP_TRY(hipEventRecord(e0, nullptr));
-        for (int r = 0; r < reps; ++r) k_mb_triad<<<grid, kBlock>>>(a, b, c, 3.0, cnt2);
-        HIP_TRY(hipEventRecord(e1, nullptr)); HIP_TRY(hipEventSynchronize(e1));
+        k_mb_triad<<<grid, kBlock, 0, ms_>>>(a, b, c, 3.0, cnt2);
+        HIP_TRY(hipEventRecord(e0, ms_));
+        for (int r = 0; r < reps; ++r) k_mb_triad<<<grid, kBlock, 0, ms_>>>(a, b, c, 3.0, cnt2);
+        HIP_TRY(hipEventRecord(e1, ms_)); HIP_TRY(hipEventSynchronize(e1));
         HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
         *triad_gbs = (double)cnt2 * 48.0 * reps / (ms * 1e-3) / 1e9;      // two reads + one write per element
         HIP_TRY(hipGetLastError());
@@ -1346,9 +1396,11 @@ int machip_membench(int device, int64_t bytes, int reps, double* read_gbs, doubl
     };
     const int st = body();
     const std::string keep = g_err;
+    if (ms_) (void)hipStreamSynchronize(ms_);
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     for (void* q : {(void*)a, (void*)b, (void*)c, (void*)out}) if (q) (void)hipFree(q);
+    if (ms_) (void)hipStreamDestroy(ms_);
     g_err = keep;
     return st;
 }

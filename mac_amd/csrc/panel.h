@@ -683,6 +683,7 @@ __global__ __launch_bounds__(BLOCK) void k_pan_fin(const Z2* __restrict__ z_cur,
 }
 
 
+#ifdef MACHIP_EXPERIMENTS      // (measured slower than the two-launch step: profiles/r4_c4_one_launch_step.md; tools/ubench7.hip builds it)
 // ------------------------------------------------------------------------------------------
 // ONE launch per step (round 4): k_pan_mul's product + k_pan_fin's row work behind a per-row-block arrival ticket.
 // ------------------------------------------------------------------------------------------
@@ -953,5 +954,7 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_step(const Z2* __restrict__
     }
     PAN_CLK(tid == 64, 10); PAN_CLK(tid == 1023, 11);
 }
+
+#endif   // MACHIP_EXPERIMENTS
 
 }  // namespace machip

@@ -8,16 +8,17 @@
 //               row-partitioned step (ShardGroup below)
 //
 // Every number here was measured on MI355X (tools/ubench*.hip, tools/sweep_pipe.py, tools/sweep_panel.py); the comments say
-// which.  The environment knobs are read on every plan ON PURPOSE: a plan is made once per eigen-solve
-// (~40 getenv calls, a few microseconds against milliseconds of solve), and the sweep tools and the variant tests switch
-// shapes between solves of one process.  Nothing in here looks at timings, so a plan -- and with it every rounding of a
-// trajectory -- is a function of (n, nnz, longest row, knobs) only.
+// which.  Shapes can be overridden through the handle's option table (options.h, machip_set_option; OPT(name, default) below):
+// a plan is made once per eigen-solve from the handle's table, so the sweep tools and the variant tests switch shapes between
+// solves of one process.  Nothing in here looks at timings or at the environment, so a plan -- and with it every rounding of a
+// trajectory -- is a function of (n, nnz, longest row, options) only.
 #pragma once
 #include <algorithm>
 #include <cstdlib>
 #include <vector>
 
 #include "kernels.h"
+#include "options.h"
 #include "panel.h"
 #include "persist.h"
 
@@ -42,31 +43,26 @@ struct SpmvPlan {
     int defer = 1;        // row tiles whose finish() waits behind the barrier (k_pipe_vec DEFER): 3 where a workgroup owns several
 };
 
-inline int env_int(const char* name, int dflt) {
-    const char* s = getenv(name);
-    return (s && *s) ? atoi(s) : dflt;
-}
-
 // Every workgroup of a step kernel re-reduces the previous step's per-workgroup partials, so
 // that traffic grows with grid^2: cap the grid (grid-stride loops cover the rest of the rows).
-inline int grid_cap() { return std::max(1, std::min(kMaxGrid, env_int("MACHIP_MAXGRID", 256))); }
+inline int grid_cap(const Options& opt) { return std::max(1, std::min(kMaxGrid, OPT(maxgrid, 256))); }
 
-inline SpmvPlan plan_spmv(int n, long nnz, int forced_variant, int cap = 0) {
-    if (cap <= 0) cap = grid_cap();
+inline SpmvPlan plan_spmv(const Options& opt, int n, long nnz, int forced_variant, int cap = 0) {
+    if (cap <= 0) cap = grid_cap(opt);
     SpmvPlan pl;
     const double mean = n > 0 ? (double)nnz / (double)n : 1.0;
     int variant = forced_variant;
     if (variant == kAuto) {
-        const char* e = getenv("MACHIP_SPMV");
-        if (e && !strcmp(e, "stream")) variant = kStream;
-        else if (e && !strcmp(e, "vec")) variant = kVec;
+        const int e = OPT(spmv, 0);       // 0 automatic, 1 LDS row tiles ("stream"), 2 sub-wave groups ("vec")
+        if (e == 1) variant = kStream;
+        else if (e == 2) variant = kVec;
         else variant = mean < 24.0 ? kStream : kVec;
     }
     pl.variant = variant;
     if (variant == kStream) {
         int tpr = 16;
         while (tpr > 1 && ((long)n * tpr / kBlock > 4L * cap || tpr > std::max(2.0, mean))) tpr >>= 1;
-        tpr = env_int("MACHIP_TPR", tpr);
+        tpr = OPT(tpr, tpr);
         pl.width = tpr;
         const int R = kBlock / tpr;
         pl.grid = (int)std::min<long>(cap, ((long)n + R - 1) / R);
@@ -74,7 +70,7 @@ inline SpmvPlan plan_spmv(int n, long nnz, int forced_variant, int cap = 0) {
         int g = 4;
         while (g < 64 && g < mean * 0.75) g <<= 1;
         if (n <= 32768) g = std::min(g, 16);   // cache-resident operand: narrower groups, more rows in flight (17 -> 7 us at config 2)
-        g = env_int("MACHIP_G", g);
+        g = OPT(g, g);
         pl.width = g;
         const int gpb = kBlock / g;
         pl.grid = (int)std::min<long>(cap, ((long)n + gpb - 1) / gpb);
@@ -84,15 +80,14 @@ inline SpmvPlan plan_spmv(int n, long nnz, int forced_variant, int cap = 0) {
 }
 
 // Launch shape of the fused Lanczos-step kernel (tools/ubench.hip ablations, MI355X):
-// sub-wave groups of 4 lanes per row up to ~40 nnz/row, 16 beyond; at most grid_cap() workgroups
+// sub-wave groups of 4 lanes per row up to ~40 nnz/row, 16 beyond; at most grid_cap(opt) workgroups
 // (each re-reads every workgroup's partials), so large n gets 1024-thread workgroups instead of
 // more of them.
-inline SpmvPlan plan_pipe(int n, long nnz, int maxlen) {
+inline SpmvPlan plan_pipe(const Options& opt, int n, long nnz, int maxlen) {
     SpmvPlan pl;
     const double mean = n > 0 ? (double)nnz / (double)n : 1.0;
-    const char* e = getenv("MACHIP_SPMV");
-    if (e && !strcmp(e, "stream")) {
-        pl = plan_spmv(n, nnz, kStream);
+    if (OPT(spmv, 0) == 1) {
+        pl = plan_spmv(opt, n, nnz, kStream);
         pl.block = kBlock;
         return pl;
     }
@@ -117,20 +112,20 @@ inline SpmvPlan plan_pipe(int n, long nnz, int maxlen) {
         // (round 4: FOUR chains while the mean stays below 12 -- a Frank-Wolfe vertex gives 4 % of the rows 40-65 entries, a 4-lane group
         // walks them in 16 rounds while its wave idles along, profiles/r4_hub_rows_pmc.txt: configs[3] iterates 1-2 14.1 -> 13.1 / 13.5 us)
         unr = g == 4 ? (maxlen > 48 ? (mean < 12.0 ? 4 : 2) : 1) : 2;
-        // at most grid_cap() workgroups (each re-reads every workgroup's partials): grow the workgroup instead of
+        // at most grid_cap(opt) workgroups (each re-reads every workgroup's partials): grow the workgroup instead of
         // the grid (wave 0 of every workgroup only runs the prologue: BLOCK - 64 threads own rows)
         blk = 256;
-        while (blk < 1024 && ((long)n + ((blk - 64) / g) - 1) / ((blk - 64) / g) > grid_cap()) blk <<= 1;
+        while (blk < 1024 && ((long)n + ((blk - 64) / g) - 1) / ((blk - 64) / g) > grid_cap(opt)) blk <<= 1;
     }
-    pl.width = env_int("MACHIP_G", g);
-    pl.unroll = env_int("MACHIP_UNROLL", unr);
-    pl.block = env_int("MACHIP_BLOCK", blk);
+    pl.width = OPT(g, g);
+    pl.unroll = OPT(unroll, unr);
+    pl.block = OPT(block, blk);
     const int gpb = (pl.block - 64) / pl.width;
     const long tiles = ((long)n + gpb - 1) / gpb;
-    pl.grid = (int)std::max<long>(1, std::min<long>(grid_cap(), tiles));
+    pl.grid = (int)std::max<long>(1, std::min<long>(grid_cap(opt), tiles));
     // a workgroup with several row tiles keeps the first three un-finished behind the barrier (the prologue's latency
     // is then hidden); with one tile per workgroup that only costs registers
-    pl.defer = env_int("MACHIP_DEFER", tiles > 2L * pl.grid ? 3 : 1);
+    pl.defer = OPT(defer, tiles > 2L * pl.grid ? 3 : 1);
     return pl;
 }
 
@@ -149,9 +144,9 @@ struct PanPlan {
 };
 // nnz_cap: the most entries the handle's L(x) can ever hold (decides the band form once per handle); shape_only: the shape the
 // automatic mode WOULD take for this n, whatever nnz is (the assembly writes the per-row tables before nnz is known, kernels.h PanSpec)
-inline PanPlan plan_panel(int n, long nnz, int maxlen, bool allowed, long nnz_cap = -1, bool shape_only = false) {
+inline PanPlan plan_panel(const Options& opt, int n, long nnz, int maxlen, bool allowed, long nnz_cap = -1, bool shape_only = false) {
     PanPlan pp;
-    const int mode = env_int("MACHIP_PANEL", -1);     // -1 auto, 0 off, 1 forced (tests: small graphs with several panels)
+    const int mode = OPT(panel, -1);     // -1 auto, 0 off, 1 forced (tests: small graphs with several panels)
     if (!allowed || mode == 0 || n < 128) return pp;
     const double mean = (double)nnz / (double)std::max(n, 1);
     // automatic: the operand must be too large for the gather path's caches to serve cheaply, and the matrix dense enough
@@ -165,8 +160,8 @@ inline PanPlan plan_panel(int n, long nnz, int maxlen, bool allowed, long nnz_ca
     pp.verify = maxlen > kPanMaxLen;
     // (other sizes, tools/panel_size_probe.py: n = 66 000 .. 145 000 with a single wave of workgroups -- a tie at 23-26 entries
     // per row, 1.3-1.5x at 43-46; beyond n = 1e5 the build's 0.25 ms per solve moves the break-even to ~26)
-    const int min_mean10 = env_int("MACHIP_PANEL_MIN_MEAN10", n <= 105000 ? 170 : 260);
-    if (mode < 0 && !(n >= env_int("MACHIP_PANEL_MIN_N", 65536) && (shape_only || mean >= 0.1 * min_mean10))) return pp;
+    const int min_mean10 = OPT(panel_min_mean10, n <= 105000 ? 170 : 260);
+    if (mode < 0 && !(n >= OPT(panel_min_n, 65536) && (shape_only || mean >= 0.1 * min_mean10))) return pp;
     // Shape: NP panels x NB row blocks with NB * NP <= 256 workgroups -- ONE wave of workgroups, one per CU (a second wave
     // doubles the kernel: n = 131 072 with 16 x 18 = 288 workgroups ran 30.5 us per step against 24.9 for the gather step) --,
     // panels of at most 13 x 960 columns (LDS next to the row block's image), row blocks of at most 120 tiles (that image).
@@ -175,35 +170,35 @@ inline PanPlan plan_panel(int n, long nnz, int maxlen, bool allowed, long nnz_ca
     const int groups = (n + 63) / 64;
     const int cmax = 13 * kPanWorkThreads, tmax = kPanWork * kPanTW;
     int np = 0, nb = 0;
-    const int np_env = env_int("MACHIP_PANEL_NP", 0), nb_env = env_int("MACHIP_PANEL_NB", 0);
+    const int np_env = OPT(panel_np, 0), nb_env = OPT(panel_nb, 0);
     if (np_env > 0 || nb_env > 0) {              // explicit shape (tests, sweeps): taken as given, clipped to what the kernels hold
         np = std::max(1, std::min(np_env > 0 ? np_env : (n + 8447) / 8448, 64));
         if ((n + np - 1) / np > cmax) np = (n + cmax - 1) / cmax;
-        nb = nb_env > 0 ? nb_env : std::max(1, grid_cap() / np);
+        nb = nb_env > 0 ? nb_env : std::max(1, grid_cap(opt) / np);
     } else {
         for (int c = std::max(1, (n + 8447) / 8448); c >= 1; --c) {
             if ((n + c - 1) / c > cmax) break;
-            const int b = std::max(1, grid_cap() / c);
+            const int b = std::max(1, grid_cap(opt) / c);
             if ((groups + b - 1) / b <= tmax) { np = c; nb = b; break; }
         }
         if (!np) {
             // no single-wave shape (n > ~145 000).  Round 4: ONE wave of workgroups all the same, each keeping its panel in LDS and
             // walking `cells` row blocks (k_pan_mul_multi): panels of ~8 448 columns, as many row blocks as the 7 680-row image needs
-            const int maxcells = env_int("MACHIP_PANEL_MAXCELLS", 12);
-            for (int c = std::max(1, (n + 8447) / 8448); c >= 1 && c <= grid_cap(); --c) {
+            const int maxcells = OPT(panel_maxcells, 12);
+            for (int c = std::max(1, (n + 8447) / 8448); c >= 1 && c <= grid_cap(opt); --c) {
                 if ((n + c - 1) / c > cmax) break;
-                const int nbg = std::max(1, grid_cap() / c);
+                const int nbg = std::max(1, grid_cap(opt) / c);
                 const int nb_min = (groups + tmax - 1) / tmax;
                 const int cl = (nb_min + nbg - 1) / nbg;
                 if (cl <= maxcells) { np = c; nb = nbg * cl; pp.cells = cl; break; }
             }
             if (!np) {
                 if (mode < 0) return pp;
-                np = (n + cmax - 1) / cmax; nb = std::max(1, grid_cap() / np);   // forced: several waves of workgroups
+                np = (n + cmax - 1) / cmax; nb = std::max(1, grid_cap(opt) / np);   // forced: several waves of workgroups
             }
         }
     }
-    if (env_int("MACHIP_PANEL_CELLS", 0) > 0) pp.cells = env_int("MACHIP_PANEL_CELLS", 0);      // (tests: the multi-cell kernel on small graphs)
+    if (OPT(panel_cells, 0) > 0) pp.cells = OPT(panel_cells, 0);      // (tests: the multi-cell kernel on small graphs)
     if (np > 64) return pp;
     int C = (n + np - 1) / np;
     np = (n + C - 1) / C;                              // panels that actually hold columns
@@ -216,16 +211,18 @@ inline PanPlan plan_panel(int n, long nnz, int maxlen, bool allowed, long nnz_ca
     // sums): measured against the gather step (tools/panel_size_probe.py, profiles/r4_panel_sizes.txt) -- per step a tie at ~29
     // entries per row for n = 150 000, ahead from there (n = 200 000: 41.1 vs 43.7 us at 29 / row, 43.8 vs 50.9 at 36; n = 400 000:
     // 119 vs 132 at 34, 129 vs 200 at 49); with the panel build (0.3-0.5 ms per solve) the whole solve wins from ~33 entries per row
-    if (mode < 0 && !shape_only && pp.cells > 1 && mean < 0.1 * env_int("MACHIP_PANEL_MULTI_MIN_MEAN10", 330)) return PanPlan();
+    if (mode < 0 && !shape_only && pp.cells > 1 && mean < 0.1 * OPT(panel_multi_min_mean10, 330)) return PanPlan();
     pp.on = true; pp.NP = np; pp.C = C; pp.NB = nb; pp.NTB = ntb; pp.TWW = (ntb + kPanWork - 1) / kPanWork;
     pp.RPT = (C + kPanWorkThreads - 1) / kPanWorkThreads;
     // MACHIP_PANEL_FUSED=1: the one-launch form (k_pan_step; tickets for 256 row blocks, one partial-sum slot per slice).  Off by
     // default: 26.9 against 19.1 us per step at configs[3] -- the in-launch hand-off costs more than the launch it saves.
-    pp.fused = env_int("MACHIP_PANEL_FUSED", 0) != 0 && nb <= 256 && nb * np <= 256 && pp.cells == 1;
-    pp.band = env_int("MACHIP_PANEL_BAND", 1) != 0 && (nnz_cap >= 0 ? nnz_cap : nnz) < (1l << 28);     // (CSR positions are packed with 3 count bits; the LOBPCG kernels finish rows without the band terms: solver.h passes band = false there)
-    pp.block2 = env_int("MACHIP_PANEL_B2", 512);
+#ifdef MACHIP_EXPERIMENTS
+    pp.fused = OPT(panel_fused, 0) != 0 && nb <= 256 && nb * np <= 256 && pp.cells == 1;
+#endif
+    pp.band = OPT(panel_band, 1) != 0 && (nnz_cap >= 0 ? nnz_cap : nnz) < (1l << 28);     // (CSR positions are packed with 3 count bits; the LOBPCG kernels finish rows without the band terms: solver.h passes band = false there)
+    pp.block2 = OPT(panel_b2, 512);
     if (pp.block2 != 256 && pp.block2 != 512 && pp.block2 != 1024) pp.block2 = 256;
-    pp.grid2 = (int)std::max<long>(1, std::min<long>(env_int("MACHIP_PANEL_G2", grid_cap()), ((long)n + pp.block2 - 1) / pp.block2));
+    pp.grid2 = (int)std::max<long>(1, std::min<long>(OPT(panel_g2, grid_cap(opt)), ((long)n + pp.block2 - 1) / pp.block2));
     return pp;
 }
 

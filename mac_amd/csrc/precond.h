@@ -452,6 +452,7 @@ struct OpLob {
     }
 };
 
+#ifdef MACHIP_EXPERIMENTS
 // Column-panel form of the product (panel.h, round 4: the diagonally preconditioned mode on large random graphs): k_pan_mul<RPT, RAW>
 // has left one partial product per (row, panel); this kernel adds them in panel order -- Lw[r] -- and takes the 15 inner products
 // exactly as the fused SpMV kernels do (OpLob::row / end).  256 threads per workgroup (OpLob's scratch), partials per workgroup.
@@ -471,6 +472,7 @@ __global__ __launch_bounds__(kBlock) void k_pan_find(OpLob op, const double* __r
     }
     op.end(nullptr);
 }
+#endif
 
 // ---- 3x3 Rayleigh-Ritz on span{x, w - mean, p - mean} -------------------------------------------
 struct LobCoef { double z0, z1, z2, theta, mx, mw, mp; int bad; };
@@ -801,6 +803,7 @@ __global__ __launch_bounds__(BLOCK) void k_lob_update_pan(LobView L, const doubl
     }
 }
 
+#ifdef MACHIP_EXPERIMENTS
 // 1 / diag(L) in natural order (Jacobi preconditioner; any CSR: the row is searched for its diagonal entry)
 __global__ __launch_bounds__(kBlock) void k_jac_dinv(CsrView A, double* __restrict__ dinv, int* bad) {
     for (int r = blockIdx.x * kBlock + threadIdx.x; r < A.n; r += gridDim.x * kBlock) {
@@ -810,6 +813,7 @@ __global__ __launch_bounds__(kBlock) void k_jac_dinv(CsrView A, double* __restri
         dinv[r] = 1.0 / d;
     }
 }
+#endif
 
 // First residual of a (re)started recurrence: x = yvec (unit, mean free), Lx = w2 = L yvec.
 template <bool JAC = false, bool SUMS = false>     // SUMS: also the inner products k_lob_update_pan expects from its predecessor (p = 0)

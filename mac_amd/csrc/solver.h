@@ -53,9 +53,16 @@ struct IpcGroup {
     int* h_err = nullptr;                // mapped pinned
     int g0 = 0, g1 = 0;                  // my workgroups of the running sequence's step launch
     bool clean_exit = false;             // the owner said goodbye (machip_comm_close_ipc): destroying the handle raises no abort
+    // (every error path of machip_ipc_export / machip_comm_init_ipc ends here: mappings closed, flag words and the error word freed)
+    ~IpcGroup() {
+        for (void* q : opened) (void)hipIpcCloseMemHandle(q);
+        if (flags_mem) (void)hipFree(flags_mem);
+        if (h_err) (void)hipHostFree(h_err);
+    }
 };
 
 struct Solver {
+    Options opt = default_options();    // the handle's option table (machip_set_option); a copy of the process defaults at creation
     int n = 0;
     hipStream_t stream = nullptr;
     size_t vcap = 0;            // Lanczos vectors that fit in V
@@ -99,7 +106,8 @@ struct Solver {
     std::map<std::tuple<int, int, int, int, int>, std::array<hipGraphExec_t, 2>> graphs;
     unsigned graph_flip = 0;
     const void* graph_csr_key = nullptr;
-    bool use_graph = true;
+    bool profiled = false;      // a rocprofiler-sdk is attached to the process (graphs are then off unless option "graph" = 1)
+    bool use_graph() const { return OPT(graph, profiled ? 0 : 1) != 0; }
     // host copies of T
     std::vector<double> ha, hb, hl1;
     std::vector<double> wk, guess;
@@ -166,19 +174,18 @@ struct Solver {
     int init(int n_, hipStream_t s, int budget_mb = 0) {
         n = n_;
         stream = s;
-        size_t budget = (size_t)(budget_mb > 0 ? budget_mb : env_int("MACHIP_VBUDGET_MB", 4096)) * (size_t)(1 << 20);
+        size_t budget = (size_t)(budget_mb > 0 ? budget_mb : OPT(vbudget_mb, 4096)) * (size_t)(1 << 20);
         vcap = budget / (sizeof(double) * (size_t)std::max(n, 1));
         vcap = std::max<size_t>(std::min<size_t>(vcap, 16384), 64);
         vcap = std::min<size_t>(vcap, (size_t)n + 10);   // a Krylov sequence never exceeds n - 1 + 8 columns (jcap)
         vcap = std::max<size_t>(vcap, 64);
-        vcap = (size_t)env_int("MACHIP_VCAP", (int)vcap);
+        vcap = (size_t)OPT(vcap, (int)vcap);
         // rocprofiler-sdk (ROCm 7.2) segfaults inside its HSA interception when short graphs are
         // launched in quick succession (reproduced under rocprofv3 --kernel-trace on the pose-graph
         // tests; eager launches of the same kernels are fine): with a profiler attached fall back to
         // eager launches unless MACHIP_GRAPH says otherwise.
-        const bool profiled = dlopen("librocprofiler-sdk.so", RTLD_NOLOAD | RTLD_LAZY) != nullptr ||
-                              dlopen("librocprofiler-sdk.so.1", RTLD_NOLOAD | RTLD_LAZY) != nullptr;
-        use_graph = env_int("MACHIP_GRAPH", profiled ? 0 : 1) != 0;
+        profiled = dlopen("librocprofiler-sdk.so", RTLD_NOLOAD | RTLD_LAZY) != nullptr ||
+                   dlopen("librocprofiler-sdk.so.1", RTLD_NOLOAD | RTLD_LAZY) != nullptr;
         ST_TRY(dev_alloc(&u, n));
         ST_TRY(dev_alloc(&V, (size_t)n * vcap));
         ST_TRY(dev_alloc(&tri, 3 * (vcap + 2)));
@@ -297,7 +304,8 @@ struct Solver {
         }
     }
     void launch_persist(const CsrView& A, int steps, bool f32 = false, const PersistCheb& ch = PersistCheb()) {
-        if (ch.deg >= 2) {       // Chebyshev-filtered recurrence (fp64)
+#ifdef MACHIP_EXPERIMENTS
+        if (ch.deg >= 2) {       // Chebyshev-filtered recurrence (fp64; measured slower: DESIGN "negatives")
             const PersistView L = persist_view<double>();
             switch ((n + 2 * kPersistThreads - 1) / (2 * kPersistThreads)) {
                 case 1: k_lan_persist<2, double, true><<<1, kPersistThreads, 0, stream>>>(ppack, L, steps, ch); break;
@@ -306,6 +314,8 @@ struct Solver {
             }
             return;
         }
+#endif
+        (void)ch;
         if (f32) launch_persist_t<float>(A, steps); else launch_persist_t<double>(A, steps);
     }
 
@@ -316,7 +326,7 @@ struct Solver {
         *out = PanSpec();
         pan_rows_ready = false;
         if (!pan_allowed || !pat.prow) return MACHIP_OK;
-        const PanPlan sh = plan_panel(n, 0, 1, true, (long)csr_cap, true);
+        const PanPlan sh = plan_panel(opt, n, 0, 1, true, (long)csr_cap, true);
         if (!sh.on) return MACHIP_OK;
         ST_TRY(pan_row_buffers(sh, sh.band));
         HIP_TRY(hipMemsetAsync(panv.ovf, 0, sizeof(int), stream));
@@ -360,7 +370,7 @@ struct Solver {
         if (!panv.tick) { ST_TRY(dev_alloc(&panv.tick, 256)); ST_TRY(dev_alloc(&panv.claim, 4096)); }     // (NB <= 256, NB NP <= 4096: plan_panel)
         // band mode (Lanczos form, two launches): diagonal and chain neighbours stay out of the tiles -- k_pan_fin adds them
         panv.band = band ? 1 : 0;
-        panv.spin_ticks = env_int("MACHIP_PANEL_SPIN_US", 20) * 100;
+        panv.spin_ticks = OPT(panel_spin_us, 20) * 100;
         panv.n = n; panv.NP = pn.NP; panv.C = pn.C; panv.NB = pn.NB; panv.NTB = pn.NTB; panv.TWW = pn.TWW; panv.CELLS = pn.cells;
         // static ranges of the cells in the value / column arrays: pattern slots of the cell + its rows (the diagonal, when the band
         // stays in the tiles) + 64 x 128 entries of zero padding (the tile heights telescope), whole 64-entry chunks; once per shape
@@ -407,7 +417,8 @@ struct Solver {
     }
     void launch_pan_step(const PipeView& L, int s) {
         const int g1 = pan.NB * pan.NP;
-        if (pan.fused) {     // one launch per step (k_pan_step)
+#ifdef MACHIP_EXPERIMENTS
+        if (pan.fused) {     // one launch per step (k_pan_step; measured slower: profiles/r4_c4_one_launch_step.md)
             switch (pan.RPT) {
 #define MACHIP_PAN_CASE(R) case R: k_pan_step<R><<<g1, kPanThreads, 0, stream>>>(PAN_STEP_ARGS(panv, L, s)); break;
                 MACHIP_PAN_CASE(1) MACHIP_PAN_CASE(2) MACHIP_PAN_CASE(3) MACHIP_PAN_CASE(4) MACHIP_PAN_CASE(5) MACHIP_PAN_CASE(6)
@@ -417,6 +428,7 @@ struct Solver {
             }
             return;
         }
+#endif
         if (pan.cells > 1) {     // several row blocks per workgroup, the panel loaded once (k_pan_mul_multi)
             const int gm = pan.NP * ((pan.NB + pan.cells - 1) / pan.cells);
             switch (pan.RPT) {
@@ -438,6 +450,7 @@ struct Solver {
         else k_pan_fin<256><<<pan.grid2, 256, 0, stream>>>(PAN_FIN_ARGS(panv, L, s));
     }
 
+#ifdef MACHIP_EXPERIMENTS
     // y_p = L[block, panel p] w for a plain operand vector (k_pan_mul<RPT, RAW = true>): the diagonally preconditioned mode's product
     void launch_pan_mul_raw(const double* w) {
         const int g1 = pan.NB * pan.NP;
@@ -452,6 +465,7 @@ struct Solver {
             default: k_pan_mul<13, true><<<g1, kPanThreads, 0, stream>>>(wz, L.part, L.st, panv.tptr, panv.thead, panv.n, panv.C, panv.NP, panv.TWW, panv, L, 0); break;
         }
     }
+#endif
 
     // ---- row-partitioned chunk: per step one launch per rank, ordered by events (ShardGroup) ----
     void shard_split(const SpmvPlan& pl) {
@@ -595,7 +609,7 @@ struct Solver {
         // row-partitioned chunks are launched eagerly: a captured chunk would be one graph of steps x ranks kernel nodes with
         // ranks - 1 cross-stream dependencies each (ROCm 7.2 crashes on it from 8 ranks on one device), and across devices
         // a single graph is not an option anyway
-        if (!use_graph || sharded) { launch_chunk(A, pl, steps, f32); HIP_TRY(hipGetLastError()); return MACHIP_OK; }
+        if (!use_graph() || sharded) { launch_chunk(A, pl, steps, f32); HIP_TRY(hipGetLastError()); return MACHIP_OK; }
         if (graph_csr_key != (const void*)A.val) {   // different matrix buffers: cached graphs are stale
             for (auto& kv : graphs) for (hipGraphExec_t ge : kv.second) if (ge) (void)hipGraphExecDestroy(ge);
             graphs.clear();
@@ -759,7 +773,7 @@ struct Solver {
         // single-workgroup launch (k_lob_fused; the same arithmetic per unknown): T W S (F W S)^(steps - 1) U instead of (T W S U)^steps
         // (small graphs only: with more unknowns per thread the one workgroup's strided reads of six vectors cost more than the two
         // launches saved -- city10000, C = 10, in the configs[4] sweep: 870 it/s fused against 1 223)
-        const bool fuse = env_int("MACHIP_LOB_FUSE", 1) != 0 && CMAX <= 4;
+        const bool fuse = OPT(lob_fuse, 1) != 0 && CMAX <= 4;
         WbView W0 = wb_active;       // (s = 0 without the exact preconditioner: the fused kernel then skips g)
         for (int s = 0; s < steps; ++s) {
             if (s == 0 || !fuse) {
@@ -778,6 +792,7 @@ struct Solver {
         k_lob_tail<<<1, 64, 0, stream>>>(L, steps);
     }
     void lob_launch_chunk(const CsrView& AT, const SpmvPlan& pl, const LobView& L, int steps) {
+#ifdef MACHIP_EXPERIMENTS
         if (lob_jacobi) {          // diagonal preconditioner: two launches per iteration (three with the column-panel product)
             OpLob op;
             op.L = L;
@@ -799,6 +814,7 @@ struct Solver {
             k_lob_tail<<<1, 64, 0, stream>>>(L, steps);
             return;
         }
+#endif
         if (n > kTriMaxN) {
             OpLob op;
             op.L = L;
@@ -829,7 +845,7 @@ struct Solver {
         }
     }
     int lob_enqueue_chunk(const CsrView& A, const CsrView& AT, const SpmvPlan& pl, const LobView& L, int steps) {
-        if (!use_graph || wb_active.s > 0) { lob_launch_chunk(AT, pl, L, steps); return MACHIP_OK; }   // (closure count is baked into the launches)
+        if (!use_graph() || wb_active.s > 0) { lob_launch_chunk(AT, pl, L, steps); return MACHIP_OK; }   // (closure count is baked into the launches)
         if (graph_csr_key != (const void*)A.val) { drop_graphs(); graph_csr_key = (const void*)A.val; }
         const auto key = std::make_tuple(1000 + pl.variant, pl.width, pl.grid, L.c + (n > kTriMaxN ? 100 : 0) + (lob_jacobi ? 1000 : 0) + (lob_pan ? 2000 + 10000 * pan.NP + 1000000 * pan.NB : 0) + (lob_pan2 ? 500 + 250 * lob_par0 : 0), steps);
         auto it = graphs.find(key);
@@ -852,10 +868,10 @@ struct Solver {
     // tridiagonal one runs first and the solve ESCALATES to the exact one only when it turns out to crawl (the dense
     // factorisation then costs tens of ms -- against seconds, or no convergence at all: fuzz seed 129, n = 36 874,
     // 3 900 active closures, lambda_2 / ||L|| = 1e-10: 200 000 iterations without converging -> 27 iterations, 36 ms).
-    int wb_soft() const { return std::max(64, std::min(16384, env_int("MACHIP_WB_MAX", kWbMaxS))); }
+    int wb_soft() const { return std::max(64, std::min(16384, OPT(wb_max, kWbMaxS))); }
     // (evaluation lanes: 4 096 -- an s x s inverse beyond that, 2 s^3 flops on the whole chip, starves the other lanes: city10000, nine
     // budgets on four lanes, 423 it/s with escalations up to 16 384 closures against 669 with the cap; profiles/r4_exact_small.md)
-    int wb_hard() const { return std::max(wb_soft(), std::min(throughput_lane ? 4096 : 16384, env_int("MACHIP_WB_HARD", 16384))); }   // (11 600 closures on 30 000 nodes at lambda_2/||L|| = 3e-9: 0.30 s escalated against 0.75-0.9 s)
+    int wb_hard() const { return std::max(wb_soft(), std::min(throughput_lane ? 4096 : 16384, OPT(wb_hard, 16384))); }   // (11 600 closures on 30 000 nodes at lambda_2/||L|| = 3e-9: 0.30 s escalated against 0.75-0.9 s)
     int wb_limit_now = kWbMaxS;   // the tier this solve_lob call may use
     bool lob_escalate = false;    // set by solve_lob when it gives up early in favour of the exact preconditioner
     int wb_cap_s = 0;      // what the buffers below were sized for
@@ -920,7 +936,7 @@ struct Solver {
         double *src = wb_Cm, *dst = wb_Cm2;
         // (from MACHIP_GJ_LOOK_MIN = 1 024 rows on, look-ahead: the workgroup holding the next pivot block inverts it for the next launch;
         // below that all tiles run in one round of workgroups and the redundant inversion is off nobody's critical path)
-        const bool look = W.ld >= env_int("MACHIP_GJ_LOOK_MIN", 1024);
+        const bool look = W.ld >= OPT(gj_look_min, 1024);
         if (look && !wb_piv) ST_TRY(dev_alloc(&wb_piv, (size_t)2 * kGjB * kGjB));
         for (int kb = 0, k = 0; kb < W.ld; kb += kGjB, ++k) {
             if (look) k_gj_step<0><<<dim3(tiles, tiles), 256, 0, stream>>>(src, dst, W.ld, kb, info, k ? wb_piv + (size_t)(k & 1) * kGjB * kGjB : nullptr,
@@ -942,31 +958,36 @@ struct Solver {
     // Lanczos) or an error.
     int solve_lob(const CsrView& A, long nnz, double lnorm, double tol, int max_steps, int start_mode,
                   double* lam, double* res, long* iters, long* spmvs, long* restarts_out, bool jacobi = false) {
+#ifndef MACHIP_EXPERIMENTS
+        jacobi = false;
+#endif
         lob_jacobi = jacobi;
         lob_pan = false;
         ST_TRY(lob_alloc(jacobi ? 0 : nnz));
         // (explicit-check kernels may use the whole chip at large n, cf. solve_lanczos)
-        SpmvPlan pl = plan_spmv(n, nnz, kAuto, jacobi && n > 32768 ? kMaxGrid : 0);
+        SpmvPlan pl = plan_spmv(opt, n, nnz, kAuto, jacobi && n > 32768 ? kMaxGrid : 0);
+#ifdef MACHIP_EXPERIMENTS
         if (jacobi) {
-            pan = plan_panel(n, nnz, maxlen_hint, pan_allowed && precision == 0 && !shard && !ipc, (long)csr_cap);
+            pan = plan_panel(opt, n, nnz, maxlen_hint, pan_allowed && precision == 0 && !shard && !ipc, (long)csr_cap);
             lob_pan = false; lob_pan2 = false;
             if (pan.on && !pan.verify) {
                 ST_TRY(ensure_panel(A, nnz, pan));
                 lob_pan = true;
-                lob_pan2 = env_int("MACHIP_LOB_PAN2", 1) != 0 && pan.NB * pan.NP <= 256 && pan.grid2 <= 256 && pan.cells == 1;
+                lob_pan2 = OPT(lob_pan2, 1) != 0 && pan.NB * pan.NP <= 256 && pan.grid2 <= 256 && pan.cells == 1;
             }
         }
+#endif
         LobView L = lview(pl);
         if (lob_pan) L.P_c = std::min(256, vgrid());           // partial sums come from k_pan_find's workgroups
         if (lob_pan && lob_pan2) L.P_a = pan.grid2;            // ... ||r||_1 partials from k_lob_update_pan's (and k_lob_start's) pan.grid2 workgroups
         const int g2 = vgrid();
-        const bool debug = env_int("MACHIP_DEBUG", 0) != 0;
+        const bool debug = OPT(debug, 0) != 0;
         const double scale = lnorm > 0 ? lnorm : 1.0;
         // ---- exact preconditioner (woodbury.h) when the graph is chain + at most kWbMaxS closures ----
         wb_active.s = 0;
         int wb_s = 0;
         lob_escalate = false;
-        const bool wb_enabled = !jacobi && env_int("MACHIP_WOODBURY", 1) != 0 && chain_like && support_hint >= 0;
+        const bool wb_enabled = !jacobi && OPT(woodbury, 1) != 0 && chain_like && support_hint >= 0;
         const bool may_escalate = wb_enabled && support_hint > wb_limit_now && support_hint <= wb_hard();
         if (wb_enabled && support_hint <= wb_limit_now) {
             ST_TRY(wb_alloc());
@@ -998,8 +1019,11 @@ struct Solver {
         // the device; gather indices in the solver's layout ----
         const double sigma = (wb_s > 0 ? 1e-8 : 2.5e-7) * scale;
         HIP_TRY(hipMemsetAsync(lx_bad, 0, sizeof(int), stream));
+#ifdef MACHIP_EXPERIMENTS
         if (jacobi) k_jac_dinv<<<g2, kBlock, 0, stream>>>(A, lx_tdinv, lx_bad);
-        else if (n > kTriMaxN) k_tri_factor_big<<<1, kTriThreads, 0, stream>>>(A, L.stride, sigma, lx_tl, lx_tdinv, lx_tcu, lx_as, lx_bs, lx_bad, chain_only);
+        else
+#endif
+        if (n > kTriMaxN) k_tri_factor_big<<<1, kTriThreads, 0, stream>>>(A, L.stride, sigma, lx_tl, lx_tdinv, lx_tcu, lx_as, lx_bs, lx_bad, chain_only);
         else {
             k_tri_band<<<g2, kBlock, 0, stream>>>(A, L.c, L.stride, lx_ba, lx_bd, lx_bu);
             switch (L.c) {
@@ -1036,19 +1060,22 @@ struct Solver {
         *lam = rq; *res = r1 / scale;
         if (*res < tol) return MACHIP_OK;
         const int cap = std::min(kLobCap, max_steps > 0 ? max_steps : kLobCap);
-        const int patience = std::max(64, env_int("MACHIP_LOB_PATIENCE", 10000));   // iterations without a new best residual
+        const int patience = std::max(64, OPT(lob_patience, 10000));   // iterations without a new best residual
         // (exact preconditioner: a handful of iterations in all, each six launches -- short chunks, no speculation)
         const bool wb = wb_active.s > 0;
-        const int chunk0 = wb ? 4 : std::min(kLobMaxChunk, std::max(1, env_int("MACHIP_LOB_CHUNK", 16)));
+        const int chunk0 = wb ? 4 : std::min(kLobMaxChunk, std::max(1, OPT(lob_chunk, 16)));
         const double ltarget = std::log(std::max(tol * scale, 1e-300));
         int it_enq = 0, restarts = 0;
         double best = r1;
         int best_it = 0;
         while (true) {
             ++epoch;
+#ifdef MACHIP_EXPERIMENTS
             if (jacobi && lob_pan && lob_pan2) k_lob_start<true, true><<<pan.grid2, kBlock, 0, stream>>>(L, yvec, w2, rq_dev, it_enq, epoch);     // (same grid as k_lob_update_pan: its prologue counts gridDim partials)
             else if (jacobi) k_lob_start<true><<<g2, kBlock, 0, stream>>>(L, yvec, w2, rq_dev, it_enq, epoch);
-            else k_lob_start<false><<<g2, kBlock, 0, stream>>>(L, yvec, w2, rq_dev, it_enq, epoch);
+            else
+#endif
+            k_lob_start<false><<<g2, kBlock, 0, stream>>>(L, yvec, w2, rq_dev, it_enq, epoch);
             std::deque<int> pend;
             std::deque<std::pair<int, double>> hist;
             double to_go = 1e18, est = 1e300;
@@ -1125,13 +1152,10 @@ struct Solver {
     // Fiedler vector (warm start).
     int solve(const CsrView& A, long nnz, double lnorm, double tol, int max_steps, int start_mode,
               int forced_variant, double* lambda2, machip_solve_stats* stats) {
-        int mode = solver_mode;
-        if (const char* e = getenv("MACHIP_SOLVER")) {
-            if (!strcmp(e, "lanczos")) mode = 1;
-            else if (!strcmp(e, "lobpcg")) mode = 2;
-            else if (!strcmp(e, "jacobi")) mode = 3;
-            else if (!strcmp(e, "auto")) mode = 0;
-        }
+        int mode = opt.is_set(kOpt_solver) ? OPT(solver, 0) : solver_mode;      // (option "solver" overrides machip_set_solver: 0 auto, 1 Lanczos, 2 preconditioned)
+#ifndef MACHIP_EXPERIMENTS
+        if (mode == 3) mode = 0;      // (3 = diagonally preconditioned LOBPCG: experiments build only)
+#endif
         // auto: chain-dominated graphs with few active closures per node (measured cross-over)
         const bool eligible = n > 256 && n <= kTriBigMaxN;
         // One preconditioned iteration costs about `ratio` Lanczos steps (three launches, one of them a
@@ -1143,7 +1167,7 @@ struct Solver {
         // measured: intel at 9 % closures/node 3.5 ms Lanczos vs 4.7 ms preconditioned, kitti_05 at 0.5 %: 8.6 vs 1.1)
         const bool small = n <= kPersistThreads * kPersistMaxRows;
         const long ratio = small ? 9 : 6;
-        const bool sparse = (double)support_hint <= env_int("MACHIP_LOB_DENSITY_PCT", small ? 3 : 12) * 0.01 * (double)n;
+        const bool sparse = (double)support_hint <= OPT(lob_density_pct, small ? 3 : 12) * 0.01 * (double)n;
         // The preconditioned mode is a block-size-1 LOBPCG preconditioned by the odometry chain: it is built for, and
         // has only been validated on (fuzz runs, every pose graph), chain-DOMINATED graphs.  On a dense random graph
         // the chain is no preconditioner at all (config 2, selected there by a mis-learnt step count: 44 us x 60-220
@@ -1164,8 +1188,8 @@ struct Solver {
         const double cost_lob = 60.0 + 2.7 * ((double)support_hint / 32.0) + 7.5 * (double)lob_it_guess;
         // (Not on evaluation lanes: there 16 single-CU Lanczos solves run side by side -- intel sweep 4 670 it/s aggregate against
         // 2 460 when every lane launches the exact mode's chip-wide kernels; profiles/r4_exact_small.txt.)
-        const bool exact_small = small && !throughput_lane && precision == 0 && support_hint >= 0 && support_hint <= env_int("MACHIP_LOB_SMALL_S", 700) &&
-                                 support_hint <= wb_soft() && env_int("MACHIP_WOODBURY", 1) != 0 &&
+        const bool exact_small = small && !throughput_lane && precision == 0 && support_hint >= 0 && support_hint <= OPT(lob_small_s, 700) &&
+                                 support_hint <= wb_soft() && OPT(woodbury, 1) != 0 &&
                                  (hist_lan_steps <= 0 || cost_lob < 0.4 * (double)hist_lan_steps);
         // Beyond the single-workgroup sizes (n <= 16 384: the one-workgroup tridiagonal kernels the figures below were measured with)
         // the same choice needs a Lanczos history: with the look-ahead inverse (woodbury.h: 1.7 ms at 2 137 closures) the exact mode
@@ -1175,7 +1199,7 @@ struct Solver {
         // 4.2 + 2e-6 nnz (tools/city_exact_probe.py, tools/ubench_gj.hip; profiles/r4_exact_big.md).
         bool exact_big = false;
         if (!small && n <= kTriMaxN && !throughput_lane && precision == 0 && support_hint > 0 && support_hint <= wb_soft() && hist_lan_steps > 0 &&
-            env_int("MACHIP_WOODBURY", 1) != 0 && env_int("MACHIP_EXACT_BIG", 1) != 0) {
+            OPT(woodbury, 1) != 0 && OPT(exact_big, 1) != 0) {
             const double sd = (double)support_hint, nd = (double)n, ldw = (double)((support_hint + kGjT - 1) / kGjT * kGjT);
             const double its = hist_exact_iters > 0 ? (double)hist_exact_iters : 14.0;
             const double est_exact = 120.0 + 4e-6 * nd * sd + 1.1e-5 * sd * sd + (ldw / kGjB) * (13.0 + 3.5e-6 * ldw * ldw) +
@@ -1195,7 +1219,7 @@ struct Solver {
         if (!((eligible && want) || want_jac) && mode == 0 && eligible && chain_dominated && chain_like && !small && n <= kTriMaxN && !throughput_lane &&
             precision == 0 && forced_variant == 0 && support_hint > 0 && support_hint <= wb_soft() &&      // (sharded / inter-process solves too: every rank
             // holds the same tridiagonal records, takes the same decision at the same step, and runs the exact mode replicated)
-            env_int("MACHIP_WOODBURY", 1) != 0 && env_int("MACHIP_EXACT_BIG", 1) != 0 && env_int("MACHIP_EXACT_SWITCH", 1) != 0) {
+            OPT(woodbury, 1) != 0 && OPT(exact_big, 1) != 0 && OPT(exact_switch, 1) != 0) {
             const double sd = (double)support_hint, nd = (double)n, ldw = (double)((support_hint + kGjT - 1) / kGjT * kGjT);
             const double its = hist_exact_iters > 0 ? (double)hist_exact_iters : 14.0;
             switch_est_us = 120.0 + 4e-6 * nd * sd + 1.1e-5 * sd * sd + (ldw / kGjB) * (13.0 + 3.5e-6 * ldw * ldw) +
@@ -1217,7 +1241,7 @@ struct Solver {
             // (evaluation lanes run many solves side by side: the exact mode's chip-wide kernels -- s column solves, the s x s inverse,
             // an n x s product per application -- are kept to the cheap cases there, the tridiagonal preconditioner serves the rest and
             // a crawling solve still escalates; city10000, 9 budgets on 4 lanes: 422 -> 664 it/s, profiles/r4_exact_small.md)
-            wb_limit_now = throughput_lane ? std::min(wb_soft(), env_int("MACHIP_WB_LANE_MAX", 256)) : wb_soft();
+            wb_limit_now = throughput_lane ? std::min(wb_soft(), OPT(wb_lane_max, 256)) : wb_soft();
             int st = solve_lob(A, nnz, lnorm, tol, max_steps, start_mode, &lam, &res, &iters, &spmvs, &rst, want_jac);
             if (st == MACHIP_NOT_CONVERGED && lob_escalate) {
                 long it1 = iters, sp1 = spmvs;
@@ -1231,6 +1255,7 @@ struct Solver {
                 float ms = 0.f;
                 HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
                 have_prev = true; last_was_lob = true; last_steps = iters; J_last = 0;
+                last_seq_sharded = false;        // (the final solve ran replicated, whatever a Lanczos prefix did: machip_comm_mode reports it)
                 hist_lob_iters = iters;
                 if (wb_active.s > 0) hist_exact_iters = iters;
                 *lambda2 = lam;
@@ -1257,8 +1282,8 @@ struct Solver {
                       int forced_variant, double* lambda2, machip_solve_stats* stats) {
         // explicit-check kernels: run once or twice per solve, nobody re-reduces their partials per step -- at large n they may
         // use the whole chip (config 4: 84 us per check with 256 workgroups of 8 rows each)
-        const SpmvPlan pl = plan_spmv(n, nnz, forced_variant, n > 32768 ? kMaxGrid : 0);
-        SpmvPlan pp = plan_pipe(n, nnz, maxlen_hint);            // fused Lanczos-step kernel
+        const SpmvPlan pl = plan_spmv(opt, n, nnz, forced_variant, n > 32768 ? kMaxGrid : 0);
+        SpmvPlan pp = plan_pipe(opt, n, nnz, maxlen_hint);            // fused Lanczos-step kernel
         const int g2 = vgrid();
         HIP_TRY(hipEventRecord(ev0, stream));
         ev1_at_check = false;
@@ -1274,7 +1299,7 @@ struct Solver {
 
         // ---- start vector ----
         // (single-workgroup form: k_persist_begin of the first sequence copies it -- one launch less per solve)
-        const bool pmode_early = env_int("MACHIP_PERSIST", 1) != 0 && chain_like && persist_fits(n, nnz - n - 2 * chain_edges);
+        const bool pmode_early = OPT(persist, 1) != 0 && chain_like && persist_fits(n, nnz - n - 2 * chain_edges);
         const double* begin_src = nullptr;
         if (start_mode == 1 && have_prev) {
             if (pmode_early) begin_src = yvec;
@@ -1286,26 +1311,26 @@ struct Solver {
             k_fill_start<<<g2, kBlock, 0, stream>>>(u, n, 0x1234567ull);
         }
 
-        const int chunk0 = std::min(kMaxChunk, std::max(2, env_int("MACHIP_CHUNK", 32) & ~1));   // even: Z parity = jrel & 1
-        const int chunk_near = std::min(chunk0, std::max(2, env_int("MACHIP_CHUNK_NEAR", 8) & ~1));   // once the residual estimate is within 1e3 of the target
+        const int chunk0 = std::min(kMaxChunk, std::max(2, OPT(chunk, 32) & ~1));   // even: Z parity = jrel & 1
+        const int chunk_near = std::min(chunk0, std::max(2, OPT(chunk_near, 8) & ~1));   // once the residual estimate is within 1e3 of the target
         if (max_steps & 1) ++max_steps;
         // An explicit check runs when the recurrence's own estimate of the residual is within this factor of the tolerance.  The estimate
         // predicts the measured residual to +/- 5 % (profiles/r5_c4_checks.txt), so round 1-4's factor of 1.5 bought nothing: every check
         // started between 1.1 and 1.5 x the tolerance failed (0.3 per solve at configs[3], ~100 us each: Ritz vector, product, wait) and
         // the solve went on to the same final step anyway.
-        const double trigger_slack = 0.01 * env_int("MACHIP_TRIGGER_PCT", 110);
-        const double near_factor = 0.1 * env_int("MACHIP_NEAR_X10", 20);   // end game (no speculation, short chunks) from this many chunks of predicted steps to go
+        const double trigger_slack = 0.01 * OPT(trigger_pct, 110);
+        const double near_factor = 0.1 * OPT(near_x10, 20);   // end game (no speculation, short chunks) from this many chunks of predicted steps to go
         std::deque<Pending> pend;
         bool done = false;
 
-        bool classic = n <= env_int("MACHIP_CLASSIC_N", 256);
+        bool classic = n <= OPT(classic_n, 256);
         // LDS-resident single-workgroup form when the matrix fits (classic recurrence: also fine after restarts)
         const bool pmode = pmode_early;
         // column-panel step (panel.h) where the gather operand is too large for the caches (fp64 sequences only)
-        pan = plan_panel(n, nnz, maxlen_hint, pan_allowed && precision == 0 && !pmode && !classic && pp.variant == kVec && !shard && !ipc, (long)csr_cap);   // (the row-partitioned solve shards the gather step)
+        pan = plan_panel(opt, n, nnz, maxlen_hint, pan_allowed && precision == 0 && !pmode && !classic && pp.variant == kVec && !shard && !ipc, (long)csr_cap);   // (the row-partitioned solve shards the gather step)
         // padded fixed-width form for short rows (pose graphs beyond the single-workgroup kernel): no row-pointer round trip
         if (!pan.on && !pmode && !classic && !shard && !ipc && precision == 0 && pp.variant == kVec && pp.width == 4 && pp.defer < 3 &&
-            maxlen_hint >= 1 && maxlen_hint <= 16 && env_int("MACHIP_ELL", 1) != 0) {
+            maxlen_hint >= 1 && maxlen_hint <= 16 && OPT(ell, 1) != 0) {
             const int W = maxlen_hint <= 8 ? 8 : 16;
             if (!ell_col) { ST_TRY(dev_alloc(&ell_col, (size_t)n * 16)); ST_TRY(dev_alloc(&ell_val, (size_t)n * 16)); }
             k_ell_build<<<(int)std::min<long>(kMaxGrid, ((long)n * W + kBlock - 1) / kBlock), kBlock, 0, stream>>>(A, W, ell_col, ell_val);
@@ -1328,8 +1353,8 @@ struct Solver {
             pp.width = pan.NP * 100 + pan.RPT; pp.unroll = pan.TWW; pp.defer = pan.NB + (pan.fused ? 1000 : 0) + 10000 * pan.cells;
         }
         const PipeView L = pview(pp);
-        const int pchunk0 = std::min(kPersistMaxSteps, std::max(2, env_int("MACHIP_PCHUNK", 64)));
-        const bool debug = env_int("MACHIP_DEBUG", 0) != 0;
+        const int pchunk0 = std::min(kPersistMaxSteps, std::max(2, OPT(pchunk, 64)));
+        const bool debug = OPT(debug, 0) != 0;
         // ---- Chebyshev-filtered recurrence for the single-workgroup kernel (persist.h, CHEB): after a short plain
         // sequence has produced a Ritz vector -- its Rayleigh quotient rq is a RIGOROUS upper bound of lambda_2 (unit
         // vector orthogonal to 1) -- the solve restarts from that vector on C = -T_d(M), M mapping [a, b] onto [-1, 1] with
@@ -1343,11 +1368,15 @@ struct Solver {
         // the plain recurrence -- a filtered step costs 3.2 us + 0.55 us per product against 2.35 us for a plain step, and
         // with a = 1.25 rq ~ 20 lambda_2 after 32 plain steps the filter needs 1.4-4x the products (intel 420-435 against
         // 488 it/s, sphere2500 900-1 013 against 1 049 for degrees 8-24).  Off by default (MACHIP_CHEB_DEG=8 turns it on).
-        const int cheb_deg_max = env_int("MACHIP_CHEB_DEG", 0) & ~1;
+#ifdef MACHIP_EXPERIMENTS
+        const int cheb_deg_max = OPT(cheb_deg, 0) & ~1;
+#else
+        const int cheb_deg_max = 0;
+#endif
         const bool cheb_ok = pmode && precision == 0 && cheb_deg_max >= 2 && persist_fits_cheb(n, nnz - n - 2 * chain_edges);
-        const int cheb_after = std::max(8, env_int("MACHIP_CHEB_AFTER", 32));      // plain steps before the hand-over
-        const int cheb_chunk = std::max(4, env_int("MACHIP_CHEB_CHUNK", 16) & ~1);  // filtered steps per launch
-        const int cheb_depth = std::max(1, env_int("MACHIP_CHEB_DEPTH", 2));
+        const int cheb_after = std::max(8, OPT(cheb_after, 32));      // plain steps before the hand-over
+        const int cheb_chunk = std::max(4, OPT(cheb_chunk, 16) & ~1);  // filtered steps per launch
+        const int cheb_depth = std::max(1, OPT(cheb_depth, 2));
         // T_d(x) and its derivative for x >= 1, and the inverse on that branch
         auto cheb_T = [](int d, double x, double* dT) {
             const double th = std::acosh(std::max(1.0, x));
@@ -1364,7 +1393,7 @@ struct Solver {
         // (measured floor of the fp32 recurrence's TRUE residual: 8e-7 at config 2 (||L|| = 50, n = 1e4), 1e-6 on
         // sphere2500, 2e-4 on city10000 (||L|| = 1600, stiff) while its own estimate keeps falling: beyond
         // ~eps_32 sqrt(n) x 10 the fp32 steps buy nothing)
-        const double f32_switch = std::max(std::max(tol, 1e-9 * (double)env_int("MACHIP_F32_SWITCH_E9", 2000)),
+        const double f32_switch = std::max(std::max(tol, 1e-9 * (double)OPT(f32_switch_e9, 2000)),
                                            3e-7 * std::sqrt((double)n));
         long steps_lowp = 0;
         if (f32_seq && !pmode) {
@@ -1398,14 +1427,17 @@ struct Solver {
             } else {
                 ++epoch;
                 k_pipe_init<<<pp.grid, kBlock, 0, stream>>>(L, u, (int)epoch);
-                if (pan.on && pan.fused) {      // arrival tickets / slice claims of k_pan_step count from the sequence's step 0
+                if (pan.on && pan.fused) {      // (experiments build) arrival tickets / slice claims of k_pan_step count from the sequence's step 0
                     HIP_TRY(hipMemsetAsync(panv.tick, 0, sizeof(unsigned int) * 256, stream));
                     HIP_TRY(hipMemsetAsync(panv.claim, 0, sizeof(unsigned int) * 4096, stream));
                 }
                 if (shard && pp.variant == kVec) {       // row-partitioned sequence: every rank starts from the same records
                     seq_sharded = true; seq_plan = pp;
                     ST_TRY(shard_broadcast_init());
-                } else if (ipc && pp.variant == kVec && pp.grid >= ipc->nranks) {
+                } else if (ipc && precision == 0 && pp.variant == kVec && pp.grid >= ipc->nranks) {
+                    // (precision 1: the fp32 sequences run replicated on the very record / partial-sum buffers the peers of a
+                    // partitioned step write into, and nothing orders a rank that is still in its fp32 phase against a peer that has
+                    // entered the fp64 one -- the mixed mode therefore never partitions; round-4 advisor finding)
                     // between processes every rank has just run k_pipe_init itself on its own copy of u: identical records
                     seq_sharded = true; seq_ipc = true; seq_plan = pp;
                 }
@@ -1424,7 +1456,7 @@ struct Solver {
             std::deque<std::pair<int, double>> hist;
             double to_go = 1e18;
             int switch_votes = 0;
-            const bool sched = env_int("MACHIP_SCHED", 1) != 0;
+            const bool sched = OPT(sched, 1) != 0;
             const double ltarget = std::log(std::max(seq_tol * tiny_l, 1e-300));
             const int jcap = (int)std::min<size_t>(vcap - 2, (size_t)std::max(2, n - 1) + 8) & ~1;
             const size_t cs = vcap + 2;   // stride of the classic alpha / beta / l1 arrays
@@ -1580,7 +1612,7 @@ struct Solver {
                 if ((trig && est < 0.5 * last_check_est) || broke || at_cap || handover) {
                     double rq = 0.0, r1 = 0.0;
                     HIP_TRY(hipEventRecord(evs1, stream));   // everything enqueued so far = steps [J_timed, J_enq)
-                    spec_likely = !f32_seq && !handover && est < 0.01 * env_int("MACHIP_SPEC_SLACK_PCT", 105) * seq_tol * lnorm;
+                    spec_likely = !f32_seq && !handover && est < 0.01 * OPT(spec_slack_pct, 105) * seq_tol * lnorm;
                     ST_TRY(explicit_check(A, pl, Jeff, sm.s.data(), &rq, &r1, f32_seq));   // syncs the stream
                     spec_likely = true;
                     {

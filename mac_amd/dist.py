@@ -37,15 +37,56 @@ def attach(problem, dist, rank: int, nranks: int):
     return shard_bounds(problem.m, rank, nranks)
 
 
+def _all_gather(dist, obj, world: int):
+    """all_gather_object under either signature: FileGroup's ``(obj) -> list`` or torch.distributed's
+    ``(object_list, obj)``."""
+    import inspect
+    try:
+        npar = len([p for p in inspect.signature(dist.all_gather_object).parameters.values()
+                    if p.default is inspect.Parameter.empty and p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD)])
+    except (TypeError, ValueError):
+        npar = 1
+    if npar >= 2:
+        out = [None] * world
+        dist.all_gather_object(out, obj)
+        return out
+    return dist.all_gather_object(obj)
+
+
 def attach_ipc(problem, dist, rank: int, nranks: int, timeout_s: float = 10.0):
     """Row-partition the eigen-solve of ``problem`` between the processes of the job (machip_comm_init_ipc): every rank
     exports IPC handles of its exchange buffers, the group carries the blobs, every rank maps its peers' buffers.  Call
     after ``attach`` when an RCCL communicator carries the gradient, or alone (ranks sharing one GPU: the gradient shards
-    then travel through the mapped buffers too).  ``detach_ipc`` before closing the problem."""
-    blob = problem.ipc_export()
-    blobs = dist.all_gather_object(blob)
-    problem.comm_init_ipc(rank, nranks, blobs, timeout_s)
-    dist.barrier()                      # everybody has mapped everybody before the first step is launched
+    then travel through the mapped buffers too).  ``detach_ipc`` before closing the problem.
+
+    Exception-safe and collective: every rank runs the same two exchanges whatever happens locally (an export or a mapping
+    that fails is carried as a flag), so no rank is left one collective behind; when ANY rank failed, every rank drops the
+    communicator again (the handle is a single-rank handle as before) and raises -- the caller falls back to a replicated
+    solve on all ranks alike."""
+    err = None
+    blob = None
+    try:
+        blob = problem.ipc_export()
+    except Exception as e:          # noqa: BLE001
+        err = e
+    blobs = _all_gather(dist, blob, nranks)
+    if err is None:
+        if any(b is None for b in blobs):
+            err = RuntimeError(f"IPC export failed on rank(s) {[r for r, b in enumerate(blobs) if b is None]}")
+        else:
+            try:
+                problem.comm_init_ipc(rank, nranks, blobs, timeout_s)
+            except Exception as e:  # noqa: BLE001
+                err = e
+    oks = _all_gather(dist, err is None, nranks)      # agreement; doubles as the barrier "everybody has mapped everybody"
+    if not all(oks):
+        if err is None:
+            err = RuntimeError(f"IPC attach failed on rank(s) {[r for r, o in enumerate(oks) if not o]}")
+        try:
+            problem.comm_drop_ipc()
+        except Exception:           # noqa: BLE001  (nothing was attached on this rank)
+            pass
+        raise err
     return shard_bounds(problem.m, rank, nranks)
 
 

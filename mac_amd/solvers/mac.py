@@ -31,11 +31,12 @@ class MAC:
         Q: Optional[np.ndarray] = None
 
     def __init__(self, fixed_edges, candidate_edges, num_nodes, fiedler_method="hip",
-                 fiedler_tol=1e-8, min_selection_weight_tol=1e-10, device=0, max_lanczos_steps=0, precision=0):
+                 fiedler_tol=1e-8, min_selection_weight_tol=1e-10, device=0, max_lanczos_steps=0, precision=0, options=None):
         """Arguments as mac/solvers/mac.py:22-24, plus (keyword-only in spirit, defaults keep the reference's call
-        sites unchanged): ``device`` (GPU ordinal), ``max_lanczos_steps`` (0 = library default) and ``precision``
+        sites unchanged): ``device`` (GPU ordinal), ``max_lanczos_steps`` (0 = library default), ``precision``
         (0 = fp64 throughout; 1 = fp32 Krylov iterate + fp64 Rayleigh / residual refinement, BASELINE.json configs[4];
-        the returned pairs obey the same stop rule either way)."""
+        the returned pairs obey the same stop rule either way) and ``options`` (dict: entries of the handle's option table,
+        machip_set_option -- launch shapes / thresholds; nothing a reference call site needs)."""
         _fiedler.check_method(fiedler_method)
         num_edges = len(fixed_edges) + len(candidate_edges)
         assert (num_nodes - 1) <= num_edges                        # mac.py:47
@@ -59,6 +60,8 @@ class MAC:
         self._dev.set_solver(_fiedler.solver_mode(fiedler_method))
         self.precision = int(precision)
         self._dev.set_precision(self.precision)
+        if options:
+            self._dev.set_options(**options)
         self.last_stats = None
 
     # -------------------------------------------------------------------------------
@@ -112,11 +115,16 @@ class MAC:
                     use_cache=False, seed=None):
         """``solve`` for several budgets of this graph at once: the loop of examples/g2o_experiment.py:306-336
         (``for pct: MAC.solve(k, w_init, ...)``) run concurrently on the device (machip_fw_sweep: one evaluation lane per
-        budget, up to 16 at a time -- MACHIP_LANES).  ``ks`` budgets, ``x_inits`` the matching initial selections.  Returns a
-        list of ``(rounded, unrounded, upper)`` in the order of ``ks``; each equals what ``solve`` returns for that budget on
-        a fresh MAC object (same kernels, same start vector, same stop rules; bit for bit unless an eigen-solve needs more
-        Lanczos steps in one sequence than a lane's share of the basis memory holds -- then to the solver tolerance).  rounding: "nearest" (device, tie-broken by
-        edge weight like mac.py:209) or "madow" (host, one draw per budget from ``seed``)."""
+        budget, up to 16 at a time -- option "lanes").  ``ks`` budgets, ``x_inits`` the matching initial selections.  Returns a
+        list of ``(rounded, unrounded, upper)`` in the order of ``ks``.  Each obeys the same stop rules from the same start
+        vector as ``solve`` for that budget on a fresh MAC object.  The two are BIT-IDENTICAL when the eigen-solver mode is pinned
+        (``fiedler_method="hip_lanczos"``: same kernels on a lane and on the handle -- unless an eigen-solve needs more Lanczos
+        steps in one sequence than a lane's share of the basis memory holds).  Under the automatic mode (``"hip"``) they agree
+        to the solver tolerance only: a standalone handle may take the exact chain + closures mode (small pose graphs up to 700
+        active closures, larger ones on a long forecast), which a lane keeps to 256 closures so as not to starve the other
+        lanes -- a 1e-8 difference in lambda_2 can move a near-tie of the top-k LP and with it the rounded selection
+        (include/machip.h, machip_fw_sweep).  rounding: "nearest" (device, tie-broken by edge weight like mac.py:209) or
+        "madow" (host, one draw per budget from ``seed``)."""
         m = len(self.weights)
         ks = [int(k) for k in ks]
         assert len(ks) == len(x_inits)

@@ -279,7 +279,7 @@ def test_lanczos_hands_over_to_the_exact_mode_on_its_own_forecast():
 
 def test_auto_mode_learns_a_stiff_problem_from_step_counts():
     """city10000 with the first 20 % of the closures selected is stiff (~10^4 Lanczos steps) although its closure density is above
-    the static threshold.  (a) Round-3 rule (MACHIP_EXACT_BIG=0): the automatic mode sees that from the first solve's step count and
+    the static threshold.  (a) Round-3 rule (option exact_big = 0): the automatic mode sees that from the first solve's step count and
     runs the preconditioned mode from then on.  (b) Round 4: the first solve itself hands over -- the Lanczos loop's own forecast of
     the steps to go exceeds the exact chain + closures mode's estimated cost (2 137 closures) twice in a row --, later solves start
     in the exact mode.  Deterministic either way: counts and bit-reproducible forecasts, never timings."""
@@ -288,17 +288,14 @@ def test_auto_mode_learns_a_stiff_problem_from_step_counts():
     x = np.zeros(m); x[: m // 5] = 1.0
     lams = []
     for big in ("0", "1"):
-        os.environ["MACHIP_EXACT_BIG"] = big
-        try:
-            P = problem_of(g)
-            P.set_x(x)
-            P.set_solver(0)
-            lam1, _, _ = P.fiedler(); s1 = int(P.stats.lanczos_steps)
-            lam2, _, _ = P.fiedler(); s2 = int(P.stats.lanczos_steps)
-            lam3, _, _ = P.fiedler(); s3 = int(P.stats.lanczos_steps)
-            P.close()
-        finally:
-            os.environ.pop("MACHIP_EXACT_BIG", None)
+        P = problem_of(g)
+        P.set_option("exact_big", int(big))
+        P.set_x(x)
+        P.set_solver(0)
+        lam1, _, _ = P.fiedler(); s1 = int(P.stats.lanczos_steps)
+        lam2, _, _ = P.fiedler(); s2 = int(P.stats.lanczos_steps)
+        lam3, _, _ = P.fiedler(); s3 = int(P.stats.lanczos_steps)
+        P.close()
         if big == "0":
             assert s1 > 2500 and s2 * 6 < s1 and s3 == s2, (s1, s2, s3)
         else:
@@ -607,17 +604,16 @@ def test_teacher_forced_config2_all_twenty_reference_iterates(precision):
     P.close()
 
 
-@pytest.mark.parametrize("form", ["auto", "panel", "panel_one_launch", "gather", "lobpcg_panel"])
+@pytest.mark.parametrize("form", ["auto", "panel", "gather"])
 def test_teacher_forced_config4_all_twenty_iterates(form):
     """BASELINE.json configs[3] (ER N = 100k, 2M candidates): lambda_2 on ALL 20 iterates of the reference's loop with
     ARPACK (tol 1e-13, residual <= 2e-13) standing in for the sparse LU that does not finish at this size
     (tests/golden/er100k_arpack.npz, generator `ER100K_ITERS=20 make_golden.py er100k_arpack`: the reference's
     MAC.laplacian / solve_subset_box_lp / update, SciPy eigsh).  These are the iterates the bench runs: nnz 0.7 M .. 4.0 M,
     the dense ones (6-19) are where the column-panel step spends its steps.  Forms: the automatic choice (gather step on
-    the sparse iterates, panel step on the dense ones), the panel step forced onto every iterate as two launches
-    (k_pan_mul + k_pan_fin) and as one (k_pan_step, arrival tickets), the gather step forced onto every iterate; the experimental
-    diagonally preconditioned LOBPCG with the column-panel product, two launches per iteration (k_pan_mul<.., RAW> with w^T L w per
-    cell + k_lob_update_pan: the other fourteen inner products from the previous update by the symmetry of L)."""
+    the sparse iterates, panel step on the dense ones), the panel step forced onto every iterate (k_pan_mul + k_pan_fin), the
+    gather step forced onto every iterate.  (The one-launch panel step and the diagonally preconditioned LOBPCG forms of round 4
+    -- measured slower, profiles/r4_c4_one_launch_step.md -- are compiled only with -DMACHIP_EXPERIMENTS and no longer tested here.)"""
     import bench
     w = bench.make_workload("c4")
     gv = load_golden("er100k_arpack")
@@ -628,19 +624,8 @@ def test_teacher_forced_config4_all_twenty_iterates(form):
     P.set_start(reference_start_block(w["n"])[:, 0].copy())
     bits = gv["ref_s_bits"]
     vert = lambda i: np.unpackbits(bits[i])[:m].astype(np.float64)    # noqa: E731
-    env = {"auto": {}, "panel": {"MACHIP_PANEL": "1", "MACHIP_PANEL_FUSED": "0"},
-           "panel_one_launch": {"MACHIP_PANEL": "1", "MACHIP_PANEL_FUSED": "1"}, "gather": {"MACHIP_PANEL": "0"},
-           "lobpcg_panel": {"MACHIP_SOLVER": "jacobi", "MACHIP_PANEL": "1"}}[form]
-    old = {kk: os.environ.get(kk) for kk in ("MACHIP_PANEL", "MACHIP_PANEL_FUSED", "MACHIP_SOLVER")}
-    try:
-        os.environ.update(env)
-        _teacher_forced(P, k, w["x0"], vert, gv["lam_traj"])
-    finally:
-        for kk, vv in old.items():
-            if vv is None:
-                os.environ.pop(kk, None)
-            else:
-                os.environ[kk] = vv
+    P.set_options(**{"auto": {}, "panel": {"panel": 1}, "gather": {"panel": 0}}[form])
+    _teacher_forced(P, k, w["x0"], vert, gv["lam_traj"])
     P.close()
 
 
@@ -926,15 +911,13 @@ def test_row_partitioned_eigensolve_is_bit_identical_at_bench_sizes(cfg, R, iter
     workgroups on its own copy of L(x) and of the operand, writes records and partial sums into every rank's copy, basis
     sharded by rows) on the BENCH workloads: several row tiles per workgroup, deferred-barrier launch shapes, hundreds
     of steps per solve, graph-captured multi-stream chunks.  f / dual bound / ||g|| / x on every rank are bit-identical
-    to a single handle running the same one-kernel step (MACHIP_PANEL=0: the column-panel form is not sharded)."""
+    to a single handle running the same one-kernel step (option panel = 0: the column-panel form is not sharded)."""
     import threading
     import bench
     w = bench.make_workload(cfg)
     n, k = w["n"], w["k"]
     start = reference_start_block(n)[:, 0].copy()
-    old = os.environ.get("MACHIP_PANEL")
-    os.environ["MACHIP_PANEL"] = "0"
-    try:
+    with _lib.default_options(panel=0):
         def mk():
             return _lib.Problem(n, w["fi"], w["fj"], w["fw"], w["ci"], w["cj"], w["cw"])
 
@@ -966,29 +949,17 @@ def test_row_partitioned_eigensolve_is_bit_identical_at_bench_sizes(cfg, R, iter
             assert out[r][2] == single[0][2] > 50
         for P in Ps:
             P.close()
-    finally:
-        if old is None:
-            os.environ.pop("MACHIP_PANEL", None)
-        else:
-            os.environ["MACHIP_PANEL"] = old
 
 
 def test_in_process_group_with_replicated_eigensolve_still_works():
-    """MACHIP_SHARD_EIG=0: round 2's mode (every rank runs the whole eigen-solve itself) stays available and agrees."""
+    """Option shard_eig = 0: round 2's mode (every rank runs the whole eigen-solve itself) stays available and agrees."""
     import threading
     g = load_golden("er2000_solve")
     k = int(g["k"])
-    old = os.environ.get("MACHIP_SHARD_EIG")
-    os.environ["MACHIP_SHARD_EIG"] = "0"
-    try:
+    with _lib.default_options(shard_eig=0):
         Ps = [problem_of(g) for _ in range(2)]
         _lib.comm_init_local(Ps)
         assert _lib.load().machip_comm_mode(Ps[0]._h) == 2
-    finally:
-        if old is None:
-            os.environ.pop("MACHIP_SHARD_EIG", None)
-        else:
-            os.environ["MACHIP_SHARD_EIG"] = old
     out = [None, None]
 
     def drive(i):
@@ -1066,65 +1037,46 @@ def test_full_size_config4_properties():
     P.close()
 
 
-@pytest.mark.parametrize("env", [
-    {"MACHIP_SPMV": "stream", "MACHIP_TPR": "4"}, {"MACHIP_SPMV": "stream", "MACHIP_TPR": "16"},
-    {"MACHIP_G": "4", "MACHIP_BLOCK": "256", "MACHIP_UNROLL": "2"}, {"MACHIP_G": "16", "MACHIP_BLOCK": "1024"},
-    {"MACHIP_G": "64", "MACHIP_BLOCK": "512"}, {"MACHIP_G": "32", "MACHIP_MAXGRID": "64"},
-    {"MACHIP_GRAPH": "0", "MACHIP_CHUNK": "6", "MACHIP_CHUNK_NEAR": "2"}, {"MACHIP_CLASSIC_N": "100000"},
-    {"MACHIP_VCAP": "80"}, {"MACHIP_ASM_G": "8"}, {"MACHIP_ASM_G": "32", "MACHIP_G": "8", "MACHIP_UNROLL": "1"},
+@pytest.mark.parametrize("opts", [
+    {"spmv": 1, "tpr": 4}, {"spmv": 1, "tpr": 16},
+    {"g": 4, "block": 256, "unroll": 2}, {"g": 16, "block": 1024},
+    {"g": 64, "block": 512}, {"g": 32, "maxgrid": 64},
+    {"graph": 0, "chunk": 6, "chunk_near": 2}, {"classic_n": 100000},
+    {"vcap": 80}, {"asm_g": 8}, {"asm_g": 32, "g": 8, "unroll": 1},
     # column-panel step (panel.h) forced onto small graphs: several panels / row blocks, ragged last panel and tile
-    {"MACHIP_PANEL": "1", "MACHIP_PANEL_NP": "3"}, {"MACHIP_PANEL": "1", "MACHIP_PANEL_NP": "1", "MACHIP_PANEL_NB": "2"},
-    {"MACHIP_PANEL": "1", "MACHIP_PANEL_NP": "5", "MACHIP_PANEL_NB": "7", "MACHIP_PANEL_B2": "512", "MACHIP_PANEL_G2": "3"},
-    {"MACHIP_PANEL": "1", "MACHIP_PANEL_NP": "7", "MACHIP_GRAPH": "0", "MACHIP_CHUNK": "6", "MACHIP_PANEL_B2": "1024"},
-    # ... several row blocks per workgroup, the panel loaded once (k_pan_mul<.., MULTI>; round 4): even split, ragged split (cells that have no row block)
-    {"MACHIP_PANEL": "1", "MACHIP_PANEL_NP": "3", "MACHIP_PANEL_NB": "6", "MACHIP_PANEL_CELLS": "2"},
-    {"MACHIP_PANEL": "1", "MACHIP_PANEL_NP": "5", "MACHIP_PANEL_NB": "7", "MACHIP_PANEL_CELLS": "3", "MACHIP_GRAPH": "0", "MACHIP_CHUNK": "6"},
-    # ... and as ONE launch per step (k_pan_step: arrival tickets, slice claims); odd n -> padded pair stride, last-arriver sweep with no waiting
-    {"MACHIP_PANEL": "1", "MACHIP_PANEL_FUSED": "1", "MACHIP_PANEL_NP": "3"},
-    {"MACHIP_PANEL": "1", "MACHIP_PANEL_FUSED": "1", "MACHIP_PANEL_NP": "5", "MACHIP_PANEL_NB": "7", "MACHIP_PANEL_SPIN_US": "0"},
-    {"MACHIP_PANEL": "1", "MACHIP_PANEL_FUSED": "1", "MACHIP_PANEL_NP": "7", "MACHIP_GRAPH": "0", "MACHIP_CHUNK": "6"},
-    # diagonally preconditioned LOBPCG (experimental mode, round 4: fewer iterations than Lanczos steps, slower per iteration)
-    {"MACHIP_SOLVER": "jacobi"},
-    # ... with the column-panel product: two launches per iteration (k_lob_update_pan; odd chunk lengths: the parity of the sums' double
-    # buffer changes from chunk to chunk), and the three-launch form it replaced
-    {"MACHIP_SOLVER": "jacobi", "MACHIP_PANEL": "1", "MACHIP_PANEL_NP": "3"},
-    {"MACHIP_SOLVER": "jacobi", "MACHIP_PANEL": "1", "MACHIP_PANEL_NP": "5", "MACHIP_PANEL_NB": "7", "MACHIP_PANEL_B2": "256", "MACHIP_PANEL_G2": "3", "MACHIP_GRAPH": "0"},
-    {"MACHIP_SOLVER": "jacobi", "MACHIP_PANEL": "1", "MACHIP_PANEL_NP": "3", "MACHIP_LOB_PAN2": "0"},
-])
-def test_solver_variants_agree(env):
+    {"panel": 1, "panel_np": 3}, {"panel": 1, "panel_np": 1, "panel_nb": 2},
+    {"panel": 1, "panel_np": 5, "panel_nb": 7, "panel_b2": 512, "panel_g2": 3},
+    {"panel": 1, "panel_np": 7, "graph": 0, "chunk": 6, "panel_b2": 1024},
+    # ... several row blocks per workgroup, the panel loaded once (k_pan_mul_multi; round 4): even split, ragged split (cells that have no row block)
+    {"panel": 1, "panel_np": 3, "panel_nb": 6, "panel_cells": 2},
+    {"panel": 1, "panel_np": 5, "panel_nb": 7, "panel_cells": 3, "graph": 0, "chunk": 6},
+    # ... the round-3 layout (tridiagonal band inside the tiles)
+    {"panel": 1, "panel_np": 3, "panel_band": 0},
+], ids=lambda o: ",".join(f"{k}={v}" for k, v in o.items()))
+def test_solver_variants_agree(opts):
     """Every launch shape / row mapping of the fused step kernel, eager vs graph launches, odd chunk
     sizes, the classic two-kernel form and a basis so small that it forces restarts must all give the
-    reference's lambda_2 (each variant runs in its own process: the knobs are read once)."""
-    import subprocess
-    import sys
-    code = r'''
-import sys; sys.path.insert(0, "."); sys.path.insert(0, "tests")
-import numpy as np
-from conftest import load_golden, sign_align
-from mac_amd import _lib
-from mac_amd.utils.fiedler import reference_start_block
-out = []
-for nm in ["er2000_xfrac", "er300_x0"]:
-    g = load_golden(nm)
-    P = _lib.Problem(int(g["n"]), g["fi"], g["fj"], g["fw"], g["ci"], g["cj"], g["cw"])
-    P.set_x(g["x"])
-    lam, v, _ = P.fiedler(tol=1e-8, x0=reference_start_block(int(g["n"]))[:, 0].copy())
-    out.append((abs(lam - float(g["lam"])) / float(g["lam"]), float(np.abs(sign_align(v, g["v"]) - g["v"]).max()), P.stats.residual))
-    P.close()
-print("RESULT", out)
-'''
-    e = dict(os.environ); e.update(env)
-    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, cwd=ROOT, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0]
-    for rel, dv, res in eval(line[len("RESULT"):]):
-        assert rel <= LAM_RTOL and dv <= 2e-6 and res < 1e-8
+    reference's lambda_2.  The variants are entries of the handle's option table (machip_set_option; creation-time ones
+    -- asm_g, vcap -- as process defaults around the handle's creation): no environment, no subprocess.  (Round 4's
+    one-launch panel step and diagonally preconditioned LOBPCG forms are compiled with -DMACHIP_EXPERIMENTS only.)"""
+    for nm in ["er2000_xfrac", "er300_x0"]:
+        g = load_golden(nm)
+        with _lib.default_options(**opts):
+            P = _lib.Problem(int(g["n"]), g["fi"], g["fj"], g["fw"], g["ci"], g["cj"], g["cw"])
+        for k_, v_ in opts.items():
+            assert P.get_option(k_) == v_
+        P.set_x(g["x"])
+        lam, v, _ = P.fiedler(tol=1e-8, x0=reference_start_block(int(g["n"]))[:, 0].copy())
+        rel = abs(lam - float(g["lam"])) / float(g["lam"])
+        dv = float(np.abs(sign_align(v, g["v"]) - g["v"]).max())
+        assert rel <= LAM_RTOL and dv <= 2e-6 and P.stats.residual < 1e-8, (nm, rel, dv, P.stats.residual)
+        P.close()
 
 
 @pytest.mark.parametrize("hub", [0, 9, 20])
 def test_padded_fixed_width_step_is_bit_identical_to_the_csr_step(hub):
     """Pose graphs beyond the single-workgroup kernel (city10000-like: 3-13 entries per row) step on a padded fixed-width
-    copy of L(x) (k_ell_build, 8 or 16 slots per row; `MACHIP_ELL`): same products in the same order plus zeros, so lambda_2
+    copy of L(x) (k_ell_build, 8 or 16 slots per row; option `ell`): same products in the same order plus zeros, so lambda_2
     and the vector must equal the CSR step's bit for bit.  hub = 9: a 12-entry row (16-slot form); hub = 20: longer than 16,
     the padded form must not be chosen (and the result is the same anyway)."""
     rng = np.random.default_rng(5 + hub)
@@ -1142,11 +1094,8 @@ def test_padded_fixed_width_step_is_bit_identical_to_the_csr_step(hub):
     P.set_solver(1)
     res = {}
     for ell in ("0", "1"):
-        os.environ["MACHIP_ELL"] = ell
-        try:
-            lam, v, _ = P.fiedler()
-        finally:
-            os.environ.pop("MACHIP_ELL", None)
+        P.set_option("ell", int(ell))
+        lam, v, _ = P.fiedler()
         assert P.stats.residual < 1e-8
         res[ell] = (lam, v.copy(), int(P.stats.lanczos_steps))
     assert res["0"][0] == res["1"][0] and res["0"][2] == res["1"][2] and np.array_equal(res["0"][1], res["1"][1])
@@ -1184,25 +1133,15 @@ def test_panel_step_multi_round_windows_hub_rows_and_odd_sizes():
         x = np.ones(m)
         P.set_x(x)
         res = {}
-        old = os.environ.get("MACHIP_PANEL")
-        try:
-            for mode in ("0", "1"):
-                os.environ["MACHIP_PANEL"] = mode
-                lam, v, _ = P.fiedler(tol=1e-10)
-                res[mode] = (lam, v, int(P.stats.lanczos_steps))
-        finally:
-            if old is None:
-                os.environ.pop("MACHIP_PANEL", None)
-            else:
-                os.environ["MACHIP_PANEL"] = old
+        for mode in ("0", "1"):
+            P.set_option("panel", int(mode))
+            lam, v, _ = P.fiedler(tol=1e-10)
+            res[mode] = (lam, v, int(P.stats.lanczos_steps))
         assert abs(res["1"][0] - res["0"][0]) <= 1e-12 * res["0"][0], (n, deg, hub, res["0"][0], res["1"][0])
         out8 = (C.c_int * 8)()
         nnz_l = n + 2 * (n - 1 + m)
-        os.environ["MACHIP_PANEL"] = "1"
-        try:
+        with _lib.default_options(panel=1):
             assert _lib.load().machip_panel_plan(n, nnz_l, hub + 3 if hub else 127, out8) == 0 and out8[0] == 1   # (the plan admits all four)
-        finally:
-            os.environ.pop("MACHIP_PANEL", None) if old is None else os.environ.__setitem__("MACHIP_PANEL", old)
         same = res["1"][0] == res["0"][0] and res["1"][2] == res["0"][2] and np.array_equal(res["1"][1], res["0"][1])
         assert same == packed, (n, deg, hub, packed, res["0"][0], res["1"][0], res["0"][2], res["1"][2])
         assert np.abs(sign_align(res["1"][1], res["0"][1]) - res["0"][1]).max() <= 1e-7
@@ -1220,7 +1159,7 @@ def test_panel_band_split_when_band_entries_are_missing_or_weightless():
     """Band split of the column-panel step (panel.h, PanView::band: diagonal and columns r -/+ 1 stay out of the tiles, k_pan_fin adds
     them) on graphs WITHOUT a complete chain: the fixed edges are a random spanning tree (most rows have no neighbour at r -/+ 1, some have
     one, a few both; rows 0 and n - 1 have one-sided bands), candidates include pairs (r, r + 1) so that a band entry can come from a
-    candidate and be zero-weighted by x.  lambda_2 / vector of the band-split form = the round-3 layout (MACHIP_PANEL_BAND=0) = the
+    candidate and be zero-weighted by x.  lambda_2 / vector of the band-split form = the round-3 layout (option panel_band = 0) = the
     gather step to 1e-12, SciPy to 1e-8; several panels and row blocks, n not a multiple of anything."""
     import scipy.sparse.linalg as spla
     rng = np.random.default_rng(23)
@@ -1241,19 +1180,13 @@ def test_panel_band_split_when_band_entries_are_missing_or_weightless():
     P.set_start(reference_start_block(n)[:, 0].copy())
     P.set_x(x)
     res = {}
-    keys = ("MACHIP_PANEL", "MACHIP_PANEL_BAND", "MACHIP_PANEL_NP", "MACHIP_PANEL_NB")
-    old = {k_: os.environ.get(k_) for k_ in keys}
-    try:
-        for tag, env in (("gather", {"MACHIP_PANEL": "0"}), ("band", {"MACHIP_PANEL": "1", "MACHIP_PANEL_NP": "5", "MACHIP_PANEL_NB": "3"}),
-                         ("tiles", {"MACHIP_PANEL": "1", "MACHIP_PANEL_NP": "5", "MACHIP_PANEL_NB": "3", "MACHIP_PANEL_BAND": "0"})):
-            for k_ in keys:
-                os.environ.pop(k_, None)
-            os.environ.update(env)
-            lam, v, _ = P.fiedler(tol=1e-10)
-            res[tag] = (lam, v)
-    finally:
-        for k_, v_ in old.items():
-            os.environ.pop(k_, None) if v_ is None else os.environ.__setitem__(k_, v_)
+    for tag, opts in (("gather", {"panel": 0}), ("band", {"panel": 1, "panel_np": 5, "panel_nb": 3}),
+                      ("tiles", {"panel": 1, "panel_np": 5, "panel_nb": 3, "panel_band": 0})):
+        for k_ in ("panel", "panel_band", "panel_np", "panel_nb"):
+            P.set_option(k_, None)
+        P.set_options(**opts)
+        lam, v, _ = P.fiedler(tol=1e-10)
+        res[tag] = (lam, v)
     for tag in ("band", "tiles"):
         assert abs(res[tag][0] - res["gather"][0]) <= 1e-12 * res["gather"][0], (tag, res[tag][0], res["gather"][0])
         assert np.abs(sign_align(res[tag][1], res["gather"][1]) - res["gather"][1]).max() <= 1e-7
@@ -1263,35 +1196,6 @@ def test_panel_band_split_when_band_entries_are_missing_or_weightless():
     w = spla.eigsh(L, k=2, which="SA", tol=1e-10, ncv=64, v0=np.ones(n) + 0.01 * rng.random(n), return_eigenvectors=False)
     assert abs(np.sort(w)[1] - res["band"][0]) <= 1e-8 * res["band"][0]
     P.close()
-
-
-@pytest.mark.parametrize("nm", ["intel", "sphere2500"])
-def test_chebyshev_filtered_single_workgroup_recurrence_matches_goldens(nm):
-    """MACHIP_CHEB_DEG=8: the single-workgroup Lanczos kernel run on C = -T_8(M(L)) after a short plain sequence (persist.h,
-    CHEB; off by default because it measured slower) must still deliver the reference's lambda_2 / vector:
-    the filter interval starts above a rigorous upper bound of lambda_2, so the pair it converges to is the Fiedler pair."""
-    code = r'''
-import sys; sys.path.insert(0, "."); sys.path.insert(0, "tests")
-import numpy as np
-from conftest import load_golden, sign_align
-from mac_amd import _lib
-from mac_amd.utils.fiedler import reference_start_block
-g = load_golden("g2o_NAME")
-P = _lib.Problem(int(g["n"]), g["fi"], g["fj"], g["fw"], g["ci"], g["cj"], g["cw"])
-P.set_start(reference_start_block(int(g["n"]))[:, 0].copy())
-P.set_x(g["x_init"])
-lam, v, _ = P.fiedler(tol=1e-8)
-fs = []
-for it in range(6):
-    fs.append(P.fw_step(int(g["k"]), it)[0]); P.fw_commit()
-print("RESULT", [abs(lam - float(g["lam_init"])) / float(g["lam_init"]), float(np.abs(sign_align(v, g["v_init"]) - g["v_init"]).max()),
-                 float(np.max(np.abs(np.array(fs) - g["f_traj"][:6]) / g["f_traj"][:6])), int(P.stats.spmv_total > P.stats.lanczos_steps)])
-'''.replace("NAME", nm)
-    e = dict(os.environ); e["MACHIP_CHEB_DEG"] = "8"
-    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, cwd=ROOT, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
-    rel, dv, traj, filtered = eval([l for l in r.stdout.splitlines() if l.startswith("RESULT")][0][len("RESULT"):])
-    assert rel <= LAM_RTOL and dv <= 2e-6 and traj <= 1e-6 and filtered == 1
 
 
 def test_degenerate_inputs():
@@ -1507,7 +1411,7 @@ def test_solve_rounding_matches_reference_goldens():
 
 def test_one_launch_select_equals_the_multi_launch_select():
     """Short candidate lists (<= 32 768: every pose graph) run the whole top-K select in one single-workgroup launch
-    (k_sel_small, `MACHIP_SEL_SMALL`); it must leave exactly the selection of the six-pass form -- rounding with its
+    (k_sel_small, option `sel_small`); it must leave exactly the selection of the six-pass form -- rounding with its
     prefer-high tie rule and the LP vertex with its lowest-index rule, on tie-heavy and on generic iterates, for every k from
     nothing to everything -- and both must equal the oracle's."""
     rng = np.random.default_rng(17)
@@ -1528,11 +1432,8 @@ def test_one_launch_select_equals_the_multi_launch_select():
             for k in sorted({0, 1, m // 7, m // 2, m - 1, m}):
                 got = {}
                 for flag in ("0", "1"):
-                    os.environ["MACHIP_SEL_SMALL"] = flag
-                    try:
-                        got[flag] = (P.round_nearest(k, decimals=10), P.lp_topk(k))
-                    finally:
-                        os.environ.pop("MACHIP_SEL_SMALL", None)
+                    P.set_option("sel_small", int(flag))
+                    got[flag] = (P.round_nearest(k, decimals=10), P.lp_topk(k))
                 assert np.array_equal(got["0"][0], got["1"][0]) and np.array_equal(got["0"][1], got["1"][1]), (n, kind, k)
                 assert np.array_equal(got["1"][0], oracle.round_nearest(x, k, cw, 10)), (n, kind, k)
                 s = got["1"][1]
@@ -1728,28 +1629,18 @@ def test_exact_chain_plus_closures_preconditioner(nm):
     iterations; same pair as the tridiagonal-preconditioned mode and as an independent SciPy solve."""
     import scipy.sparse.linalg as spla
     g = load_golden("g2o_" + nm)
-    code = r"""
-import sys; sys.path.insert(0, "."); sys.path.insert(0, "tests")
-import numpy as np
-from test_gpu_parity import load_golden, problem_of
-from mac_amd.utils.fiedler import reference_start_block
-g = load_golden("g2o_%s")
-P = problem_of(g)
-P.set_start(reference_start_block(int(g["n"]))[:, 0].copy())
-x = np.zeros(len(g["cw"])); x[: min(len(x), 1000)] = 1.0          # <= 2 048 active closures
-x[::3] *= 0.37
-P.set_x(x)
-P.set_solver(2)
-lam, v, _ = P.fiedler()
-print(repr(lam), int(P.stats.lanczos_steps), repr(P.stats.residual), repr(float(np.abs(v).sum())))
-""" % nm
     out = {}
     for flag in ("1", "0"):
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT,
-                           env=dict(os.environ, MACHIP_WOODBURY=flag))
-        assert r.returncode == 0, r.stderr[-2000:]
-        lam, its, res, l1 = r.stdout.strip().split()[-4:]
-        out[flag] = (float(lam), int(its), float(res), float(l1))
+        P = problem_of(g)
+        P.set_option("woodbury", int(flag))
+        P.set_start(reference_start_block(int(g["n"]))[:, 0].copy())
+        x = np.zeros(len(g["cw"])); x[: min(len(x), 1000)] = 1.0          # <= 2 048 active closures
+        x[::3] *= 0.37
+        P.set_x(x)
+        P.set_solver(2)
+        lam, v, _ = P.fiedler()
+        out[flag] = (float(lam), int(P.stats.lanczos_steps), float(P.stats.residual), float(np.abs(v).sum()))
+        P.close()
     x = np.zeros(len(g["cw"])); x[: min(len(x), 1000)] = 1.0
     x[::3] *= 0.37
     n = int(g["n"])
@@ -1992,7 +1883,7 @@ def test_trajectory_is_bit_reproducible_run_to_run():
 
 
 def test_column_panel_step_is_bit_reproducible_run_to_run():
-    """The panel form deals rows of equal length to tiles in ARRIVAL order (LDS atomics in k_pan_count), so two builds of the same
+    """The panel form deals rows of equal length to tiles in ARRIVAL order (LDS atomics in k_pan_build), so two builds of the same
     matrix differ by a permutation among such rows.  Results must not: the product-sum of k_pan_mul rounds the same way at every
     chunk position (no contraction), which makes a row's sum independent of the slot it lands in.  Regression test for a last-digit
     run-to-run difference of lambda_2 found by tools/soak.sh: six solves of a dense configs[3] iterate (multi-round chunk ranges),
@@ -2004,19 +1895,12 @@ def test_column_panel_step_is_bit_reproducible_run_to_run():
     P.set_x(w["x0"])
     for it in range(7):
         P.fw_step(w["k"], it); P.fw_commit()
-    old = os.environ.get("MACHIP_PANEL")
-    os.environ["MACHIP_PANEL"] = "1"
-    try:
-        outs = []
-        for rep in range(6):
-            P.assemble()                                   # new solve, panel form rebuilt
-            lam, v, _ = P.fiedler()
-            outs.append((lam, v.copy(), int(P.stats.lanczos_steps)))
-    finally:
-        if old is None:
-            os.environ.pop("MACHIP_PANEL", None)
-        else:
-            os.environ["MACHIP_PANEL"] = old
+    P.set_option("panel", 1)
+    outs = []
+    for rep in range(6):
+        P.assemble()                                   # new solve, panel form rebuilt
+        lam, v, _ = P.fiedler()
+        outs.append((lam, v.copy(), int(P.stats.lanczos_steps)))
     for o in outs[1:]:
         assert o[0] == outs[0][0] and o[2] == outs[0][2] and np.array_equal(o[1], outs[0][1])
     P.close()
@@ -2072,6 +1956,8 @@ from mac_amd.dist import FileGroup, attach_ipc, detach_ipc
 from mac_amd.utils.fiedler import reference_start_block
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 wl, iters, die_at = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+for k_, v_ in json.loads(sys.argv[4] if len(sys.argv) > 4 else "{}").items():
+    _lib.set_default_option(k_, v_)           # options of the handle created below (and of its solver), on every rank alike
 if wl.startswith("golden:"):
     from conftest import load_golden
     g = load_golden(wl[7:])
@@ -2109,7 +1995,7 @@ except _lib.MachipError as e:
 '''
 
 
-def _run_ipc_job(world, wl, iters, die_at=-1, timeout=300, env_extra=None):
+def _run_ipc_job(world, wl, iters, die_at=-1, timeout=300, env_extra=None, opts=None):
     import json
     import uuid
     key = uuid.uuid4().hex
@@ -2117,7 +2003,7 @@ def _run_ipc_job(world, wl, iters, die_at=-1, timeout=300, env_extra=None):
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MACHIP_RDZV_KEY=key, HSA_ENABLE_IPC_MODE_LEGACY="0")
         env.update(env_extra or {})
-        procs.append(subprocess.Popen([sys.executable, "-c", IPC_WORKER, wl, str(iters), str(die_at)], env=env, cwd=ROOT,
+        procs.append(subprocess.Popen([sys.executable, "-c", IPC_WORKER, wl, str(iters), str(die_at), json.dumps(opts or {})], env=env, cwd=ROOT,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     res = []
     for p in procs:
@@ -2148,17 +2034,17 @@ def test_ipc_row_partitioned_eigensolve_between_processes_is_bit_identical(world
         assert msg[1]["mode"] == 5, msg[1]["mode"]              # the last eigen-solve really ran row-partitioned between the processes
 
 
-@pytest.mark.parametrize("wl,env", [("golden:er2000_solve", {"MACHIP_VCAP": "80"}), ("golden:g2o_kitti_05", {}), ("golden:g2o_city10000", {}),
-                                    ("golden:er2000_solve", {"MACHIP_GRAPH": "0", "MACHIP_CHUNK": "6"})])
-def test_ipc_communicator_with_restarts_and_unpartitioned_solver_modes(wl, env):
+@pytest.mark.parametrize("wl,opts", [("golden:er2000_solve", {"vcap": 80}), ("golden:g2o_kitti_05", {}), ("golden:g2o_city10000", {}),
+                                     ("golden:er2000_solve", {"graph": 0, "chunk": 6})])
+def test_ipc_communicator_with_restarts_and_unpartitioned_solver_modes(wl, opts):
     """The inter-process communicator when the eigen-solve is NOT one plain partitioned sequence: a basis so small that the
     sequence restarts (the restart continues in the classic two-kernel form, replicated on every rank), a pose graph whose solves
     run in the preconditioned mode (replicated; only the gradient is exchanged), city10000 (padded fixed-width step: replicated;
     then partitioned gather steps after a restart), eager launches with odd chunk lengths.  Two processes on one GPU, bit-identical
     to one process run with the same settings."""
-    single = _run_ipc_job(1, wl, 3, env_extra=env)[0]
+    single = _run_ipc_job(1, wl, 3, opts=opts)[0]
     assert single[0] == 0 and single[1][0] == "RESULT", single
-    for rc, msg, se in _run_ipc_job(2, wl, 3, env_extra=env):
+    for rc, msg, se in _run_ipc_job(2, wl, 3, opts=opts):
         assert rc == 0 and msg and msg[0] == "RESULT", (rc, msg, se)
         assert msg[1]["out"] == single[1][1]["out"] and msg[1]["xsum"] == single[1][1]["xsum"] and msg[1]["xdot"] == single[1][1]["xdot"]
 

@@ -189,8 +189,7 @@ def test_panel_plan_covers_every_row_and_column_within_the_kernel_limits():
     import ctypes as C
     lib = _lib.load()
     out = (C.c_int * 8)()
-    old = {k: os.environ.pop(k, None) for k in ("MACHIP_PANEL", "MACHIP_PANEL_NP", "MACHIP_PANEL_NB")}
-    try:
+    with _lib.default_options(panel=None, panel_np=None, panel_nb=None):
         # automatic rule (BASELINE configs[3]: on for the dense iterates only)
         for n, nnz, maxlen, want in ((100000, 700344, 30, 0), (100000, 1747218, 40, 1), (100000, 4044528, 70, 1), (100000, 4044528, 200, 1), (100000, 4044528, 9000, 0),
                                      (10000, 956618, 120, 0), (1728, 5496, 9, 0), (65536, 65536 * 20, 60, 1), (500000, 500000 * 30, 60, 0)):
@@ -199,14 +198,11 @@ def test_panel_plan_covers_every_row_and_column_within_the_kernel_limits():
         assert list(out)[:1] == [0]
         lib.machip_panel_plan(100000, 2700000, 60, out)
         assert list(out)[:7] == [1, 12, 8334, 21, 75, 5, 9]               # the shape profiles/r3_c4_panel.md measures
-        os.environ["MACHIP_PANEL"] = "1"
         rng = np.random.default_rng(3)
         for n in [128, 129, 300, 2000, 8448, 8449, 65536, 100000, 123457, 399999, 1000003] + [int(t) for t in rng.integers(130, 3000000, 40)]:
-            for extra in ({}, {"MACHIP_PANEL_NP": str(int(rng.integers(1, 40)))}, {"MACHIP_PANEL_NB": str(int(rng.integers(1, 400)))}):
-                for k_ in ("MACHIP_PANEL_NP", "MACHIP_PANEL_NB"):
-                    os.environ.pop(k_, None)
-                os.environ.update(extra)
-                assert lib.machip_panel_plan(n, 20 * n, 60, out) == _lib.OK
+            for extra in ({}, {"panel_np": int(rng.integers(1, 40))}, {"panel_nb": int(rng.integers(1, 400))}):
+                with _lib.default_options(panel=1, **extra):          # (process defaults: what machip_panel_plan plans under)
+                    assert lib.machip_panel_plan(n, 20 * n, 60, out) == _lib.OK
                 on, NP, Cc, NB, NTB, TWW, RPT, g2 = list(out)
                 if not on:
                     continue
@@ -216,12 +212,41 @@ def test_panel_plan_covers_every_row_and_column_within_the_kernel_limits():
                 assert 1 <= TWW <= 8 and TWW * 15 >= NTB and NTB <= 120        # a worker wave's tiles
                 assert 1 <= g2 <= 1024
         assert lib.machip_panel_plan(0, 0, 0, out) == _lib.BAD_ARG
-    finally:
-        for k_ in ("MACHIP_PANEL", "MACHIP_PANEL_NP", "MACHIP_PANEL_NB"):
-            os.environ.pop(k_, None)
-        for k_, v in old.items():
-            if v is not None:
-                os.environ[k_] = v
+
+
+def test_option_table_roundtrip_and_environment_is_read_once():
+    """machip_set_option / machip_get_option (round 5: the MACHIP_* environment knobs of rounds 1-4 became a per-handle table):
+    every name the library lists is settable as a process default, unknown names are BAD_ARG, MACHIP_OPTION_AUTO restores the
+    default, and the environment is consulted ONCE, when the library is first used -- later changes of os.environ do nothing."""
+    import ctypes as C
+    import subprocess
+    import sys
+    lib = _lib.load()
+    names = _lib.option_names()
+    assert len(names) >= 40 and "panel" in names and "chunk" in names and len(set(names)) == len(names)
+    v = C.c_int64(0)
+    for nm in names:
+        assert lib.machip_get_option(None, nm.encode(), C.byref(v)) == _lib.OK
+        old = v.value
+        assert lib.machip_set_option(None, nm.encode(), 7) == _lib.OK
+        assert lib.machip_get_option(None, nm.encode(), C.byref(v)) == _lib.OK and v.value == 7
+        assert lib.machip_set_option(None, nm.encode(), old) == _lib.OK
+    assert lib.machip_set_option(None, b"no_such_option", 1) == _lib.BAD_ARG
+    assert lib.machip_get_option(None, b"panel", None) == _lib.BAD_ARG
+    code = ("import os, sys; sys.path.insert(0, %r)\n"
+            "from mac_amd import _lib\n"
+            "import ctypes as C\n"
+            "lib = _lib.load(); v = C.c_int64(0)\n"
+            "lib.machip_get_option(None, b'chunk', C.byref(v)); a = v.value\n"
+            "os.environ['MACHIP_CHUNK'] = '48'; os.environ['MACHIP_PANEL'] = '1'\n"
+            "lib.machip_get_option(None, b'chunk', C.byref(v)); b = v.value\n"
+            "lib.machip_get_option(None, b'panel', C.byref(v)); c = v.value\n"
+            "print(a, b, c == _lib.OPTION_AUTO)\n") % ROOT
+    env = {k: v_ for k, v_ in os.environ.items() if not k.startswith("MACHIP_")}
+    env["MACHIP_CHUNK"] = "16"
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert r.stdout.split() == ["16", "16", "True"], r.stdout
 
 
 def test_loading_the_library_leaves_the_process_environment_alone():

@@ -1,29 +1,31 @@
 #!/usr/bin/env python3
-"""Same-GPU A/B/C... of environment settings of libmachip, one handle per setting (create-time knobs included), alternating
-passes of 20 Frank-Wolfe iterations.   usage: ab_multi.py cfg rounds "A=1,B=2" "A=3" ...   ("-" = no setting)"""
+"""Same-GPU A/B/C... of option settings of libmachip (mac_amd/csrc/options.h), one handle per setting (creation-time options
+included: they are applied as process defaults around the handle's creation), alternating passes of 20 Frank-Wolfe iterations.
+usage: ab_multi.py cfg rounds "panel=1,chunk=16" "asm_g=16" ...   ("-" = defaults; MACHIP_FOO=1 is read as foo=1)"""
 import os, sys, time
 sys.path.insert(0, ".")
 import numpy as np, bench
 from mac_amd import _lib
 from mac_amd.utils.fiedler import reference_start_block
 cfg, rounds = sys.argv[1], int(sys.argv[2])
-sets = [dict(kv.split("=") for kv in a.split(",")) if a != "-" else {} for a in sys.argv[3:]]
-allkeys = sorted({k for s in sets for k in s})
+def parse(a):
+    out = {}
+    for kv in a.split(","):
+        k, v = kv.split("=")
+        k = k.lower()
+        out[k[7:] if k.startswith("machip_") else k] = int(v)
+    return out
+sets = [parse(a) if a != "-" else {} for a in sys.argv[3:]]
 w = bench.make_workload(cfg)
-def apply(s):
-    for k in allkeys:
-        os.environ.pop(k, None)
-    os.environ.update(s)
 Ps = []
 for s in sets:
-    apply(s)
-    P = _lib.Problem(w["n"], w["fi"], w["fj"], w["fw"], w["ci"], w["cj"], w["cw"])
+    with _lib.default_options(**s):
+        P = _lib.Problem(w["n"], w["fi"], w["fj"], w["fw"], w["ci"], w["cj"], w["cw"])
     P.set_start(reference_start_block(w["n"])[:, 0].copy())
     Ps.append(P)
 res = [[] for _ in sets]; us = [[] for _ in sets]; lam = [None] * len(sets); steps = [0] * len(sets)
 for r in range(rounds + 1):
     for i, s in enumerate(sets):
-        apply(s)
         P = Ps[i]
         P.set_x(w["x0"]); P.synchronize()
         t0 = time.perf_counter()
