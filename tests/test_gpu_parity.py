@@ -1787,6 +1787,48 @@ def test_concurrent_budget_sweep_is_bit_identical_to_sequential_solves(nm):
     assert np.array_equal(both[0][0], np.ones(m)) and np.array_equal(both[1][1], seq[1][1]) and both[1][0].sum() == ks[1]
 
 
+def test_sweep_lanes_capture_graphs_while_other_threads_create_handles():
+    """Round-4 advisor finding: the lanes' CU-masked streams are BLOCKING streams (hipExtStreamCreateWithCUMask takes no flags),
+    so any legacy-stream call of the library -- round 4 still issued hipMemcpy / hipMemset in machip_create, machip_fiedler_csr
+    and prepare_lanes -- serialises with every lane and, while a lane captures a chunk graph, fails with 'operation would make the
+    legacy stream depend on a capturing blocking stream'.  Every copy now names the handle's own stream: a budget sweep (lanes
+    capturing their graphs for the first time) runs while other threads create / destroy handles and call find_fiedler_pair;
+    nothing may fail and every result equals the quiet run's."""
+    import threading
+    g = load_golden("g2o_intel")
+    fixed, cand, n = edges_of(g, "f"), edges_of(g, "c"), int(g["n"])
+    m = len(cand)
+    ks = [int(p_ * m) for p_ in (0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8)]
+    inits = [NaiveGreedy(cand).subset(k) for k in ks]
+    quiet = MAC(fixed, cand, n, fiedler_method="hip_lanczos").solve_sweep(ks, inits, max_iters=6)
+    L5 = weight_graph_lap_from_edge_list([Edge(i, j, 1.0) for i in range(5) for j in range(i + 1, 5)], 5)
+    errs, stop = [], threading.Event()
+
+    def churn(kind):
+        try:
+            while not stop.is_set():
+                if kind == 0:
+                    P = problem_of(load_golden("er300_x0")); P.set_x(load_golden("er300_x0")["x"]); P.fiedler(want_vec=False); P.close()
+                else:
+                    lam = find_fiedler_pair(L5)[0]
+                    assert abs(lam - 5.0) < 1e-6
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=churn, args=(i % 2,)) for i in range(3)]
+    for t in th:
+        t.start()
+    try:
+        mac = MAC(fixed, cand, n, fiedler_method="hip_lanczos")          # fresh handle: its lanes are created and capture inside the sweep
+        noisy = mac.solve_sweep(ks, inits, max_iters=6)
+    finally:
+        stop.set()
+        for t in th:
+            t.join(timeout=120)
+    assert not errs, errs
+    for a, b in zip(noisy, quiet):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+
+
 @pytest.mark.parametrize("nm", ["intel", "sphere2500"])
 def test_concurrent_budget_sweep_matches_the_reference_on_every_budget(nm):
     """MAC.solve_sweep against the REFERENCE's own budget sweep (tests/golden/g2o_sweep_<name>.npz, generated by running

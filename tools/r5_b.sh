@@ -1,10 +1,10 @@
 #!/bin/bash
 set -u
-out=$GRAFT_REPO_ROOT/gpurun_out/r5f
+out=$GRAFT_REPO_ROOT/gpurun_out/r5g
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests -m gpu -x -q -k "assembl or config4 or panel" >> $out/pytest.log; tail -5 $out/pytest.log
-timeout 600 python tools/ab_multi.py c4 5 "-" > $out/ab_c4.txt 2>&1; cat $out/ab_c4.txt
+timeout 1200 python -m pytest tests -m gpu -x -q >> $out/pytest.log; tail -5 $out/pytest.log
+timeout 600 python tools/ab_multi.py c4 5 "-" "sel_fuse=0" > $out/ab_c4.txt 2>&1; cat $out/ab_c4.txt; timeout 300 python tools/ab_multi.py c2 5 "-" > $out/ab_c2.txt 2>&1; cat $out/ab_c2.txt
 true
 MACHIP_DEBUG=1 timeout 300 python - > $out/debug_c4.txt 2>&1 <<PY
 import sys; sys.path.insert(0,'.')
