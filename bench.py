@@ -2,7 +2,7 @@
 """bench.py -- Frank-Wolfe iterations/second (each including the full Fiedler solve) of the
 MAC hot path on MI355X, with the CPU paths timed beside it.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c4|c2|c3|c5a|c5b|c5|c5s] [--mode shard|replicas]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c4|c2|c3|c5a|c5b|c5|c5s|c4s|c2s] [--mode all|shard|replicas|ipc_eig]
 
 One "step" = one Frank-Wolfe iteration (mac/optimization/frankwolfe.py:53-76 with
 problem = MAC.problem): assemble L(x) -> Fiedler pair to the reference's stop rule at tol 1e-8 ->
@@ -321,6 +321,59 @@ def pmc_traffic(cfg, steps, precision=0, timeout_s=150):
 
 
 # ---------------------------------------------------------------------------------------------
+# roofline unit per solver mode: the object describes the launch group that
+# actually ran (machip_solve_mode), with its own algorithmic bytes and its own in-solve duration
+# ---------------------------------------------------------------------------------------------
+MODE_INFO = {
+    1: ("fused Lanczos step, gather form: ONE launch of k_pipe_vec (CSR SpMV with gathered 16-byte records + all vector work of the step)", "step"),
+    2: ("fused Lanczos step, column-panel form: k_pan_mul + k_pan_fin (operand in LDS; mac_amd/csrc/panel.h)", "step"),
+    3: ("fused Lanczos step on the padded fixed-width copy of L(x): ONE launch of k_pipe_vec<.., ELLW>", "step"),
+    4: ("one Lanczos step INSIDE the single-workgroup kernel k_lan_persist (matrix in registers / LDS; 64 steps per launch; mac_amd/csrc/persist.h)", "step"),
+    5: ("classic two-kernel Lanczos step: k_spmv_* <OpLanczos> + k_lan_update", "step"),
+    6: ("one LOBPCG iteration preconditioned by the odometry chain: k_tri_solve + product + k_lob_update (mac_amd/csrc/precond.h)", "iter"),
+    7: ("one preconditioned iteration of the exact chain + closures mode: k_lob_fused (update + tridiagonal solve) + k_wb_h (s x s) + k_wb_w (n x s) + product; "
+        "set-up (s column solves, capacitance matrix, its inverse on the f64 matrix cores) included in the duration (mac_amd/csrc/woodbury.h)", "iter"),
+    8: ("fused Lanczos step with fp32 storage (8-byte records, fp32 values and basis), fp64 refinement sequences behind it", "step"),
+}
+
+
+def mode_bytes(mode, n, nnz, closures, precision):
+    """Algorithmic bytes of ONE unit of the mode (SURVEY 8(d) B_spmv + the vector passes the unit makes)."""
+    if mode in (1, 2, 3, 5):
+        return step_bytes(n, nnz)
+    if mode == 8:
+        return 8.0 * nnz + 4.0 * (n + 1) + 32.0 * n
+    if mode == 4:
+        return 8.0 * n                                   # the basis column the step stores; L(x) and the operand stay on the CU
+    spmv = 12.0 * nnz + 4.0 * (n + 1) + 16.0 * n
+    if mode == 6:
+        return spmv + 16 * 8.0 * n                       # 16 vector passes per iteration (machip_solve_stats.vec_passes)
+    return spmv + 16 * 8.0 * n + 8.0 * n * closures + 8.0 * closures * closures     # + Z = T^-1 U (n x s) and C^-1 (s x s) per application
+
+
+def roofline_by_mode(passes, n, precision):
+    """Group every timed iteration by the solver mode that served it; the object describes the group with the most device time."""
+    groups = {}
+    for _, rec in passes:
+        for r in rec:
+            mode, clos = (r[7], r[8]) if len(r) > 8 else (1, 0)
+            unit = MODE_INFO.get(mode, MODE_INFO[1])[1]
+            units = r[6] if unit == "step" else r[1]
+            ms = r[5] if unit == "step" else r[4]         # steps: events around the Krylov chunks; iterations: the whole solve
+            if units <= 0 or ms <= 0:
+                continue
+            g = groups.setdefault(mode, dict(units=0, ms=0.0, bytes=0.0, iters=0, closures=0))
+            g["units"] += units; g["ms"] += ms; g["iters"] += 1; g["closures"] = max(g["closures"], clos)
+            g["bytes"] += units * mode_bytes(mode, n, r[2], clos, precision)
+    if not groups:
+        return None, []
+    listing = [dict(mode=m_, unit=MODE_INFO.get(m_, MODE_INFO[1])[1], units=g["units"], frac_of_solve_time=g["ms"] / sum(x["ms"] for x in groups.values()),
+                    us_per_unit=1e3 * g["ms"] / g["units"], fw_iterations=g["iters"]) for m_, g in sorted(groups.items())]
+    top = max(groups, key=lambda m_: groups[m_]["ms"])
+    return (top, groups[top]), listing
+
+
+# ---------------------------------------------------------------------------------------------
 def bench_c5_batched(args):
     """BASELINE.json configs[4] on ONE GPU: city10000 + sphere2500 as a batch of independent problems (replicas,
     no collective): one handle + stream + host thread per graph on the same GPU; ctypes releases the GIL, the
@@ -434,6 +487,60 @@ def bench_c5_sweep(args):
 
 
 # ---------------------------------------------------------------------------------------------
+def bench_er_sweep(args, base):
+    """The reference's sweep (examples/g2o_experiment.py:306-336: one MAC.solve per budget on the same graph) at the ER sizes of
+    BASELINE.json configs[1] / configs[3] (--config c2s / c4s): B budgets K_b = K (0.5 + b/(B-1)) of the same graph through
+    machip_fw_sweep -- every budget on an evaluation lane of its own (own x / gradient / CSR / panel form / Krylov basis / stream on
+    its own hardware queue), the chip-filling step kernels of the lanes interleaving on the GPU.  A step = one Frank-Wolfe iteration of one
+    budget; value = all iterations of all budgets / wall time of the concurrent sweep; `sequential_value` = the same budgets one at
+    a time on one handle.  Stop tests disabled, cold eigen-solves, as every other config is timed."""
+    from mac_amd import _lib
+    from mac_amd.utils.fiedler import reference_start_block
+    w = make_workload(base)
+    n, m, k = w["n"], len(w["cw"]), w["k"]
+    B = 4
+    ks = [max(1, int(round(k * (0.5 + b / (B - 1))))) for b in range(B)]
+    rng = np.random.default_rng(0)
+    X0 = np.zeros((B, m))
+    for b, kb in enumerate(ks):
+        X0[b, rng.choice(m, kb, replace=False)] = 1.0
+    P = _lib.Problem(n, w["fi"], w["fj"], w["fw"], w["ci"], w["cj"], w["cw"])
+    P.set_start(reference_start_block(n)[:, 0].copy())
+    scan = {}
+    res = None
+    for lanes in (2, 4):
+        P.set_option("lanes", lanes)
+        P.fw_sweep(ks, X0, max_iters=max(1, args.warmup), gap_tol=0.0, grad_tol=0.0, want_rounded=False)        # lanes, graphs, buffers
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            res = P.fw_sweep(ks, X0, max_iters=args.steps, gap_tol=0.0, grad_tol=0.0, want_rounded=False)
+            ts.append(time.perf_counter() - t0)
+        its = int(res["iters"].sum())
+        scan[lanes] = dict(value=its / sorted(ts)[1], pass_ms=[round(1e3 * t, 3) for t in ts], lambda2_last=[float(res["f_traj"][b, -1]) for b in range(B)])
+    for b in range(B):
+        run_pass(P, ks[b], 1, X0[b])
+    t1 = time.perf_counter()
+    seq_f = []
+    for b in range(B):
+        rec = run_pass(P, ks[b], args.steps, X0[b])
+        seq_f.append(rec[-1]["f"])
+    P.synchronize()
+    seq = B * args.steps / (time.perf_counter() - t1)
+    best = max(scan, key=lambda l: scan[l]["value"])
+    print(json.dumps({"metric": "frank_wolfe_iters_per_sec", "value": scan[best]["value"], "unit": "iter/s", "n_gpus": 1, "steps": args.steps,
+                      "warmup": args.warmup, "ms_per_step": 1e3 / scan[best]["value"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                      "dtype": "f64", "data": "synthetic",
+                      "config": {"workload": w["name"] + f" as the reference's budget sweep: {B} budgets K_b = K (0.5 + b/{B - 1}) x {args.steps} Frank-Wolfe iterations, "
+                                             "concurrently on one GPU (machip_fw_sweep)", "N": n, "m_candidates": m, "K": ks, "lanes": best,
+                                 "parallelism": f"{best} evaluation lanes, one host thread and one hardware queue each"},
+                      "lane_scan": {str(l): v for l, v in scan.items()}, "sequential_value": seq,
+                      "aggregate_vs_one_at_a_time": scan[best]["value"] / seq,
+                      "lambda2_last_equal_to_sequential": [scan[best]["lambda2_last"][b] == seq_f[b] for b in range(B)]}))
+    P.close()
+
+
+# ---------------------------------------------------------------------------------------------
 def self_launch(args):
     """--gpus N without a launcher: spawn N rank processes (one GPU each) of this script."""
     from mac_amd import _lib
@@ -544,13 +651,236 @@ def dry_run(args, dist, rank, local_rank, world, ndev, nccl_log):
         dist.close()
 
 
+# ---------------------------------------------------------------------------------------------
+# --gpus N > 1: ONE invocation yields all the multi-GPU evidence: the candidate-shard pass (headline), the
+# replicas pass and the row-partitioned (IPC) eigen-solve pass, in that order, inside one process group; a leg whose first
+# contact fails is reported under `errors` and the others still print.
+# ---------------------------------------------------------------------------------------------
+def _agree(dist, ok):
+    return all(dist.all_gather_object(bool(ok)))
+
+
+def _attach_leg(P, dist, rank, world, rccl, ipc, shard_eig):
+    """First contact of one leg, collective and exception-safe: every rank runs the same exchanges whatever happens locally;
+    when any rank fails, every rank drops what it had attached.  Returns (ok, message)."""
+    from mac_amd.dist import attach, attach_ipc
+    msgs = []
+    if rccl:
+        err = None
+        try:
+            attach(P, dist, rank, world)            # ncclCommInitRank inside libmachip under its watchdog
+        except Exception as e:                      # noqa: BLE001
+            err = f"rank {rank}: RCCL communicator: {e}"
+        errs = [e for e in dist.all_gather_object(err) if e]
+        if errs:
+            P.comm_drop()
+            return False, "; ".join(errs)
+    if ipc:
+        P.set_option("shard_eig", 1 if shard_eig else 0)
+        err = None
+        try:
+            attach_ipc(P, dist, rank, world, timeout_s=float(os.environ.get("MACHIP_IPC_TIMEOUT", "20")))
+        except Exception as e:                      # noqa: BLE001  (attach_ipc has already agreed and dropped on every rank)
+            err = f"rank {rank}: IPC attach: {e}"
+        errs = [e for e in dist.all_gather_object(err) if e]
+        if errs:
+            P.comm_drop()
+            return False, "; ".join(errs)
+    return True, ""
+
+
+def _timed_passes(P, k, steps, x0, dist, npass, comm_timing=False):
+    """npass passes of `steps` Frank-Wolfe iterations from x0, barrier + synchronise on both sides, max over ranks.
+    Returns (median seconds, records of the median pass); a failing rank makes every rank return an error string."""
+    passes = []
+    for _ in range(npass):
+        err = None
+        rec, el = [], 0.0
+        try:
+            P.set_x(x0); P.synchronize()
+        except Exception as e:                      # noqa: BLE001
+            err = str(e)
+        dist.barrier()
+        t0 = time.perf_counter()
+        if err is None:
+            try:
+                for it in range(steps):
+                    f, dual, gn = P.fw_step(k, it)
+                    st = P.stats
+                    r = dict(f=f, steps=int(st.lanczos_steps), nnz=int(st.nnz), step_ms=float(st.step_ms), steps_timed=int(st.steps_timed),
+                             gpu_ms=float(st.gpu_ms))
+                    if comm_timing:
+                        r["grad_us"], r["exchange_us"] = P.comm_timing()
+                    rec.append(r)
+                    P.fw_commit()
+                P.synchronize()
+            except Exception as e:                  # noqa: BLE001
+                err = f"rank {dist.rank}: {e}"
+        el = time.perf_counter() - t0
+        errs = [e for e in dist.all_gather_object(err) if e]
+        if errs:
+            return None, "; ".join(errs)
+        passes.append((dist.max(el), rec))
+    passes.sort(key=lambda t: t[0])
+    return passes[(len(passes) - 1) // 2]
+
+
+def bench_multi(args, dist, rank, local_rank, world, ndev, nccl_log):
+    from mac_amd import _lib
+    from mac_amd.dist import detach_ipc
+    from mac_amd.utils.fiedler import reference_start_block
+    cfg = args.config
+    w = make_workload(cfg)
+    n, m, k = w["n"], len(w["cw"]), w["k"]
+    dev = local_rank % max(1, ndev)
+    share = os.environ.get("MACHIP_SHARE_GPU") == "1" and ndev < world       # protocol run: several ranks on one GPU (RCCL refuses that)
+    start = reference_start_block(n)[:, 0].copy()
+    errors, legs = {}, {}
+    want = ("shard", "replicas", "ipc_eig") if args.mode == "all" else (args.mode,)
+
+    def mk():
+        P = _lib.Problem(n, w["fi"], w["fj"], w["fw"], w["ci"], w["cj"], w["cw"], device=dev)
+        P.set_precision(args.precision)
+        P.set_start(start)
+        return P
+
+    # ---- leg 1: candidate shard + one exchange of the gradient per iteration, eigen-solve replicated (the north star's split) ----
+    head = None
+    if "shard" in want:
+        P = mk()
+        ok, msg = _attach_leg(P, dist, rank, world, rccl=not share, ipc=share, shard_eig=False)
+        if not ok:
+            errors["shard"] = ("refused: two ranks on one device -- " if share else "") + msg
+        else:
+            run_pass(P, k, args.warmup, w["x0"])
+            passes, total = [], 0.0
+            while True:
+                r = _timed_passes(P, k, args.steps, w["x0"], dist, 1, comm_timing=True)
+                if r[0] is None:
+                    errors["shard"] = r[1]; break
+                passes.append(r); total += r[0]
+                if total >= args.min_seconds or len(passes) >= args.max_repeats:
+                    break
+            if "shard" not in errors:
+                passes.sort(key=lambda t: t[0])
+                el, rec = passes[(len(passes) - 1) // 2]
+                head = dict(el=el, rec=rec, pass_ms=[round(1e3 * p_[0], 3) for p_ in passes], total=total,
+                            mode=int(_lib.load().machip_comm_mode(P._h)))
+                legs["shard"] = {"value": args.steps / el, "unit": "iter/s", "scaling": "strong", "ms_per_step": 1e3 * el / args.steps,
+                                 "grad_us": float(np.mean([r_["grad_us"] for r_ in rec])), "exchange_us": float(np.mean([r_["exchange_us"] for r_ in rec])),
+                                 "exchange": "IPC peer writes (ranks share a GPU)" if share else "ncclAllGather of the padded m-vector (RCCL over xGMI)",
+                                 "eig_ms_per_iter": float(np.mean([r_["gpu_ms"] for r_ in rec])), "comm_mode": head["mode"],
+                                 "lambda2_first_last": [rec[0]["f"], rec[-1]["f"]], "lanczos_steps_per_iter": float(np.mean([r_["steps"] for r_ in rec]))}
+            if share and ok:
+                try:
+                    detach_ipc(P, dist)
+                except Exception:               # noqa: BLE001
+                    pass
+        P.close()
+        dist.barrier()
+    # ---- leg 2: replicas -- the reference's budget sweep (examples/g2o_experiment.py:306-336), one budget per GPU, no collective ----
+    if "replicas" in want:
+        kr = max(1, int(round(k * (0.5 + rank / max(1, world - 1)))))
+        P = mk()
+        run_pass(P, kr, min(args.warmup, 2), w["x0"])
+        r = _timed_passes(P, kr, args.steps, w["x0"], dist, 3)
+        P.close()
+        if r[0] is None:
+            errors["replicas"] = r[1]
+        else:
+            el, rec = r
+            rates = dist.all_gather_object(dict(rank=rank, K=kr, eig_ms_per_iter=float(np.mean([r_["gpu_ms"] for r_ in rec])),
+                                                lanczos_steps_per_iter=float(np.mean([r_["steps"] for r_ in rec]))))
+            legs["replicas"] = {"value": args.steps * world / el, "unit": "iter/s", "scaling": "weak", "ms_per_pass_max_over_ranks": 1e3 * el,
+                                "per_rank": rates, "what": "every rank runs its own budget K_r = K (0.5 + r/(R-1)) of the same graph, no collective; "
+                                "value = all ranks' iterations / max-over-ranks time"}
+        dist.barrier()
+    # ---- leg 3: eigen-solve row-partitioned between the processes (IPC-mapped buffers, device-side flags), gradient by RCCL ----
+    if "ipc_eig" in want:
+        P = mk()
+        ok, msg = _attach_leg(P, dist, rank, world, rccl=not share, ipc=True, shard_eig=True)
+        if not ok:
+            errors["ipc_eig"] = msg
+        else:
+            run_pass(P, k, min(args.warmup, 2), w["x0"])
+            r = _timed_passes(P, k, args.steps, w["x0"], dist, 3, comm_timing=True)
+            if r[0] is None:
+                errors["ipc_eig"] = r[1]
+            else:
+                el, rec = r
+                sm, sc = sum(r_["step_ms"] for r_ in rec), sum(r_["steps_timed"] for r_ in rec)
+                legs["ipc_eig"] = {"value": args.steps / el, "unit": "iter/s", "scaling": "strong", "ms_per_step": 1e3 * el / args.steps,
+                                   "us_per_lanczos_step": 1e3 * sm / max(1, sc), "steps_timed": sc, "comm_mode": int(_lib.load().machip_comm_mode(P._h)),
+                                   "exchange_us": float(np.mean([r_["exchange_us"] for r_ in rec])), "lambda2_first_last": [rec[0]["f"], rec[-1]["f"]],
+                                   "bit_identical_to_shard_leg": (head is not None and [r_["f"] for r_ in rec] == [r_["f"] for r_ in head["rec"]]),
+                                   "what": "every rank launches its share of the workgroups of every fused Lanczos step on its own copy of L(x) and writes "
+                                           "records / partial sums into every rank's copy (peer-mapped); steps ordered by flag words in device memory"}
+            try:
+                detach_ipc(P, dist)
+            except Exception:                   # noqa: BLE001
+                pass
+        P.close()
+        dist.barrier()
+    if rank == 0:
+        # headline: the shard pass; if its first contact failed, the replicas aggregate (named so)
+        if "shard" in legs:
+            value, scaling, el = legs["shard"]["value"], "strong", head["el"]
+            par = (f"candidate shard x{world} + " + ("IPC peer writes of the gradient (ranks share a GPU)" if share else "ncclAllGather of the gradient (RCCL)") +
+                   ", eigen-solve replicated on every rank")
+        elif "replicas" in legs:
+            value, scaling, el = legs["replicas"]["value"], "weak", 1e-3 * legs["replicas"]["ms_per_pass_max_over_ranks"]
+            par = f"replicas x{world} (the shard leg failed first contact: see errors)"
+        elif "ipc_eig" in legs:
+            value, scaling, el = legs["ipc_eig"]["value"], "strong", args.steps / legs["ipc_eig"]["value"]
+            par = f"row-partitioned eigen-solve x{world}"
+        else:
+            value, scaling, el, par = 0.0, "strong", 0.0, "every leg failed: see errors"
+        out = {"metric": "frank_wolfe_iters_per_sec", "value": value, "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": 1e3 * el / args.steps if el else None, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+               "dtype": "f64" if args.precision == 0 else "f32 iterate + f64 Rayleigh/residual refinement",
+               "data": "synthetic" if cfg in ("c2", "c4") else "dataset (tests/golden/data)",
+               "config": {"workload": w["name"], "N": n, "m_candidates": m, "K": k, "fixed_edges": int(len(w["fw"])), "fw_iters": args.steps,
+                          "fiedler_tol": 1e-8, "parallelism": par},
+               "legs_run": list(want)}
+        if head is not None:
+            out.update(repeats=len(head["pass_ms"]), pass_ms=head["pass_ms"], timed_wall_s=head["total"])
+            # the roofline unit of the headline leg: the replicated Lanczos step, as at N = 1
+            sm, sc = sum(r_["step_ms"] for r_ in head["rec"]), sum(r_["steps_timed"] for r_ in head["rec"])
+            if sc > 0 and sm > 0 and not args.no_roofline:
+                by = sum(r_["steps_timed"] * step_bytes(n, r_["nnz"]) for r_ in head["rec"]) / sc
+                us = 1e3 * sm / sc
+                out["roofline"] = {"bound": "hbm", "kernel": KERNEL, "achieved": by / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": by / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": us, "algorithmic_bytes_per_launch": by,
+                                   "launches_timed": sc, "note": "rank 0's replicated eigen-solve of the shard leg (median pass); same unit as the N = 1 line"}
+        for nm in ("shard", "replicas", "ipc_eig"):
+            if nm in legs:
+                out[nm] = legs[nm]
+        if "shard" in legs and "replicas" in legs:
+            out["replicas"]["vs_shard_leg"] = legs["replicas"]["value"] / legs["shard"]["value"]
+        out["predicted_vs_1gpu"] = {"shard": {2: 0.99, 4: 0.98, 8: 0.97}.get(world, 1.0 - 0.004 * world), "replicas": 0.8 * world,
+                                    "why": "DESIGN section 6: the shard divides only the supergradient (0.5 % of an iteration) and pays one all-gather of 16 MB; "
+                                           "replicas are independent problems (the 1.5 K budget has ~1.4x the entries of the 0.5 K one)"}
+        errs = dict(errors)
+        if share:
+            errs["rccl"] = ("refused: two ranks on one device (MACHIP_SHARE_GPU=1 protocol run) -- RCCL was not initialised; the shard leg exchanged its "
+                            "gradient through the IPC-mapped buffers instead")
+        if nccl_log:
+            lines = collect_nccl_log(nccl_log)
+            if lines:
+                errs["nccl_log"] = lines
+        out["errors"] = errs
+        print(json.dumps(out))
+    dist.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c4")
-    ap.add_argument("--mode", default="shard", choices=["shard", "replicas"], help="N > 1: candidate shard + RCCL (strong) or independent problems (weak)")
+    ap.add_argument("--mode", default="all", choices=["all", "shard", "replicas", "ipc_eig"],
+                    help="N > 1: all = candidate shard (headline, strong) + replicas (weak) + row-partitioned eigen-solve, one JSON line; or one leg only")
     ap.add_argument("--precision", type=int, default=0, help="0 = f64 throughout; 1 = f32 Krylov iterate + f64 Rayleigh/residual refinement (configs[4])")
     ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the K-iteration pass until this much wall time is measured")
     ap.add_argument("--max-repeats", type=int, default=50)
@@ -595,10 +925,14 @@ def main():
 
     if args.dry:
         return dry_run(args, dist, rank, local_rank, world, ndev, nccl_log)
+    if world > 1 and args.config not in ("c5", "c5s"):
+        return bench_multi(args, dist, rank, local_rank, world, ndev, nccl_log)
     if args.config == "c5" and world == 1:
         return bench_c5_batched(args)
     if args.config == "c5s" and world == 1:
         return bench_c5_sweep(args)
+    if args.config in ("c4s", "c2s") and world == 1:
+        return bench_er_sweep(args, args.config[:2])
     replicas = world > 1 and (args.mode == "replicas" or args.config == "c5")
     cfg = args.config
     if cfg == "c5":                      # one pose graph per rank (SURVEY 8(e) last row)
@@ -656,7 +990,7 @@ def main():
         for it in range(args.steps):
             f, dual, gn = P.fw_step(k, it)
             st = P.stats
-            rec.append((f, int(st.lanczos_steps), int(st.nnz), int(st.support), float(st.gpu_ms), float(st.step_ms), int(st.steps_timed)))
+            rec.append((f, int(st.lanczos_steps), int(st.nnz), int(st.support), float(st.gpu_ms), float(st.step_ms), int(st.steps_timed)) + P.solve_mode())
             P.fw_commit()
         P.synchronize()
         barrier()
@@ -757,24 +1091,45 @@ def main():
     # ---- roofline of the dominant kernel: in-solve duration from the hipEvents that bracket the Krylov chunks
     #      on the handle's stream (machip_solve_stats.step_ms / steps_timed), summed over EVERY timed pass ----
     if not args.no_roofline and rank == 0:
-        sm = sum(r[5] for p in passes for r in p[1])
-        sc = sum(r[6] for p in passes for r in p[1])
-        by_num = sum(r[6] * step_bytes(n, r[2]) for p in passes for r in p[1])
-        if args.precision == 1:
-            by_num = sum(r[6] * (8.0 * r[2] + 4.0 * (n + 1) + 32.0 * n) for p in passes for r in p[1])
+        top, mode_list = roofline_by_mode(passes, n, args.precision)
+        if top is not None and top[0] in (1, 2, 3):
+            # the fused step in whichever forms ran (gather on sparse iterates, panel on dense ones): ONE unit, as in rounds 1-4
+            sel = (1, 2, 3)
+            sm = sum(r[5] for p in passes for r in p[1] if len(r) <= 8 or r[7] in sel)
+            sc = sum(r[6] for p in passes for r in p[1] if len(r) <= 8 or r[7] in sel)
+            by_num = sum(r[6] * step_bytes(n, r[2]) for p in passes for r in p[1] if len(r) <= 8 or r[7] in sel)
+            kernel_name = KERNEL
+        elif top is not None:
+            sm, sc, by_num = top[1]["ms"], top[1]["units"], top[1]["bytes"]
+            kernel_name = MODE_INFO[top[0]][0] + (f" (up to {top[1]['closures']} closures)" if top[0] == 7 else "")
+        else:
+            sm = sc = by_num = 0
         if sc > 0 and sm > 0:
             us = 1e3 * sm / sc
             by = by_num / sc
             ach = by / (us * 1e-6) / 1e9
             traffic, tnote = None, "PMC passes skipped"
-            if world == 1 and not args.no_pmc:
+            if world == 1 and not args.no_pmc and top[0] in (1, 2, 3, 8):
                 traffic, tnote = pmc_traffic(args.config, args.steps, args.precision)
-            note = ("unit = one Lanczos step (one launch of k_pipe_vec, or k_pan_mul + k_pan_fin where the column-panel form runs); "
-                    "avg_launch_us = step_ms / steps_timed of machip_solve_stats: hipEvents on the handle's stream around the Krylov "
-                    "chunks of every solve in the timed passes (step kernels + one 1-wave tail kernel per chunk, so slightly above "
-                    "the pure kernel sums rocprofv3 reports); algorithmic bytes = 12 nnz + 4 (n+1) + 56 n per step whichever "
-                    "kernels run it, step-weighted over the iterations; the CSR and the operand are Infinity-Cache resident "
-                    "(<= 60 MB), peak is the 8 TB/s HBM figure all the same; " + tnote)
+            elif top[0] not in (1, 2, 3, 8):
+                tnote = "traffic: null -- the PMC passes count the fused step kernels only; this mode's unit spans several kernels of a chain (or a slice of one persistent launch)"
+            if top[0] in (1, 2, 3):
+                note = ("unit = one Lanczos step (one launch of k_pipe_vec, or k_pan_mul + k_pan_fin where the column-panel form runs); "
+                        "avg_launch_us = step_ms / steps_timed of machip_solve_stats: hipEvents on the handle's stream around the Krylov "
+                        "chunks of every solve in the timed passes (step kernels + one 1-wave tail kernel per chunk, so slightly above "
+                        "the pure kernel sums rocprofv3 reports); algorithmic bytes = 12 nnz + 4 (n+1) + 56 n per step whichever "
+                        "kernels run it, step-weighted over the iterations; the CSR and the operand are Infinity-Cache resident "
+                        "(<= 60 MB), peak is the 8 TB/s HBM figure all the same; " + tnote)
+            elif MODE_INFO[top[0]][1] == "step":
+                note = ("unit = one Lanczos step of the mode named in `kernel` (machip_solve_mode says which launch group served each timed solve: "
+                        "`solver_modes`); avg_launch_us = in-solve duration per step (hipEvents around the Krylov chunks); algorithmic bytes per step as "
+                        "that mode moves them (single-workgroup kernel: the 8n-byte basis column -- matrix and operand never leave the CU, so an "
+                        "HBM fraction near zero is the design, not a defect: the step is a latency chain); " + tnote)
+            else:
+                note = ("unit = one preconditioned iteration of the mode named in `kernel` (`solver_modes` lists every mode that served a timed solve); "
+                        "avg_launch_us = device time of the whole solve / its iterations (hipEvents ev0..ev1 of machip_solve_stats.gpu_ms: set-up -- "
+                        "closure list, column solves, capacitance inverse -- and the explicit checks included); algorithmic bytes per iteration = "
+                        "12 nnz + 4 (n+1) + 16 n (product) + 16 vector passes of 8n + (exact mode) 8 n s + 8 s^2 for the low-rank correction; " + tnote)
             peak_meas = None
             try:                          # the achievable peak measured on this box, reported next to the nominal one
                 rd, tr = _lib.membench(1 << 30, 8, local_rank % max(1, ndev))
@@ -787,10 +1142,7 @@ def main():
             nnz_mean = sum(r[6] * r[2] for p in passes for r in p[1]) / sc
             req = nnz_mean * 1.1 + (12.0 * nnz_mean + 60.0 * n) / 128.0
             l2_frac = (req / (us * 1e-6)) / (128 * 2.1e9)
-            if w["n"] <= 3072:   # small chain-like graphs run the single-workgroup solver, not this kernel
-                note = ("at this size the solve runs in the LDS/register-resident single-workgroup kernel k_lan_persist (HBM traffic: one "
-                        "8n-byte basis column per step); bytes are still counted with the multi-workgroup formula; " + note)
-            out["roofline"] = {"bound": "hbm", "kernel": KERNEL, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            out["roofline"] = {"bound": "hbm", "kernel": kernel_name, "solver_modes": mode_list, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_us": us,
                                "algorithmic_bytes_per_launch": by, "launches_timed": sc, "peak_measured": peak_meas,
                                "l2_request_frac": l2_frac,

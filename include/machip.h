@@ -189,6 +189,18 @@ int machip_comm_close_ipc(machip_problem* p);
  * solve when the attach succeeded here but failed on a peer (mac_amd.dist.attach_ipc).  Collective in spirit: call it on
  * every rank, behind a barrier, before anybody launches another step. */
 int machip_comm_drop_ipc(machip_problem* p);
+/* Leave whatever inter-process communicator the handle belongs to (RCCL: ncclCommAbort; IPC: as above): the handle is a
+ * single-rank handle again.  For a first contact that failed on SOME rank: every rank drops, behind an agreement exchange. */
+int machip_comm_drop(machip_problem* p);
+/* Device time of the last sharded gradient of this handle (hipEvents on its stream): the gradient kernel over this rank's
+ * candidate range, and the exchange behind it (ncclAllGather, or the IPC publish / wait pair) -- SURVEY section 8(e)'s two
+ * terms, measured per Frank-Wolfe iteration by bench.py --gpus N. */
+int machip_comm_timing(machip_problem* p, double* grad_us, double* exchange_us);
+/* Which launch group the steps of the last eigen-solve were: 1 fused gather step (k_pipe_vec), 2 column-panel step
+ * (k_pan_mul + k_pan_fin), 3 padded fixed-width step, 4 single-workgroup kernel (k_lan_persist), 5 classic two-kernel step,
+ * 6 LOBPCG preconditioned by the chain, 7 exact chain + closures mode (*closures = size of its capacitance matrix),
+ * 8 fp32 sequence + fp64 refinement.  bench.py prices the roofline of THAT group. */
+int machip_solve_mode(machip_problem* p, int64_t* closures);
 /* With 2..8 handles the in-process communicator also ROW-PARTITIONS THE EIGEN-SOLVE (MACHIP_SHARD_EIG=0 turns that off):
  * inside machip_fw_step rank 0's solver drives every rank's stream; per Lanczos step each rank launches its share of
  * the step's workgroups on its own copy of L(x) and of the gather operand and writes the records / partial sums it

@@ -86,6 +86,9 @@ SIGNATURES = {
     "machip_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
     "machip_option_name": (C.c_char_p, [C.c_int]),
     "machip_comm_drop_ipc": (C.c_int, [C.c_void_p]),
+    "machip_comm_drop": (C.c_int, [C.c_void_p]),
+    "machip_comm_timing": (C.c_int, [C.c_void_p, _f64p, _f64p]),
+    "machip_solve_mode": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "machip_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "machip_synchronize": (C.c_int, [C.c_void_p]),
     "machip_membench": (C.c_int, [C.c_int, C.c_int64, C.c_int, _f64p, _f64p]),
@@ -340,6 +343,21 @@ class Problem:
     def comm_drop_ipc(self):
         """Leave the inter-process communicator again (back to a single-rank handle)."""
         check(self._lib.machip_comm_drop_ipc(self._h))
+
+    def comm_drop(self):
+        """Leave any inter-process communicator (RCCL and / or IPC): single-rank handle again."""
+        check(self._lib.machip_comm_drop(self._h))
+
+    def comm_timing(self):
+        """(gradient kernel us, exchange us) of the last sharded gradient (machip_comm_timing)."""
+        a, b = C.c_double(0.0), C.c_double(0.0)
+        check(self._lib.machip_comm_timing(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def solve_mode(self):
+        """(mode, closures) of the last eigen-solve (machip_solve_mode)."""
+        c = C.c_int64(0)
+        return int(self._lib.machip_solve_mode(self._h, C.byref(c))), int(c.value)
 
     def set_option(self, name, value=None):
         """Entry `name` of this handle's option table (mac_amd/csrc/options.h; value None = the measured default)."""

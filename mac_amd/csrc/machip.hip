@@ -123,6 +123,8 @@ struct machip_problem {
     ncclComm_t comm = nullptr;
     std::shared_ptr<LocalGroup> lgroup;
     bool first_collective_pending = false;   // the communicator's first ncclAllGather is awaited with a time limit
+    hipEvent_t ev_g0 = nullptr, ev_g1 = nullptr, ev_g2 = nullptr;   // around the last gradient kernel / exchange of a communicator (machip_comm_timing)
+    bool ev_g_valid = false;
     std::unique_ptr<IpcGroup> ipcg;      // inter-process communicator with a row-partitioned eigen-solve (machip_comm_init_ipc)
     int rank = 0, nranks = 1;
     // evaluation lanes (machip_eval_batch): lightweight copies that share the pattern and the candidate arrays
@@ -377,6 +379,12 @@ int compute_gradient(machip_problem* p, bool have_vec_now = false, long fuse_k =
         k_ipc_publish<<<1, 64, 0, p->stream>>>(p->ipcg->view, 3);
         k_ipc_wait<<<1, 64, 0, p->stream>>>(p->ipcg->view, 3);
     }
+    const bool timed = p->nranks > 1;      // (communicators only: three event records per iteration)
+    if (timed) {
+        if (!p->ev_g0) { HIP_TRY(hipEventCreate(&p->ev_g0)); HIP_TRY(hipEventCreate(&p->ev_g1)); HIP_TRY(hipEventCreate(&p->ev_g2)); }
+        p->ev_g_valid = false;
+        HIP_TRY(hipEventRecord(p->ev_g0, p->stream));
+    }
     if (hi > lo) {
         const int grid = (int)std::min<long>(kMaxGrid * 4, (hi - lo + kBlock - 1) / kBlock);
         PeerVecs all;
@@ -389,10 +397,13 @@ int compute_gradient(machip_problem* p, bool have_vec_now = false, long fuse_k =
         } else k_grad<false><<<grid, kBlock, 0, p->stream>>>(p->ci, p->cj, p->cw, p->sol.yvec, lo, hi, p->g, all);
         HIP_TRY(hipGetLastError());
     }
+    if (timed) HIP_TRY(hipEventRecord(p->ev_g1, p->stream));
     if (ipc_gather) {
         k_ipc_publish<<<1, 64, 0, p->stream>>>(p->ipcg->view, 2);
         k_ipc_wait<<<1, 64, 0, p->stream>>>(p->ipcg->view, 2);
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(p->ev_g2, p->stream));
+        p->ev_g_valid = true;
         return MACHIP_OK;
     }
     if (p->nranks > 1) {
@@ -423,6 +434,8 @@ int compute_gradient(machip_problem* p, bool have_vec_now = false, long fuse_k =
         }
         else if (p->lgroup) { const int st = local_allgather(p, shard); if (st != MACHIP_OK) { p->lgroup->abort(); return st; } }
         else return fail(MACHIP_BAD_ARG, "nranks > 1 without a communicator");
+        HIP_TRY(hipEventRecord(p->ev_g2, p->stream));
+        p->ev_g_valid = true;
     }
     return MACHIP_OK;
 }
@@ -587,6 +600,7 @@ void machip_destroy(machip_problem* p) {
     void* ptrs[] = {p->prow, p->pcol, p->pk, p->pw, p->ci, p->cj, p->cw, p->x, p->x_next, p->g, p->s, p->scratch_m, p->cnt,
                     p->blk_sum, p->rowptr, p->col, p->val, p->blk_lnorm, p->xb, p->xb_next, p->hist, p->sel, p->part_fw};
     for (void* q : ptrs) if (q) (void)hipFree(q);
+    for (hipEvent_t e : {p->ev_g0, p->ev_g1, p->ev_g2}) if (e) (void)hipEventDestroy(e);
     if (p->h_int) (void)hipHostFree(p->h_int);
     if (p->h_dbl) (void)hipHostFree(p->h_dbl);
     if (p->stream) (void)hipStreamDestroy(p->stream);
@@ -1333,6 +1347,37 @@ int machip_get_option(machip_problem* p, const char* name, int64_t* value) {
 }
 
 const char* machip_option_name(int i) { return (i >= 0 && i < kNumOpts) ? option_names()[i] : nullptr; }
+
+int machip_comm_timing(machip_problem* p, double* grad_us, double* exchange_us) {
+    if (!p || !grad_us || !exchange_us) return fail(MACHIP_BAD_ARG, "machip_comm_timing: NULL argument");
+    *grad_us = 0.0; *exchange_us = 0.0;
+    if (!p->ev_g_valid) return fail(MACHIP_BAD_ARG, "machip_comm_timing: no sharded gradient has been computed on this handle");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipEventSynchronize(p->ev_g2));
+    float a = 0.f, b = 0.f;
+    HIP_TRY(hipEventElapsedTime(&a, p->ev_g0, p->ev_g1));
+    HIP_TRY(hipEventElapsedTime(&b, p->ev_g1, p->ev_g2));
+    *grad_us = 1e3 * (double)a; *exchange_us = 1e3 * (double)b;
+    return MACHIP_OK;
+}
+
+int machip_solve_mode(machip_problem* p, int64_t* closures) {
+    if (!p) return -1;
+    if (closures) *closures = p->sol.last_wb_s;
+    return p->sol.last_mode;
+}
+
+int machip_comm_drop(machip_problem* p) {
+    if (!p) return fail(MACHIP_BAD_ARG, "machip_comm_drop: NULL handle");
+    if (p->lgroup) return fail(MACHIP_BAD_ARG, "machip_comm_drop: in-process communicators end with their handles");
+    HIP_TRY(hipSetDevice(p->device));
+    (void)hipStreamSynchronize(p->stream);
+    if (p->ipcg) { p->sol.ipc = nullptr; p->ipcg.reset(); }
+    if (p->comm) { (void)ncclCommAbort(p->comm); p->comm = nullptr; }     // (abort, not destroy: the peers may never have arrived)
+    p->first_collective_pending = false; p->ev_g_valid = false;
+    p->rank = 0; p->nranks = 1; p->m_pad = p->m;
+    return MACHIP_OK;
+}
 
 int machip_comm_drop_ipc(machip_problem* p) {
     if (!p || !p->ipcg) return fail(MACHIP_BAD_ARG, "machip_comm_drop_ipc: no inter-process communicator");

@@ -139,6 +139,11 @@ struct Solver {
     LobState* lx_st = nullptr;
     double *h_lrec = nullptr, *d_hlrec = nullptr;
     bool lob_ready = false, last_was_lob = false;
+    // what the last solve's steps were (machip_solve_mode; bench.py prices the roofline of THAT launch group):
+    // 1 fused gather step (k_pipe_vec on the CSR), 2 column-panel step, 3 padded fixed-width step, 4 single-workgroup kernel,
+    // 5 classic two-kernel step, 6 preconditioned by the tridiagonal chain, 7 exact chain + closures mode, 8 fp32 + fp64 sequences
+    int last_mode = 0;
+    long last_wb_s = 0;          // closures of the exact mode's capacitance matrix in that solve
     int solver_mode = 0;        // 0 = auto, 1 = Lanczos, 2 = preconditioned (LOBPCG + tridiagonal solve)
     bool throughput_lane = false;   // this solver serves an evaluation lane (machip_eval_batch / machip_fw_sweep): many solves run at
                                     // once, so the automatic mode keeps to kernels that occupy ONE CU per solve where it can
@@ -1254,6 +1259,7 @@ struct Solver {
                 HIP_TRY(hipEventSynchronize(ev1));
                 float ms = 0.f;
                 HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+                last_mode = wb_active.s > 0 ? 7 : 6; last_wb_s = wb_active.s;
                 have_prev = true; last_was_lob = true; last_steps = iters; J_last = 0;
                 last_seq_sharded = false;        // (the final solve ran replicated, whatever a Lanczos prefix did: machip_comm_mode reports it)
                 hist_lob_iters = iters;
@@ -1669,6 +1675,8 @@ struct Solver {
             classic = true;   // refine with the accurate form (see enqueue_classic)
             if (restarts > 64) break;
         }
+        // (what most steps of this solve were: a restart's classic tail does not change that)
+        last_mode = steps_lowp > 0 ? 8 : pmode ? 4 : n <= OPT(classic_n, 256) ? 5 : pp.variant == kPanel ? 2 : pp.variant == kEll ? 3 : 1;
         if (switch_out) {        // (no Ritz vector was formed: have_prev keeps its value; the caller continues with the exact mode)
             last_steps = steps_total; last_steps_lowp = steps_lowp;
             return kSwitchToExact;

@@ -2105,6 +2105,32 @@ def test_ipc_peers_of_a_dead_rank_return_an_error_within_the_time_limit():
     assert el < 60.0, el
 
 
+def test_bench_two_ranks_emit_all_three_multi_gpu_legs_in_one_line():
+    """ONE `bench.py --gpus N` invocation must yield all the multi-GPU evidence -- the candidate-shard pass
+    (headline value, hipEvent-timed gradient and exchange), the replicas pass (per-rank figures) and the row-partitioned (IPC)
+    eigen-solve pass (us per Lanczos step) -- and a leg that fails first contact is reported under `errors` while the others
+    still print.  Two rank processes on this one GPU (MACHIP_SHARE_GPU=1: RCCL refuses two ranks on a device, so the shard
+    leg exchanges its gradient through the IPC-mapped buffers with the eigen-solve replicated, comm_mode 6)."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "c2", "--steps", "4", "--warmup", "1",
+                        "--min-seconds", "0.1", "--max-repeats", "2"], capture_output=True, text=True, cwd=ROOT, timeout=900,
+                       env=dict({k_: v_ for k_, v_ in os.environ.items() if k_ not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")},
+                                MACHIP_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["legs_run"] == ["shard", "replicas", "ipc_eig"] and isinstance(d["errors"], dict)
+    for leg in ("shard", "replicas", "ipc_eig"):
+        assert leg in d or leg in d["errors"], leg
+    sh, rp, ip = d["shard"], d["replicas"], d["ipc_eig"]
+    assert d["value"] == sh["value"] > 0 and d["scaling"] == "strong" and sh["comm_mode"] == 6
+    assert sh["grad_us"] > 0 and sh["exchange_us"] > 0
+    assert rp["scaling"] == "weak" and len(rp["per_rank"]) == 2 and rp["per_rank"][0]["K"] < rp["per_rank"][1]["K"] and rp["value"] > 0
+    assert ip["comm_mode"] in (4, 5) and ip["us_per_lanczos_step"] > 0 and ip["bit_identical_to_shard_leg"] is True
+    assert d["roofline"]["frac"] > 0 and d["config"]["workload"].startswith("configs[1]")
+
+
 def test_bench_dry_run_checks_first_contact_on_one_gpu():
     """`bench.py --gpus 2 --dry` (MACHIP_SHARE_GPU=1: both ranks on this GPU): device visibility, peer-access row, IPC
     exchange and two Frank-Wolfe iterations of a tiny problem through the whole communicator stack, reported as one JSON line;
