@@ -1199,7 +1199,10 @@ int prepare_lanes(machip_problem* p, int B, bool fw, int* nl_out) {
     // four hardware queues of those at once collapse (city10000 sweep: 647 it/s with 4 lanes, 277 with 8, 240 with 12).
     const bool small = p->sol.chain_like && persist_fits(p->n, std::max(0l, (long)p->P - 2 * p->sol.chain_edges));   // (P: off-diagonal slots of the union pattern)
     const Options& opt = p->sol.opt;
-    int nl = std::max(1, std::min(B, std::min(16, OPT(lanes, small ? 16 : 4))));
+    // Round 5 (profiles/r5_bench_c4s.json, r5_bench_c2s.json): problems whose every step fills the chip for 7-17 us (ER sizes: union
+    // pattern beyond ~400 000 slots) gain from ONE more problem in flight -- 2 lanes 1.27x (configs[3]) / 1.48x (configs[1]) the
+    // one-at-a-time rate, 4 lanes 1.03x / 0.95x: two problems already cover each other's launch gaps, more only thrash the L2s.
+    int nl = std::max(1, std::min(B, std::min(16, OPT(lanes, small ? 16 : (p->P > 400000 ? 2 : 4)))));
     while ((int)p->lanes.size() < nl) {
         machip_problem* q = nullptr;
         const int st = make_lane(p, &q);

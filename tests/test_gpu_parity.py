@@ -1829,6 +1829,44 @@ def test_sweep_lanes_capture_graphs_while_other_threads_create_handles():
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
 
 
+def test_er_size_budget_sweep_equals_fresh_sequential_solves():
+    """bench.py --config c2s / c4s: the reference's budget sweep at ER size -- four budgets of the
+    BASELINE.json configs[1] graph through machip_fw_sweep, chip-filling step kernels of the lanes interleaving on the GPU.
+    Every budget's relaxed x, dual bound and lambda_2 trajectory must equal a FRESH handle running the same loop one budget at a
+    time in the same solver mode (Lanczos pinned on both: the lanes never take other modes on this graph anyway), bit for bit,
+    with 2 and with 4 lanes."""
+    import bench
+    w = bench.make_workload("c2")
+    n, m, k = w["n"], len(w["cw"]), w["k"]
+    ks = [max(1, int(round(k * (0.5 + b / 3)))) for b in range(4)]
+    rng = np.random.default_rng(0)
+    X0 = np.zeros((4, m))
+    for b, kb in enumerate(ks):
+        X0[b, rng.choice(m, kb, replace=False)] = 1.0
+    start = reference_start_block(n)[:, 0].copy()
+    seq = []
+    for b in range(4):
+        P = _lib.Problem(n, w["fi"], w["fj"], w["fw"], w["ci"], w["cj"], w["cw"])
+        P.set_solver(1); P.set_start(start); P.set_x(X0[b])
+        fs, u = [], np.inf
+        for it in range(5):
+            f, dual, gn = P.fw_step(ks[b], it)
+            fs.append(f); u = min(u, dual)
+            P.fw_commit()
+        seq.append((np.array(fs), P.get_x(), u))
+        P.close()
+    P = _lib.Problem(n, w["fi"], w["fj"], w["fw"], w["ci"], w["cj"], w["cw"])
+    P.set_solver(1); P.set_start(start)
+    for lanes in (2, 4):
+        P.set_option("lanes", lanes)
+        r = P.fw_sweep(ks, X0, max_iters=5, gap_tol=0.0, grad_tol=0.0, want_rounded=False)
+        assert list(r["iters"]) == [5] * 4 and list(r["status"]) == [0] * 4
+        for b in range(4):
+            assert np.array_equal(r["f_traj"][b], seq[b][0]), (lanes, b)
+            assert np.array_equal(r["x"][b], seq[b][1]) and r["upper"][b] == seq[b][2], (lanes, b)
+    P.close()
+
+
 @pytest.mark.parametrize("nm", ["intel", "sphere2500"])
 def test_concurrent_budget_sweep_matches_the_reference_on_every_budget(nm):
     """MAC.solve_sweep against the REFERENCE's own budget sweep (tests/golden/g2o_sweep_<name>.npz, generated by running
