@@ -133,14 +133,15 @@ def step_bytes(n, nnz):
 def run_pass(P, k, iters, x0, tol=1e-8):
     """iters Frank-Wolfe iterations from x0 with the stop tests disabled (device-resident loop)."""
     P.set_x(x0)
+    if iters <= 0:
+        return []
+    r = P.fw_run(k, iters, tol=tol)               # the loop runs on the C side (machip_fw_run): no Python between iterations
     rec = []
-    for it in range(iters):
-        f, dual, gn = P.fw_step(k, it, tol=tol)
-        st = P.stats
-        rec.append(dict(f=f, dual=dual, gnorm=gn, steps=int(st.lanczos_steps), nnz=int(st.nnz), support=int(st.support),
-                        gpu_ms=float(st.gpu_ms), step_ms=float(st.step_ms), steps_timed=int(st.steps_timed), steps_lowp=int(st.steps_lowp),
-                        residual=float(st.residual)))
-        P.fw_commit()
+    for it in range(r["iters"]):
+        st = r["stats"][it]
+        rec.append(dict(f=float(r["f"][it]), dual=float(r["dual"][it]), gnorm=float(r["gnorm"][it]), steps=int(st.lanczos_steps), nnz=int(st.nnz),
+                        support=int(st.support), gpu_ms=float(st.gpu_ms), step_ms=float(st.step_ms), steps_timed=int(st.steps_timed),
+                        steps_lowp=int(st.steps_lowp), residual=float(st.residual), mode=r["modes"][it]))
     return rec
 
 
@@ -704,25 +705,36 @@ def _timed_passes(P, k, steps, x0, dist, npass, comm_timing=False):
         t0 = time.perf_counter()
         if err is None:
             try:
-                for it in range(steps):
-                    f, dual, gn = P.fw_step(k, it)
-                    st = P.stats
-                    r = dict(f=f, steps=int(st.lanczos_steps), nnz=int(st.nnz), step_ms=float(st.step_ms), steps_timed=int(st.steps_timed),
-                             gpu_ms=float(st.gpu_ms))
-                    if comm_timing:
-                        r["grad_us"], r["exchange_us"] = P.comm_timing()
-                    rec.append(r)
-                    P.fw_commit()
+                r = P.fw_run(k, steps)               # exactly `steps` iterations on the C side, as at N = 1
                 P.synchronize()
+                el = time.perf_counter() - t0
+                rec = [dict(f=float(r["f"][it]), steps=int(st.lanczos_steps), nnz=int(st.nnz), step_ms=float(st.step_ms), steps_timed=int(st.steps_timed),
+                            gpu_ms=float(st.gpu_ms)) for it, st in enumerate(r["stats"])]
             except Exception as e:                  # noqa: BLE001
                 err = f"rank {dist.rank}: {e}"
-        el = time.perf_counter() - t0
         errs = [e for e in dist.all_gather_object(err) if e]
         if errs:
             return None, "; ".join(errs)
         passes.append((dist.max(el), rec))
     passes.sort(key=lambda t: t[0])
-    return passes[(len(passes) - 1) // 2]
+    el, rec = passes[(len(passes) - 1) // 2]
+    if comm_timing:
+        # per-iteration device time of the gradient kernel and of the exchange behind it (hipEvents, machip_comm_timing): an untimed
+        # pass of the same iterations driven one machip_fw_step at a time
+        err = None
+        try:
+            P.set_x(x0)
+            for it in range(steps):
+                P.fw_step(k, it)
+                rec[it]["grad_us"], rec[it]["exchange_us"] = P.comm_timing()
+                P.fw_commit()
+            P.synchronize()
+        except Exception as e:                      # noqa: BLE001
+            err = f"rank {dist.rank}: {e}"
+        errs = [e for e in dist.all_gather_object(err) if e]
+        if errs:
+            return None, "; ".join(errs)
+    return el, rec
 
 
 def bench_multi(args, dist, rank, local_rank, world, ndev, nccl_log):
@@ -986,15 +998,12 @@ def main():
         P.synchronize()
         barrier()
         t0 = time.perf_counter()
-        rec = []
-        for it in range(args.steps):
-            f, dual, gn = P.fw_step(k, it)
-            st = P.stats
-            rec.append((f, int(st.lanczos_steps), int(st.nnz), int(st.support), float(st.gpu_ms), float(st.step_ms), int(st.steps_timed)) + P.solve_mode())
-            P.fw_commit()
+        r = P.fw_run(k, args.steps)               # exactly K iterations, stop tests disabled, on the C side (machip_fw_run)
         P.synchronize()
         barrier()
         el = time.perf_counter() - t0
+        rec = [(float(r["f"][it]), int(st.lanczos_steps), int(st.nnz), int(st.support), float(st.gpu_ms), float(st.step_ms), int(st.steps_timed)) + r["modes"][it]
+               for it, st in enumerate(r["stats"])]
         if dist is not None:
             el = dist.max(el)             # every rank sees the same number, so every rank stops after the same pass
         passes.append((el, rec))
@@ -1012,11 +1021,8 @@ def main():
             P.set_x(w["x0"])
             P.synchronize()
             t0 = time.perf_counter()
-            wrec = []
-            for it in range(args.steps):
-                f, dual, gn = P.fw_step(k, it, warm_start=it > 0)
-                wrec.append((f, int(P.stats.lanczos_steps)))
-                P.fw_commit()
+            r = P.fw_run(k, args.steps, warm_start=True)
+            wrec = [(float(r["f"][it]), int(st.lanczos_steps)) for it, st in enumerate(r["stats"])]
             P.synchronize()
             wp.append((time.perf_counter() - t0, wrec))
         wel, wrec = sorted(wp, key=lambda t: t[0])[1]

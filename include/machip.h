@@ -123,6 +123,16 @@ int machip_lp_topk(machip_problem* p, int64_t k, double* s_out);
 int machip_fw_step(machip_problem* p, int64_t k, int iter, double tol, int max_steps, int warm_start,
                    double* f, double* dual, double* gnorm, machip_solve_stats* stats);
 int machip_fw_commit(machip_problem* p);
+/* The loop itself (mac/optimization/frankwolfe.py:53-76 as mac/solvers/mac.py:196-200 calls it) without returning to the caller
+ * between iterations: for i = first_iter .. first_iter + max_iters - 1: machip_fw_step; upper = min(upper, dual); stop when
+ * ||g|| < grad_tol (the current x stays) or (upper - f) < gap_tol |f|; else machip_fw_commit.  *upper_inout carries the dual
+ * bound in and out (start: +inf).  Optional per-iteration outputs (max_iters entries each, NULL to skip): f_traj, dual_traj,
+ * gnorm_traj, stats, modes (2 ints per iteration: machip_solve_mode and its closure count).  *iters_done = iterations run.
+ * Between two iterations a Python caller of machip_fw_step / machip_fw_commit leaves the GPU idle for ~50 us (measured,
+ * profiles/r5_c4_gaps.txt); this entry point is what MAC.solve and bench.py drive. */
+int machip_fw_run(machip_problem* p, int64_t k, int first_iter, int max_iters, double gap_tol, double grad_tol, double tol,
+                  int max_steps, int warm_start, double* upper_inout, double* f_traj, double* dual_traj, double* gnorm_traj,
+                  machip_solve_stats* stats, int* modes, int* iters_done);
 
 /* round_nearest(w, k, weights, break_ties_decimal_tol) on the device-resident x
  * (mac/utils/rounding.py:7-42, called at mac/solvers/mac.py:209): indicator of the k largest

@@ -62,6 +62,8 @@ SIGNATURES = {
     "machip_fw_step": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_int, C.c_int, _f64p, _f64p,
                                  _f64p, C.POINTER(SolveStats)]),
     "machip_fw_commit": (C.c_int, [C.c_void_p]),
+    "machip_fw_run": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, _f64p, _f64p,
+                                _f64p, _f64p, C.POINTER(SolveStats), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "machip_round_nearest": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, _f64p]),
     "machip_fiedler_csr": (C.c_int, [C.c_int, C.c_int64, _i32p, _i32p, _f64p, C.c_double, C.c_int, _f64p, _f64p,
                                      _f64p, _f64p, C.c_int, C.POINTER(SolveStats)]),
@@ -304,6 +306,24 @@ class Problem:
 
     def fw_commit(self):
         check(self._lib.machip_fw_commit(self._h))
+
+    def fw_run(self, k, max_iters, first_iter=0, gap_tol=0.0, grad_tol=0.0, tol=1e-8, max_steps=0, warm_start=False, upper=float("inf")):
+        """The Frank-Wolfe loop on the C side (machip_fw_run): up to max_iters iterations from the resident x with the
+        reference's stop tests (0.0 disables them), no return to Python in between.  Returns a dict: f, dual, gnorm (arrays of
+        the iterations done), upper, iters, stats (list of SolveStats), modes (list of (mode, closures))."""
+        n = max(1, int(max_iters))
+        f = np.zeros(n); d = np.zeros(n); gn = np.zeros(n)
+        st = (SolveStats * n)()
+        modes = (C.c_int * (2 * n))()
+        up = C.c_double(float(upper)); done = C.c_int(0)
+        status = self._lib.machip_fw_run(self._h, int(k), int(first_iter), int(max_iters), float(gap_tol), float(grad_tol), float(tol),
+                                         int(max_steps), int(bool(warm_start)), C.byref(up), p_f64(f), p_f64(d), p_f64(gn), st, modes, C.byref(done))
+        it = int(done.value)
+        if it:
+            C.memmove(C.byref(self.stats), C.byref(st[it - 1]), C.sizeof(SolveStats))
+        check(status)
+        return dict(f=f[:it], dual=d[:it], gnorm=gn[:it], upper=up.value, iters=it, stats=[st[i] for i in range(it)],
+                    modes=[(int(modes[2 * i]), int(modes[2 * i + 1])) for i in range(it)])
 
     def round_nearest(self, k, decimals=10):
         """Device round_nearest of the resident x; decimals=None -> plain top-k."""

@@ -965,10 +965,12 @@ __global__ __launch_bounds__(64) void k_pipe_tail(PipeViewT<T> L, int adv) {
         if (j > 0) { L.htri[sa] = c.alpha; L.htri[sl] = c.l1prev; }
         L.htri[sb] = c.beta;
     }
-    __threadfence_system();
+    // (round 5: no system-scope fence / release in front of the flag -- they made the one wave wait for the PCIe round trip of its
+    // record stores.  The host never trusts the flag alone: every record slot of the chunk was poisoned with NaN before the chunk
+    // was enqueued and is awaited individually (solver.h wait_slot), so a flag that overtakes its records costs nothing.)
     if (threadIdx.x == 0) {
         const unsigned long long epoch = (unsigned long long)(unsigned int)L.st->epoch;
-        __hip_atomic_store(L.hflag, (epoch << 32) | (unsigned long long)(unsigned int)j, __ATOMIC_RELEASE,
+        __hip_atomic_store(L.hflag, (epoch << 32) | (unsigned long long)(unsigned int)j, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }

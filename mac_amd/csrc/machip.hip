@@ -290,7 +290,10 @@ int assemble(machip_problem* p) {
     }
     HIP_TRY(hipGetLastError());       // a refused launch must not leave stale row offsets behind a MACHIP_OK
     const int gb = p->asm_grid;
-    HIP_TRY(hipStreamSynchronize(p->stream));      // (both kernels wrote the host's copies into mapped pinned memory)
+    // (both kernels wrote the host's copies into mapped pinned memory.  Round 5 tried a completion word published by the fill pass's
+    // last workgroup -- system-scope fence + ticket per workgroup -- for the host to spin on instead of this wait: 3 125 fences made
+    // the launch 312 us instead of 82)
+    HIP_TRY(hipStreamSynchronize(p->stream));
     long nnz = 0, supp = 0;
     int maxlen = 0;
     double ln = 0.0;
@@ -757,6 +760,34 @@ int machip_fw_step(machip_problem* p, int64_t k, int iter, double tol, int max_s
     *dual = lam + d;
     *gnorm = std::sqrt(q2);
     guard.ok = true;
+    return MACHIP_OK;
+}
+
+int machip_fw_run(machip_problem* p, int64_t k, int first_iter, int max_iters, double gap_tol, double grad_tol, double tol, int max_steps,
+                  int warm_start, double* upper_inout, double* f_traj, double* dual_traj, double* gnorm_traj, machip_solve_stats* stats,
+                  int* modes, int* iters_done) {
+    if (!p || p->csr_only || max_iters < 0 || first_iter < 0 || !upper_inout || !iters_done) return fail(MACHIP_BAD_ARG, "machip_fw_run: bad argument");
+    double u = *upper_inout;
+    int done = 0;
+    *iters_done = 0;
+    for (int i = 0; i < max_iters; ++i) {
+        double f = 0.0, dual = 0.0, gn = 0.0;
+        machip_solve_stats st;
+        memset(&st, 0, sizeof(st));
+        const int rc = machip_fw_step(p, k, first_iter + i, tol, max_steps, (warm_start && (first_iter + i) > 0) ? 1 : 0, &f, &dual, &gn, &st);
+        if (rc != MACHIP_OK) { *upper_inout = u; *iters_done = done; return rc; }
+        u = std::min(u, dual);                                      // frankwolfe.py:62
+        if (f_traj) f_traj[i] = f;
+        if (dual_traj) dual_traj[i] = dual;
+        if (gnorm_traj) gnorm_traj[i] = gn;
+        if (stats) stats[i] = st;
+        if (modes) { modes[2 * i] = p->sol.last_mode; modes[2 * i + 1] = (int)p->sol.last_wb_s; }
+        done = i + 1;
+        if (gn < grad_tol) break;                                   // frankwolfe.py:65-68 (x stays the current iterate)
+        if ((u - f) < gap_tol * std::fabs(f)) break;                // frankwolfe.py:70-74
+        ST_TRY(machip_fw_commit(p));                                // frankwolfe.py:76
+    }
+    *upper_inout = u; *iters_done = done;
     return MACHIP_OK;
 }
 

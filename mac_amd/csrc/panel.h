@@ -191,6 +191,9 @@ __global__ __launch_bounds__(kBlock) void k_pan_cellcap(PatternView Pt, int R, i
 // An image holds kPanStage entries; a larger cell takes several rounds (ranges of the cell's entries, whatever tile they belong to).
 // Tile table: tptr[cell (NTP + 1) + physical tile], the cell's last entry = end of its data (cells are not adjacent in memory).
 constexpr int kPanStage = 15360;       // entries of the LDS image (120 KB of values + 30 KB of columns: one workgroup per CU)
+// RT = rows per thread = ceil(rows of a row block / 1 024): the per-row state lives in registers (configs[3]: 5, not the 8 the largest
+// row block needs -- with 8 the kernel spilled 156 bytes per thread).
+template <int RT>
 __global__ __launch_bounds__(kPanThreads) void k_pan_build(CsrView A, PanView P) {
     __shared__ double sval[kPanStage];
     __shared__ __attribute__((aligned(16))) unsigned short scol[kPanStage];
@@ -205,15 +208,15 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_build(CsrView A, PanView P)
     const int c0 = p * P.C;
     if (tid <= kPanMaxLen) { hist[tid] = 0; fill[tid] = 0; }
     __syncthreads();
-    int c[kPanRT], st[kPanRT], hole[kPanRT], hlen[kPanRT];
+    int c[RT], st[RT], hole[RT], hlen[RT];
 #pragma unroll
-    for (int j = 0; j < kPanRT; ++j) {
+    for (int j = 0; j < RT; ++j) {
         const int rl = tid + kPanThreads * j, r = b * R + rl;
         st[j] = 0; hole[j] = 0; hlen[j] = 0;
         c[j] = (rl < R && r < A.n) ? pan_row_count(P, A.n, r, p, &st[j], &hole[j], &hlen[j]) : 0;
     }
 #pragma unroll
-    for (int j = 0; j < kPanRT; ++j)
+    for (int j = 0; j < RT; ++j)
         if (tid + kPanThreads * j < R) atomicAdd(&hist[c[j]], 1);
     __syncthreads();
     // (the scans below are wave scans / binary searches: as loops of one thread over LDS they were ~15 us of this launch)
@@ -251,9 +254,9 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_build(CsrView A, PanView P)
     __syncthreads();
     if (tid <= NTP) P.tptr[(size_t)cell * (NTP + 1) + tid] = toff[tid];
     const size_t vtb = (size_t)cell * NTP;
-    int dst0[kPanRT];
+    int dst0[RT];
 #pragma unroll
-    for (int j = 0; j < kPanRT; ++j) {
+    for (int j = 0; j < RT; ++j) {
         const int rl = tid + kPanThreads * j;
         dst0[j] = 0x3fffffff;
         if (rl < R) {
@@ -272,17 +275,19 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_build(CsrView A, PanView P)
         // diagonal; band form: the run skips the hole of columns r - 1 / r + 1); it sits at dst0 + 64 i of the cell.  Lanes with
         // nothing to fetch load entry 0 of the matrix (one line for everybody): unconditional loads stay batched.
 #pragma unroll
-        for (int j0 = 0; j0 < kPanRT; j0 += 4) {
+        for (int j0 = 0; j0 < RT; j0 += 4) {
+            constexpr int JN = 4;       // (rows of a batch; the last batch of an RT that is no multiple of 4 masks the rest out below)
             // the entries [lo, hi) of each row that fall into this round, and the longest such range among the wave's rows: the
             // batches below run that often for everybody (a loop per row over ITS run length is one dependent round trip per
             // entry for the whole wave: 70 of the first build's 117 us)
             int lo[4], hi[4], cm = 0;
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int j = j0 + jj;
+            for (int jj = 0; jj < JN; ++jj) {
+                const int j = min(j0 + jj, RT - 1);
+                const bool real = j0 + jj < RT;
                 lo[jj] = rb > dst0[j] ? (rb - dst0[j] + 63) >> 6 : 0;
                 const int t = rb + ext - dst0[j];
-                hi[jj] = t > 0 ? min(c[j], (t + 63) >> 6) : 0;
+                hi[jj] = (real && t > 0) ? min(c[j], (t + 63) >> 6) : 0;
                 cm = max(cm, hi[jj] - lo[jj]);
             }
 #pragma unroll
@@ -291,8 +296,8 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_build(CsrView A, PanView P)
                 double v[4][4];
                 int cc[4][4];
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const int j = j0 + jj;
+                for (int jj = 0; jj < JN; ++jj) {
+                    const int j = min(j0 + jj, RT - 1);
                     const int r = b * R + tid + kPanThreads * j;
                     const bool mine = lo[jj] + i0 < hi[jj];
                     const int shift = (!P.band && c[j] > 0 && r / P.C == p) ? 1 : 0;
@@ -307,8 +312,8 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_build(CsrView A, PanView P)
                     }
                 }
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const int j = j0 + jj;
+                for (int jj = 0; jj < JN; ++jj) {
+                    const int j = min(j0 + jj, RT - 1);
                     const int d0 = dst0[j] - rb;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {

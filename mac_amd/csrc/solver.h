@@ -415,7 +415,19 @@ struct Solver {
             HIP_TRY(hipMemsetAsync(panv.ovf, 0, sizeof(int), stream));
             k_pan_rows<<<(n + kBlock - 1) / kBlock, kBlock, 0, stream>>>(A, panv);
         }
-        k_pan_build<<<pan_build_grid(pn.NB, pn.NP), kPanThreads, 0, stream>>>(A, panv);
+        {
+            const int g = pan_build_grid(pn.NB, pn.NP);
+            switch ((64 * pn.NTB + kPanThreads - 1) / kPanThreads) {      // rows per thread of the build kernel
+                case 1: k_pan_build<1><<<g, kPanThreads, 0, stream>>>(A, panv); break;
+                case 2: k_pan_build<2><<<g, kPanThreads, 0, stream>>>(A, panv); break;
+                case 3: k_pan_build<3><<<g, kPanThreads, 0, stream>>>(A, panv); break;
+                case 4: k_pan_build<4><<<g, kPanThreads, 0, stream>>>(A, panv); break;
+                case 5: k_pan_build<5><<<g, kPanThreads, 0, stream>>>(A, panv); break;
+                case 6: k_pan_build<6><<<g, kPanThreads, 0, stream>>>(A, panv); break;
+                case 7: k_pan_build<7><<<g, kPanThreads, 0, stream>>>(A, panv); break;
+                default: k_pan_build<8><<<g, kPanThreads, 0, stream>>>(A, panv); break;
+            }
+        }
         HIP_TRY(hipGetLastError());
         (void)nnz;
         return MACHIP_OK;

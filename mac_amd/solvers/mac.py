@@ -165,22 +165,19 @@ class MAC:
         assert len(x_init) == m                                       # mac.py:183
         dev = self._dev
         dev.set_x(np.asarray(x_init, dtype=np.float64))
-        u = float("inf")
+        # frankwolfe.py:53-76 as mac.py:196-200 calls it, run on the C side (machip_fw_run: no return to Python between iterations)
+        r = dev.fw_run(k, max_iters, gap_tol=relative_duality_gap_tol, grad_tol=grad_norm_tol, tol=1e-8,
+                       max_steps=self.max_lanczos_steps, warm_start=bool(use_cache))
+        u = float(r["upper"])
         self.trace = []
-        for i in range(max_iters):                                    # frankwolfe.py:53-76
-            f, dual, gnorm = dev.fw_step(k, i, tol=1e-8, max_steps=self.max_lanczos_steps,
-                                         warm_start=bool(use_cache and i > 0))
-            u = min(u, dual)
-            st = dev.stats
-            self.trace.append((f, u, gnorm, int(st.support), int(st.lanczos_steps)))
+        ub = float("inf")
+        for i in range(r["iters"]):
+            ub = min(ub, float(r["dual"][i]))
+            st = r["stats"][i]
+            self.trace.append((float(r["f"][i]), ub, float(r["gnorm"][i]), int(st.support), int(st.lanczos_steps)))
             if verbose:
-                print(f"[mac_amd] it {i}: f={f:.12g} u={u:.12g} |g|={gnorm:.3g} "
+                print(f"[mac_amd] it {i}: f={r['f'][i]:.12g} u={ub:.12g} |g|={r['gnorm'][i]:.3g} "
                       f"supp={st.support} lanczos={st.lanczos_steps}")
-            if gnorm < grad_norm_tol:
-                break
-            if (u - f) < relative_duality_gap_tol * abs(f):
-                break
-            dev.fw_commit()
         w = dev.get_x()
 
         start = timer()
