@@ -824,6 +824,9 @@ def bench_multi(args, dist, rank, local_rank, world, ndev, nccl_log):
                 legs["ipc_eig"] = {"value": args.steps / el, "unit": "iter/s", "scaling": "strong", "ms_per_step": 1e3 * el / args.steps,
                                    "us_per_lanczos_step": 1e3 * sm / max(1, sc), "steps_timed": sc, "comm_mode": int(_lib.load().machip_comm_mode(P._h)),
                                    "exchange_us": float(np.mean([r_["exchange_us"] for r_ in rec])), "lambda2_first_last": [rec[0]["f"], rec[-1]["f"]],
+                                   # (identical bits where the shard leg ran the same gather step; at sizes where a single rank takes the
+                                   # column-panel form -- which the partitioned solve does not shard -- the two agree to the last digits)
+                                   "lambda2_max_rel_diff_vs_shard_leg": (None if head is None else float(max(abs(a_["f"] - b_["f"]) / abs(b_["f"]) for a_, b_ in zip(rec, head["rec"])))),
                                    "bit_identical_to_shard_leg": (head is not None and [r_["f"] for r_ in rec] == [r_["f"] for r_ in head["rec"]]),
                                    "what": "every rank launches its share of the workgroups of every fused Lanczos step on its own copy of L(x) and writes "
                                            "records / partial sums into every rank's copy (peer-mapped); steps ordered by flag words in device memory"}

@@ -96,4 +96,9 @@ with open(out_md, "w") as fh:
     for r in rows:
         fh.write(f"| `{r['kernel'][:60]}` | {r['calls']} | {r['total_ms']:.2f} | {r['avg_us']:.2f} | {r['min_us']:.2f} | {r['max_us']:.2f} | "
                  f"{r['pct']:.2f} | {r['fetch_kib']:.1f} | {r['write_kib']:.1f} |\n")
+# hand-written notes of the round (what was tried, before / after tables) ride along: profiles/<tag>_notes.md
+notes = os.path.join("profiles", tag + "_notes.md")
+if os.path.exists(notes):
+    with open(out_md, "a") as fh:
+        fh.write(open(notes).read())
 print(open(out_md).read()[:3000])
