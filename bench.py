@@ -605,7 +605,7 @@ def dry_run(args, dist, rank, local_rank, world, ndev, nccl_log):
     (under libmachip's watchdog), IPC export / open of the peers' buffers and a row-partitioned eigen-solve, results equal on
     every rank."""
     from mac_amd import _lib
-    from mac_amd.dist import attach, attach_ipc, detach_ipc
+    from mac_amd.dist import detach_ipc
     from mac_amd.utils.fiedler import reference_start_block
     lib = _lib.load()
     dev = local_rank % max(1, ndev)
@@ -617,17 +617,15 @@ def dry_run(args, dist, rank, local_rank, world, ndev, nccl_log):
     steps = {}
     share = os.environ.get("MACHIP_SHARE_GPU") == "1" and ndev < world
     if dist is not None and world > 1:
+        # first contact is collective and exception-safe (_attach_leg): a step that fails on ANY rank is dropped on every rank, so
+        # nobody walks into a collective its peers never joined
         if not share:
-            try:
-                attach(P, dist, rank, world); steps["rccl_comm_init"] = "ok"
-            except Exception as e:     # noqa: BLE001
-                steps["rccl_comm_init"] = f"FAILED: {e}"
+            ok, msg = _attach_leg(P, dist, rank, world, rccl=True, ipc=False, shard_eig=False)
+            steps["rccl_comm_init"] = "ok" if ok else f"FAILED: {msg}"
         else:
             steps["rccl_comm_init"] = "skipped (ranks share a GPU: RCCL refuses that)"
-        try:
-            attach_ipc(P, dist, rank, world, timeout_s=10.0); steps["ipc_exchange"] = "ok"
-        except Exception as e:         # noqa: BLE001
-            steps["ipc_exchange"] = f"FAILED: {e}"
+        ok, msg = _attach_leg(P, dist, rank, world, rccl=False, ipc=True, shard_eig=True)
+        steps["ipc_exchange"] = "ok" if ok else f"FAILED: {msg}"
     P.set_x(w["x0"])
     fs = []
     try:
@@ -688,6 +686,17 @@ def _attach_leg(P, dist, rank, world, rccl, ipc, shard_eig):
             P.comm_drop()
             return False, "; ".join(errs)
     return True, ""
+
+
+def _collective(dist, fn):
+    """Run fn() on every rank; whatever happens locally, every rank then learns every rank's error (no rank is left behind in a
+    collective or dies alone).  Returns the list of error strings (empty = all fine)."""
+    err = None
+    try:
+        fn()
+    except Exception as e:                          # noqa: BLE001
+        err = f"rank {dist.rank}: {e}"
+    return [e for e in dist.all_gather_object(err) if e]
 
 
 def _timed_passes(P, k, steps, x0, dist, npass, comm_timing=False):
@@ -764,9 +773,11 @@ def bench_multi(args, dist, rank, local_rank, world, ndev, nccl_log):
         if not ok:
             errors["shard"] = ("refused: two ranks on one device -- " if share else "") + msg
         else:
-            run_pass(P, k, args.warmup, w["x0"])
+            werr = _collective(dist, lambda: run_pass(P, k, args.warmup, w["x0"]))      # (the communicator's first collective runs in here, under libmachip's watchdog)
             passes, total = [], 0.0
             while True:
+                if werr:
+                    errors["shard"] = "warm-up: " + "; ".join(werr); break
                 r = _timed_passes(P, k, args.steps, w["x0"], dist, 1, comm_timing=True)
                 if r[0] is None:
                     errors["shard"] = r[1]; break
@@ -783,19 +794,24 @@ def bench_multi(args, dist, rank, local_rank, world, ndev, nccl_log):
                                  "exchange": "IPC peer writes (ranks share a GPU)" if share else "ncclAllGather of the padded m-vector (RCCL over xGMI)",
                                  "eig_ms_per_iter": float(np.mean([r_["gpu_ms"] for r_ in rec])), "comm_mode": head["mode"],
                                  "lambda2_first_last": [rec[0]["f"], rec[-1]["f"]], "lanczos_steps_per_iter": float(np.mean([r_["steps"] for r_ in rec]))}
-            if share and ok:
+            if share and ok and "shard" not in errors:
                 try:
                     detach_ipc(P, dist)
                 except Exception:               # noqa: BLE001
                     pass
+        if "shard" in errors:
+            try:
+                P.comm_drop()                   # (a failed leg: abort the communicator rather than wait for peers in its destructor)
+            except Exception:                   # noqa: BLE001
+                pass
         P.close()
         dist.barrier()
     # ---- leg 2: replicas -- the reference's budget sweep (examples/g2o_experiment.py:306-336), one budget per GPU, no collective ----
     if "replicas" in want:
         kr = max(1, int(round(k * (0.5 + rank / max(1, world - 1)))))
         P = mk()
-        run_pass(P, kr, min(args.warmup, 2), w["x0"])
-        r = _timed_passes(P, kr, args.steps, w["x0"], dist, 3)
+        werr = _collective(dist, lambda: run_pass(P, kr, min(args.warmup, 2), w["x0"]))
+        r = (None, "warm-up: " + "; ".join(werr)) if werr else _timed_passes(P, kr, args.steps, w["x0"], dist, 3)
         P.close()
         if r[0] is None:
             errors["replicas"] = r[1]
@@ -814,8 +830,8 @@ def bench_multi(args, dist, rank, local_rank, world, ndev, nccl_log):
         if not ok:
             errors["ipc_eig"] = msg
         else:
-            run_pass(P, k, min(args.warmup, 2), w["x0"])
-            r = _timed_passes(P, k, args.steps, w["x0"], dist, 3, comm_timing=True)
+            werr = _collective(dist, lambda: run_pass(P, k, min(args.warmup, 2), w["x0"]))
+            r = (None, "warm-up: " + "; ".join(werr)) if werr else _timed_passes(P, k, args.steps, w["x0"], dist, 3, comm_timing=True)
             if r[0] is None:
                 errors["ipc_eig"] = r[1]
             else:
@@ -830,8 +846,14 @@ def bench_multi(args, dist, rank, local_rank, world, ndev, nccl_log):
                                    "bit_identical_to_shard_leg": (head is not None and [r_["f"] for r_ in rec] == [r_["f"] for r_ in head["rec"]]),
                                    "what": "every rank launches its share of the workgroups of every fused Lanczos step on its own copy of L(x) and writes "
                                            "records / partial sums into every rank's copy (peer-mapped); steps ordered by flag words in device memory"}
+            if "ipc_eig" not in errors:
+                try:
+                    detach_ipc(P, dist)
+                except Exception:               # noqa: BLE001
+                    pass
+        if "ipc_eig" in errors:
             try:
-                detach_ipc(P, dist)
+                P.comm_drop()
             except Exception:                   # noqa: BLE001
                 pass
         P.close()

@@ -1847,6 +1847,51 @@ def test_concurrent_budget_sweep_is_bit_identical_to_sequential_solves(nm):
     assert np.array_equal(both[0][0], np.ones(m)) and np.array_equal(both[1][1], seq[1][1]) and both[1][0].sum() == ks[1]
 
 
+def test_fw_run_equals_the_step_by_step_loop_and_reports_solver_modes():
+    """machip_fw_run (round 5: the loop of frankwolfe.py:53-76 on the C side -- what MAC.solve and bench.py drive) against the same loop
+    driven one machip_fw_step / machip_fw_commit at a time: f, dual bound, ||g||, iteration count under the reference's stop tests
+    (mac.py:196-200: gap 1e-4, gradient 1e-8) and the final x are bit-identical, also when a stop test fires early (intel, 80 %
+    budget); machip_solve_mode names the launch group that served each solve: single-workgroup kernel, then fused gather step on er2000, the column-panel step when
+    forced, the exact chain + closures mode on intel, the single-workgroup kernel on sphere2500's dense iterate, the padded form on city10000."""
+    for nm, frac, iters in (("er2000_solve", None, 6), ("g2o_intel", 0.8, 20)):
+        g = load_golden(nm)
+        m = len(g["cw"])
+        k = int(g["k"]) if frac is None else int(frac * m)
+        x0 = g["x_init"] if frac is None else NaiveGreedy(edges_of(g, "c")).subset(k)
+        P = problem_of(g); P.set_start(reference_start_block(int(g["n"]))[:, 0].copy()); P.set_x(x0)
+        ref, u = [], np.inf
+        for i in range(iters):
+            f, dual, gn = P.fw_step(k, i)
+            u = min(u, dual); ref.append((f, dual, gn))
+            if gn < 1e-8 or (u - f) < 1e-4 * abs(f):
+                break
+            P.fw_commit()
+        x_ref = P.get_x(); P.close()
+        P = problem_of(g); P.set_start(reference_start_block(int(g["n"]))[:, 0].copy()); P.set_x(x0)
+        r = P.fw_run(k, iters, gap_tol=1e-4, grad_tol=1e-8)
+        assert r["iters"] == len(ref) and r["upper"] == u
+        assert [(a, b, c) for a, b, c in zip(r["f"], r["dual"], r["gnorm"])] == ref
+        assert np.array_equal(P.get_x(), x_ref)
+        assert len(r["stats"]) == r["iters"] and all(int(s_.nnz) > 0 for s_ in r["stats"])
+        mds = [md[0] for md in r["modes"]]
+        if nm == "er2000_solve":      # a chain + random closures on 2 000 nodes: the single-workgroup kernel while the closures fit it, the fused gather step after
+            assert set(mds) <= {1, 4} and mds[-1] == 1, r["modes"]
+        else:                         # intel: the exact chain + closures mode (<= 700 active closures), its closure count reported
+            assert set(mds) <= {4, 7} and mds[0] == 7 and r["modes"][0][1] > 0, r["modes"]
+        if nm == "g2o_intel":
+            assert len(ref) < iters                       # (the duality-gap test fired: the reference stops early on this budget too)
+        P.close()
+    g = load_golden("er2000_xfrac")
+    P = problem_of(g); P.set_option("panel", 1); P.set_x(g["x"]); P.fiedler(want_vec=False)
+    assert P.solve_mode()[0] == 2
+    P.close()
+    for nm, want in (("g2o_sphere2500", 4), ("g2o_city10000", 3)):
+        g = load_golden(nm)
+        P = problem_of(g); P.set_x(np.ones(len(g["cw"]))); P.fiedler(want_vec=False)
+        assert P.solve_mode()[0] == want, (nm, P.solve_mode())
+        P.close()
+
+
 def test_sweep_lanes_capture_graphs_while_other_threads_create_handles():
     """Round-4 advisor finding: the lanes' CU-masked streams are BLOCKING streams (hipExtStreamCreateWithCUMask takes no flags),
     so any legacy-stream call of the library -- round 4 still issued hipMemcpy / hipMemset in machip_create, machip_fiedler_csr
