@@ -14,14 +14,18 @@ Default workload (N = 1): BASELINE.json configs[3], the configuration the north 
 exactly K iterations from x0; passes are repeated until >= --min-seconds of wall time have been measured and
 the MEDIAN pass is reported (`repeats`, `pass_ms`), so the figure is reproducible and visible from outside.
 
---gpus N > 1:
-  * --mode shard (default; the north star's split): the same workload with the
-    candidates sharded over the ranks: every rank evaluates the supergradient of its contiguous candidate
-    range, one RCCL all-gather rebuilds the m-vector on every rank, everything else is replicated.
-    "scaling": "strong".  DESIGN section 6 states what this can and cannot scale.
-  * --mode replicas: every rank runs an independent problem of the same graph with its own budget K_r
-    (the reference's budget sweep, examples/g2o_experiment.py:306-336; --config c5: one pose graph per
-    rank), no collective; value = all ranks' iterations / max-over-ranks time.  "scaling": "weak".
+--gpus N > 1 (default --mode all): ONE invocation runs, in one process group and in this order,
+  * the SHARD pass (headline `value`, "scaling": "strong"; the north star's split): the candidates
+    sharded over the ranks, every rank evaluates the supergradient of its contiguous range, one ncclAllGather rebuilds the
+    m-vector on every rank, everything else is replicated; hipEvent-timed gradient / exchange per iteration (`shard`);
+  * the REPLICAS pass ("scaling": "weak"): every rank runs an independent problem of the same graph with its own budget K_r
+    (the reference's budget sweep, examples/g2o_experiment.py:306-336), no collective; value = all ranks' iterations /
+    max-over-ranks time (`replicas`);
+  * the ROW-PARTITIONED eigen-solve pass: every rank launches its share of each fused Lanczos step, buffers IPC-mapped, steps
+    ordered by device-side flags (`ipc_eig`: us per step);
+  a leg whose first contact fails on any rank is dropped on every rank and reported under `errors`; the others still print.
+  DESIGN section 7 states what each can and cannot scale.  --mode shard|replicas|ipc_eig runs one leg; --config c5: one pose
+  graph per rank (replicas).
   Launched by `torch.distributed.run` (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in the environment) or, when those
   are absent, by bench.py itself: it spawns N rank processes, one GPU each, and refuses to run when fewer
   than N devices are visible.
@@ -416,7 +420,7 @@ def bench_c5_batched(args):
                       "data": "dataset (tests/golden/data)",
                       "config": {"workload": "configs[4]: city10000.g2o + sphere2500.g2o batched (2 concurrent handles, 1 GPU), K=20%"
                                              + ("" if args.precision == 0 else " -- precision 1 (fp32 iterate + fp64 refinement) as BASELINE.json words it; "
-                                                "measured SLOWER than the fp64 default on this hardware (DESIGN 4.2d)"),
+                                                "measured SLOWER than the fp64 default on this hardware (DESIGN 4.2, docs/log_r1_r4.md 4.2d)"),
                                  "precision_note": "default --precision 0 (fp64) is the faster mode; --precision 1 is the fp32 + fp64-refinement arithmetic configs[4] names",
                                  "fw_iters_each": args.steps, "parallelism": "replicas: one stream + host thread per graph"},
                       "sequential_value": 2 * args.steps / seq, "lambda2_last": [fs[0][-1], fs[1][-1]]}))
@@ -428,7 +432,7 @@ def bench_c5_batched(args):
 def bench_c5_sweep(args):
     """The reference's real experiment on BASELINE.json configs[4]'s two pose graphs (examples/g2o_experiment.py:306-336: a
     sweep of budgets, MAC.solve(max_iters = 20) each) on ONE GPU: per graph one handle whose evaluation lanes run the
-    budgets 10 % .. 90 % concurrently (machip_fw_sweep, DESIGN 4.4d), the two graphs in two host threads.  A step = one
+    budgets 10 % .. 90 % concurrently (machip_fw_sweep, DESIGN 6), the two graphs in two host threads.  A step = one
     Frank-Wolfe iteration of one budget; value = all iterations of all budgets of both graphs / wall time.  Stop tests
     disabled, cold eigen-solves, exactly as the other configs are timed."""
     import threading
@@ -895,7 +899,7 @@ def bench_multi(args, dist, rank, local_rank, world, ndev, nccl_log):
         if "shard" in legs and "replicas" in legs:
             out["replicas"]["vs_shard_leg"] = legs["replicas"]["value"] / legs["shard"]["value"]
         out["predicted_vs_1gpu"] = {"shard": {2: 0.99, 4: 0.98, 8: 0.97}.get(world, 1.0 - 0.004 * world), "replicas": 0.8 * world,
-                                    "why": "DESIGN section 6: the shard divides only the supergradient (0.5 % of an iteration) and pays one all-gather of 16 MB; "
+                                    "why": "DESIGN section 7: the shard divides only the supergradient (0.5 % of an iteration) and pays one all-gather of 16 MB; "
                                            "replicas are independent problems (the 1.5 K budget has ~1.4x the entries of the 0.5 K one)"}
         errs = dict(errors)
         if share:
@@ -1098,7 +1102,7 @@ def main():
             warm["value_vs_cold"] = warm["value"] / (units / el)
             out["warm_start"] = warm
         if world > 1:
-            # DESIGN section 6: what this mode can be expected to deliver, printed next to what it did
+            # DESIGN section 7: what this mode can be expected to deliver, printed next to what it did
             if replicas:
                 pred = 1.0 * world if args.config == "c5" else 0.8 * world
                 why = ("independent problems, no collective: R x the single-GPU rate x (mean rate / slowest rank's rate); the 1.5 K budget of the "

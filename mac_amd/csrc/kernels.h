@@ -501,7 +501,7 @@ using PipeView = PipeViewT<double>;
 
 struct PipeCoef { double alpha, mu, beta, inv, l1prev; };
 
-// Row-partitioned step (in-process communicator, machip_comm_init_local; DESIGN section 6): rank r launches workgroups
+// Row-partitioned step (in-process communicator, machip_comm_init_local; DESIGN section 7): rank r launches workgroups
 // [first, first + gridDim.x) of the SAME `total`-workgroup launch a single rank would run -- same rows per workgroup,
 // same partial sums, same order of additions, hence bit-identical results -- on its own copy of the matrix and of the
 // gather operand, and writes what it produces (next records, partial sums) into every rank's copy (peer-mapped pointers
@@ -516,7 +516,7 @@ struct PeerSet {
     double* part[kMaxPeers];
 };
 
-// ---- device-ordered exchange between PROCESSES (round 4; machip_comm_init_ipc, DESIGN section 6) ----------------------------
+// ---- device-ordered exchange between PROCESSES (round 4; machip_comm_init_ipc, DESIGN section 7) ----------------------------
 // Every rank maps the peers' record / partial-sum / vector / gradient buffers (hipIpcOpenMemHandle) and writes what it
 // produces into every copy (PeerSet).  Ordering needs no host and no cross-stream edge: per channel (Lanczos steps, Ritz
 // vector rows, gradient shards) a rank counts what it has published (`done`, its own memory) and publishes that count into a

@@ -999,7 +999,7 @@ int machip_comm_init(machip_problem* p, int rank, int nranks, const void* id128)
     return MACHIP_OK;
 }
 
-// ---- communicator between processes with a row-partitioned eigen-solve (round 4; DESIGN section 6) ----
+// ---- communicator between processes with a row-partitioned eigen-solve (round 4; DESIGN section 7) ----
 // Blob a rank hands to its peers: IPC handles of its record buffers, partial sums, Ritz staging vector, gradient and flag words.
 namespace {
 struct IpcBlob {

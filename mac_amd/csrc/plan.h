@@ -5,7 +5,7 @@
 //   plan_pipe   shape of the one-kernel Lanczos step (lanes per row, load chains, workgroup size, deferred barrier)
 //   plan_panel  whether the column-panel form runs, and its panels / row blocks (panel.h)
 //   launch_*    the switch from a plan to a template instantiation; launch_pipe_shard: one rank's share of a
-//               row-partitioned step (ShardGroup below, DESIGN section 6)
+//               row-partitioned step (ShardGroup below, DESIGN section 7)
 //
 // Every number here was measured on MI355X (tools/ubench*.hip, tools/sweep_pipe.py, tools/sweep_panel.py); the comments say
 // which.  Shapes can be overridden through the handle's option table (options.h, machip_set_option; OPT(name, default) below):
@@ -336,7 +336,7 @@ inline int pipe_gpb(const SpmvPlan& pl) {
     return (pl.block - 64) / g;
 }
 
-// Row-partitioned eigen-solve of an in-process communicator (machip_comm_init_local, DESIGN section 6): the LEADER's
+// Row-partitioned eigen-solve of an in-process communicator (machip_comm_init_local, DESIGN section 7): the LEADER's
 // solver (rank 0) drives every rank's stream -- per Lanczos step one launch per rank (that rank's share of the step's
 // workgroups, on that rank's copy of matrix and operand, writing next records and partial sums into every copy),
 // ordered by events: step s of rank r waits for step s - 1 of every rank.  Everything else of the solve (host analysis

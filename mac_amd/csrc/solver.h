@@ -1173,7 +1173,7 @@ struct Solver {
 #ifndef MACHIP_EXPERIMENTS
         if (mode == 3) mode = 0;      // (3 = diagonally preconditioned LOBPCG: experiments build only)
 #endif
-        // auto: chain-dominated graphs with few active closures per node (measured cross-over, DESIGN 4.6)
+        // auto: chain-dominated graphs with few active closures per node (measured cross-over, DESIGN 4.5)
         const bool eligible = n > 256 && n <= kTriBigMaxN;
         // One preconditioned iteration costs about `ratio` Lanczos steps (three launches, one of them a
         // single workgroup).  Sparse closures: preconditioned.  Denser closures: only when the last
