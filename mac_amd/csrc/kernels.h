@@ -36,9 +36,11 @@ struct PatternView {
 
 struct LanState {   // device-resident step counters: kernels take no per-step arguments,
     int jA;         // so a chunk of steps can be replayed from a hipGraph.  Fused form: jA = first
-    int jB;         // step of the current chunk (only k_pipe_tail writes it).  Classic form: jA is
+    int jB;         // step of the current chunk.  Classic form: jA is
     int epoch;      // read by the SpMV kernel, jB by k_lan_update.  epoch tags the host flag.
-    int pad;
+    int jN;         // fused form: first step of the NEXT chunk.  A chunk's first step (jrel == 0) reads jN and sets jA = jN, its other
+                    // steps read jA; its last step (or its tail kernel) sets jN = jA + steps.  No launch reads a counter that
+                    // a workgroup of the same launch writes (chunks have at least two steps).
 };
 
 struct LanView {
@@ -487,6 +489,9 @@ struct PipeViewT {
                       // writes the other, so a late-starting workgroup never sees partials that a
                       // fast workgroup of the SAME launch has already replaced
     int P;            // valid partials per quantity (= grid of the step kernel, <= 256)
+    int chunk;        // > 0: this chunk has no tail kernel -- its last step (jrel == chunk - 1) advances jN itself, and its records
+                      // reach the host through the NEXT chunk's first step (or a tail kernel the host adds when no chunk follows)
+    int pub;          // > 0: the chunk before this one had `pub` steps and no tail: the first step publishes its records
 #ifdef PIPE_CLOCKS
     long long* clk;   // tools/ubench5.hip: 8 wall-clock stamps (100 MHz) per workgroup
 #endif
@@ -636,13 +641,43 @@ __device__ __forceinline__ PipeCoef pipe_coefs(const double (&a)[kNP], int n) {
 // Prologue, run by wave 0 only: sum the P (<= 256) partials of each quantity, derive the
 // coefficients, publish them to the workgroup through LDS (scoef) and -- workgroup 0 -- to the
 // tridiagonal record.  The other waves go straight to their CSR loads.
+// Zero-copy hand-off to the host (wave 0 of one workgroup): records [j-adv-1, j] of tri -> pinned host memory, then the flag.
 template <class PV>
-__device__ __forceinline__ PipeCoef pipe_prologue_wave0(const PV& L, int jrel, int adv_jA, double* scoef, int* j_out, int bid = -1) {
+__device__ __forceinline__ void pipe_publish(const PV& L, const PipeCoef& c, int j, int adv) {
+    const int lo = max(0, j - adv - 1);
+    const int cnt = 3 * (j - lo + 1);
+    // every host address is written exactly once: the three values this launch has just produced (alpha_{j-1},
+    // l1_{j-1}, beta_j) go from registers, the bulk copy skips their slots (L.tri may still hold the old ones)
+    const int sa = j > 0 ? 3 * (j - 1) : -1, sl = j > 0 ? 3 * (j - 1) + 2 : -1, sb = 3 * j + 1;
+    for (int i = threadIdx.x; i < cnt; i += 64) {
+        const int q = 3 * lo + i;
+        if (q != sa && q != sl && q != sb && q < 3 * j) L.htri[q] = L.tri[q];   // (alpha_j, l1_j belong to the next chunk)
+    }
+    if (threadIdx.x == 0) {
+        if (j > 0) { L.htri[sa] = c.alpha; L.htri[sl] = c.l1prev; }
+        L.htri[sb] = c.beta;
+    }
+    // (round 5: no system-scope fence / release in front of the flag -- they made the one wave wait for the PCIe round trip of its
+    // record stores.  The host never trusts the flag alone: every record slot of the chunk was poisoned with NaN before the chunk
+    // was enqueued and is awaited individually (solver.h wait_slot), so a flag that overtakes its records costs nothing.)
+    if (threadIdx.x == 0) {
+        const unsigned long long epoch = (unsigned long long)(unsigned int)L.st->epoch;
+        __hip_atomic_store(L.hflag, (epoch << 32) | (unsigned long long)(unsigned int)j, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// `lead`: this launch is the one of its step that advances the counters (the panel form runs the prologue in both of its launches);
+// `pub_wg`: the workgroup that hands a tail-less predecessor chunk's records to the host (any workgroup can: all compute the same
+// coefficients) -- the caller names one with slack.
+template <class PV>
+__device__ __forceinline__ PipeCoef pipe_prologue_wave0(const PV& L, int jrel, int adv_jA, double* scoef, int* j_out, int bid = -1,
+                                                        bool lead = true, int pub_wg = 0) {
     // (sharded step: the tridiagonal records go to the launching rank's own arrays -- its first workgroup writes them; ranks of
     // one process share the leader's arrays and all write the same values, ranks in different processes each keep their own)
     bid = (int)blockIdx.x;
     const int lane = threadIdx.x;   // caller guarantees threadIdx.x < 64
-    const int jA = L.st->jA;        // (requested first, consumed last: in flight together with the partial loads below)
+    const int jA = *(jrel == 0 && adv_jA < 0 ? &L.st->jN : &L.st->jA);        // (requested first, consumed last: in flight together with the partial loads below)
     const double* __restrict__ pin = L.part + (size_t)(jrel & 1) * (kNP * kMaxGrid);
     double a[kNP];
     {   // The first 256 partials per quantity: 24 UNCONDITIONAL loads per lane (always in bounds: the arrays hold kMaxGrid
@@ -690,9 +725,14 @@ __device__ __forceinline__ PipeCoef pipe_prologue_wave0(const PV& L, int jrel, i
         if (bid == 0) {
             if (j > 0) { L.tri[3 * (j - 1)] = c.alpha; L.tri[3 * (j - 1) + 2] = c.l1prev; }
             L.tri[3 * j + 1] = c.beta;
-            if (adv_jA >= 0) L.st->jA = j;   // tail kernel: new chunk base
+            if (adv_jA >= 0) { L.st->jA = j; L.st->jN = j; }   // tail kernel: new chunk base
+            else if (lead) {
+                if (jrel == 0) L.st->jA = j;
+                if (L.chunk > 0 && jrel == L.chunk - 1) L.st->jN = jA + L.chunk;
+            }
         }
     }
+    if (lead && adv_jA < 0 && jrel == 0 && L.pub > 0 && j > 0 && (int)blockIdx.x == pub_wg) pipe_publish(L, c, j, L.pub);
     *j_out = j;
     return c;
 }
@@ -823,7 +863,7 @@ __global__ __launch_bounds__(BLOCK) void k_pipe_vec(const int* __restrict__ a_ro
     const int lane = wt >= 0 ? wt % G : 0, g = wt >= 0 ? wt / G : 0;
     PIPE_CLK(threadIdx.x == 0, 0);
     PIPE_CLK(wt == 0, 2);
-    if (threadIdx.x < 64) { int jdummy; (void)pipe_prologue_wave0(L, jrel, -1, scoef, &jdummy, bid); }
+    if (threadIdx.x < 64) { int jdummy; (void)pipe_prologue_wave0(L, jrel, -1, scoef, &jdummy, bid, true, (int)gridDim.x - 1); }
     PIPE_CLK(threadIdx.x == 0, 1);
     const Z2* __restrict__ Zc = ELLW ? ((jrel & 1) ? L.Z1 : L.Z0) : z_cur;
     Z2* __restrict__ Zn = (jrel & 1) ? L.Z0 : L.Z1;
@@ -884,7 +924,7 @@ __global__ __launch_bounds__(kBlock) void k_pipe_stream(CsrView A, PipeView L, i
     constexpr int R = kBlock / TPR;
     const int tid = threadIdx.x;
     const int row = tid / TPR, sub = tid % TPR;
-    if (tid < 64) { int jdummy; (void)pipe_prologue_wave0(L, jrel, -1, scoef, &jdummy); }
+    if (tid < 64) { int jdummy; (void)pipe_prologue_wave0(L, jrel, -1, scoef, &jdummy, -1, true, (int)gridDim.x - 1); }
     const Z2* __restrict__ Zc = (jrel & 1) ? L.Z1 : L.Z0;
     Z2* __restrict__ Zn = (jrel & 1) ? L.Z0 : L.Z1;
     PipeRow pr;
@@ -940,7 +980,7 @@ __global__ __launch_bounds__(kBlock) void k_pipe_init(PipeViewT<T> L, const doub
         for (int q = 0; q < kNP; ++q) L.part[q * kMaxGrid + blockIdx.x] = 0.0;
         L.part[0 * kMaxGrid + blockIdx.x] = s2;
         L.part[3 * kMaxGrid + blockIdx.x] = s1;
-        if (blockIdx.x == 0) { L.st->jA = 0; L.st->epoch = epoch; }
+        if (blockIdx.x == 0) { L.st->jA = 0; L.st->jN = 0; L.st->epoch = epoch; }
     }
 }
 // One wave, end of a chunk of `adv` steps: finish (alpha_{J-1}, beta_J, l1_{J-1}) for J = jA + adv
@@ -952,27 +992,7 @@ __global__ __launch_bounds__(64) void k_pipe_tail(PipeViewT<T> L, int adv) {
     __shared__ double scoef[8];
     int j = 0;
     const PipeCoef c = pipe_prologue_wave0(L, adv, adv, scoef, &j);
-    const int lo = max(0, j - adv - 1);
-    const int cnt = 3 * (j - lo + 1);
-    // every host address is written exactly once: the three values this kernel has just produced (alpha_{j-1},
-    // l1_{j-1}, beta_j) go from registers, the bulk copy skips their slots (L.tri may still hold the old ones)
-    const int sa = j > 0 ? 3 * (j - 1) : -1, sl = j > 0 ? 3 * (j - 1) + 2 : -1, sb = 3 * j + 1;
-    for (int i = threadIdx.x; i < cnt; i += 64) {
-        const int q = 3 * lo + i;
-        if (q != sa && q != sl && q != sb && q < 3 * j) L.htri[q] = L.tri[q];   // (alpha_j, l1_j belong to the next chunk)
-    }
-    if (threadIdx.x == 0) {
-        if (j > 0) { L.htri[sa] = c.alpha; L.htri[sl] = c.l1prev; }
-        L.htri[sb] = c.beta;
-    }
-    // (round 5: no system-scope fence / release in front of the flag -- they made the one wave wait for the PCIe round trip of its
-    // record stores.  The host never trusts the flag alone: every record slot of the chunk was poisoned with NaN before the chunk
-    // was enqueued and is awaited individually (solver.h wait_slot), so a flag that overtakes its records costs nothing.)
-    if (threadIdx.x == 0) {
-        const unsigned long long epoch = (unsigned long long)(unsigned int)L.st->epoch;
-        __hip_atomic_store(L.hflag, (epoch << 32) | (unsigned long long)(unsigned int)j, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    pipe_publish(L, c, j, adv);
 }
 
 // Partial sums (sum, sum of squares, sum of abs) of a vector -> part_u layout.
@@ -998,7 +1018,7 @@ __global__ __launch_bounds__(kBlock) void k_to_f32(const double* __restrict__ sr
 }
 
 __global__ void k_set_state(LanState* st, int j) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) { st->jA = j; st->jB = j; }
+    if (threadIdx.x == 0 && blockIdx.x == 0) { st->jA = j; st->jB = j; st->jN = j; }
 }
 
 // Deterministic pseudo-random start vector in (-1,1) (splitmix64 of the index).

@@ -178,7 +178,7 @@ template <typename T>
 __global__ void k_persist_begin(PersistViewT<T> L, int epoch, const double* __restrict__ src = nullptr) {
     // (src: the start vector of the sequence, copied into the state u here instead of by a copy kernel of its own)
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < L.n; r += gridDim.x * blockDim.x) { L.vprev[r] = 0.0; if (src) L.u[r] = src[r]; }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { L.st->jA = 0; L.st->epoch = epoch; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { L.st->jA = 0; L.st->jN = 0; L.st->epoch = epoch; }
 }
 
 // Matrix layout inside the workgroup (pose graph = odometry chain + loop closures): the tridiagonal
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(kPersistThreads) void k_lan_persist(PersistPack P, 
     if (t == 0) L.clk[11] = wall_clock64();
 #endif
     if (t == 0) {
-        L.st->jA = J;
+        L.st->jA = J; L.st->jN = J;
         const unsigned long long epoch = (unsigned long long)(unsigned int)L.st->epoch;
         __hip_atomic_store(L.hflag, (epoch << 32) | (unsigned long long)(unsigned int)J, __ATOMIC_RELEASE,
                            __HIP_MEMORY_SCOPE_SYSTEM);

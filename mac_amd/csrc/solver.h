@@ -247,7 +247,7 @@ struct Solver {
     template <typename T = double>
     PipeViewT<T> pview(const SpmvPlan& pl) const {
         PipeViewT<T> L;     // T = float: records and basis live in the same buffers, read as fp32
-        L.n = n; L.st = st; L.Z0 = reinterpret_cast<ZRec<T>*>(Z0); L.Z1 = reinterpret_cast<ZRec<T>*>(Z1); L.V = reinterpret_cast<T*>(V); L.tri = tri; L.htri = d_htri; L.hflag = d_hflag; L.part = part; L.P = pl.grid;
+        L.n = n; L.st = st; L.Z0 = reinterpret_cast<ZRec<T>*>(Z0); L.Z1 = reinterpret_cast<ZRec<T>*>(Z1); L.V = reinterpret_cast<T*>(V); L.tri = tri; L.htri = d_htri; L.hflag = d_hflag; L.part = part; L.P = pl.grid; L.chunk = 0; L.pub = 0;
         return L;
     }
     LanView check_view(const SpmvPlan& pl) const {   // "column 0" machinery for the explicit check
@@ -600,39 +600,48 @@ struct Solver {
     }
 
     // ---- one chunk = `steps` step kernels + the tail kernel ------------------------------------
-    void launch_chunk(const CsrView& A, const SpmvPlan& pl, int steps, bool f32 = false) {
+    // tailless: no tail kernel -- the chunk's last step advances the counters and the NEXT chunk's first step (pub = this chunk's
+    // step count there) hands the records to the host; a chunk that turns out to have no successor gets its tail from flush_tail.
+    void launch_chunk(const CsrView& A, const SpmvPlan& pl, int steps, bool f32 = false, bool tailless = false, int pub = 0) {
         if (pl.variant == kPanel) {
-            const PipeView L = pview(pl);
+            PipeView L = pview(pl);
+            L.chunk = tailless ? steps : 0; L.pub = pub;
             for (int s = 0; s < steps; ++s) launch_pan_step(L, s);
-            k_pipe_tail<<<1, 64, 0, stream>>>(L, steps);
+            if (!tailless) k_pipe_tail<<<1, 64, 0, stream>>>(L, steps);
             return;
         }
         if (shard && pl.variant == kVec && !f32) { launch_chunk_sharded(pl, steps); return; }
         if (seq_ipc && pl.variant == kVec && !f32) { launch_chunk_ipc(A, pl, steps); return; }
         if (f32) {
-            const PipeViewT<float> L = pview<float>(pl);
+            PipeViewT<float> L = pview<float>(pl);
+            L.chunk = tailless ? steps : 0; L.pub = pub;
             const CsrViewT<float> Af{A.n, A.rowptr, A.col, valf};
             for (int s = 0; s < steps; ++s) launch_pipe(pl, stream, Af, L, s);
-            k_pipe_tail<<<1, 64, 0, stream>>>(L, steps);
+            if (!tailless) k_pipe_tail<<<1, 64, 0, stream>>>(L, steps);
             return;
         }
-        const PipeView L = pview(pl);
+        PipeView L = pview(pl);
+        L.chunk = tailless ? steps : 0; L.pub = pub;
         const CsrView& As = pl.variant == kEll ? ell_view : A;
         for (int s = 0; s < steps; ++s) launch_pipe(pl, stream, As, L, s);
-        k_pipe_tail<<<1, 64, 0, stream>>>(L, steps);
+        if (!tailless) k_pipe_tail<<<1, 64, 0, stream>>>(L, steps);
     }
-    int enqueue_chunk(const CsrView& A, const SpmvPlan& pl, int steps, bool f32 = false) {
+    void flush_tail(const SpmvPlan& pl, int steps, bool f32) {
+        if (f32) k_pipe_tail<<<1, 64, 0, stream>>>(pview<float>(pl), steps);
+        else k_pipe_tail<<<1, 64, 0, stream>>>(pview(pl), steps);
+    }
+    int enqueue_chunk(const CsrView& A, const SpmvPlan& pl, int steps, bool f32 = false, bool tailless = false, int pub = 0) {
         const bool sharded = shard && pl.variant == kVec && !f32;
         // row-partitioned chunks are launched eagerly: a captured chunk would be one graph of steps x ranks kernel nodes with
         // ranks - 1 cross-stream dependencies each (ROCm 7.2 crashes on it from 8 ranks on one device), and across devices
         // a single graph is not an option anyway
-        if (!use_graph() || sharded) { launch_chunk(A, pl, steps, f32); HIP_TRY(hipGetLastError()); return MACHIP_OK; }
+        if (!use_graph() || sharded) { launch_chunk(A, pl, steps, f32, tailless, pub); HIP_TRY(hipGetLastError()); return MACHIP_OK; }
         if (graph_csr_key != (const void*)A.val) {   // different matrix buffers: cached graphs are stale
             for (auto& kv : graphs) for (hipGraphExec_t ge : kv.second) if (ge) (void)hipGraphExecDestroy(ge);
             graphs.clear();
             graph_csr_key = (const void*)A.val;
         }
-        const auto key = std::make_tuple(pl.variant + (f32 ? 100 : 0) + 1000 * pl.defer + (sharded ? 100000 * (int)shard->rk.size() : 0) + (seq_ipc && pl.variant == kVec && !f32 ? 10000000 : 0), pl.width * 10 + pl.unroll, pl.grid, pl.block, steps);
+        const auto key = std::make_tuple(pl.variant + (f32 ? 100 : 0) + 1000 * pl.defer + (sharded ? 100000 * (int)shard->rk.size() : 0) + (seq_ipc && pl.variant == kVec && !f32 ? 10000000 : 0), pl.width * 10 + pl.unroll, pl.grid, pl.block, steps + 1000 * (tailless ? 1 : 0) + 10000 * pub);
         auto it = graphs.find(key);
         if (it == graphs.end()) it = graphs.emplace(key, std::array<hipGraphExec_t, 2>{nullptr, nullptr}).first;
         // two executables per shape, used alternately: with one chunk running ahead, the same
@@ -641,7 +650,7 @@ struct Solver {
         if (!ge) {
             hipGraph_t g = nullptr;
             HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-            launch_chunk(A, pl, steps, f32);
+            launch_chunk(A, pl, steps, f32, tailless, pub);
             HIP_TRY(hipStreamEndCapture(stream, &g));
             HIP_TRY(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
             (void)hipGraphDestroy(g);
@@ -691,7 +700,7 @@ struct Solver {
         return MACHIP_OK;
     }
 
-    struct Pending { int jend; hipEvent_t ev; int jstart; bool classic; };
+    struct Pending { int jend; hipEvent_t ev; int jstart; bool classic; int tailless; };   // tailless: step count of a chunk without tail kernel (0: it had one)
 
     // Spin on the pinned flag the tail kernel publishes; fall back to a stream query now and then so
     // a device fault cannot hang the host.
@@ -1462,6 +1471,8 @@ struct Solver {
             }
             const double seq_tol = f32_seq ? f32_switch : tol;     // what this sequence's residual estimate aims for
             int J_enq = 0;        // steps enqueued in this sequence
+            int prev_tailless = 0;   // step count of the last enqueued chunk if its records still wait for a successor's first step
+            const bool tail_ok = !pmode && !classic && !seq_sharded && cheb.deg == 0 && !(pan.on && pan.fused) && OPT(tailless, 1) != 0;
             int J_timed = 0;      // ... of which already accounted in step_ms
             HIP_TRY(hipEventRecord(evs0, stream));
             ha.clear(); hb.assign(1, 0.0); hl1.assign(1, 0.0);
@@ -1525,10 +1536,14 @@ struct Solver {
                             HIP_TRY(hipMemcpyAsync(hp + q * (size_t)(kMaxChunk + 2), ctri + q * cs + (size_t)J_enq,
                                                    sizeof(double) * (size_t)(chunk + 1), hipMemcpyDeviceToHost, stream));
                     } else {
-                        ST_TRY(enqueue_chunk(A, pp, chunk, f32_seq));
+                        // far from the end (a successor will follow): no tail kernel, the successor's first step publishes
+                        const bool tailless = tail_ok && depth >= 2 && chunk >= 2;
+                        ST_TRY(enqueue_chunk(A, pp, chunk, f32_seq, tailless, prev_tailless));
+                        prev_tailless = tailless ? chunk : 0;
                     }
                     (void)lo;
                     Pending p;
+                    p.tailless = (pmode || classic) ? 0 : prev_tailless;
                     p.jstart = J_enq;
                     p.classic = use_classic;
                     p.jend = hi;
@@ -1543,8 +1558,17 @@ struct Solver {
                     if (f32_seq) steps_lowp += chunk;
                 }
                 if (pend.empty()) { need_restart = true; break; }
+                // a tail-less chunk that gets no successor now (end game, caps): its tail kernel after all
+                if (prev_tailless && pend.back().tailless && (depth == 1 || J_enq >= jcap || steps_total >= max_steps)) {
+                    flush_tail(pp, prev_tailless, f32_seq);
+                    pend.back().tailless = 0; prev_tailless = 0;
+                }
                 Pending p = pend.front();
                 pend.pop_front();
+                if (p.tailless && pend.empty()) {     // (cannot happen after the test above; a lost record would stall the host)
+                    flush_tail(pp, p.tailless, f32_seq);
+                    prev_tailless = 0;
+                }
                 if (p.classic) {
                     HIP_TRY(hipEventSynchronize(p.ev));
                     ev_pool.push_back(p.ev);
