@@ -1539,6 +1539,7 @@ struct Solver {
                         // far from the end (a successor will follow): no tail kernel, the successor's first step publishes
                         const bool tailless = tail_ok && depth >= 2 && chunk >= 2;
                         ST_TRY(enqueue_chunk(A, pp, chunk, f32_seq, tailless, prev_tailless));
+                        if (debug) fprintf(stderr, "[machip] enqueue J=%d chunk=%d tailless=%d pub=%d depth=%d near=%d\n", J_enq, chunk, (int)tailless, prev_tailless, depth, (int)near);
                         prev_tailless = tailless ? chunk : 0;
                     }
                     (void)lo;
