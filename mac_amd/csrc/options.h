@@ -34,7 +34,8 @@ namespace machip {
     X(sel_small) X(sel_fuse) X(asm_g) X(asm_maxgrid) X(vbudget_mb) X(vcap) X(lanes) X(lane_vbudget_mb) X(lane_queues) X(shard_eig) \
     X(rccl_timeout_s)                                                                                                              \
     /* experiments (compiled in with -DMACHIP_EXPERIMENTS only: tools/) */                                                         \
-    X(cheb_deg) X(cheb_after) X(cheb_chunk) X(cheb_depth) X(panel_fused) X(panel_spin_us) X(lob_pan2)
+    X(cheb_deg) X(cheb_after) X(cheb_chunk) X(cheb_depth) X(panel_fused) X(panel_spin_us) X(lob_pan2)                              \
+    X(blocklan) X(blocklan_min_steps) X(blk_chunk) X(blk_chunk_near)
 
 enum OptId {
 #define X(n) kOpt_##n,

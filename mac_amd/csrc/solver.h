@@ -30,6 +30,10 @@
 #include "panel.h"
 #include "plan.h"
 #include "tridiag.h"
+#ifdef MACHIP_EXPERIMENTS
+#include "band.h"
+#include "blocklan.h"
+#endif
 
 namespace machip {
 
@@ -231,6 +235,11 @@ struct Solver {
             for (void* q : pk) if (q) (void)hipFree(q);
         }
         if (h_lrec) (void)hipHostFree(h_lrec);
+#ifdef MACHIP_EXPERIMENTS
+        if (h_brec) (void)hipHostFree(h_brec);
+        if (h_bs) (void)hipHostFree(h_bs);
+        { void* pb2[] = {bZ0, bZ1, bpart, bU0, bwarm, bsdev, brec, (void*)bclk}; for (void* q : pb2) if (q) (void)hipFree(q); }
+#endif
         for (void* p : ptrs) if (p) (void)hipFree(p);
         if (h_tri) (void)hipHostFree(h_tri);
         if (h_flag) (void)hipHostFree(h_flag);
@@ -1174,6 +1183,245 @@ struct Solver {
         }
     }
 
+#ifdef MACHIP_EXPERIMENTS      // (measured: ties with the scalar recurrence on city10000 -- profiles/r5_city_block.md)
+    // ---- block Lanczos mode (blocklan.h, band.h) --------------------------------------------------------------------------------
+    static constexpr int kBlockFallback = 1001;       // internal status of solve_block: the scalar recurrence takes over
+    BRec* bZ0 = nullptr; BRec* bZ1 = nullptr;
+    double* bpart = nullptr;      // 2 x kBQ x kMaxGrid partial sums
+    double* bU0 = nullptr;        // start block, column-major n x 4
+    double* bwarm = nullptr;      // Ritz vectors 2..4 of the last block solve (n x 3): columns 1..3 of the next start block
+    double* bsdev = nullptr;      // their coefficient vectors (3 x (vcap + 2))
+    double* h_bs = nullptr;       // ... pinned staging
+    double* brec = nullptr;       // records in device memory
+    double* h_brec = nullptr; double* d_hbrec = nullptr;      // records, kBRec doubles per block step (pinned, device-mapped)
+    size_t brec_steps = 0;
+    bool blk_have_warm = false;
+    long long* bclk = nullptr;    // (probe)
+    long hist_blk_steps = -1;     // block steps of the last block solve (counts only: the mode choice stays reproducible)
+    band::Factor bfac; band::Smallest bsm; std::vector<double> bh, bguess, bwk;
+
+    int blk_G(long nnz) const { const long mean = nnz / std::max(1, n); return mean < 5 ? 2 : mean < 12 ? 4 : 8; }
+    int blk_threads(long) const { return kBlkThreads; }
+    int blk_rpb(long nnz) const { return (blk_threads(nnz) - 64) / blk_G(nnz); }
+    bool blk_fits(long nnz) const {
+        const int rpb = blk_rpb(nnz);
+        return n > 256 && (n + rpb - 1) / rpb <= kBlkMaxGrid && vcap >= 256 && precision == 0 && !shard && !ipc;
+    }
+    BlkView bview(int grid) const {
+        BlkView L; L.n = n; L.st = st; L.Z0 = bZ0; L.Z1 = bZ1; L.V = V; L.rec = brec; L.hrec = d_hbrec; L.hflag = d_hflag; L.part = bpart; L.P = grid; L.clk = bclk; L.inv_n = 1.0 / (double)n;
+        return L;
+    }
+    int blk_alloc() {
+        if (bZ0) return MACHIP_OK;
+        ST_TRY(dev_alloc(&bZ0, (size_t)n)); ST_TRY(dev_alloc(&bZ1, (size_t)n));
+        ST_TRY(dev_alloc(&bpart, (size_t)2 * kBQ * kMaxGrid));
+        ST_TRY(dev_alloc(&bU0, (size_t)n * kBW)); ST_TRY(dev_alloc(&bwarm, (size_t)n * (kBW - 1)));
+        ST_TRY(dev_alloc(&bsdev, (size_t)(kBW - 1) * (vcap + 2)));
+        brec_steps = vcap / kBW + 2;
+        ST_TRY(dev_alloc(&brec, brec_steps * kBRec));
+        HIP_TRY(hipHostMalloc((void**)&h_brec, brec_steps * kBRec * sizeof(double), hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void**)&d_hbrec, h_brec, 0));
+        HIP_TRY(hipHostMalloc((void**)&h_bs, (size_t)(kBW - 1) * (vcap + 2) * sizeof(double), 0));
+        return MACHIP_OK;
+    }
+    void blk_launch_chunk(const CsrView& A, int G, int threads, int grid, int steps) {
+        const BlkView L = bview(grid);
+        for (int s = 0; s < steps; ++s) {
+            if (G == 2) k_blk_vec<2, kBlkThreads><<<grid, threads, 0, stream>>>(A, L, s);
+            else if (G == 4) k_blk_vec<4, kBlkThreads><<<grid, threads, 0, stream>>>(A, L, s);
+            else k_blk_vec<8, kBlkThreads><<<grid, threads, 0, stream>>>(A, L, s);
+        }
+        k_blk_tail<<<1, 64, 0, stream>>>(L, steps);
+    }
+    int blk_enqueue_chunk(const CsrView& A, int G, int threads, int grid, int steps) {
+        if (!use_graph()) { blk_launch_chunk(A, G, threads, grid, steps); HIP_TRY(hipGetLastError()); return MACHIP_OK; }
+        if (graph_csr_key != (const void*)A.val) {   // different matrix buffers: cached graphs are stale
+            for (auto& kv : graphs) for (hipGraphExec_t ge : kv.second) if (ge) (void)hipGraphExecDestroy(ge);
+            graphs.clear();
+            graph_csr_key = (const void*)A.val;
+        }
+        const auto key = std::make_tuple(9000 + G, 0, grid, threads, steps);
+        auto it = graphs.find(key);
+        if (it == graphs.end()) it = graphs.emplace(key, std::array<hipGraphExec_t, 2>{nullptr, nullptr}).first;
+        hipGraphExec_t& ge = it->second[(size_t)(graph_flip++ & 1)];
+        if (!ge) {
+            hipGraph_t g = nullptr;
+            HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+            blk_launch_chunk(A, G, threads, grid, steps);
+            HIP_TRY(hipStreamEndCapture(stream, &g));
+            HIP_TRY(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(g);
+        }
+        HIP_TRY(hipGraphLaunch(ge, stream));
+        return MACHIP_OK;
+    }
+
+    // Block Lanczos solve.  Returns MACHIP_OK (pair in yvec / *lambda2, passed the explicit check), kBlockFallback (breakdown of the
+    // block, basis full, or no convergence within the step budget: the caller continues with the scalar recurrence), or an error.
+    int solve_block(const CsrView& A, long nnz, double lnorm, double tol, int max_steps, int start_mode, double* lambda2,
+                    machip_solve_stats* stats) {
+        ST_TRY(blk_alloc());
+        if (OPT(debug, 0) == 2 && !bclk) { HIP_TRY(hipMalloc((void**)&bclk, sizeof(long long) * 16 * 256)); HIP_TRY(hipMemset(bclk, 0, sizeof(long long) * 16 * 256)); }
+        const SpmvPlan pl = plan_spmv(opt, n, nnz, 0, n > 32768 ? kMaxGrid : 0);
+        const int G = blk_G(nnz), threads = blk_threads(nnz), rpb = blk_rpb(nnz), grid = (n + rpb - 1) / rpb, g2 = vgrid();
+        const bool debug = OPT(debug, 0) != 0;
+        const double tiny_l = (lnorm > 0 ? lnorm : 1.0);
+        HIP_TRY(hipEventRecord(ev0, stream));
+        ev1_at_check = false;
+        // ---- start block: column 0 as the scalar recurrence would start, the others from the last block solve's Ritz vectors ----
+        if (start_mode == 1 && have_prev) HIP_TRY(hipMemcpyAsync(bU0, yvec, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream));
+        else if (have_start) HIP_TRY(hipMemcpyAsync(bU0, start, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream));
+        else k_fill_start<<<g2, kBlock, 0, stream>>>(bU0, n, 0x1234567ull);
+        if (blk_have_warm && start_mode == 1) HIP_TRY(hipMemcpyAsync(bU0 + (size_t)n, bwarm, sizeof(double) * (size_t)n * (kBW - 1), hipMemcpyDeviceToDevice, stream));
+        else for (int c = 1; c < kBW; ++c) k_fill_start<<<g2, kBlock, 0, stream>>>(bU0 + (size_t)c * n, n, 0x1234567ull + 0x9E37ull * (unsigned long long)c);
+        ++epoch;
+        k_blk_init<<<grid, kBlock, 0, stream>>>(bview(grid), bU0, (int)epoch);
+        HIP_TRY(hipGetLastError());
+        const int cap_steps = (int)std::min<size_t>(std::min<size_t>((vcap - 2) / kBW, brec_steps - 2), (size_t)std::max(8, (n - 1) / kBW)) & ~1;
+        const int chunk0 = std::max(2, OPT(blk_chunk, 16) & ~1), chunk_near = std::max(2, OPT(blk_chunk_near, 4) & ~1);
+        const double trigger_slack = 0.01 * OPT(trigger_pct, 110);
+        if (max_steps <= 0) max_steps = 200000;
+        std::deque<std::pair<int, int>> bp;       // (jstart, jend) of the chunks in flight
+        std::deque<std::pair<int, double>> hist;
+        int J_enq = 0, J = 0;
+        double to_go = 1e18, est_latest = 1e300, last_check_est = 1e300, theta_prev = 0.0, lam = 0.0, res = 0.0;
+        bguess.clear();
+        const double qnan = std::numeric_limits<double>::quiet_NaN();
+        const double ltarget = std::log(std::max(tol * tiny_l, 1e-300));
+        bool converged = false, fallback = false;
+        long checks = 0;
+        HIP_TRY(hipEventRecord(evs0, stream));
+        while (!converged && !fallback) {
+            const bool near = to_go < 2.0 * chunk0 || (to_go >= 1e17 && est_latest < 1e3 * tol * lnorm);
+            const int depth = near ? 1 : 2;
+            while ((int)bp.size() < depth && J_enq < cap_steps && J_enq < max_steps) {
+                int chunk = near ? chunk_near : chunk0;
+                if (near && to_go < 1e17) chunk = std::min(chunk0, std::max(chunk_near, ((int)(0.75 * to_go) + 1) & ~1));
+                chunk = std::min(chunk, cap_steps - J_enq);
+                if (chunk <= 0) break;
+                const int hi = J_enq + chunk;
+                // poison what this chunk delivers for the first time: B_j for j in (J_enq, hi] (and B_0), A_j / l1_j for j in [J_enq, hi)
+                for (int j = J_enq ? J_enq + 1 : 0; j <= hi; ++j) for (int i = 0; i < 16; ++i) h_brec[(size_t)j * kBRec + 16 + i] = qnan;
+                for (int j = J_enq; j < hi; ++j) { for (int i = 0; i < 16; ++i) h_brec[(size_t)j * kBRec + i] = qnan; for (int i = 0; i < 4; ++i) h_brec[(size_t)j * kBRec + 32 + i] = qnan; }
+                ST_TRY(blk_enqueue_chunk(A, G, threads, grid, chunk));
+                if (debug) fprintf(stderr, "[machip] block enqueue J=%d chunk=%d depth=%d\n", J_enq, chunk, depth);
+                bp.emplace_back(J_enq, hi);
+                J_enq = hi;
+            }
+            if (bp.empty()) { fallback = true; break; }
+            const std::pair<int, int> p = bp.front();
+            bp.pop_front();
+            ST_TRY(wait_flag(((unsigned long long)epoch << 32) | (unsigned long long)(unsigned int)p.second));
+            {
+                unsigned long budget = 5000000ul;
+                auto wait_slot = [&](size_t idx) { volatile double* slot = h_brec + idx; while (*slot != *slot && budget) { --budget; __builtin_ia32_pause(); } };
+                for (int j = p.first ? p.first + 1 : 0; j <= p.second && budget; ++j) for (int i = 0; i < 16; ++i) wait_slot((size_t)j * kBRec + 16 + i);
+                for (int j = p.first; j < p.second && budget; ++j) { for (int i = 0; i < 16; ++i) wait_slot((size_t)j * kBRec + i); for (int i = 0; i < 4; ++i) wait_slot((size_t)j * kBRec + 32 + i); }
+                if (!budget) { fallback = true; break; }         // (a genuine NaN: the scalar path reports it)
+            }
+            J = p.second;
+            // ---- breakdown: a vanishing pivot of some B_j ----
+            bool broke = false;
+            for (int j = 0; j <= J && !broke; ++j) for (int c = 0; c < kBW; ++c) if (!(h_brec[(size_t)j * kBRec + 16 + c * 5] > 0.0)) { broke = true; break; }
+            if (broke) { if (debug) fprintf(stderr, "[machip] block J=%d: breakdown\n", J); fallback = true; break; }
+            // ---- banded matrix of the J blocks, its smallest pair ----
+            const int N = J * kBW;
+            bh.assign((size_t)(kBW + 1) * N, 0.0);
+            for (int j = 0; j < J; ++j) {
+                const double* Aj = h_brec + (size_t)j * kBRec;
+                for (int c = 0; c < kBW; ++c) for (int r = c; r < kBW; ++r) bh[(size_t)(r - c) * N + 4 * j + c] = Aj[r * 4 + c];
+                if (j + 1 < J) {
+                    const double* Bn = h_brec + (size_t)(j + 1) * kBRec + 16;
+                    for (int r = 0; r < kBW; ++r) for (int c = r; c < kBW; ++c) bh[(size_t)(kBW + r - c) * N + 4 * j + c] = Bn[r * 4 + c];
+                }
+            }
+            band::smallest_eigpair(bh.data(), N, kBW, bguess.data(), (int)bguess.size(), theta_prev, bsm, bfac, bwk,
+                                   /*rough=*/est_latest > 1e4 * tol * lnorm);
+            bguess = bsm.s; theta_prev = bsm.theta;
+            const double* BJ = h_brec + (size_t)J * kBRec + 16;
+            const double* l1 = h_brec + (size_t)(J - 1) * kBRec + 32;
+            double est = 0.0;
+            for (int r = 0; r < kBW; ++r) {
+                double rho = 0.0;
+                for (int c = r; c < kBW; ++c) rho += BJ[r * 4 + c] * bsm.s[(size_t)N - kBW + c];
+                est += std::fabs(rho) * (l1[r] > 0 ? l1[r] : std::sqrt((double)n));
+            }
+            est_latest = est;
+            if (est > 0.0) {
+                hist.emplace_back(J, std::log(est));
+                while (hist.size() > 2 && hist[1].first <= J - 32) hist.pop_front();
+                to_go = 1e18;
+                if (hist.front().first < J) {
+                    const double slope = (hist.front().second - hist.back().second) / (double)(J - hist.front().first);
+                    if (slope > 1e-7) to_go = std::max(0.0, (hist.back().second - ltarget) / slope);
+                }
+            }
+            if (debug) fprintf(stderr, "[machip] block J=%d theta=%.15g est=%.3e to_go=%.0f pend=%zu fact=%d\n", J, bsm.theta, est / tiny_l, std::min(to_go, 1e9), bp.size(), bsm.factorisations);
+            const bool at_cap = J >= cap_steps || J >= max_steps;
+            const bool trig = est < trigger_slack * tol * lnorm;
+            if ((trig && est < 0.5 * last_check_est) || at_cap) {
+                double rq = 0.0, r1 = 0.0;
+                HIP_TRY(hipEventRecord(evs1, stream));
+                spec_likely = est < 0.01 * OPT(spec_slack_pct, 105) * tol * lnorm;
+                ST_TRY(explicit_check(A, pl, N, bsm.s.data(), &rq, &r1, false));      // syncs the stream
+                spec_likely = true;
+                ++checks;
+                last_check_est = std::max(est, 1e-300);
+                lam = rq; res = lnorm > 0 ? r1 / lnorm : r1;
+                if (debug) fprintf(stderr, "[machip]    block check J=%d rq=%.15g res=%.3e (tol %.1e)\n", J, rq, res, tol);
+                if (res < tol) { converged = true; final_check_seq = check_seq; break; }
+                if (at_cap) { fallback = true; break; }
+            }
+        }
+        if (!bp.empty()) HIP_TRY(hipStreamSynchronize(stream));
+        bp.clear();
+        if (bclk) {
+            std::vector<long long> hc(16 * 256);
+            HIP_TRY(hipMemcpy(hc.data(), bclk, sizeof(long long) * hc.size(), hipMemcpyDeviceToHost));
+            for (int b : {0, grid / 2, grid - 1}) {
+                const long long* c = hc.data() + 16 * b; const long long t0 = std::min(c[0], c[8]);
+                fprintf(stderr, "[machip] blk clocks wg %d (x10 ns from kernel start): prologue loads %lld tot %lld G %lld chol %lld Ri %lld published %lld wave0 at barrier %lld | rows start %lld gathered %lld past barrier %lld finished %lld end %lld\n", b, c[1] - t0, c[2] - t0, c[5] - t0, c[6] - t0, c[3] - t0, c[7] - t0, c[4] - t0, c[8] - t0, c[9] - t0, c[10] - t0, c[11] - t0, c[12] - t0);
+            }
+        }
+        if (fallback || !converged) {
+            if (debug) fprintf(stderr, "[machip] block mode gives up at J=%d: the scalar recurrence takes over\n", J);
+            hist_blk_steps = 1l << 40;          // (never again for this handle unless a caller forces it)
+            return kBlockFallback;
+        }
+        // ---- start block of the next solve: the Ritz vectors behind the next three Ritz values (good start vectors is all they
+        // have to be: a few sweeps of subspace iteration) ----
+        {
+            const int N = J * kBW;
+            std::vector<double> th, S;
+            band::lowest_block(bh.data(), N, kBW, kBW, bsm.theta, bsm.s.data(), th, S, bfac, 3);
+            const int KS = std::max(1, std::min(ks_max, N / 8));
+            for (int c = 1; c < kBW; ++c) memcpy(h_bs + (size_t)(c - 1) * (vcap + 2), S.data() + (size_t)c * N, sizeof(double) * (size_t)N);
+            HIP_TRY(hipMemcpyAsync(bsdev, h_bs, sizeof(double) * (size_t)(kBW - 1) * (vcap + 2), hipMemcpyHostToDevice, stream));
+            for (int c = 1; c < kBW; ++c) {
+                k_ritz_partial<<<dim3(g2, KS), kBlock, 0, stream>>>(V, n, N, bsdev + (size_t)(c - 1) * (vcap + 2), ypart);
+                k_ritz_combine<<<g2, kBlock, 0, stream>>>(ypart, n, KS, bwarm + (size_t)(c - 1) * n, part_c);
+            }
+            HIP_TRY(hipGetLastError());
+            blk_have_warm = true;
+        }
+        have_prev = true; last_was_lob = true; J_last = 0; last_seq_sharded = false; last_seq_f32 = false;
+        last_steps = J_enq; last_steps_lowp = 0; hist_blk_steps = J_enq;
+        last_mode = 9;
+        float ms = 0.f, sms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+        HIP_TRY(hipEventElapsedTime(&sms, evs0, evs1));
+        *lambda2 = lam;
+        if (stats) {
+            stats->lanczos_steps = J_enq; stats->spmv_total = (long)J_enq * kBW + checks; stats->vec_passes = (long)J_enq * 7 * kBW;
+            stats->restarts = 0; stats->nnz = nnz; stats->residual = res; stats->lnorm = lnorm; stats->gpu_ms = ms;
+            stats->step_ms = sms; stats->steps_timed = J_enq; stats->steps_lowp = 0;
+        }
+        if (lam < 1e-12 * tiny_l) return fail(MACHIP_DISCONNECTED, "lambda_2 ~ 0: the graph is not connected");
+        return MACHIP_OK;
+    }
+
+#endif
+
     // start_mode: 0 = stored cold-start vector (or device pseudo-random if none), 1 = previous
     // Fiedler vector (warm start).
     int solve(const CsrView& A, long nnz, double lnorm, double tol, int max_steps, int start_mode,
@@ -1298,6 +1546,21 @@ struct Solver {
             if (st != MACHIP_NOT_CONVERGED) return st;
             // stagnated / T not positive definite: the Lanczos path takes over from its own start
         }
+#ifdef MACHIP_EXPERIMENTS
+        // Block Lanczos (blocklan.h) where the scalar recurrence has been seen to need many steps on a matrix small enough for the
+        // one-row-per-lane-group step: counts only (hist_lan_steps = steps of the last scalar solve, hist_blk_steps = block steps of
+        // the last block solve; a block step is priced at 1.5 scalar steps), so the choice is reproducible.  option blocklan: 0 never, 1 always.
+        {
+            const int bo = OPT(blocklan, 0);      // (experiments build: opt-in only)
+            const bool pmode_fits = OPT(persist, 1) != 0 && chain_like && persist_fits(n, nnz - n - 2 * chain_edges);
+            const bool auto_ok = bo < 0 && mode == 0 && !pmode_fits && forced_variant == 0 && hist_lan_steps > OPT(blocklan_min_steps, 400) &&
+                                 (hist_blk_steps < 0 || 3 * hist_blk_steps < 2 * hist_lan_steps);
+            if ((bo == 1 || auto_ok) && blk_fits(nnz) && n > 1024) {
+                const int sb = solve_block(A, nnz, lnorm, tol, max_steps, start_mode, lambda2, stats);
+                if (sb != kBlockFallback) return sb;
+            }
+        }
+#endif
         const int st = solve_lanczos(A, nnz, lnorm, tol, max_steps, start_mode, forced_variant, lambda2, stats);
         // (mixed precision: the fp32 pre-phase inflates the count by roughly a third of its length; the learning rule
         // above is calibrated on fp64 step counts)

@@ -38,4 +38,4 @@ for r in range(rounds + 1):
         lam[i] = [x["f"].hex() for x in rec]; steps[i] = sum(x["steps"] for x in rec)
 for i, s in enumerate(sets):
     print(f"{cfg} {s or '-'}: {np.median(res[i]):.1f} it/s ({1e3/np.median(res[i]):.3f} ms/it), {np.median(us[i]):.2f} us/step, steps {steps[i]}, "
-          f"lambda trajectory {'== first' if lam[i] == lam[0] else 'DIFFERS from first'}")
+          f"lambda trajectory {'== first' if lam[i] == lam[0] else 'DIFFERS from first (max rel %.2e)' % max(abs(float.fromhex(a) - float.fromhex(b)) / abs(float.fromhex(b)) for a, b in zip(lam[i], lam[0]))}")
