@@ -1,4 +1,4 @@
-"""developer probe: a few Frank-Wolfe iterations of city10000 with the block Lanczos mode forced (eager launches, for kernel traces)"""
+"""developer probe (needs the experiments build: MACHIP_BUILD_FLAGS=-DMACHIP_EXPERIMENTS MACHIP_BUILD_OUT=libmachip_exp.so bash mac_amd/csrc/build.sh; MACHIP_LIB=mac_amd/libmachip_exp.so): a few Frank-Wolfe iterations of city10000 with the block Lanczos mode forced (eager launches, for kernel traces)"""
 import sys; sys.path.insert(0, '.')
 import bench, numpy as np
 from mac_amd import _lib
