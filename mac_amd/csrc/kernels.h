@@ -537,16 +537,14 @@ struct IpcView {
     int* err = nullptr;                  // mapped pinned host word: 1 = a wait timed out (a peer stalled or died), 2 = a peer raised abort
     long long timeout_ticks = 0;         // bound of one wait (100 MHz ticks)
 };
-__global__ void k_ipc_publish(IpcView I, int ch) {
-    if (threadIdx.x != 0) return;
+__device__ __forceinline__ void ipc_publish(const IpcView& I, int ch) {
     const unsigned long long c = I.done[ch] + 1ull;
     I.done[ch] = c;
     __threadfence_system();              // (the producing kernel has ended; its writes are performed)
     for (int q = 0; q < I.n; ++q)
         if (q != I.rank) __hip_atomic_store(I.peer_flags[q] + ch * kMaxPeers + I.rank, c, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__global__ void k_ipc_wait(IpcView I, int ch) {
-    if (threadIdx.x != 0) return;
+__device__ __forceinline__ void ipc_wait(const IpcView& I, int ch) {
     if (*I.err) return;                  // already broken: do not spin again (a dead peer must cost ONE timeout, not one per step)
     const unsigned long long want = I.done[ch];
     const long long t0 = wall_clock64();
@@ -562,6 +560,11 @@ __global__ void k_ipc_wait(IpcView I, int ch) {
         }
     }
 }
+__global__ void k_ipc_publish(IpcView I, int ch) { if (threadIdx.x == 0) ipc_publish(I, ch); }
+__global__ void k_ipc_wait(IpcView I, int ch) { if (threadIdx.x == 0) ipc_wait(I, ch); }
+// "my part of phase c is delivered" + "everybody's is": one launch between two kernels of a phase chain instead of two (round 5:
+// a launch boundary, ~2.5 us, per Lanczos step of the row-partitioned solve)
+__global__ void k_ipc_pubwait(IpcView I, int ch) { if (threadIdx.x == 0) { ipc_publish(I, ch); ipc_wait(I, ch); } }
 __global__ void k_ipc_abort(IpcView I) {   // best effort: release the peers' waits with an error
     if (threadIdx.x != 0) return;
     for (int q = 0; q < I.n; ++q)

@@ -379,8 +379,7 @@ int compute_gradient(machip_problem* p, bool have_vec_now = false, long fuse_k =
     // then wait until every peer has arrived too.  Without an eigen-solve that is partitioned between the ranks nothing else
     // orders a fast rank against a slow one (round-4 advisor finding).
     if (ipc_gather) {
-        k_ipc_publish<<<1, 64, 0, p->stream>>>(p->ipcg->view, 3);
-        k_ipc_wait<<<1, 64, 0, p->stream>>>(p->ipcg->view, 3);
+        k_ipc_pubwait<<<1, 64, 0, p->stream>>>(p->ipcg->view, 3);
     }
     const bool timed = p->nranks > 1;      // (communicators only: three event records per iteration)
     if (timed) {
@@ -402,8 +401,7 @@ int compute_gradient(machip_problem* p, bool have_vec_now = false, long fuse_k =
     }
     if (timed) HIP_TRY(hipEventRecord(p->ev_g1, p->stream));
     if (ipc_gather) {
-        k_ipc_publish<<<1, 64, 0, p->stream>>>(p->ipcg->view, 2);
-        k_ipc_wait<<<1, 64, 0, p->stream>>>(p->ipcg->view, 2);
+        k_ipc_pubwait<<<1, 64, 0, p->stream>>>(p->ipcg->view, 2);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(p->ev_g2, p->stream));
         p->ev_g_valid = true;

@@ -542,12 +542,11 @@ struct Solver {
         ipc_split(pl);
         const PipeView L = pview(pl);
         const PeerSet PS = ipc_peers(pl);
+        k_ipc_wait<<<1, 64, 0, stream>>>(ipc->view, 0);              // (whatever the previous chunk / the sequence start left pending)
         for (int s = 0; s < steps; ++s) {
-            k_ipc_wait<<<1, 64, 0, stream>>>(ipc->view, 0);          // every peer has delivered its records / partial sums of the step before
             launch_pipe_shard(pl, stream, A, L, s, PS, ipc->g1 - ipc->g0);
-            k_ipc_publish<<<1, 64, 0, stream>>>(ipc->view, 0);
+            k_ipc_pubwait<<<1, 64, 0, stream>>>(ipc->view, 0);       // mine delivered; every peer has delivered its records / partial sums of this step
         }
-        k_ipc_wait<<<1, 64, 0, stream>>>(ipc->view, 0);
         k_pipe_tail<<<1, 64, 0, stream>>>(L, steps);
     }
     // y_raw = V[:, :J] s: my rows of the basis -> my rows of EVERY rank's y_raw, then everybody holds the whole vector
@@ -562,8 +561,7 @@ struct Solver {
         for (int q = 0; q < all.n; ++q) all.v[q] = ipc->yraw[q];
         k_ritz_partial<<<dim3(g2, KS), kBlock, 0, stream>>>(V, n, J, sdev, ypart, own);
         k_ritz_own_rows<<<g2, kBlock, 0, stream>>>(ypart, n, KS, y_raw, own, all);
-        k_ipc_publish<<<1, 64, 0, stream>>>(ipc->view, 1);
-        k_ipc_wait<<<1, 64, 0, stream>>>(ipc->view, 1);
+        k_ipc_pubwait<<<1, 64, 0, stream>>>(ipc->view, 1);
         k_vec_sums<<<g2, kBlock, 0, stream>>>(y_raw, n, part_c);
         HIP_TRY(hipGetLastError());
         return MACHIP_OK;
