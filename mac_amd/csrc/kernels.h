@@ -492,6 +492,8 @@ struct PipeViewT {
     int chunk;        // > 0: this chunk has no tail kernel -- its last step (jrel == chunk - 1) advances jN itself, and its records
                       // reach the host through the NEXT chunk's first step (or a tail kernel the host adds when no chunk follows)
     int pub;          // > 0: the chunk before this one had `pub` steps and no tail: the first step publishes its records
+    int pubstep;      // != 0: EVERY step hands its three values (alpha_{j-1}, l1_{j-1}, beta_j) to the host as it derives them (solver.h,
+                      // "streamed records": the host follows the recurrence step by step and decides where the solve ends)
 #ifdef PIPE_CLOCKS
     long long* clk;   // tools/ubench5.hip: 8 wall-clock stamps (100 MHz) per workgroup
 #endif
@@ -736,6 +738,12 @@ __device__ __forceinline__ PipeCoef pipe_prologue_wave0(const PV& L, int jrel, i
         }
     }
     if (lead && adv_jA < 0 && jrel == 0 && L.pub > 0 && j > 0 && (int)blockIdx.x == pub_wg) pipe_publish(L, c, j, L.pub);
+    if (lead && adv_jA < 0 && L.pubstep && (int)blockIdx.x == pub_wg && lane == 0) {
+        // streamed records: three posted 8-byte stores into pinned host memory from ONE lane of one workgroup, ~4 us into a step --
+        // acknowledged long before the launch ends.  No flag: the host awaits each (NaN-poisoned) slot.
+        if (j > 0) { L.htri[3 * (j - 1)] = c.alpha; L.htri[3 * (j - 1) + 2] = c.l1prev; }
+        L.htri[3 * j + 1] = c.beta;
+    }
     *j_out = j;
     return c;
 }

@@ -256,7 +256,7 @@ struct Solver {
     template <typename T = double>
     PipeViewT<T> pview(const SpmvPlan& pl) const {
         PipeViewT<T> L;     // T = float: records and basis live in the same buffers, read as fp32
-        L.n = n; L.st = st; L.Z0 = reinterpret_cast<ZRec<T>*>(Z0); L.Z1 = reinterpret_cast<ZRec<T>*>(Z1); L.V = reinterpret_cast<T*>(V); L.tri = tri; L.htri = d_htri; L.hflag = d_hflag; L.part = part; L.P = pl.grid; L.chunk = 0; L.pub = 0;
+        L.n = n; L.st = st; L.Z0 = reinterpret_cast<ZRec<T>*>(Z0); L.Z1 = reinterpret_cast<ZRec<T>*>(Z1); L.V = reinterpret_cast<T*>(V); L.tri = tri; L.htri = d_htri; L.hflag = d_hflag; L.part = part; L.P = pl.grid; L.chunk = 0; L.pub = 0; L.pubstep = 0;
         return L;
     }
     LanView check_view(const SpmvPlan& pl) const {   // "column 0" machinery for the explicit check
@@ -612,7 +612,7 @@ struct Solver {
     void launch_chunk(const CsrView& A, const SpmvPlan& pl, int steps, bool f32 = false, bool tailless = false, int pub = 0) {
         if (pl.variant == kPanel) {
             PipeView L = pview(pl);
-            L.chunk = tailless ? steps : 0; L.pub = pub;
+            L.chunk = tailless ? steps : 0; L.pub = std::max(pub, 0); L.pubstep = pub < 0;
             for (int s = 0; s < steps; ++s) launch_pan_step(L, s);
             if (!tailless) k_pipe_tail<<<1, 64, 0, stream>>>(L, steps);
             return;
@@ -621,14 +621,14 @@ struct Solver {
         if (seq_ipc && pl.variant == kVec && !f32) { launch_chunk_ipc(A, pl, steps); return; }
         if (f32) {
             PipeViewT<float> L = pview<float>(pl);
-            L.chunk = tailless ? steps : 0; L.pub = pub;
+            L.chunk = tailless ? steps : 0; L.pub = std::max(pub, 0); L.pubstep = pub < 0;
             const CsrViewT<float> Af{A.n, A.rowptr, A.col, valf};
             for (int s = 0; s < steps; ++s) launch_pipe(pl, stream, Af, L, s);
             if (!tailless) k_pipe_tail<<<1, 64, 0, stream>>>(L, steps);
             return;
         }
         PipeView L = pview(pl);
-        L.chunk = tailless ? steps : 0; L.pub = pub;
+        L.chunk = tailless ? steps : 0; L.pub = std::max(pub, 0); L.pubstep = pub < 0;
         const CsrView& As = pl.variant == kEll ? ell_view : A;
         for (int s = 0; s < steps; ++s) launch_pipe(pl, stream, As, L, s);
         if (!tailless) k_pipe_tail<<<1, 64, 0, stream>>>(L, steps);
@@ -1577,6 +1577,7 @@ struct Solver {
         ev1_at_check = false;
         if (max_steps <= 0) max_steps = 200000;
         long steps_total = 0, spmv_total = 0, restarts = 0;
+        long steps_used = 0;        // steps up to the analysis point each sequence ended at (a function of the records alone; steps_total counts launches)
         double step_ms_acc = 0.0;   // stream time of the Krylov chunks alone (step kernels + one tail kernel per chunk)
         long steps_timed_acc = 0;
         int status = MACHIP_NOT_CONVERGED;
@@ -1751,6 +1752,196 @@ struct Solver {
             const int jcap = (int)std::min<size_t>(vcap - 2, (size_t)std::max(2, n - 1) + 8) & ~1;
             const size_t cs = vcap + 2;   // stride of the classic alpha / beta / l1 arrays
 
+            // ---- streamed records (round 5): where the solve ends is decided step by step, not chunk by chunk ----
+            // Every step hands its (alpha_{j-1}, l1_{j-1}, beta_j) to the host as it derives them (PipeView::pubstep), so the host
+            // (a) analyses T_a at a DETERMINISTIC sequence of points a_0 < a_1 < ... -- each next point a function of the analyses
+            //     before it only (a third of the forecast distance to the target, at most 32 steps) -- and ends the sequence at the FIRST
+            //     point whose residual estimate is below the trigger: the Ritz pair, and with it every later result, is a function
+            //     of the records alone, never of timing;
+            // (b) feeds the queue from the forecast: far from the end 32-step chunks one chunk ahead, then chunks of about half
+            //     the predicted remainder, each enqueued only when the GPU is within `look` steps of running dry, none beyond the
+            //     predicted crossing (+ margin), a one-wave tail kernel behind the last.  How many steps run BEYOND the final
+            //     analysis point depends on timing; nothing reads them.
+            // The chunk-granular loop below overshoots the crossing by 8.7 steps per solve at configs[3] (3.6 % of 242:
+            // tools/sched_probe.sh) and idles the GPU for a host round trip at each of its 2-3 end-game hops.
+            // Row-partitioned sequences (every rank has to launch the same steps) and option stream = 2 feed the queue from the analyses
+            // alone instead: one chunk with a tail kernel at a time, sized by the forecast once every record of its predecessor has been
+            // analysed.  Same points, same rule, same final point: a partitioned solve still reproduces the single-rank one bit for bit.
+            const bool stream_mode = !pmode && !classic && cheb.deg == 0 && !(pan.on && pan.fused) && !f32_seq && OPT(stream, 1) != 0;
+            const bool feed_chunks = seq_sharded || OPT(stream, 1) == 2 || OPT(tailless, 1) == 0;
+            if (stream_mode) {
+                const double trig_s = 0.01 * OPT(stream_trigger_pct, 95);      // (the estimate predicts the measured residual to +/- 5 %: profiles/r5_c4_checks.txt)
+                const double retry_s = 0.01 * OPT(stream_retry_pct, 80);       // after a failed check: the next one when the estimate has fallen to this fraction
+                const int margin = std::max(0, OPT(stream_margin, 0));
+                const double step_us = 4.2 + 2e-6 * (double)nnz;               // (the model the hand-over forecast uses)
+                const int look_opt = OPT(stream_look, 0);                      // steps of queued work below which the queue is fed (0: from the step-time model)
+                const int far_rem = std::max(34, OPT(stream_far, 80));         // whole chunks one ahead while at least this many steps are predicted to remain
+                const int win_max = std::max(8, OPT(stream_window, 64));
+                double e_target = trig_s * seq_tol * tiny_l;                   // the estimate has to get below this for a check
+                int prog = -1;               // records up to beta_prog (alpha, l1 up to prog - 1) have landed
+                int tail_at = -1;            // a tail kernel has been enqueued behind step tail_at - 1 (delivers beta_tail_at)
+                int last_chunk = 0;          // steps of the last enqueued chunk (what its tail kernel advances by)
+                int next_a = std::min(16, jcap);
+                int T = INT_MAX;             // forecast: no step >= T is wanted (INT_MAX: no forecast yet)
+                int Jold = 0;
+                unsigned long spins = 0;
+                bool stalled = false;
+                auto landed = [&](int j) {
+                    const volatile double* t3 = h_tri;
+                    if (t3[3 * (size_t)j + 1] != t3[3 * (size_t)j + 1]) return false;
+                    if (j > 0 && (t3[3 * (size_t)(j - 1)] != t3[3 * (size_t)(j - 1)] || t3[3 * (size_t)(j - 1) + 2] != t3[3 * (size_t)(j - 1) + 2])) return false;
+                    return true;
+                };
+                for (;;) {
+                    // (1) how far has the GPU got?
+                    const int limit = std::min(tail_at == J_enq ? J_enq : J_enq - 1, jcap);
+                    while (prog < limit && (stalled || landed(prog + 1))) ++prog;
+                    // (2) feed the queue
+                    const bool room = J_enq < jcap && steps_total < max_steps;
+                    const int want = std::max(T, next_a);      // beta_{next_a} comes from step next_a -- or from a tail kernel when the queue ends exactly there
+                    if (feed_chunks) {
+                        // (decided in a state that is a function of the records: all of the queue delivered, every point up to there analysed)
+                        if (room && J_enq < want && prog >= J_enq - (J_enq == 0) && next_a > prog) {
+                            const long remaining = (long)want - J_enq;
+                            // (far: long chunks, a host round trip each; near: a little short of the predicted crossing -- the forecast errs on the long side)
+                            int chunk = remaining >= 4 * chunk0 ? std::min(kMaxChunk, 2 * chunk0) : remaining >= 2 * chunk0 ? chunk0
+                                        : remaining >= 12 ? (int)std::min<long>(chunk0, ((long)(0.7 * (double)remaining) + 1) & ~1L) : (int)((remaining + 1) & ~1L);
+                            chunk = std::min(std::max(chunk, 2), jcap - J_enq);
+                            chunk = (int)std::min<long>(chunk, max_steps - steps_total) & ~1;
+                            if (chunk >= 2) {
+                                const int hi = J_enq + chunk;
+                                const double qnan = std::numeric_limits<double>::quiet_NaN();
+                                for (int j = J_enq ? J_enq + 1 : 0; j <= hi; ++j) h_tri[3 * (size_t)j + 1] = qnan;
+                                for (int j = J_enq; j < hi; ++j) { h_tri[3 * (size_t)j] = qnan; h_tri[3 * (size_t)j + 2] = qnan; }
+                                ST_TRY(enqueue_chunk(A, pp, chunk, false, false, 0));
+                                if (debug) fprintf(stderr, "[machip] chunk enqueue J=%d chunk=%d T=%d next_a=%d\n", J_enq, chunk, T == INT_MAX ? -1 : T, next_a);
+                                J_enq = hi; last_chunk = chunk; tail_at = hi;
+                                steps_total += chunk; spmv_total += chunk;
+                                continue;
+                            }
+                        }
+                    } else if (room && J_enq < want) {
+                        const long remaining = (long)want - J_enq;
+                        const int ahead = J_enq - std::max(prog, 0);
+                        // (the host must be back before the queue runs dry: a graph launch + one O(J) analysis of the tridiagonal)
+                        const int look = look_opt > 0 ? look_opt : std::max(2, std::min(24, (int)((36.0 + 0.07 * (double)J_enq) / step_us) + 1));
+                        int chunk = 0;
+                        if (remaining >= far_rem) { if (ahead <= 16 + look) chunk = J_enq >= 4096 ? std::min(kMaxChunk, 2 * chunk0) : chunk0; }
+                        else if (ahead <= look) {
+                            chunk = 2;
+                            while (2 * chunk <= chunk0 && 5 * (long)(2 * chunk) <= 3 * remaining + 4) chunk *= 2;      // about 0.6 of the remainder, a power of two
+                        }
+                        if (chunk > 0) {
+                            chunk = std::min(chunk, jcap - J_enq);
+                            chunk = (int)std::min<long>(chunk, max_steps - steps_total) & ~1;
+                            if (chunk >= 2) {
+                                const int hi = J_enq + chunk;
+                                const double qnan = std::numeric_limits<double>::quiet_NaN();
+                                for (int j = J_enq ? J_enq + 1 : 0; j <= hi; ++j) h_tri[3 * (size_t)j + 1] = qnan;
+                                for (int j = J_enq; j < hi; ++j) { h_tri[3 * (size_t)j] = qnan; h_tri[3 * (size_t)j + 2] = qnan; }
+                                ST_TRY(enqueue_chunk(A, pp, chunk, false, true, -1));
+                                if (debug) fprintf(stderr, "[machip] stream enqueue J=%d chunk=%d prog=%d T=%d next_a=%d\n", J_enq, chunk, prog, T == INT_MAX ? -1 : T, next_a);
+                                J_enq = hi; last_chunk = chunk;
+                                steps_total += chunk; spmv_total += chunk;
+                                continue;
+                            }
+                        }
+                    }
+                    // nothing more is wanted (or allowed) and the last record needs a tail kernel: beta_{J_enq} comes from the step that follows, or from a tail
+                    if (!feed_chunks && tail_at != J_enq && J_enq > 0 && (J_enq >= want || !room) && next_a >= J_enq) {
+                        flush_tail(pp, last_chunk, false);
+                        tail_at = J_enq;
+                        if (debug) fprintf(stderr, "[machip] stream tail at J=%d (prog=%d T=%d next_a=%d)\n", J_enq, prog, T == INT_MAX ? -1 : T, next_a);
+                        continue;
+                    }
+                    // (3) analysis
+                    const int a = std::min(next_a, std::min(J_enq, jcap));       // (J_enq < next_a only at the caps)
+                    if (prog < a) {
+                        if ((++spins & 0xfffff) == 0) {     // a device fault or a genuine NaN (non-finite input) must not hang the host
+                            const hipError_t q = hipStreamQuery(stream);
+                            if (q != hipSuccess && q != hipErrorNotReady)
+                                return fail(MACHIP_HIP_ERROR, std::string("stream error while following the Lanczos steps: ") + hipGetErrorString(q));
+                            if (q == hipSuccess && !landed(prog + 1)) stalled = true;        // everything enqueued has run: the slot holds a NaN of the recurrence's own
+                            ST_TRY(ipc_check_err("Lanczos steps"));
+                        }
+                        __builtin_ia32_pause();
+                        continue;
+                    }
+                    ST_TRY(ipc_check_err("Lanczos steps"));
+                    const int J = a;
+                    ha.resize((size_t)J); hb.resize((size_t)J + 1); hl1.resize((size_t)J + 1);
+                    for (int j = std::max(0, Jold - 1); j < J; ++j) { ha[(size_t)j] = h_tri[3 * (size_t)j]; hl1[(size_t)j] = h_tri[3 * (size_t)j + 2]; }
+                    for (int j = Jold; j <= J; ++j) hb[(size_t)j] = h_tri[3 * (size_t)j + 1];
+                    if (Jold == 0 && (hb[0] <= 0.0 || !(hb[0] == hb[0])))
+                        return fail(MACHIP_BAD_ARG, "start vector is constant, zero or not finite");
+                    int Jeff = J;
+                    bool broke = false;
+                    for (int j = std::max(1, Jold); j <= J; ++j)
+                        if (!(hb[(size_t)j] > 1e-13 * tiny_l)) { Jeff = j; broke = true; break; }
+                    Jold = J;
+                    tri::smallest_eigpair(ha.data(), hb.data(), Jeff, guess.data(), (int)guess.size(), theta_prev, sm, wk);
+                    guess = sm.s;
+                    theta_prev = sm.theta;
+                    const double rho = broke ? 0.0 : std::fabs(hb[(size_t)Jeff] * sm.s[(size_t)Jeff - 1]);
+                    const double l1v = hl1[(size_t)Jeff - 1] > 0 ? hl1[(size_t)Jeff - 1] : std::sqrt((double)n);
+                    const double est = rho * l1v;
+                    est_latest = est;
+                    // forecast: slope of ln(est) over a window that shrinks with the distance (the convergence accelerates: a long
+                    // window under-estimates the current rate), to the estimate a check needs
+                    const double lt = std::log(std::max(e_target, 1e-300));
+                    if (!broke && est > 0.0) {
+                        hist.emplace_back(J, std::log(est));
+                        const int win = (to_go < 1e17) ? std::max(12, std::min(win_max, (int)(2.0 * to_go))) : win_max;
+                        while (hist.size() > 2 && hist[1].first <= J - win) hist.pop_front();
+                        to_go = 1e18;
+                        if (hist.front().first < J) {
+                            const double slope = (hist.front().second - hist.back().second) / (double)(J - hist.front().first);
+                            if (slope > 1e-7) to_go = std::max(0.0, (hist.back().second - lt) / slope);
+                        }
+                    }
+                    T = to_go < 1e17 ? (int)std::min<double>(2e9, (double)J + std::ceil(to_go) + margin) : INT_MAX;
+                    {   // the next analysis point: half-way to the predicted crossing, at most a chunk away -- from the analyses alone
+                        const int far = J >= 4096 ? 2 * chunk0 : (J < 64 ? 16 : chunk0);
+                        const int stride = to_go < 1e17 ? std::max(1, std::min(far, (int)(to_go / 3.0))) : far;
+                        next_a = std::min(J + stride, jcap);
+                    }
+                    const bool at_cap = (J >= jcap) || (steps_total >= max_steps && J >= J_enq);
+                    const bool trig = broke || est < e_target;
+                    if (switch_est_us > 0.0 && restarts == 0 && !broke && !trig && !at_cap && J >= 128 && to_go < 1e17 &&
+                        to_go * (4.2 + 2e-6 * (double)nnz) > 1.3 * switch_est_us) {
+                        if (++switch_votes >= 2) {
+                            if (debug) fprintf(stderr, "[machip]    J=%d: forecast %.0f steps to go -- handing over to the exact chain + closures mode (estimate %.0f us)\n", J, to_go, switch_est_us);
+                            switch_to_go = to_go; switch_out = true; steps_used += J; break;
+                        }
+                    } else switch_votes = 0;
+                    if (debug) fprintf(stderr, "[machip] stream J=%d Jeff=%d theta=%.15g est=%.3e to_go=%.1f T=%d next_a=%d enq=%d prog=%d broke=%d passes=%d\n", J, Jeff, sm.theta, lnorm > 0 ? est / lnorm : est, std::min(to_go, 1e9), T == INT_MAX ? -1 : T, next_a, J_enq, prog, (int)broke, sm.passes);
+                    if (trig || at_cap) {
+                        double rq = 0.0, r1 = 0.0;
+                        if (tail_at != J_enq && J_enq > 0 && last_chunk > 0) { flush_tail(pp, last_chunk, false); tail_at = J_enq; }    // (a tail-less chunk never ends a sequence: the counters move with its successor)
+                        HIP_TRY(hipEventRecord(evs1, stream));
+                        spec_likely = est < 0.01 * OPT(spec_slack_pct, 105) * seq_tol * lnorm;
+                        ST_TRY(explicit_check(A, pl, Jeff, sm.s.data(), &rq, &r1, false));   // syncs the stream: every enqueued step has run
+                        spec_likely = true;
+                        {
+                            float sms = 0.f;
+                            HIP_TRY(hipEventElapsedTime(&sms, evs0, evs1));
+                            step_ms_acc += sms; steps_timed_acc += J_enq - J_timed;
+                            J_timed = J_enq;
+                            HIP_TRY(hipEventRecord(evs0, stream));
+                        }
+                        spmv_total += 1;
+                        J_last = Jeff;
+                        last_check_est = std::max(est, 1e-300);
+                        lam = rq;
+                        res = lnorm > 0 ? r1 / lnorm : r1;
+                        if (debug) fprintf(stderr, "[machip]    check J=%d rq=%.15g res=%.3e (tol %.1e) ran=%d\n", Jeff, rq, res, tol, J_enq);
+                        if (res < tol) { converged = true; status = MACHIP_OK; final_check_seq = check_seq; steps_used += Jeff; break; }
+                        if (broke || at_cap) { need_restart = true; steps_used += Jeff; break; }
+                        e_target = std::min(e_target, retry_s * last_check_est);      // the estimate flattered the residual: further down before the next check
+                        T = std::max(T, J_enq + 2);
+                    }
+                }
+            } else
             while (!converged && !need_restart) {
                 // keep one chunk in flight beyond the one being analysed
                 // one chunk runs ahead of the host -- except in the end game (same threshold as the
@@ -1817,6 +2008,7 @@ struct Solver {
                     pend.push_back(p);
                     J_enq = hi;
                     steps_total += chunk; spmv_total += cheb.deg ? (long)chunk * cheb.deg : chunk;
+                    steps_used += chunk;
                     if (f32_seq) steps_lowp += chunk;
                 }
                 if (pend.empty()) { need_restart = true; break; }
@@ -1948,6 +2140,8 @@ struct Solver {
                     if (broke || at_cap || f32_seq) { need_restart = true; break; }   // fp32 sequence: one check, then fp64
                 }
             }
+            // streamed records: steps still in flight keep writing record slots the next sequence / mode would poison and await
+            if (stream_mode && switch_out) HIP_TRY(hipStreamSynchronize(stream));
             // drain what is still in flight (its results are not needed)
             for (const Pending& p : pend) {
                 if (p.ev) { HIP_TRY(hipEventSynchronize(p.ev)); ev_pool.push_back(p.ev); }
@@ -1976,11 +2170,11 @@ struct Solver {
         // (what most steps of this solve were: a restart's classic tail does not change that)
         last_mode = steps_lowp > 0 ? 8 : pmode ? 4 : n <= OPT(classic_n, 256) ? 5 : pp.variant == kPanel ? 2 : pp.variant == kEll ? 3 : 1;
         if (switch_out) {        // (no Ritz vector was formed: have_prev keeps its value; the caller continues with the exact mode)
-            last_steps = steps_total; last_steps_lowp = steps_lowp;
+            last_steps = steps_used; last_steps_lowp = steps_lowp;
             return kSwitchToExact;
         }
         have_prev = true;
-        last_steps = steps_total;
+        last_steps = steps_used;
         last_steps_lowp = steps_lowp;
         if (!(ev1_at_check && status == MACHIP_OK)) {     // (a converged Lanczos solve ends with its explicit check: ev1 is there)
             HIP_TRY(hipEventRecord(ev1, stream));
@@ -1990,7 +2184,7 @@ struct Solver {
         HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
         *lambda2 = lam;
         if (stats) {
-            stats->lanczos_steps = steps_total;
+            stats->lanczos_steps = steps_used;      // (streamed records: up to the analysis point the solve ended at; steps_timed counts what was launched)
             stats->spmv_total = spmv_total;
             stats->vec_passes = steps_total * 7;   // per step and row: Z gathered (2) + Z own-row read (2) + Z written (2) + V written (1)
             stats->restarts = restarts;

@@ -1067,6 +1067,7 @@ def test_full_size_config4_properties():
     {"g": 4, "block": 256, "unroll": 2}, {"g": 16, "block": 1024},
     {"g": 64, "block": 512}, {"g": 32, "maxgrid": 64},
     {"graph": 0, "chunk": 6, "chunk_near": 2}, {"classic_n": 100000},
+    {"stream": 0}, {"stream": 2}, {"stream": 0, "graph": 0, "chunk": 6, "chunk_near": 2}, {"stream": 1, "stream_look": 2, "stream_far": 34},
     {"vcap": 80}, {"asm_g": 8}, {"asm_g": 32, "g": 8, "unroll": 1},
     # column-panel step (panel.h) forced onto small graphs: several panels / row blocks, ragged last panel and tile
     {"panel": 1, "panel_np": 3}, {"panel": 1, "panel_np": 1, "panel_nb": 2},
@@ -1096,6 +1097,54 @@ def test_solver_variants_agree(opts):
         dv = float(np.abs(sign_align(v, g["v"]) - g["v"]).max())
         assert rel <= LAM_RTOL and dv <= 2e-6 and P.stats.residual < 1e-8, (nm, rel, dv, P.stats.residual)
         P.close()
+
+
+def _stream_cases():
+    rng = np.random.default_rng(77)
+    # (a) gather step, ER-like (golden er2000); (b) padded fixed-width step on a chain + closures graph beyond the single-workgroup sizes;
+    # (c) column-panel step forced onto er2000
+    g = load_golden("er2000_xfrac")
+    yield "er2000", (int(g["n"]), g["fi"], g["fj"], g["fw"], g["ci"], g["cj"], g["cw"]), g["x"], {}
+    n = 6001
+    fi = np.arange(n - 1, dtype=np.int32)
+    a = rng.integers(0, n, 1500); b = rng.integers(0, n, 1500)
+    keep = np.abs(a - b) > 1
+    ci = np.minimum(a, b)[keep].astype(np.int32); cj = np.maximum(a, b)[keep].astype(np.int32)
+    yield "chain6001", (n, fi, fi + 1, rng.uniform(50.0, 300.0, n - 1), ci, cj, rng.uniform(50.0, 150.0, len(ci))), np.ones(len(ci)), {}
+    yield "er2000_panel", (int(g["n"]), g["fi"], g["fj"], g["fw"], g["ci"], g["cj"], g["cw"]), g["x"], {"panel": 1, "panel_np": 3}
+
+
+@pytest.mark.parametrize("case", list(_stream_cases()), ids=lambda c: c[0])
+def test_streamed_records_end_a_solve_at_the_same_step_whatever_feeds_the_queue(case):
+    """Round 5, streamed records (solver.h): every Lanczos step hands its (alpha, l1, beta) to the host, which analyses the
+    tridiagonal at a sequence of points that depends on the records alone and ends the solve at the first point whose residual
+    estimate is below the trigger.  WHAT feeds the queue -- the timing-driven feeder of the unpartitioned solve (stream = 1), the
+    chunk-at-a-time feeder of the row-partitioned solves (stream = 2), an impatient feeder (look 2, no whole chunks ahead) -- must
+    not change the final step, lambda_2 or one bit of the vector, run after run; the steps launched beyond the final point are few;
+    and the chunk-granular schedule of rounds 1-4 (stream = 0) agrees to the solver tolerance."""
+    name, args, x, opts = case
+    with _lib.default_options(**opts):
+        P = _lib.Problem(*args)
+    P.set_x(x)
+    P.set_solver(1)
+    runs = {}
+    for tag, so in (("s1", {"stream": 1}), ("s1b", {"stream": 1}), ("s2", {"stream": 2}), ("s1_impatient", {"stream": 1, "stream_look": 2, "stream_far": 34}),
+                    ("s1_eager", {"stream": 1, "graph": 0}), ("s0", {"stream": 0})):
+        for k_, v_ in {"stream_look": _lib.OPTION_AUTO, "stream_far": _lib.OPTION_AUTO, "graph": _lib.OPTION_AUTO, **so}.items():
+            P.set_option(k_, v_)
+        lam, v, _ = P.fiedler(tol=1e-8)
+        st = P.stats
+        assert st.residual < 1e-8, (name, tag, st.residual)
+        runs[tag] = (lam, v.copy(), int(st.lanczos_steps), int(st.steps_timed))
+    ref = runs["s1"]
+    for tag in ("s1b", "s2", "s1_impatient", "s1_eager"):
+        r = runs[tag]
+        assert r[0] == ref[0] and r[2] == ref[2] and np.array_equal(r[1], ref[1]), (name, tag, r[0], ref[0], r[2], ref[2])
+    # launched beyond the final analysis point: a handful (the forecast errs by a step or two; chunks are even)
+    assert 0 <= ref[3] - ref[2] <= 16, (name, ref[2], ref[3])
+    assert runs["s0"][3] >= runs["s0"][2]
+    assert abs(runs["s0"][0] - ref[0]) <= 1e-8 * ref[0] and np.abs(sign_align(runs["s0"][1], ref[1]) - ref[1]).max() <= 2e-6
+    P.close()
 
 
 @pytest.mark.parametrize("hub", [0, 9, 20])
@@ -2038,7 +2087,10 @@ def test_bench_line_contract_on_a_small_config():
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["launches_timed"] > 0
     assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["host_cores"] >= 1 and d["cpu_baseline"]["kind"] == "port"
-    assert d["cpu_parity_lambda2_rel"] < 1e-8
+    if "cpu_parity_lambda2_rel" in d:
+        assert d["cpu_parity_lambda2_rel"] < 1e-8
+    else:       # (a host so slow that the bounded CPU leg did not finish one iteration: the line must say so)
+        assert d["cpu_baseline"].get("upper_bound") is True
 
 
 def test_graft_entry_smoke():

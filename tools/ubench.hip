@@ -73,7 +73,7 @@ int main() {
             CK(hipMemcpy(dval, val.data(), nnz * 8, hipMemcpyHostToDevice));
             CsrView A{n, drp, dcol, dval};
             CK(hipMalloc(&x, n * 8)); CK(hipMalloc(&y, n * 8)); CK(hipMemset(x, 0, n * 8));
-            PipeView L; L.n = n;
+            PipeView L{}; L.n = n;
             CK(hipMalloc(&L.st, sizeof(LanState))); CK(hipMemset(L.st, 0, sizeof(LanState)));
             CK(hipMalloc(&L.Z0, n * sizeof(Z2))); CK(hipMalloc(&L.Z1, n * sizeof(Z2))); CK(hipMemset(L.Z0, 0, n * sizeof(Z2)));
             CK(hipMalloc(&L.V, (size_t)n * 8 * 4)); CK(hipMalloc(&L.tri, 8 * 64));

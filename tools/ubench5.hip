@@ -63,7 +63,7 @@ int main() {
         CK(hipMemcpy(drp, rp.data(), (n + 1) * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dcol, col.data(), nnz * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(dval, val.data(), nnz * 8, hipMemcpyHostToDevice));
         CsrView A{n, drp, dcol, dval};
-        PipeView L; L.n = n;
+        PipeView L{}; L.n = n;
         CK(hipMalloc(&L.st, sizeof(LanState))); CK(hipMemset(L.st, 0, sizeof(LanState)));
         CK(hipMalloc(&L.Z0, n * sizeof(Z2))); CK(hipMalloc(&L.Z1, n * sizeof(Z2)));
         CK(hipMalloc(&L.V, (size_t)n * 8 * 64)); CK(hipMalloc(&L.tri, 8 * 3 * 80));
