@@ -315,6 +315,13 @@ int machip_panel_plan(int64_t n, int64_t nnz, int maxlen, int* out8);
  * Python layer calls it at interpreter exit). */
 void machip_release_cache(void);
 int machip_host_tridiag_smallest(const double* a, const double* b, int J, double* theta, double* s);
+/* Host only, no GPU: the rule a Lanczos solve ends by (mac_amd/csrc/follow.h; round 5, streamed records) applied to a finished
+ * record array.  tri3 = interleaved (alpha_j, beta_j, ||v_j||_1) triples valid through beta_J; e_target = the residual estimate
+ * (||r||_1, not yet divided by ||L||_inf) a check needs; tiny_l = ||L||_inf; jcap = basis capacity (0: none).  Out: the analysis
+ * points visited (a function of the records alone), the order of the tridiagonal the sequence ends on (-1: not within J) and
+ * the estimate there.  The reference's counterpart is the per-iteration test of nx:246. */
+int machip_host_follow_records(const double* tri3, int J, int n, double e_target, double tiny_l, int jcap, int* points, int cap,
+                               int* npoints, int* jeff, double* est);
 
 #ifdef __cplusplus
 }

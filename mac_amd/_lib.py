@@ -95,6 +95,8 @@ SIGNATURES = {
     "machip_synchronize": (C.c_int, [C.c_void_p]),
     "machip_membench": (C.c_int, [C.c_int, C.c_int64, C.c_int, _f64p, _f64p]),
     "machip_host_tridiag_smallest": (C.c_int, [_f64p, _f64p, C.c_int, _f64p, _f64p]),
+    "machip_host_follow_records": (C.c_int, [_f64p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int), C.c_int,
+                                             C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "machip_release_cache": (None, []),
     "machip_panel_plan": (C.c_int, [C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_int)]),
 }
@@ -502,3 +504,18 @@ def host_tridiag_smallest(a, b):
     s = np.empty(J)
     check(lib.machip_host_tridiag_smallest(p_f64(a), p_f64(b), J, C.byref(th), p_f64(s)))
     return th.value, s
+
+
+def host_follow_records(alpha, beta, l1, n, e_target, tiny_l=1.0, jcap=0, J=None):
+    """The rule a Lanczos solve ends by (mac_amd/csrc/follow.h), applied on the host to a finished record array:
+    alpha[0..J), beta[0..J], l1[0..J) -> (analysis points visited, order of the final tridiagonal or -1, estimate there)."""
+    lib = load()
+    alpha, beta, l1 = f64(alpha), f64(beta), f64(l1)
+    J = int(len(alpha) if J is None else J)
+    tri3 = np.zeros(3 * (J + 1))
+    tri3[0:3 * J:3] = alpha[:J]; tri3[1:3 * (J + 1):3] = beta[:J + 1]; tri3[2:3 * J:3] = l1[:J]
+    pts = (C.c_int * (J + 2))()
+    npts, jeff, est = C.c_int(), C.c_int(), C.c_double()
+    check(lib.machip_host_follow_records(p_f64(tri3), J, int(n), float(e_target), float(tiny_l), int(jcap), pts, J + 2,
+                                         C.byref(npts), C.byref(jeff), C.byref(est)))
+    return list(pts[:npts.value]), jeff.value, est.value

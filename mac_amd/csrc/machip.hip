@@ -1231,7 +1231,11 @@ int prepare_lanes(machip_problem* p, int B, bool fw, int* nl_out) {
     // Round 5 (profiles/r5_bench_c4s.json, r5_bench_c2s.json): problems whose every step fills the chip for 7-17 us (ER sizes: union
     // pattern beyond ~400 000 slots) gain from ONE more problem in flight -- 2 lanes 1.27x (configs[3]) / 1.48x (configs[1]) the
     // one-at-a-time rate, 4 lanes 1.03x / 0.95x: two problems already cover each other's launch gaps, more only thrash the L2s.
-    int nl = std::max(1, std::min(B, std::min(16, OPT(lanes, small ? 16 : (p->P > 400000 ? 2 : 4)))));
+    // Later in round 5 (tools/r5_eager3.sh): that was the captured chunks -- a lane's hipGraph executables take hardware queues away from
+    // the other lanes.  Lanes launch eagerly now (Solver::use_graph) and 4 lanes win at the ER sizes too: configs[3] 267 (2 lanes) ->
+    // 293 it/s (4), configs[1] 943 -> 1 180.  Beyond 4 lanes the queues are shared whatever the launch form (city10000 sweep: 1 099 it/s
+    // with 4 lanes, 733 with 8, 474 with 12).
+    int nl = std::max(1, std::min(B, std::min(16, OPT(lanes, small ? 16 : 4))));
     while ((int)p->lanes.size() < nl) {
         machip_problem* q = nullptr;
         const int st = make_lane(p, &q);
@@ -1491,6 +1495,32 @@ int machip_host_tridiag_smallest(const double* a, const double* b, int J, double
     tri::smallest_eigpair(a, b, J, nullptr, 0, 0.0, sm, wk);
     *theta = sm.theta;
     for (int i = 0; i < J; ++i) s[i] = sm.s[(size_t)i];
+    return MACHIP_OK;
+}
+
+// Host-only: the deterministic reading of a Lanczos sequence (follow.h) over a finished record array -- tri3 = interleaved
+// (alpha_j, beta_j, ||v_j||_1) triples valid through beta_J.  points[0..*npoints) = the analysis points visited (at most cap are
+// stored), *jeff = order of the tridiagonal the sequence ends on (-1: the estimate never fell below e_target within J),
+// *est = the estimate at the last point.  For the `-m "not gpu"` tests of the rule the solver ends its solves by.
+int machip_host_follow_records(const double* tri3, int J, int n, double e_target, double tiny_l, int jcap, int* points, int cap,
+                               int* npoints, int* jeff, double* est) {
+    if (!tri3 || J < 1 || n < 2 || !npoints || !jeff || !est || !(e_target > 0.0) || cap < 0 || (cap > 0 && !points))
+        return fail(MACHIP_BAD_ARG, "bad argument");
+    std::vector<double> ha, hb, hl1, guess, wk;
+    tri::Smallest sm;
+    FollowCfg fc;
+    fc.n = n; fc.jcap = jcap > 0 ? (jcap & ~1) : INT_MAX; fc.tiny_l = tiny_l > 0 ? tiny_l : 1.0;
+    Follower F(fc, e_target, ha, hb, hl1, guess, sm, wk);
+    *npoints = 0; *jeff = -1; *est = 0.0;
+    while (F.next_a <= J) {
+        const int a = F.next_a;
+        if (!F.analyse(tri3, a)) return fail(MACHIP_BAD_ARG, "start vector is constant, zero or not finite");
+        if (*npoints < cap) points[*npoints] = a;
+        ++*npoints;
+        *est = F.est;
+        if (F.triggered()) { *jeff = F.Jeff; break; }
+        if (a >= fc.jcap) break;
+    }
     return MACHIP_OK;
 }
 

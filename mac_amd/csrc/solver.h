@@ -30,6 +30,7 @@
 #include "panel.h"
 #include "plan.h"
 #include "tridiag.h"
+#include "follow.h"
 #ifdef MACHIP_EXPERIMENTS
 #include "band.h"
 #include "blocklan.h"
@@ -111,7 +112,22 @@ struct Solver {
     unsigned graph_flip = 0;
     const void* graph_csr_key = nullptr;
     bool profiled = false;      // a rocprofiler-sdk is attached to the process (graphs are then off unless option "graph" = 1)
-    bool use_graph() const { return OPT(graph, profiled ? 0 : 1) != 0; }
+    // Captured chunks or eager launches (option `graph`: 1 / 0; unset = automatic).  Rounds 1-4 captured every chunk: the host had to
+    // get a whole chunk out at each end-game hop.  With streamed records (round 5) the queue is fed continuously, and eager launches
+    // -- no submission seam per graph -- are faster wherever a launch runs longer than the host needs to issue one (~4.4 us):
+    // configs[3] 241.5 -> 246.0 it/s, configs[1] 706 -> 721, two-lane sweeps c4s 265 -> 293, c2s 923 -> 1 178; city10000's 4.2 us
+    // steps lose 3.7 % and keep their graphs (tools/r5_eager.sh).  launch_us: measured in-solve time per launch of this handle's last
+    // solve in the same step form, the model before there is one; either way the results are the same bits.
+    double launch_us_hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // by step form (SpmvPlan::variant)
+    double cur_launch_us = 0.0;                           // what the running solve's fused chunks go by
+    bool use_graph(double launch_us = 0.0) const {
+        if (opt.is_set(kOpt_graph)) return OPT(graph, 1) != 0;
+        if (profiled) return false;
+        // (evaluation lanes never capture: a lane's hipGraph executables cost the other lanes their hardware queues -- configs[1] as a
+        // 4-lane sweep 1 185 -> 635 it/s after one captured solve per lane -- and city10000's lanes run as fast eagerly, 1 216 vs 1 224)
+        if (throughput_lane) return false;
+        return launch_us > 0.0 && launch_us < 5.2;
+    }
     // host copies of T
     std::vector<double> ha, hb, hl1;
     std::vector<double> wk, guess;
@@ -642,7 +658,7 @@ struct Solver {
         // row-partitioned chunks are launched eagerly: a captured chunk would be one graph of steps x ranks kernel nodes with
         // ranks - 1 cross-stream dependencies each (ROCm 7.2 crashes on it from 8 ranks on one device), and across devices
         // a single graph is not an option anyway
-        if (!use_graph() || sharded) { launch_chunk(A, pl, steps, f32, tailless, pub); HIP_TRY(hipGetLastError()); return MACHIP_OK; }
+        if (!use_graph(cur_launch_us) || sharded) { launch_chunk(A, pl, steps, f32, tailless, pub); HIP_TRY(hipGetLastError()); return MACHIP_OK; }
         if (graph_csr_key != (const void*)A.val) {   // different matrix buffers: cached graphs are stale
             for (auto& kv : graphs) for (hipGraphExec_t ge : kv.second) if (ge) (void)hipGraphExecDestroy(ge);
             graphs.clear();
@@ -1641,6 +1657,14 @@ struct Solver {
             pp.variant = kPanel; pp.grid = pan.fused ? pan.NB * pan.NP : pan.grid2; pp.block = pan.fused ? kBlock : pan.block2;   // (grid = partial sums per quantity)
             pp.width = pan.NP * 100 + pan.RPT; pp.unroll = pan.TWW; pp.defer = pan.NB + (pan.fused ? 1000 : 0) + 10000 * pan.cells;
         }
+        {   // eager launches or captured chunks for this solve's fused steps (use_graph)
+            const int vk = std::max(0, std::min(7, (int)pp.variant));
+            // (model before the first measurement: the gather step's; a panel launch never runs under ~8 us -- n >= 65 536.  A first solve must not
+            // capture by mistake: on a handle with evaluation lanes, hipGraph executables take hardware queues away from the lanes'
+            // streams for good -- c4s with 4 lanes 294 -> 231 it/s after ONE captured solve per lane, tools/r5_eager3.sh)
+            cur_launch_us = launch_us_hist[vk] > 0.0 ? launch_us_hist[vk] : (pp.variant == kPanel ? 8.0 : 4.2 + 2e-6 * (double)nnz);
+        }
+        if (OPT(debug, 0)) fprintf(stderr, "[machip] fused steps: variant %d, %.2f us per launch (%s) -> %s\n", (int)pp.variant, cur_launch_us, launch_us_hist[std::max(0, std::min(7, (int)pp.variant))] > 0.0 ? "measured" : "model", use_graph(cur_launch_us) ? "captured chunks" : "eager launches");
         const PipeView L = pview(pp);
         const int pchunk0 = std::min(kPersistMaxSteps, std::max(2, OPT(pchunk, 64)));
         const bool debug = OPT(debug, 0) != 0;
@@ -1777,13 +1801,14 @@ struct Solver {
                 const int look_opt = OPT(stream_look, 0);                      // steps of queued work below which the queue is fed (0: from the step-time model)
                 const int far_rem = std::max(34, OPT(stream_far, 80));         // whole chunks one ahead while at least this many steps are predicted to remain
                 const int win_max = std::max(8, OPT(stream_window, 64));
-                double e_target = trig_s * seq_tol * tiny_l;                   // the estimate has to get below this for a check
+                FollowCfg fc;
+                fc.n = n; fc.jcap = jcap; fc.chunk0 = chunk0; fc.win_max = win_max; fc.margin = margin; fc.tiny_l = tiny_l;
+                Follower F(fc, trig_s * seq_tol * tiny_l, ha, hb, hl1, guess, sm, wk);      // (follow.h: the analysis points, the estimate, the forecast)
+                int& next_a = F.next_a;      // the next analysis point
+                int& T = F.T;                // forecast: no step >= T is wanted (INT_MAX: no forecast yet)
                 int prog = -1;               // records up to beta_prog (alpha, l1 up to prog - 1) have landed
                 int tail_at = -1;            // a tail kernel has been enqueued behind step tail_at - 1 (delivers beta_tail_at)
                 int last_chunk = 0;          // steps of the last enqueued chunk (what its tail kernel advances by)
-                int next_a = std::min(16, jcap);
-                int T = INT_MAX;             // forecast: no step >= T is wanted (INT_MAX: no forecast yet)
-                int Jold = 0;
                 unsigned long spins = 0;
                 bool stalled = false;
                 auto landed = [&](int j) {
@@ -1796,7 +1821,56 @@ struct Solver {
                     // (1) how far has the GPU got?
                     const int limit = std::min(tail_at == J_enq ? J_enq : J_enq - 1, jcap);
                     while (prog < limit && (stalled || landed(prog + 1))) ++prog;
-                    // (2) feed the queue
+                    // (2) analysis, as soon as the records of the next point are there -- BEFORE the queue is fed: a host that cannot launch as
+                    // fast as the GPU runs (eager launches under a profiler) would otherwise feed for ever and never look
+                    const int a = std::min(next_a, std::min(J_enq, jcap));       // (J_enq < next_a only at the caps)
+                    bool analysed = false;
+                    if (prog >= a && a > 0) {
+                    analysed = true;
+                    ST_TRY(ipc_check_err("Lanczos steps"));
+                    const int J = a;
+                    if (!F.analyse(h_tri, a)) return fail(MACHIP_BAD_ARG, "start vector is constant, zero or not finite");
+                    const int Jeff = F.Jeff;
+                    const bool broke = F.broke;
+                    const double est = F.est;
+                    est_latest = est; to_go = F.to_go;
+                    const bool at_cap = (J >= jcap) || (steps_total >= max_steps && J >= J_enq);
+                    const bool trig = F.triggered();
+                    if (switch_est_us > 0.0 && restarts == 0 && !broke && !trig && !at_cap && J >= 128 && to_go < 1e17 &&
+                        to_go * (4.2 + 2e-6 * (double)nnz) > 1.3 * switch_est_us) {
+                        if (++switch_votes >= 2) {
+                            if (debug) fprintf(stderr, "[machip]    J=%d: forecast %.0f steps to go -- handing over to the exact chain + closures mode (estimate %.0f us)\n", J, to_go, switch_est_us);
+                            switch_to_go = to_go; switch_out = true; steps_used += J; break;
+                        }
+                    } else switch_votes = 0;
+                    if (debug) fprintf(stderr, "[machip] stream J=%d Jeff=%d theta=%.15g est=%.3e to_go=%.1f T=%d next_a=%d enq=%d prog=%d broke=%d passes=%d\n", J, Jeff, sm.theta, lnorm > 0 ? est / lnorm : est, std::min(to_go, 1e9), T == INT_MAX ? -1 : T, next_a, J_enq, prog, (int)broke, sm.passes);
+                    if (trig || at_cap) {
+                        double rq = 0.0, r1 = 0.0;
+                        if (tail_at != J_enq && J_enq > 0 && last_chunk > 0) { flush_tail(pp, last_chunk, false); tail_at = J_enq; }    // (a tail-less chunk never ends a sequence: the counters move with its successor)
+                        HIP_TRY(hipEventRecord(evs1, stream));
+                        spec_likely = est < 0.01 * OPT(spec_slack_pct, 105) * seq_tol * lnorm;
+                        ST_TRY(explicit_check(A, pl, Jeff, sm.s.data(), &rq, &r1, false));   // syncs the stream: every enqueued step has run
+                        spec_likely = true;
+                        {
+                            float sms = 0.f;
+                            HIP_TRY(hipEventElapsedTime(&sms, evs0, evs1));
+                            step_ms_acc += sms; steps_timed_acc += J_enq - J_timed;
+                            J_timed = J_enq;
+                            HIP_TRY(hipEventRecord(evs0, stream));
+                        }
+                        spmv_total += 1;
+                        J_last = Jeff;
+                        last_check_est = std::max(est, 1e-300);
+                        lam = rq;
+                        res = lnorm > 0 ? r1 / lnorm : r1;
+                        if (debug) fprintf(stderr, "[machip]    check J=%d rq=%.15g res=%.3e (tol %.1e) ran=%d\n", Jeff, rq, res, tol, J_enq);
+                        if (res < tol) { converged = true; status = MACHIP_OK; final_check_seq = check_seq; steps_used += Jeff; break; }
+                        if (broke || at_cap) { need_restart = true; steps_used += Jeff; break; }
+                        F.lower_target(retry_s * last_check_est);      // the estimate flattered the residual: further down before the next check
+                        T = std::max(T, J_enq + 2);
+                    }
+                    }
+                    // (3) feed the queue
                     const bool room = J_enq < jcap && steps_total < max_steps;
                     const int want = std::max(T, next_a);      // beta_{next_a} comes from step next_a -- or from a tail kernel when the queue ends exactly there
                     if (feed_chunks) {
@@ -1854,91 +1928,16 @@ struct Solver {
                         if (debug) fprintf(stderr, "[machip] stream tail at J=%d (prog=%d T=%d next_a=%d)\n", J_enq, prog, T == INT_MAX ? -1 : T, next_a);
                         continue;
                     }
-                    // (3) analysis
-                    const int a = std::min(next_a, std::min(J_enq, jcap));       // (J_enq < next_a only at the caps)
-                    if (prog < a) {
+                    // (4) nothing to do: wait for records
+                    if (!analysed) {
                         if ((++spins & 0xfffff) == 0) {     // a device fault or a genuine NaN (non-finite input) must not hang the host
                             const hipError_t q = hipStreamQuery(stream);
                             if (q != hipSuccess && q != hipErrorNotReady)
                                 return fail(MACHIP_HIP_ERROR, std::string("stream error while following the Lanczos steps: ") + hipGetErrorString(q));
-                            if (q == hipSuccess && !landed(prog + 1)) stalled = true;        // everything enqueued has run: the slot holds a NaN of the recurrence's own
+                            if (q == hipSuccess && prog < limit && !landed(prog + 1)) stalled = true;        // everything enqueued has run: the slot holds a NaN of the recurrence's own
                             ST_TRY(ipc_check_err("Lanczos steps"));
                         }
                         __builtin_ia32_pause();
-                        continue;
-                    }
-                    ST_TRY(ipc_check_err("Lanczos steps"));
-                    const int J = a;
-                    ha.resize((size_t)J); hb.resize((size_t)J + 1); hl1.resize((size_t)J + 1);
-                    for (int j = std::max(0, Jold - 1); j < J; ++j) { ha[(size_t)j] = h_tri[3 * (size_t)j]; hl1[(size_t)j] = h_tri[3 * (size_t)j + 2]; }
-                    for (int j = Jold; j <= J; ++j) hb[(size_t)j] = h_tri[3 * (size_t)j + 1];
-                    if (Jold == 0 && (hb[0] <= 0.0 || !(hb[0] == hb[0])))
-                        return fail(MACHIP_BAD_ARG, "start vector is constant, zero or not finite");
-                    int Jeff = J;
-                    bool broke = false;
-                    for (int j = std::max(1, Jold); j <= J; ++j)
-                        if (!(hb[(size_t)j] > 1e-13 * tiny_l)) { Jeff = j; broke = true; break; }
-                    Jold = J;
-                    tri::smallest_eigpair(ha.data(), hb.data(), Jeff, guess.data(), (int)guess.size(), theta_prev, sm, wk);
-                    guess = sm.s;
-                    theta_prev = sm.theta;
-                    const double rho = broke ? 0.0 : std::fabs(hb[(size_t)Jeff] * sm.s[(size_t)Jeff - 1]);
-                    const double l1v = hl1[(size_t)Jeff - 1] > 0 ? hl1[(size_t)Jeff - 1] : std::sqrt((double)n);
-                    const double est = rho * l1v;
-                    est_latest = est;
-                    // forecast: slope of ln(est) over a window that shrinks with the distance (the convergence accelerates: a long
-                    // window under-estimates the current rate), to the estimate a check needs
-                    const double lt = std::log(std::max(e_target, 1e-300));
-                    if (!broke && est > 0.0) {
-                        hist.emplace_back(J, std::log(est));
-                        const int win = (to_go < 1e17) ? std::max(12, std::min(win_max, (int)(2.0 * to_go))) : win_max;
-                        while (hist.size() > 2 && hist[1].first <= J - win) hist.pop_front();
-                        to_go = 1e18;
-                        if (hist.front().first < J) {
-                            const double slope = (hist.front().second - hist.back().second) / (double)(J - hist.front().first);
-                            if (slope > 1e-7) to_go = std::max(0.0, (hist.back().second - lt) / slope);
-                        }
-                    }
-                    T = to_go < 1e17 ? (int)std::min<double>(2e9, (double)J + std::ceil(to_go) + margin) : INT_MAX;
-                    {   // the next analysis point: half-way to the predicted crossing, at most a chunk away -- from the analyses alone
-                        const int far = J >= 4096 ? 2 * chunk0 : (J < 64 ? 16 : chunk0);
-                        const int stride = to_go < 1e17 ? std::max(1, std::min(far, (int)(to_go / 3.0))) : far;
-                        next_a = std::min(J + stride, jcap);
-                    }
-                    const bool at_cap = (J >= jcap) || (steps_total >= max_steps && J >= J_enq);
-                    const bool trig = broke || est < e_target;
-                    if (switch_est_us > 0.0 && restarts == 0 && !broke && !trig && !at_cap && J >= 128 && to_go < 1e17 &&
-                        to_go * (4.2 + 2e-6 * (double)nnz) > 1.3 * switch_est_us) {
-                        if (++switch_votes >= 2) {
-                            if (debug) fprintf(stderr, "[machip]    J=%d: forecast %.0f steps to go -- handing over to the exact chain + closures mode (estimate %.0f us)\n", J, to_go, switch_est_us);
-                            switch_to_go = to_go; switch_out = true; steps_used += J; break;
-                        }
-                    } else switch_votes = 0;
-                    if (debug) fprintf(stderr, "[machip] stream J=%d Jeff=%d theta=%.15g est=%.3e to_go=%.1f T=%d next_a=%d enq=%d prog=%d broke=%d passes=%d\n", J, Jeff, sm.theta, lnorm > 0 ? est / lnorm : est, std::min(to_go, 1e9), T == INT_MAX ? -1 : T, next_a, J_enq, prog, (int)broke, sm.passes);
-                    if (trig || at_cap) {
-                        double rq = 0.0, r1 = 0.0;
-                        if (tail_at != J_enq && J_enq > 0 && last_chunk > 0) { flush_tail(pp, last_chunk, false); tail_at = J_enq; }    // (a tail-less chunk never ends a sequence: the counters move with its successor)
-                        HIP_TRY(hipEventRecord(evs1, stream));
-                        spec_likely = est < 0.01 * OPT(spec_slack_pct, 105) * seq_tol * lnorm;
-                        ST_TRY(explicit_check(A, pl, Jeff, sm.s.data(), &rq, &r1, false));   // syncs the stream: every enqueued step has run
-                        spec_likely = true;
-                        {
-                            float sms = 0.f;
-                            HIP_TRY(hipEventElapsedTime(&sms, evs0, evs1));
-                            step_ms_acc += sms; steps_timed_acc += J_enq - J_timed;
-                            J_timed = J_enq;
-                            HIP_TRY(hipEventRecord(evs0, stream));
-                        }
-                        spmv_total += 1;
-                        J_last = Jeff;
-                        last_check_est = std::max(est, 1e-300);
-                        lam = rq;
-                        res = lnorm > 0 ? r1 / lnorm : r1;
-                        if (debug) fprintf(stderr, "[machip]    check J=%d rq=%.15g res=%.3e (tol %.1e) ran=%d\n", Jeff, rq, res, tol, J_enq);
-                        if (res < tol) { converged = true; status = MACHIP_OK; final_check_seq = check_seq; steps_used += Jeff; break; }
-                        if (broke || at_cap) { need_restart = true; steps_used += Jeff; break; }
-                        e_target = std::min(e_target, retry_s * last_check_est);      // the estimate flattered the residual: further down before the next check
-                        T = std::max(T, J_enq + 2);
                     }
                 }
             } else
@@ -2183,6 +2182,10 @@ struct Solver {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
         *lambda2 = lam;
+        if (steps_timed_acc >= 16 && last_mode >= 1 && last_mode <= 3) {     // (fused forms: gather, panel, padded)
+            const int vk = std::max(0, std::min(7, (int)pp.variant));
+            launch_us_hist[vk] = 1e3 * step_ms_acc / (double)steps_timed_acc / (pp.variant == kPanel ? 2.0 : 1.0);
+        }
         if (stats) {
             stats->lanczos_steps = steps_used;      // (streamed records: up to the analysis point the solve ended at; steps_timed counts what was launched)
             stats->spmv_total = spmv_total;

@@ -298,3 +298,85 @@ def test_rccl_first_contact_watchdog_turns_a_stall_into_an_error():
     assert st == _lib.RCCL_ERROR and el < 1.5, (st, el)
     msg = _lib.last_error()
     assert "did not return within" in msg and "peer rank is missing" in msg
+
+
+import scipy.sparse as sp  # noqa: E402
+
+
+def _lanczos_records(L, u0, J):
+    """Plain Lanczos on L restricted to the complement of the constant vector, in the conventions of the device records
+    (kernels.h): beta_0 = ||u0 - mean||, v_0 = u0 / beta_0, beta_j couples v_{j-1} and v_j, l1_j = ||v_j||_1."""
+    n = L.shape[0]
+    alpha, beta, l1 = np.zeros(J), np.zeros(J + 1), np.zeros(J)
+    u = u0 - u0.mean()
+    vprev = np.zeros(n)
+    for j in range(J + 1):
+        beta[j] = np.linalg.norm(u)
+        if j == J or beta[j] < 1e-13:
+            break
+        v = u / beta[j]
+        l1[j] = np.abs(v).sum()
+        w = L @ v
+        w -= w.mean()
+        alpha[j] = v @ w
+        u = w - alpha[j] * v - beta[j] * vprev
+        vprev = v
+    return alpha, beta, l1
+
+
+def _estimates(alpha, beta, l1, J):
+    """est_a = beta_a |s_a| ||v_{a-1}||_1 for a = 1..J with LAPACK's eigenvectors (the quantity follow.h tracks)."""
+    out = np.full(J + 1, np.inf)
+    for a in range(1, J + 1):
+        T = np.diag(alpha[:a]) + np.diag(beta[1:a], 1) + np.diag(beta[1:a], -1)
+        w, V = np.linalg.eigh(T)
+        out[a] = beta[a] * abs(V[a - 1, 0]) * l1[a - 1]
+    return out
+
+
+def test_record_follower_ends_a_sequence_on_the_records_alone():
+    """Round 5, streamed records (mac_amd/csrc/follow.h through machip_host_follow_records): the analysis points are strictly
+    increasing, at most a chunk apart, every point before the last has its estimate above the target and the last one below
+    (estimates recomputed here with LAPACK); the last point is the first crossing (to within two steps); records beyond it do not
+    matter, fewer records give a prefix of the same points; a breakdown ends the sequence where it happens; a constant start
+    vector is refused."""
+    rng = np.random.default_rng(3)
+    n = 600
+    a = rng.integers(0, n, 6 * n); b = rng.integers(0, n, 6 * n)
+    keep = a != b
+    W = sp.coo_matrix((rng.uniform(0.5, 1.5, keep.sum()), (a[keep], b[keep])), shape=(n, n))
+    W = W + W.T + sp.diags(np.ones(n - 1), 1) + sp.diags(np.ones(n - 1), -1)
+    L = (sp.diags(np.asarray(W.sum(axis=1)).ravel()) - W).tocsr()
+    lnorm = abs(L).sum(axis=1).max()
+    J = 160
+    alpha, beta, l1 = _lanczos_records(L, rng.standard_normal(n), J)
+    est = _estimates(alpha, beta, l1, J)
+    target = 0.95e-8 * lnorm
+    crossing = int(np.argmax(est < target))
+    assert 40 < crossing < J - 10, crossing                      # (the test matrix converges well inside the record array)
+    pts, jeff, e_last = _lib.host_follow_records(alpha, beta, l1, n, target, lnorm)
+    assert pts == sorted(set(pts)) and pts[0] == 16 and pts[-1] == jeff
+    assert max(np.diff(pts)) <= 32 and all(d <= 16 for p, d in zip(pts, np.diff(pts)) if p < 64)
+    assert all(est[p] >= target for p in pts[:-1]) and est[jeff] < target
+    assert abs(e_last - est[jeff]) <= 1e-6 * est[jeff]
+    assert 0 <= jeff - crossing <= 2, (jeff, crossing)
+    assert np.diff(pts)[-1] <= 8                                  # (the points close in on the crossing: a third of the forecast distance at a time)
+    # records beyond the final point do not matter; fewer records: a prefix, no end yet
+    for Jc in (jeff, jeff + 1, jeff + 7):
+        assert _lib.host_follow_records(alpha, beta, l1, n, target, lnorm, J=Jc)[:2] == (pts, jeff)
+    for Jc in (20, 47, jeff - 1):
+        p2, j2, _ = _lib.host_follow_records(alpha, beta, l1, n, target, lnorm, J=Jc)
+        assert j2 == -1 and p2 == [p for p in pts if p <= Jc]
+    # a looser target ends earlier on a prefix of the same early points
+    p3, j3, _ = _lib.host_follow_records(alpha, beta, l1, n, 1e-4 * lnorm, lnorm)
+    assert j3 < jeff and est[j3] < 1e-4 * lnorm and p3[:2] == pts[:2]
+    # basis capacity: the last point is the (even) cap
+    p4, j4, _ = _lib.host_follow_records(alpha, beta, l1, n, target, lnorm, jcap=50)
+    assert j4 == -1 and p4[-1] == 50
+    # breakdown: on the complete graph the Krylov space of any start vector (orthogonal to 1) has dimension 1
+    K = n * np.eye(8) - np.ones((8, 8))
+    ak, bk, lk = _lanczos_records(K[:8, :8] * 1.0, np.arange(8.0), 20)
+    pk, jk, _ = _lib.host_follow_records(ak, bk, lk, 8, 1e-8, 8.0, J=16)
+    assert jk == 1 and pk == [16]
+    with pytest.raises(AssertionError, match="start vector"):          # (BAD_ARG surfaces as the reference's assert does)
+        _lib.host_follow_records(np.ones(20), np.zeros(21), np.ones(20), 8, 1e-8, 1.0)
