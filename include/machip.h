@@ -41,7 +41,9 @@ typedef struct machip_problem machip_problem; /* one MAC instance (mac/solvers/m
 
 /* Statistics of the last eigen-solve (n_mv, n_vec counters). */
 typedef struct machip_solve_stats {
-    int64_t lanczos_steps; /* = SpMV count of the Krylov phase                             */
+    int64_t lanczos_steps; /* Lanczos steps the solve used: up to the analysis point it ended at
+                            * (a function of the records alone, round 5); steps_timed counts the
+                            * launches, a few more when the queue ran past that point              */
     int64_t spmv_total;    /* + SpMVs of the explicit residual checks                      */
     int64_t vec_passes;    /* length-n vector reads+writes outside the SpMV                */
     int64_t restarts;
