@@ -1797,7 +1797,9 @@ struct Solver {
                 const double trig_s = 0.01 * OPT(stream_trigger_pct, 95);      // (the estimate predicts the measured residual to +/- 5 %: profiles/r5_c4_checks.txt)
                 const double retry_s = 0.01 * OPT(stream_retry_pct, 80);       // after a failed check: the next one when the estimate has fallen to this fraction
                 const int margin = std::max(0, OPT(stream_margin, 0));
-                const double step_us = 4.2 + 2e-6 * (double)nnz;               // (the model the hand-over forecast uses)
+                // time of one step: measured in-solve on this handle's last solve in the same step form, the hand-over forecast's model before
+                const bool eager = !use_graph(cur_launch_us);
+                const double step_us = std::max(1.0, cur_launch_us * (pp.variant == kPanel ? 2.0 : 1.0));
                 const int look_opt = OPT(stream_look, 0);                      // steps of queued work below which the queue is fed (0: from the step-time model)
                 const int far_rem = std::max(34, OPT(stream_far, 80));         // whole chunks one ahead while at least this many steps are predicted to remain
                 const int win_max = std::max(8, OPT(stream_window, 64));
@@ -1826,49 +1828,49 @@ struct Solver {
                     const int a = std::min(next_a, std::min(J_enq, jcap));       // (J_enq < next_a only at the caps)
                     bool analysed = false;
                     if (prog >= a && a > 0) {
-                    analysed = true;
-                    ST_TRY(ipc_check_err("Lanczos steps"));
-                    const int J = a;
-                    if (!F.analyse(h_tri, a)) return fail(MACHIP_BAD_ARG, "start vector is constant, zero or not finite");
-                    const int Jeff = F.Jeff;
-                    const bool broke = F.broke;
-                    const double est = F.est;
-                    est_latest = est; to_go = F.to_go;
-                    const bool at_cap = (J >= jcap) || (steps_total >= max_steps && J >= J_enq);
-                    const bool trig = F.triggered();
-                    if (switch_est_us > 0.0 && restarts == 0 && !broke && !trig && !at_cap && J >= 128 && to_go < 1e17 &&
-                        to_go * (4.2 + 2e-6 * (double)nnz) > 1.3 * switch_est_us) {
-                        if (++switch_votes >= 2) {
-                            if (debug) fprintf(stderr, "[machip]    J=%d: forecast %.0f steps to go -- handing over to the exact chain + closures mode (estimate %.0f us)\n", J, to_go, switch_est_us);
-                            switch_to_go = to_go; switch_out = true; steps_used += J; break;
+                        analysed = true;
+                        ST_TRY(ipc_check_err("Lanczos steps"));
+                        const int J = a;
+                        if (!F.analyse(h_tri, a)) return fail(MACHIP_BAD_ARG, "start vector is constant, zero or not finite");
+                        const int Jeff = F.Jeff;
+                        const bool broke = F.broke;
+                        const double est = F.est;
+                        est_latest = est; to_go = F.to_go;
+                        const bool at_cap = (J >= jcap) || (steps_total >= max_steps && J >= J_enq);
+                        const bool trig = F.triggered();
+                        if (switch_est_us > 0.0 && restarts == 0 && !broke && !trig && !at_cap && J >= 128 && to_go < 1e17 &&
+                            to_go * (4.2 + 2e-6 * (double)nnz) > 1.3 * switch_est_us) {
+                            if (++switch_votes >= 2) {
+                                if (debug) fprintf(stderr, "[machip]    J=%d: forecast %.0f steps to go -- handing over to the exact chain + closures mode (estimate %.0f us)\n", J, to_go, switch_est_us);
+                                switch_to_go = to_go; switch_out = true; steps_used += J; break;
+                            }
+                        } else switch_votes = 0;
+                        if (debug) fprintf(stderr, "[machip] stream J=%d Jeff=%d theta=%.15g est=%.3e to_go=%.1f T=%d next_a=%d enq=%d prog=%d broke=%d passes=%d\n", J, Jeff, sm.theta, lnorm > 0 ? est / lnorm : est, std::min(to_go, 1e9), T == INT_MAX ? -1 : T, next_a, J_enq, prog, (int)broke, sm.passes);
+                        if (trig || at_cap) {
+                            double rq = 0.0, r1 = 0.0;
+                            if (tail_at != J_enq && J_enq > 0 && last_chunk > 0) { flush_tail(pp, last_chunk, false); tail_at = J_enq; }    // (a tail-less chunk never ends a sequence: the counters move with its successor)
+                            HIP_TRY(hipEventRecord(evs1, stream));
+                            spec_likely = est < 0.01 * OPT(spec_slack_pct, 105) * seq_tol * lnorm;
+                            ST_TRY(explicit_check(A, pl, Jeff, sm.s.data(), &rq, &r1, false));   // syncs the stream: every enqueued step has run
+                            spec_likely = true;
+                            {
+                                float sms = 0.f;
+                                HIP_TRY(hipEventElapsedTime(&sms, evs0, evs1));
+                                step_ms_acc += sms; steps_timed_acc += J_enq - J_timed;
+                                J_timed = J_enq;
+                                HIP_TRY(hipEventRecord(evs0, stream));
+                            }
+                            spmv_total += 1;
+                            J_last = Jeff;
+                            last_check_est = std::max(est, 1e-300);
+                            lam = rq;
+                            res = lnorm > 0 ? r1 / lnorm : r1;
+                            if (debug) fprintf(stderr, "[machip]    check J=%d rq=%.15g res=%.3e (tol %.1e) ran=%d\n", Jeff, rq, res, tol, J_enq);
+                            if (res < tol) { converged = true; status = MACHIP_OK; final_check_seq = check_seq; steps_used += Jeff; break; }
+                            if (broke || at_cap) { need_restart = true; steps_used += Jeff; break; }
+                            F.lower_target(retry_s * last_check_est);      // the estimate flattered the residual: further down before the next check
+                            T = std::max(T, J_enq + 2);
                         }
-                    } else switch_votes = 0;
-                    if (debug) fprintf(stderr, "[machip] stream J=%d Jeff=%d theta=%.15g est=%.3e to_go=%.1f T=%d next_a=%d enq=%d prog=%d broke=%d passes=%d\n", J, Jeff, sm.theta, lnorm > 0 ? est / lnorm : est, std::min(to_go, 1e9), T == INT_MAX ? -1 : T, next_a, J_enq, prog, (int)broke, sm.passes);
-                    if (trig || at_cap) {
-                        double rq = 0.0, r1 = 0.0;
-                        if (tail_at != J_enq && J_enq > 0 && last_chunk > 0) { flush_tail(pp, last_chunk, false); tail_at = J_enq; }    // (a tail-less chunk never ends a sequence: the counters move with its successor)
-                        HIP_TRY(hipEventRecord(evs1, stream));
-                        spec_likely = est < 0.01 * OPT(spec_slack_pct, 105) * seq_tol * lnorm;
-                        ST_TRY(explicit_check(A, pl, Jeff, sm.s.data(), &rq, &r1, false));   // syncs the stream: every enqueued step has run
-                        spec_likely = true;
-                        {
-                            float sms = 0.f;
-                            HIP_TRY(hipEventElapsedTime(&sms, evs0, evs1));
-                            step_ms_acc += sms; steps_timed_acc += J_enq - J_timed;
-                            J_timed = J_enq;
-                            HIP_TRY(hipEventRecord(evs0, stream));
-                        }
-                        spmv_total += 1;
-                        J_last = Jeff;
-                        last_check_est = std::max(est, 1e-300);
-                        lam = rq;
-                        res = lnorm > 0 ? r1 / lnorm : r1;
-                        if (debug) fprintf(stderr, "[machip]    check J=%d rq=%.15g res=%.3e (tol %.1e) ran=%d\n", Jeff, rq, res, tol, J_enq);
-                        if (res < tol) { converged = true; status = MACHIP_OK; final_check_seq = check_seq; steps_used += Jeff; break; }
-                        if (broke || at_cap) { need_restart = true; steps_used += Jeff; break; }
-                        F.lower_target(retry_s * last_check_est);      // the estimate flattered the residual: further down before the next check
-                        T = std::max(T, J_enq + 2);
-                    }
                     }
                     // (3) feed the queue
                     const bool room = J_enq < jcap && steps_total < max_steps;
@@ -1898,12 +1900,14 @@ struct Solver {
                         const long remaining = (long)want - J_enq;
                         const int ahead = J_enq - std::max(prog, 0);
                         // (the host must be back before the queue runs dry: a graph launch + one O(J) analysis of the tridiagonal)
-                        const int look = look_opt > 0 ? look_opt : std::max(2, std::min(24, (int)((36.0 + 0.07 * (double)J_enq) / step_us) + 1));
+                        const int look = look_opt > 0 ? look_opt : std::max(2, std::min(24, (int)(((eager ? 28.0 : 36.0) + 0.07 * (double)J_enq) / step_us) + 1));
                         int chunk = 0;
                         if (remaining >= far_rem) { if (ahead <= 16 + look) chunk = J_enq >= 4096 ? std::min(kMaxChunk, 2 * chunk0) : chunk0; }
                         else if (ahead <= look) {
                             chunk = 2;
-                            while (2 * chunk <= chunk0 && 5 * (long)(2 * chunk) <= 3 * remaining + 4) chunk *= 2;      // about 0.6 of the remainder, a power of two
+                            // captured chunks: about 0.6 of the remainder, a power of two (few shapes to capture); eager launches have no
+                            // shapes -- two steps at a time, every decision on the latest forecast
+                            if (!eager) while (2 * chunk <= chunk0 && 5 * (long)(2 * chunk) <= 3 * remaining + 4) chunk *= 2;
                         }
                         if (chunk > 0) {
                             chunk = std::min(chunk, jcap - J_enq);
