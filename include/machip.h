@@ -154,6 +154,16 @@ int machip_fiedler_csr(int device, int64_t n, const int32_t* indptr, const int32
  * SpMV kernel. variant: 0 = auto, 1 = LDS row-tile ("stream"), 2 = sub-wave vector. */
 int machip_spmv(machip_problem* p, const double* v, double* y, int variant);
 
+/* Landscape of L(x) behind the cold start of a Lanczos solve (late round 5): u after `sweeps` Jacobi sweeps
+ * u <- u + D^-1 (1 - L u) from u = D^-1 (n doubles to the host).  A cold start multiplies the start vector
+ * (machip_set_start: the reference's RandomState(7) column, mac/utils/fiedler.py:27-32) entry by entry by
+ * (u / max u)^p -- options start_land (sweeps, default 3, 0 = off) and start_pow (p, default 128): the Fiedler
+ * vector of a sparse random graph is localised on the peaks of u, and the reference's start block is only a
+ * first guess (nx:151-256 iterates it to the same stop rule).  A caller's own start vector (x0 of
+ * machip_fiedler / machip_fiedler_csr: the X argument of find_fiedler_pair) and a warm start are never
+ * touched.  Parity probe for the k_land_* kernels and a diagnostic. */
+int machip_landscape(machip_problem* p, int sweeps, double* u_out);
+
 /* Average duration (microseconds, hipEvents on the handle's stream) of `reps`
  * back-to-back launches of the fused Lanczos SpMV kernel on the assembled L(x),
  * and its algorithmic bytes per launch (SURVEY section 8(d) B_spmv + the fused vector

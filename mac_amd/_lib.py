@@ -68,6 +68,7 @@ SIGNATURES = {
     "machip_fiedler_csr": (C.c_int, [C.c_int, C.c_int64, _i32p, _i32p, _f64p, C.c_double, C.c_int, _f64p, _f64p,
                                      _f64p, _f64p, C.c_int, C.POINTER(SolveStats)]),
     "machip_spmv": (C.c_int, [C.c_void_p, _f64p, _f64p, C.c_int]),
+    "machip_landscape": (C.c_int, [C.c_void_p, C.c_int, _f64p]),
     "machip_profile_spmv": (C.c_int, [C.c_void_p, C.c_int, _f64p, _f64p]),
     "machip_comm_unique_id": (C.c_int, [C.c_void_p]),
     "machip_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -272,6 +273,13 @@ class Problem:
         y = np.empty(self.n)
         check(self._lib.machip_spmv(self._h, p_f64(v), p_f64(y), int(variant)))
         return y
+
+    def landscape(self, sweeps=3):
+        """u after `sweeps` Jacobi sweeps on L(x) u = 1 from u = 1/diag (machip_landscape): what a cold Lanczos start is
+        weighted by (options start_land / start_pow)."""
+        u = np.empty(self.n)
+        check(self._lib.machip_landscape(self._h, int(sweeps), p_f64(u)))
+        return u
 
     # ---- eigen-solve / gradient / LP ----
     def fiedler(self, tol=1e-8, max_steps=0, x0=None, warm_start=False, want_vec=True, q=0):

@@ -393,6 +393,61 @@ __global__ __launch_bounds__(kBlock) void k_spmv_stream(CsrView A, const double*
     op.end(sm);
 }
 
+// ---- landscape weighting of the cold-start vector (late round 5; solver.h `landscape_start`) ----------------
+// On sparse random graphs the Fiedler vector is LOCALISED: a handful of vertices carry it (participation ratio 1-5 on every
+// iterate of configs[1] / configs[3]) -- the weakest spot of the graph, which the Frank-Wolfe update then reinforces, so the
+// spot moves every iteration and the previous vector is no better a start than a random one (measured: `use_cache` +3 % steps).
+// Where low eigenvectors of a Laplacian-like operator localise is predicted by its landscape function u, L u = 1
+// (Filoche & Mayboroda 2012): they live on the peaks of u.  A few Jacobi sweeps u <- u + D^-1 (1 - L u) from u = D^-1 give u's
+// shape over a few hops (the sweeps do not converge -- L is singular -- and need not); the start vector z is then multiplied
+// entry by entry by (u / max u)^p, p ~ 100: the signs and relative sizes of z stay, the mass moves to the peaks.  Lanczos sorts
+// out the rest; CPU emulation on the bench trajectories (tools/experiments/start_landscape_emulation.py): -16 % steps at
+// configs[1], -17 % at configs[3], -11 % / +-1 % on city10000 / sphere2500, for k SpMV-priced launches per solve.
+__global__ __launch_bounds__(kBlock) void k_land_init(CsrView A, double* __restrict__ dg, double* __restrict__ u) {
+    for (int r = blockIdx.x * kBlock + threadIdx.x; r < A.n; r += gridDim.x * kBlock) {
+        double d = 0.0;
+        for (int p = A.rowptr[r], e = A.rowptr[r + 1]; p < e; ++p)
+            if (A.col[p] == r) { d = A.val[p]; break; }        // (assembled matrices carry the diagonal first; a caller's CSR anywhere)
+        dg[r] = d;
+        u[r] = d > 0.0 ? 1.0 / d : 0.0;
+    }
+}
+struct OpLand {
+    const double* uin;
+    double* uout;
+    const double* dg;
+    double* pmax;       // per-workgroup maxima of the sweep's output
+    double mx;
+    __device__ __forceinline__ void begin(double*) { mx = 0.0; }
+    __device__ __forceinline__ double gather(const double* __restrict__ x, int c) const { return x[c]; }
+    __device__ __forceinline__ void row(int r, double acc) {
+        const double d = dg[r];
+        double v = d > 0.0 ? uin[r] + (1.0 - acc) / d : 0.0;     // = (1 + sum_j w_rj u_j) / d_r for a Laplacian: positive
+        v = v > 0.0 && v < 1e300 ? v : 0.0;                       // (a caller's matrix need not be a Laplacian)
+        uout[r] = v;
+        mx = fmax(mx, v);
+    }
+    __device__ __forceinline__ void end(double* sm) {
+        const double m = block_max(mx, sm);
+        if (threadIdx.x == 0) pmax[blockIdx.x] = m;
+    }
+};
+// z_r <- z_r (u_r / max u)^p.  The maximum is re-reduced by every workgroup in the same order; a zero landscape (no positive
+// diagonal at all) leaves z alone.
+__global__ __launch_bounds__(kBlock) void k_land_weight(const double* __restrict__ u, const double* __restrict__ pmax, int npart,
+                                                        double* __restrict__ z, int n, double p) {
+    __shared__ double sm[4];
+    double m = 0.0;
+    for (int i = threadIdx.x; i < npart; i += kBlock) m = fmax(m, pmax[i]);
+    m = block_max(m, sm);
+    if (!(m > 0.0)) return;
+    const double inv = 1.0 / m;
+    for (int r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
+        const double q = u[r] * inv;
+        z[r] *= q > 0.0 ? exp(p * log(q)) : 0.0;
+    }
+}
+
 // ---- fused Lanczos step, part 2 ----------------------------------------------------------------
 // alpha_j = sum of partials; u <- (w - alpha_j v_j) - beta_j v_{j-1}; partial sums of u for the
 // next normalisation.  Advances the step counter read by part 1.

@@ -454,8 +454,10 @@ int run_fiedler(machip_problem* p, double tol, int max_steps, const double* x0, 
     memset(&local, 0, sizeof(local));
     p->sol.maxlen_hint = p->maxlen;
     p->sol.support_hint = (p->csr_only && !p->sol.chain_like) ? -1 : p->support;
+    p->sol.start_guess = x0 != nullptr;      // a caller's own start vector is taken as it is (no landscape weighting)
     const int st = p->sol.solve(p->csr(), p->nnz, p->lnorm, tol, max_steps, (x0 == nullptr && warm_start) ? 1 : 0,
                                 kAuto, lambda2, &local);
+    p->sol.start_guess = false;
     local.support = p->support;
     if (stats) *stats = local;
     p->have_vec = (st == MACHIP_OK || st == MACHIP_NOT_CONVERGED || st == MACHIP_DISCONNECTED);
@@ -924,6 +926,18 @@ int machip_spmv(machip_problem* p, const double* v, double* y, int variant) {
     OpPlain op{p->sol.w2};
     launch_spmv(pl, p->stream, p->csr(), p->sol.y_raw, op);
     HIP_TRY(hipMemcpyAsync(y, p->sol.w2, sizeof(double) * (size_t)p->n, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return MACHIP_OK;
+}
+
+int machip_landscape(machip_problem* p, int sweeps, double* u_out) {
+    if (!p || !u_out || sweeps < 0 || sweeps > 16) return fail(MACHIP_BAD_ARG, "bad argument (0 <= sweeps <= 16)");
+    HIP_TRY(hipSetDevice(p->device));
+    if (!p->assembled) ST_TRY(assemble(p));
+    const SpmvPlan pl = plan_spmv(p->sol.opt, p->n, p->nnz, kAuto, p->n > 32768 ? kMaxGrid : 0);
+    const double* f = p->sol.landscape_field(p->csr(), pl, sweeps);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(u_out, f, sizeof(double) * (size_t)p->n, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
     return MACHIP_OK;
 }

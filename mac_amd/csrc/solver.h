@@ -267,6 +267,30 @@ struct Solver {
         for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
     }
 
+    // Cold start: u (the stored start vector or the pseudo-random fill, already in place) is multiplied by (landscape / max)^p after
+    // `start_land` Jacobi sweeps (kernels.h).  Scratch: wc (diagonal), y_raw / w2 (sweeps), part_c (maxima) -- all idle until the
+    // first explicit check.  Deterministic (fixed-order maxima), identical on every rank of a partitioned solve.
+    bool start_guess = false;   // the start vector of this solve is the caller's own guess (machip_fiedler x0): left as it is
+    // the landscape after `sweeps` Jacobi sweeps (in y_raw or w2; per-workgroup maxima of the last sweep in part_c[0 .. pl.grid))
+    const double* landscape_field(const CsrView& A, const SpmvPlan& pl, int sweeps) {
+        k_land_init<<<vgrid(), kBlock, 0, stream>>>(A, wc, y_raw);
+        double *src = y_raw, *dst = w2;
+        for (int s = 0; s < sweeps; ++s) {
+            OpLand op{src, dst, wc, part_c, 0.0};
+            launch_spmv(pl, stream, A, src, op);
+            std::swap(src, dst);
+        }
+        return src;
+    }
+    int landscape_start(const CsrView& A, const SpmvPlan& pl) {
+        const int sweeps = std::min(16, OPT(start_land, 3));
+        if (sweeps <= 0) return MACHIP_OK;
+        const double pw = (double)std::max(1, OPT(start_pow, 128));
+        const double* f = landscape_field(A, pl, sweeps);
+        k_land_weight<<<vgrid(), kBlock, 0, stream>>>(f, part_c, pl.grid, u, n, pw);
+        HIP_TRY(hipGetLastError());
+        return MACHIP_OK;
+    }
     int vgrid() const { return (int)std::min<long>(kMaxGrid, ((long)n + kBlock - 1) / kBlock); }
 
     template <typename T = double>
@@ -1615,6 +1639,11 @@ struct Solver {
         } else {
             k_fill_start<<<g2, kBlock, 0, stream>>>(u, n, 0x1234567ull);
         }
+
+        // ---- landscape weighting of a cold start (kernels.h, k_land_*): the multi-workgroup recurrence only (a single-workgroup solve
+        // costs less than the sweeps would), never a caller's own guess or a warm start ----
+        if (!(start_mode == 1 && have_prev) && !start_guess && !pmode_early && n > OPT(classic_n, 256))
+            ST_TRY(landscape_start(A, pl));
 
         const int chunk0 = std::min(kMaxChunk, std::max(2, OPT(chunk, 32) & ~1));   // even: Z parity = jrel & 1
         const int chunk_near = std::min(chunk0, std::max(2, OPT(chunk_near, 8) & ~1));   // once the residual estimate is within 1e3 of the target

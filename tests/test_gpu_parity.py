@@ -292,7 +292,7 @@ def test_lanczos_hands_over_to_the_exact_mode_on_its_own_forecast():
     P.set_solver(0)
     lam_a, v_a, _ = P.fiedler(); st_a = int(P.stats.lanczos_steps)
     lam_b, v_b, _ = P.fiedler(); st_b = int(P.stats.lanczos_steps)
-    assert st_l > 2000 and 128 < st_a < st_l // 3 and st_b <= 40, (st_l, st_a, st_b)
+    assert st_l > 1500 and 128 < st_a < st_l // 3 and st_b <= 40, (st_l, st_a, st_b)      # (1 977 forced-Lanczos steps with the landscape-weighted cold start, 2 100 without)
     assert abs(lam_a - lam_l) <= LAM_RTOL * lam_l and abs(lam_b - lam_l) <= LAM_RTOL * lam_l and P.stats.residual < 1e-8
     assert np.abs(sign_align(v_a, v_l) - v_l).max() < 1e-5
     ip, ix, da = P.laplacian_csr()
@@ -651,6 +651,62 @@ def test_teacher_forced_config4_all_twenty_iterates(form):
     vert = lambda i: np.unpackbits(bits[i])[:m].astype(np.float64)    # noqa: E731
     P.set_options(**{"auto": {}, "panel": {"panel": 1}, "gather": {"panel": 0}}[form])
     _teacher_forced(P, k, w["x0"], vert, gv["lam_traj"])
+    P.close()
+
+
+def test_landscape_field_matches_numpy_and_weighted_cold_start_needs_fewer_steps():
+    """Late round 5 (kernels.h k_land_*, solver.h landscape_start): a cold Lanczos start is the stored start vector times
+    (u / max u)^128, u = three Jacobi sweeps on L u = 1 from u = 1/diag -- the Fiedler vector of a sparse random graph is localised
+    on the peaks of that landscape (participation ratio 1-5 on every iterate of configs[1] / configs[3]).  (a) machip_landscape
+    against NumPy on the assembled Laplacian, both SpMV row mappings; (b) on the first two matrices of the configs[1] trajectory the
+    weighted start ends at the same lambda_2 (1e-8, residual rule as ever) in fewer steps; (c) with the option off the solve is
+    bit-identical to handing the same vector over as the caller's own guess, which is never weighted; (d) a warm start is not
+    weighted either."""
+    import bench
+    w = bench.make_workload("c2")
+    n, m, k = w["n"], len(w["cw"]), w["k"]
+    z = reference_start_block(n)[:, 0].copy()
+    P = _lib.Problem(n, w["fi"], w["fj"], w["fw"], w["ci"], w["cj"], w["cw"])
+    P.set_start(z)
+    P.set_x(w["x0"])
+    ip, ix, da = P.laplacian_csr()
+    L = sp.csr_matrix((da, ix, ip), shape=(n, n))
+    d = L.diagonal()
+    for spmv in (1, 2):
+        P.set_option("spmv", spmv)
+        assert np.allclose(P.landscape(0), 1.0 / d, rtol=1e-15, atol=0)
+        for sweeps in (1, 2, 3, 5):
+            u = 1.0 / d
+            for _ in range(sweeps):
+                u = u + (1.0 - L @ u) / d
+            got = P.landscape(sweeps)
+            assert np.all(got > 0) and np.allclose(got, u, rtol=1e-12, atol=0), (spmv, sweeps, float(np.abs(got / u - 1).max()))
+    P.set_option("spmv", _lib.OPTION_AUTO)
+    x = w["x0"].copy()
+    for it in range(2):
+        P.set_x(x)
+        P.set_option("start_land", _lib.OPTION_AUTO)
+        lam_on, v_on, _ = P.fiedler(tol=1e-8); st_on = int(P.stats.lanczos_steps); assert P.stats.residual < 1e-8
+        P.set_option("start_land", 0)
+        lam_off, v_off, _ = P.fiedler(tol=1e-8); st_off = int(P.stats.lanczos_steps); assert P.stats.residual < 1e-8
+        assert abs(lam_on - lam_off) <= LAM_RTOL * lam_off and np.abs(sign_align(v_on, v_off) - v_off).max() <= 2e-6
+        assert st_on < 0.95 * st_off, (it, st_on, st_off)         # measured 141 / 155 and 221 / 285
+        # (c) the caller's own guess: same bits whether the option is on or off, and the same bits as the unweighted cold start
+        lam_g0, v_g0, _ = P.fiedler(tol=1e-8, x0=z)
+        P.set_option("start_land", _lib.OPTION_AUTO)
+        lam_g1, v_g1, _ = P.fiedler(tol=1e-8, x0=z)
+        assert lam_g0 == lam_g1 == lam_off and np.array_equal(v_g0, v_g1) and np.array_equal(v_g0, v_off)
+        # (d) warm start from the vector that solve left: option on or off alike
+        lam_w1, v_w1, _ = P.fiedler(tol=1e-8, warm_start=True); st_w1 = int(P.stats.lanczos_steps)
+        P.set_option("start_land", 0)
+        P.fiedler(tol=1e-8, x0=z)
+        lam_w0, v_w0, _ = P.fiedler(tol=1e-8, warm_start=True); st_w0 = int(P.stats.lanczos_steps)
+        P.set_option("start_land", _lib.OPTION_AUTO)
+        assert st_w1 == st_w0 and lam_w1 == lam_w0 and np.array_equal(v_w1, v_w0) and st_w1 < st_on, (st_w1, st_w0, st_on)
+        P.set_start(z)
+        g = P.gradient()
+        s = np.zeros(m); s[np.argpartition(g, -k)[-k:]] = 1.0
+        x = x + 2.0 / (it + 2) * (s - x)
     P.close()
 
 
@@ -1140,8 +1196,9 @@ def test_streamed_records_end_a_solve_at_the_same_step_whatever_feeds_the_queue(
     for tag in ("s1b", "s2", "s1_impatient", "s1_eager"):
         r = runs[tag]
         assert r[0] == ref[0] and r[2] == ref[2] and np.array_equal(r[1], ref[1]), (name, tag, r[0], ref[0], r[2], ref[2])
-    # launched beyond the final analysis point: a handful (the forecast errs by a step or two; chunks are even)
-    assert 0 <= ref[3] - ref[2] <= 16, (name, ref[2], ref[3])
+    # launched beyond the final analysis point: a handful (the forecast errs by a step or two; chunks are even) -- less than a chunk
+    # even on a solve this short (er2000: 106 steps, whole 32-step chunks up to step 128 on the forecast made at step 64)
+    assert 0 <= ref[3] - ref[2] <= 24, (name, ref[2], ref[3])
     assert runs["s0"][3] >= runs["s0"][2]
     assert abs(runs["s0"][0] - ref[0]) <= 1e-8 * ref[0] and np.abs(sign_align(runs["s0"][1], ref[1]) - ref[1]).max() <= 2e-6
     P.close()
