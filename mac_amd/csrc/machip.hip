@@ -934,7 +934,7 @@ int machip_landscape(machip_problem* p, int sweeps, double* u_out) {
     if (!p || !u_out || sweeps < 0 || sweeps > 16) return fail(MACHIP_BAD_ARG, "bad argument (0 <= sweeps <= 16)");
     HIP_TRY(hipSetDevice(p->device));
     if (!p->assembled) ST_TRY(assemble(p));
-    const SpmvPlan pl = plan_spmv(p->sol.opt, p->n, p->nnz, kAuto, p->n > 32768 ? kMaxGrid : 0);
+    const SpmvPlan pl = p->sol.landscape_plan(p->nnz);
     const double* f = p->sol.landscape_field(p->csr(), pl, sweeps);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(u_out, f, sizeof(double) * (size_t)p->n, hipMemcpyDeviceToHost, p->stream));

@@ -272,6 +272,8 @@ struct Solver {
     // first explicit check.  Deterministic (fixed-order maxima), identical on every rank of a partitioned solve.
     bool start_guess = false;   // the start vector of this solve is the caller's own guess (machip_fiedler x0): left as it is
     // the landscape after `sweeps` Jacobi sweeps (in y_raw or w2; per-workgroup maxima of the last sweep in part_c[0 .. pl.grid))
+    // (the sweeps' only per-workgroup output are the maxima in part_c, 3 x kMaxGrid doubles: their grid may exceed kMaxGrid)
+    SpmvPlan landscape_plan(long nnz) const { return plan_spmv(opt, n, nnz, kAuto, n > 32768 ? 3 * kMaxGrid : 0); }
     const double* landscape_field(const CsrView& A, const SpmvPlan& pl, int sweeps) {
         k_land_init<<<vgrid(), kBlock, 0, stream>>>(A, wc, y_raw);
         double *src = y_raw, *dst = w2;
@@ -1643,7 +1645,7 @@ struct Solver {
         // ---- landscape weighting of a cold start (kernels.h, k_land_*): the multi-workgroup recurrence only (a single-workgroup solve
         // costs less than the sweeps would), never a caller's own guess or a warm start ----
         if (!(start_mode == 1 && have_prev) && !start_guess && !pmode_early && n > OPT(classic_n, 256))
-            ST_TRY(landscape_start(A, pl));
+            ST_TRY(landscape_start(A, landscape_plan(nnz)));
 
         const int chunk0 = std::min(kMaxChunk, std::max(2, OPT(chunk, 32) & ~1));   // even: Z parity = jrel & 1
         const int chunk_near = std::min(chunk0, std::max(2, OPT(chunk_near, 8) & ~1));   // once the residual estimate is within 1e3 of the target

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-5 measurement round on the GPU box: bench lines of every config, rocprofv3 summaries (c4, c2, c3), sweeps.
 set -u
-out=$GRAFT_REPO_ROOT/gpurun_out/r5final
+out=$GRAFT_REPO_ROOT/gpurun_out/r5final2
 mkdir -p $out
 cd $GRAFT_REPO_ROOT
 timeout 900 python bench.py > $out/r5_bench_c4.json 2> $out/bench_c4.err
