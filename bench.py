@@ -14,6 +14,11 @@ Default workload (N = 1): BASELINE.json configs[3], the configuration the north 
 exactly K iterations from x0; passes are repeated until >= --min-seconds of wall time have been measured and
 the MEDIAN pass is reported (`repeats`, `pass_ms`), so the figure is reproducible and visible from outside.
 
+Every cold eigen-solve starts from the reference's start column (fiedler.py:27-32) multiplied by the landscape weighting of DESIGN
+section 4.2 (inside the timed region: five launches per solve); the object `cold_start` of the line holds the same pass with the
+weighting off and -- configs[1] / configs[3] -- both settings on the reference's own 20 iterates (tests/golden).  `warm_start`: the
+same pass with use_cache=True made real.
+
 --gpus N > 1 (default --mode all): ONE invocation runs, in one process group and in this order,
   * the SHARD pass (headline `value`, "scaling": "strong"; the north star's split): the candidates
     sharded over the ranks, every rank evaluates the supergradient of its contiguous range, one ncclAllGather rebuilds the

@@ -571,12 +571,14 @@ def test_city10000_vertices_until_the_fork():
 # dv = 2e-6 (the Fiedler-vector tolerance of this file) gives |dg| <= 2 sqrt(w T) dv + w dv^2 (the golden stores the
 # reference's own relative gap at the K-th place: 1e-7 .. 1e-4, near-ties are the rule with equal weights).
 # --------------------------------------------------------------------------------------------
-def _teacher_forced(P, k, x0, ref_vertices, lam_ref, wmax=1.0, dv=2e-6):
+def _teacher_forced(P, k, x0, ref_vertices, lam_ref, wmax=1.0, dv=2e-6, steps_out=None):
     x = np.array(x0, dtype=np.float64)
     worst = 0.0
     for i, lam_gold in enumerate(lam_ref):
         P.set_x(x)
         lam, _, _ = P.fiedler(tol=1e-8, want_vec=False)
+        if steps_out is not None:
+            steps_out.append(int(P.stats.lanczos_steps))
         rel = abs(lam - lam_gold) / abs(lam_gold)
         worst = max(worst, rel)
         assert rel <= LAM_RTOL, (i, lam, lam_gold, rel)
@@ -625,8 +627,11 @@ def test_teacher_forced_config2_all_twenty_reference_iterates(precision):
     P.set_precision(precision)
     P.set_start(reference_start_block(w["n"])[:, 0].copy())
     bits = gv["ref_s_bits"]
-    _teacher_forced(P, k, w["x0"], lambda i: np.unpackbits(bits[i])[:m].astype(np.float64), gv["f_traj"])
+    steps = []
+    _teacher_forced(P, k, w["x0"], lambda i: np.unpackbits(bits[i])[:m].astype(np.float64), gv["f_traj"], steps_out=steps)
     P.close()
+    if precision == 0:      # landscape-weighted cold start (profiles/r5_landscape.md): 3 482 steps on these 20 matrices, 4 044 from the start column as drawn
+        assert sum(steps) <= 3750, sum(steps)
 
 
 @pytest.mark.parametrize("form", ["auto", "panel", "gather"])
@@ -650,8 +655,10 @@ def test_teacher_forced_config4_all_twenty_iterates(form):
     bits = gv["ref_s_bits"]
     vert = lambda i: np.unpackbits(bits[i])[:m].astype(np.float64)    # noqa: E731
     P.set_options(**{"auto": {}, "panel": {"panel": 1}, "gather": {"panel": 0}}[form])
-    _teacher_forced(P, k, w["x0"], vert, gv["lam_traj"])
+    steps = []
+    _teacher_forced(P, k, w["x0"], vert, gv["lam_traj"], steps_out=steps)
     P.close()
+    assert sum(steps) <= 4250, sum(steps)       # landscape-weighted cold start: 3 913 steps on these 20 matrices, 4 632 from the start column as drawn
 
 
 def test_landscape_field_matches_numpy_and_weighted_cold_start_needs_fewer_steps():
