@@ -271,6 +271,15 @@ struct Solver {
     // `start_land` Jacobi sweeps (kernels.h).  Scratch: wc (diagonal), y_raw / w2 (sweeps), part_c (maxima) -- all idle until the
     // first explicit check.  Deterministic (fixed-order maxima), identical on every rank of a partitioned solve.
     bool start_guess = false;   // the start vector of this solve is the caller's own guess (machip_fiedler x0): left as it is
+    // A warm start (MAC.Cache made real) only pays where consecutive Fiedler vectors resemble each other.  On the localised vectors of the
+    // Erdos-Renyi configs they do not (overlap < 0.005: the weak spot moves every iteration), and the weighted cold start is 13 % faster.
+    // The overlap of a solve's start vector with its result is free -- |s_0|, the first Ritz coefficient -- so a warm-started solve that
+    // finds it below 2 / sqrt(n) -- no better than a random vector's -- sends the next `kWarmSkip` warm requests to the weighted cold start,
+    // then probes again.  (Not a larger threshold: city10000's consecutive vectors overlap by 0.03 - 0.09 only and its warm start still
+    // saves 16 % of the steps -- a smooth vector is rich in the low end of the spectrum.)  A function of the records alone: every rank of
+    // a partitioned solve takes the same turn.
+    static constexpr int kWarmSkip = 7;
+    int warm_skip = 0;
     // the landscape after `sweeps` Jacobi sweeps (in y_raw or w2; per-workgroup maxima of the last sweep in part_c[0 .. pl.grid))
     // (the sweeps' only per-workgroup output are the maxima in part_c, 3 x kMaxGrid doubles: their grid may exceed kMaxGrid)
     SpmvPlan landscape_plan(long nnz) const { return plan_spmv(opt, n, nnz, kAuto, n > 32768 ? 3 * kMaxGrid : 0); }
@@ -1632,7 +1641,12 @@ struct Solver {
         // (single-workgroup form: k_persist_begin of the first sequence copies it -- one launch less per solve)
         const bool pmode_early = OPT(persist, 1) != 0 && chain_like && persist_fits(n, nnz - n - 2 * chain_edges);
         const double* begin_src = nullptr;
-        if (start_mode == 1 && have_prev) {
+        const bool land_ok = !start_guess && !pmode_early && n > OPT(classic_n, 256) && OPT(start_land, 3) > 0;
+        bool warm = start_mode == 1 && have_prev;
+        if (warm && land_ok && warm_skip > 0) { --warm_skip; warm = false; }      // (the last warm start was no better than a random vector)
+        const bool warm_probe = warm && land_ok;      // this solve measures what its warm start was worth
+        double start_overlap = -1.0;
+        if (warm) {
             if (pmode_early) begin_src = yvec;
             else HIP_TRY(hipMemcpyAsync(u, yvec, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, stream));
         } else if (have_start) {
@@ -1644,8 +1658,7 @@ struct Solver {
 
         // ---- landscape weighting of a cold start (kernels.h, k_land_*): the multi-workgroup recurrence only (a single-workgroup solve
         // costs less than the sweeps would), never a caller's own guess or a warm start ----
-        if (!(start_mode == 1 && have_prev) && !start_guess && !pmode_early && n > OPT(classic_n, 256))
-            ST_TRY(landscape_start(A, landscape_plan(nnz)));
+        if (!warm && land_ok) ST_TRY(landscape_start(A, landscape_plan(nnz)));
 
         const int chunk0 = std::min(kMaxChunk, std::max(2, OPT(chunk, 32) & ~1));   // even: Z parity = jrel & 1
         const int chunk_near = std::min(chunk0, std::max(2, OPT(chunk_near, 8) & ~1));   // once the residual estimate is within 1e3 of the target
@@ -1897,7 +1910,11 @@ struct Solver {
                             lam = rq;
                             res = lnorm > 0 ? r1 / lnorm : r1;
                             if (debug) fprintf(stderr, "[machip]    check J=%d rq=%.15g res=%.3e (tol %.1e) ran=%d\n", Jeff, rq, res, tol, J_enq);
-                            if (res < tol) { converged = true; status = MACHIP_OK; final_check_seq = check_seq; steps_used += Jeff; break; }
+                            if (res < tol) {
+                                converged = true; status = MACHIP_OK; final_check_seq = check_seq; steps_used += Jeff;
+                                if (restarts == 0 && !sm.s.empty()) start_overlap = std::fabs(sm.s[0]);     // <v_0, y>: what the start vector was worth
+                                break;
+                            }
                             if (broke || at_cap) { need_restart = true; steps_used += Jeff; break; }
                             F.lower_target(retry_s * last_check_est);      // the estimate flattered the residual: further down before the next check
                             T = std::max(T, J_enq + 2);
@@ -2210,6 +2227,8 @@ struct Solver {
         have_prev = true;
         last_steps = steps_used;
         last_steps_lowp = steps_lowp;
+        if (warm_probe && start_overlap >= 0.0 && start_overlap < 2.0 / std::sqrt((double)n)) warm_skip = kWarmSkip;    // (a random unit vector's overlap is ~1/sqrt(n))
+        if (OPT(debug, 0) && warm_probe) fprintf(stderr, "[machip] warm start: overlap of the previous vector with the result %.3f%s\n", start_overlap, warm_skip ? " -> the next warm requests start cold (landscape-weighted)" : "");
         if (!(ev1_at_check && status == MACHIP_OK)) {     // (a converged Lanczos solve ends with its explicit check: ev1 is there)
             HIP_TRY(hipEventRecord(ev1, stream));
             HIP_TRY(hipEventSynchronize(ev1));

@@ -713,7 +713,19 @@ def test_landscape_field_matches_numpy_and_weighted_cold_start_needs_fewer_steps
         P.set_start(z)
         g = P.gradient()
         s = np.zeros(m); s[np.argpartition(g, -k)[-k:]] = 1.0
+        x_prev = x
         x = x + 2.0 / (it + 2) * (s - x)
+    # (e) a warm start that turns out no better than a random vector (the localised vector has moved: overlap < 2 / sqrt(n)) sends the next
+    # warm requests to the weighted cold start: same bits as asking for a cold solve
+    P.set_x(x_prev); P.fiedler(tol=1e-8)
+    P.set_x(x)
+    lam_c, v_c, _ = P.fiedler(tol=1e-8); st_c = int(P.stats.lanczos_steps)
+    P.set_x(x_prev); P.fiedler(tol=1e-8)
+    P.set_x(x)
+    lam_p, _, _ = P.fiedler(tol=1e-8, warm_start=True); st_p = int(P.stats.lanczos_steps)      # the probe: really warm-started
+    assert abs(lam_p - lam_c) <= LAM_RTOL * lam_c and st_p > st_c, (st_p, st_c)
+    lam_f, v_f, _ = P.fiedler(tol=1e-8, warm_start=True); st_f = int(P.stats.lanczos_steps)      # warm asked for, cold (weighted) run
+    assert lam_f == lam_c and st_f == st_c and np.array_equal(v_f, v_c), (st_f, st_c)
     P.close()
 
 
