@@ -282,7 +282,7 @@ struct Solver {
     int warm_skip = 0;
     // the landscape after `sweeps` Jacobi sweeps (in y_raw or w2; per-workgroup maxima of the last sweep in part_c[0 .. pl.grid))
     // (the sweeps' only per-workgroup output are the maxima in part_c, 3 x kMaxGrid doubles: their grid may exceed kMaxGrid)
-    SpmvPlan landscape_plan(long nnz) const { return plan_spmv(opt, n, nnz, kAuto, n > 32768 ? 3 * kMaxGrid : 0); }
+    SpmvPlan landscape_plan(long nnz) const { return plan_spmv(opt, n, nnz, kAuto, 3 * kMaxGrid); }
     const double* landscape_field(const CsrView& A, const SpmvPlan& pl, int sweeps) {
         k_land_init<<<vgrid(), kBlock, 0, stream>>>(A, wc, y_raw);
         double *src = y_raw, *dst = w2;

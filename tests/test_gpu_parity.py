@@ -1215,9 +1215,10 @@ def test_streamed_records_end_a_solve_at_the_same_step_whatever_feeds_the_queue(
     for tag in ("s1b", "s2", "s1_impatient", "s1_eager"):
         r = runs[tag]
         assert r[0] == ref[0] and r[2] == ref[2] and np.array_equal(r[1], ref[1]), (name, tag, r[0], ref[0], r[2], ref[2])
-    # launched beyond the final analysis point: a handful (the forecast errs by a step or two; chunks are even) -- less than a chunk
-    # even on a solve this short (er2000: 106 steps, whole 32-step chunks up to step 128 on the forecast made at step 64)
-    assert 0 <= ref[3] - ref[2] <= 24, (name, ref[2], ref[3])
+    # launched beyond the final analysis point: a handful on the bench configs (the forecast errs by a step or two; chunks are even); on a
+    # solve this short (er2000: 106 steps) the whole 32-step chunks of the far regime reach step 128 on the forecast made at step 64, and a
+    # slow host (the AddressSanitizer build: 160) lets the GPU run one chunk further -- timing decides this number, nothing reads those steps
+    assert 0 <= ref[3] - ref[2] <= 64, (name, ref[2], ref[3])
     assert runs["s0"][3] >= runs["s0"][2]
     assert abs(runs["s0"][0] - ref[0]) <= 1e-8 * ref[0] and np.abs(sign_align(runs["s0"][1], ref[1]) - ref[1]).max() <= 2e-6
     P.close()
