@@ -689,6 +689,9 @@ def test_landscape_field_matches_numpy_and_weighted_cold_start_needs_fewer_steps
             got = P.landscape(sweeps)
             assert np.all(got > 0) and np.allclose(got, u, rtol=1e-12, atol=0), (spmv, sweeps, float(np.abs(got / u - 1).max()))
     P.set_option("spmv", _lib.OPTION_AUTO)
+    for bad in (-1, 17):
+        with pytest.raises(AssertionError):          # BAD_ARG, like the reference's asserts
+            P.landscape(bad)
     x = w["x0"].copy()
     for it in range(2):
         P.set_x(x)
