@@ -278,8 +278,8 @@ struct Solver {
     // then probes again.  (Not a larger threshold: city10000's consecutive vectors overlap by 0.03 - 0.09 only and its warm start still
     // saves 16 % of the steps -- a smooth vector is rich in the low end of the spectrum.)  A function of the records alone: every rank of
     // a partitioned solve takes the same turn.
-    static constexpr int kWarmSkip = 7;
-    int warm_skip = 0;
+    static constexpr int kWarmSkip = 7;      // doubled by every further probe that fails in a row (at most 63): a trajectory whose vectors keep
+    int warm_skip = 0, warm_fails = 0;       // moving pays for ever fewer probes
     // the landscape after `sweeps` Jacobi sweeps (in y_raw or w2; per-workgroup maxima of the last sweep in part_c[0 .. pl.grid))
     // (the sweeps' only per-workgroup output are the maxima in part_c, 3 x kMaxGrid doubles: their grid may exceed kMaxGrid)
     SpmvPlan landscape_plan(long nnz) const { return plan_spmv(opt, n, nnz, kAuto, 3 * kMaxGrid); }
@@ -2227,7 +2227,10 @@ struct Solver {
         have_prev = true;
         last_steps = steps_used;
         last_steps_lowp = steps_lowp;
-        if (warm_probe && start_overlap >= 0.0 && start_overlap < 2.0 / std::sqrt((double)n)) warm_skip = kWarmSkip;    // (a random unit vector's overlap is ~1/sqrt(n))
+        if (warm_probe && start_overlap >= 0.0) {
+            if (start_overlap < 2.0 / std::sqrt((double)n)) { warm_skip = std::min(63, kWarmSkip << std::min(warm_fails, 4)); ++warm_fails; }    // (a random unit vector's overlap is ~1/sqrt(n))
+            else warm_fails = 0;
+        }
         if (OPT(debug, 0) && warm_probe) fprintf(stderr, "[machip] warm start: overlap of the previous vector with the result %.3f%s\n", start_overlap, warm_skip ? " -> the next warm requests start cold (landscape-weighted)" : "");
         if (!(ev1_at_check && status == MACHIP_OK)) {     // (a converged Lanczos solve ends with its explicit check: ev1 is there)
             HIP_TRY(hipEventRecord(ev1, stream));
