@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MACHIP_ABI_VERSION 5   /* 5: per-handle option table (machip_set_option), machip_comm_drop_ipc; 4: inter-process communicator */
+#define MACHIP_ABI_VERSION 6   /* 6: machip_solve_stats.drift, machip_panel_plan fills 12 entries; 5: per-handle option table (machip_set_option), machip_comm_drop_ipc; 4: inter-process communicator */
 
 typedef enum machip_status {
     MACHIP_OK = 0,
@@ -59,6 +59,12 @@ typedef struct machip_solve_stats {
                               duration of one fused step launch                            */
     int64_t steps_lowp;    /* of lanczos_steps, those run with fp32 storage
                               (machip_set_precision(1)); the rest are fp64                 */
+    double drift;          /* column-panel steps with an 8-byte operand (mac_amd/csrc/panel_u.h):
+                              largest accumulated factor by which a rounding error of the
+                              recurred product L v_j was carried forward, from the tridiagonal
+                              records (0: the solve took no such step); beyond option
+                              "panel_u_amp" (1e5) the sequence ends and the solve goes on
+                              in the two-kernel form                                        */
 } machip_solve_stats;
 
 int machip_version(void);
@@ -318,10 +324,12 @@ int machip_synchronize(machip_problem* p);
  * runs on every chunk of steps; exported so that `-m "not gpu"` tests can check it against LAPACK. */
 int machip_membench(int device, int64_t bytes, int reps, double* read_gbs, double* triad_gbs);
 /* Host only, no GPU: the shape the column-panel Lanczos step (mac_amd/csrc/panel.h) would use for a matrix of n rows, nnz
- * entries and longest row maxlen -- out8 = {on, NP panels, C columns per panel, NB row blocks, NTB 64-row tiles per block,
- * TWW tiles per worker wave, RPT records per worker thread, workgroups of k_pan_fin} -- under the process-default options
- * ("panel" etc.).  For CPU tests of the shape arithmetic (coverage of all rows / columns, LDS and register limits). */
-int machip_panel_plan(int64_t n, int64_t nnz, int maxlen, int* out8);
+ * entries and longest row maxlen -- out12 = {on, NP panels, C columns per panel, NB row blocks, NTB 64-row tiles per block,
+ * TWW tiles per worker wave, RPT records per worker thread (record form), workgroups of the row kernel, u (1: the shifted
+ * recurrence with an 8-byte operand, mac_amd/csrc/panel_u.h), LPT 16-byte operand loads per worker thread, TWT tiles per worker
+ * wave its kernel instantiation holds, row blocks per workgroup} -- under the process-default options ("panel", "panel_u" etc.).
+ * For CPU tests of the shape arithmetic (coverage of all rows / columns, LDS and register limits). */
+int machip_panel_plan(int64_t n, int64_t nnz, int maxlen, int* out12);
 /* machip_fiedler_csr keeps one CSR-only handle (stream, device buffers, chunk graphs) between calls and reuses it when
  * device and n match and the matrix fits -- every solve still starts from a clean solver state.  This frees it (the
  * Python layer calls it at interpreter exit). */

@@ -31,7 +31,7 @@ class SolveStats(C.Structure):
     _fields_ = [("lanczos_steps", C.c_int64), ("spmv_total", C.c_int64), ("vec_passes", C.c_int64),
                 ("restarts", C.c_int64), ("nnz", C.c_int64), ("support", C.c_int64),
                 ("residual", C.c_double), ("lnorm", C.c_double), ("gpu_ms", C.c_double),
-                ("step_ms", C.c_double), ("steps_timed", C.c_int64), ("steps_lowp", C.c_int64)]
+                ("step_ms", C.c_double), ("steps_timed", C.c_int64), ("steps_lowp", C.c_int64), ("drift", C.c_double)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

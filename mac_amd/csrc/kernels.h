@@ -565,6 +565,9 @@ struct PipeViewT {
     int pub;          // > 0: the chunk before this one had `pub` steps and no tail: the first step publishes its records
     int pubstep;      // != 0: EVERY step hands its three values (alpha_{j-1}, l1_{j-1}, beta_j) to the host as it derives them (solver.h,
                       // "streamed records": the host follows the recurrence step by step and decides where the solve ends)
+    double* sig;      // != nullptr: SHIFTED records (panel_u.h, round 6): the sums are those of (u_j, v_j) with u_j = t_j - sigma_j v_j,
+                      // sigma_j = alpha_{j-1}; sig[jrel & 1] = sigma_{j-1} on entry of step j, the prologue adds alpha'_{j-1} = u.v and
+                      // leaves sigma_j in sig[(jrel + 1) & 1].  The tridiagonal records always carry the TRUE alpha.
 #ifdef PIPE_CLOCKS
     long long* clk;   // tools/ubench5.hip: 8 wall-clock stamps (100 MHz) per workgroup
 #endif
@@ -577,7 +580,7 @@ using PipeView = PipeViewT<double>;
 #define PIPE_CLK(cond, i) do { } while (0)
 #endif
 
-struct PipeCoef { double alpha, mu, beta, inv, l1prev; };
+struct PipeCoef { double alpha, mu, beta, inv, l1prev, atrue; };      // atrue: alpha of the un-shifted recurrence (= alpha unless PipeView::sig)
 
 // Row-partitioned step (in-process communicator, machip_comm_init_local): rank r launches workgroups
 // [first, first + gridDim.x) of the SAME `total`-workgroup launch a single rank would run -- same rows per workgroup,
@@ -730,7 +733,7 @@ __device__ __forceinline__ void pipe_publish(const PV& L, const PipeCoef& c, int
         if (q != sa && q != sl && q != sb && q < 3 * j) L.htri[q] = L.tri[q];   // (alpha_j, l1_j belong to the next chunk)
     }
     if (threadIdx.x == 0) {
-        if (j > 0) { L.htri[sa] = c.alpha; L.htri[sl] = c.l1prev; }
+        if (j > 0) { L.htri[sa] = c.atrue; L.htri[sl] = c.l1prev; }
         L.htri[sb] = c.beta;
     }
     // (round 5: no system-scope fence / release in front of the flag -- they made the one wave wait for the PCIe round trip of its
@@ -755,6 +758,7 @@ __device__ __forceinline__ PipeCoef pipe_prologue_wave0(const PV& L, int jrel, i
     const int lane = threadIdx.x;   // caller guarantees threadIdx.x < 64
     const int jA = *(jrel == 0 && adv_jA < 0 ? &L.st->jN : &L.st->jA);        // (requested first, consumed last: in flight together with the partial loads below)
     const double* __restrict__ pin = L.part + (size_t)(jrel & 1) * (kNP * kMaxGrid);
+    const double sg_prev = L.sig ? L.sig[jrel & 1] : 0.0;      // (shifted records: requested with the partials)
     double a[kNP];
     {   // The first 256 partials per quantity: 24 UNCONDITIONAL loads per lane (always in bounds: the arrays hold kMaxGrid
         // entries), masked afterwards.  Round 2, tools/ubench5.hip + the ISA: written as `i < P ? pin[..] : 0` (or as a loop
@@ -794,12 +798,14 @@ __device__ __forceinline__ PipeCoef pipe_prologue_wave0(const PV& L, int jrel, i
     if (lane == 0) L.clk[blockIdx.x * 8 + 7] = wall_clock64();
 #endif
     wave_total_n<kNP>(a);
-    const PipeCoef c = pipe_coefs(a, L.n);
+    PipeCoef c = pipe_coefs(a, L.n);
+    c.atrue = sg_prev + c.alpha;                // (record form: sg_prev = 0)
     const int j = jA + jrel;
     if (lane == 0) {
-        scoef[0] = c.alpha; scoef[1] = c.beta; scoef[2] = c.mu; scoef[3] = c.inv; scoef[4] = (double)j;
+        scoef[0] = c.alpha; scoef[1] = c.beta; scoef[2] = c.mu; scoef[3] = c.inv; scoef[4] = (double)j; scoef[5] = c.atrue;
         if (bid == 0) {
-            if (j > 0) { L.tri[3 * (j - 1)] = c.alpha; L.tri[3 * (j - 1) + 2] = c.l1prev; }
+            if (L.sig && lead && adv_jA < 0) L.sig[(jrel + 1) & 1] = c.atrue;      // sigma_j = alpha_{j-1}
+            if (j > 0) { L.tri[3 * (j - 1)] = c.atrue; L.tri[3 * (j - 1) + 2] = c.l1prev; }
             L.tri[3 * j + 1] = c.beta;
             if (adv_jA >= 0) { L.st->jA = j; L.st->jN = j; }   // tail kernel: new chunk base
             else if (lead) {
@@ -812,7 +818,7 @@ __device__ __forceinline__ PipeCoef pipe_prologue_wave0(const PV& L, int jrel, i
     if (lead && adv_jA < 0 && L.pubstep && (int)blockIdx.x == pub_wg && lane == 0) {
         // streamed records: three posted 8-byte stores into pinned host memory from ONE lane of one workgroup, ~4 us into a step --
         // acknowledged long before the launch ends.  No flag: the host awaits each (NaN-poisoned) slot.
-        if (j > 0) { L.htri[3 * (j - 1)] = c.alpha; L.htri[3 * (j - 1) + 2] = c.l1prev; }
+        if (j > 0) { L.htri[3 * (j - 1)] = c.atrue; L.htri[3 * (j - 1) + 2] = c.l1prev; }
         L.htri[3 * j + 1] = c.beta;
     }
     *j_out = j;

@@ -1169,12 +1169,27 @@ int machip_comm_mode(machip_problem* p) {
     return 0;
 }
 
-int machip_panel_plan(int64_t n, int64_t nnz, int maxlen, int* out8) {
-    if (n < 1 || n > 2000000000ll || nnz < 0 || !out8) return fail(MACHIP_BAD_ARG, "machip_panel_plan: bad argument");
-    const PanPlan pp = plan_panel(default_options(), (int)n, (long)nnz, maxlen, true);
-    out8[0] = pp.on ? 1 : 0; out8[1] = pp.NP; out8[2] = pp.C; out8[3] = pp.NB; out8[4] = pp.NTB; out8[5] = pp.TWW; out8[6] = pp.RPT; out8[7] = pp.grid2;
+int machip_panel_plan(int64_t n, int64_t nnz, int maxlen, int* out12) {
+    if (n < 1 || n > 2000000000ll || nnz < 0 || !out12) return fail(MACHIP_BAD_ARG, "machip_panel_plan: bad argument");
+    const Options& opt = default_options();
+    const PanPlan pp = plan_panel(opt, (int)n, (long)nnz, maxlen, true, -1, false, OPT(stream, 1) != 0);
+    out12[0] = pp.on ? 1 : 0; out12[1] = pp.NP; out12[2] = pp.C; out12[3] = pp.NB; out12[4] = pp.NTB; out12[5] = pp.TWW; out12[6] = pp.RPT; out12[7] = pp.grid2;
+    out12[8] = pp.u ? 1 : 0; out12[9] = pp.LPT; out12[10] = pp.TWT; out12[11] = pp.cells;
     return MACHIP_OK;
 }
+
+#ifdef PAN_CLOCKS
+// developer build (MACHIP_BUILD_FLAGS=-DPAN_CLOCKS, tools/pan_clocks.py): the 16 wall-clock stamps (100 MHz) every workgroup of the
+// LAST column-panel matrix launch left
+extern "C" int machip_debug_pan_clocks(machip_problem* p, long long* out, int groups) {
+    if (!p || !out || groups < 1 || groups > kMaxGrid || !p->sol.panv.clk) return fail(MACHIP_BAD_ARG, "machip_debug_pan_clocks: no clock buffer");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    HIP_TRY(hipMemcpy(out, p->sol.panv.clk, sizeof(long long) * 16 * (size_t)groups, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(p->sol.panv.clk, 0, sizeof(long long) * 16 * (size_t)kMaxGrid));      // (the next read sees one launch shape only)
+    return MACHIP_OK;
+}
+#endif
 
 int machip_shard_plan(int64_t m, int nranks, int rank, int64_t* lo, int64_t* hi, int64_t* shard) {
     if (m < 0 || nranks < 1 || rank < 0 || rank >= nranks || !lo || !hi || !shard) return fail(MACHIP_BAD_ARG, "machip_shard_plan: bad argument");

@@ -20,6 +20,7 @@
 #include "kernels.h"
 #include "options.h"
 #include "panel.h"
+#include "panel_u.h"
 #include "persist.h"
 
 namespace machip {
@@ -141,11 +142,16 @@ struct PanPlan {
     bool band = false;               // diagonal + columns r -/+ 1 kept out of the tiles and added by k_pan_fin (evens out the diagonal cells)
     bool verify = false;             // a row is longer than 127 entries: the build must confirm that no (row, panel) count exceeds 127
     bool fused = false;              // one launch per step (k_pan_step) instead of k_pan_mul + k_pan_fin (measured SLOWER: profiles/r4_c4_one_launch_step.md)
+    bool u = false;                  // shifted recurrence with an 8-byte operand (panel_u.h: k_pan_mul8<LPT, TWT> + k_pan_finu); C is even then
+    int LPT = 1, TWT = 8;            // ... 16-byte operand loads per thread, tiles per worker wave the instantiation holds (3 | 5 | 8)
 };
+constexpr int kPanUCmax = pan_u_cols(9, 3);      // widest panel any k_pan_mul8 instantiation holds (17 568 columns)
 // nnz_cap: the most entries the handle's L(x) can ever hold (decides the band form once per handle); shape_only: the shape the
 // automatic mode WOULD take for this n, whatever nnz is (the assembly writes the per-row tables before nnz is known, kernels.h PanSpec)
-inline PanPlan plan_panel(const Options& opt, int n, long nnz, int maxlen, bool allowed, long nnz_cap = -1, bool shape_only = false) {
+// allow_u: the shifted recurrence may be planned (its panels may be wider than the record form's 12 480 columns)
+inline PanPlan plan_panel(const Options& opt, int n, long nnz, int maxlen, bool allowed, long nnz_cap = -1, bool shape_only = false, bool allow_u = true) {
     PanPlan pp;
+    const bool want_u = allow_u && OPT(panel_u, 1) != 0;
     const int mode = OPT(panel, -1);     // -1 auto, 0 off, 1 forced (tests: small graphs with several panels)
     if (!allowed || mode == 0 || n < 128) return pp;
     const double mean = (double)nnz / (double)std::max(n, 1);
@@ -160,7 +166,9 @@ inline PanPlan plan_panel(const Options& opt, int n, long nnz, int maxlen, bool 
     pp.verify = maxlen > kPanMaxLen;
     // (other sizes, tools/panel_size_probe.py: n = 66 000 .. 145 000 with a single wave of workgroups -- a tie at 23-26 entries
     // per row, 1.3-1.5x at 43-46; beyond n = 1e5 the build's 0.25 ms per solve moves the break-even to ~26)
-    const int min_mean10 = OPT(panel_min_mean10, n <= 105000 ? 170 : 260);
+    // (shifted recurrence, round 6, tools/sweep_panel_u.py at n = 1e5: 6 x 42 runs 12.8 us per step at 7 entries per row and 15.1 at 40 -- ahead of
+    // the gather step from ~10.7 entries per row)
+    const int min_mean10 = OPT(panel_min_mean10, want_u ? (n <= 105000 ? 110 : 200) : (n <= 105000 ? 170 : 260));
     if (mode < 0 && !(n >= OPT(panel_min_n, 65536) && (shape_only || mean >= 0.1 * min_mean10))) return pp;
     // Shape: NP panels x NB row blocks with NB * NP <= 256 workgroups -- ONE wave of workgroups, one per CU (a second wave
     // doubles the kernel: n = 131 072 with 16 x 18 = 288 workgroups ran 30.5 us per step against 24.9 for the gather step) --,
@@ -168,15 +176,31 @@ inline PanPlan plan_panel(const Options& opt, int n, long nnz, int maxlen, bool 
     // Preferred panel width ~8 448 columns (measured best at n = 1e5: 12 x 21); wider panels where the row blocks would
     // otherwise not fit.  No such shape beyond n ~ 145 000: the automatic mode then stays with the gather step.
     const int groups = (n + 63) / 64;
-    const int cmax = 13 * kPanWorkThreads, tmax = kPanWork * kPanTW;
+    const int cmax = want_u ? kPanUCmax : 13 * kPanWorkThreads, tmax = kPanWork * kPanTW;
+    const int cpref = 8448;     // preferred panel width of the record form
     int np = 0, nb = 0;
     const int np_env = OPT(panel_np, 0), nb_env = OPT(panel_nb, 0);
-    if (np_env > 0 || nb_env > 0) {              // explicit shape (tests, sweeps): taken as given, clipped to what the kernels hold
-        np = std::max(1, std::min(np_env > 0 ? np_env : (n + 8447) / 8448, 64));
+    if (want_u && np_env <= 0 && nb_env <= 0) {
+        // Shifted recurrence: the WIDEST panels an instantiation of k_pan_mul8 holds next to the row block's image -- every panel less
+        // is n x 8 bytes of partial products neither written nor read back, and the operand costs 8 bytes per column only
+        // (n = 1e5: 6 x 42, 13.5 us per step against 15.9 at 12 x 21 and 16.7 for the record form; profiles/r6_panel_u.md)
+        for (int c = std::max(1, (n + kPanUCmax - 1) / kPanUCmax); c <= 64 && !np; ++c) {
+            const int Cc = (((n + c - 1) / c) + 1) & ~1;
+            const int b = std::max(1, std::min(grid_cap(opt) / c, groups));
+            const int nt = (groups + b - 1) / b;
+            if (nt > tmax) break;                    // (narrower panels leave fewer row blocks: no single-wave shape)
+            const int tww = (nt + kPanWork - 1) / kPanWork, twt = tww <= 3 ? 3 : tww <= 5 ? 5 : 8;
+            const int lpt = ((Cc + 1) / 2 + kPanWorkThreads - 1) / kPanWorkThreads;
+            const int cap = twt == 3 ? pan_u_cols(lpt <= 9 ? lpt : 9, 3) : twt == 5 ? pan_u_cols(lpt <= 8 ? lpt : 8, 5) : pan_u_cols(lpt <= 8 ? lpt : 8, 8);
+            if (lpt <= (twt == 3 ? 9 : 8) && Cc <= cap) { np = c; nb = b; }
+        }
+        if (!np) return plan_panel(opt, n, nnz, maxlen, allowed, nnz_cap, shape_only, false);      // (the record form's shape rules, multi-cell shapes included)
+    } else if (np_env > 0 || nb_env > 0) {              // explicit shape (tests, sweeps): taken as given, clipped to what the kernels hold
+        np = std::max(1, std::min(np_env > 0 ? np_env : (n + cpref - 1) / cpref, 64));
         if ((n + np - 1) / np > cmax) np = (n + cmax - 1) / cmax;
         nb = nb_env > 0 ? nb_env : std::max(1, grid_cap(opt) / np);
     } else {
-        for (int c = std::max(1, (n + 8447) / 8448); c >= 1; --c) {
+        for (int c = std::max(1, (n + cpref - 1) / cpref); c >= 1; --c) {
             if ((n + c - 1) / c > cmax) break;
             const int b = std::max(1, grid_cap(opt) / c);
             if ((groups + b - 1) / b <= tmax) { np = c; nb = b; break; }
@@ -201,6 +225,7 @@ inline PanPlan plan_panel(const Options& opt, int n, long nnz, int maxlen, bool 
     if (OPT(panel_cells, 0) > 0) pp.cells = OPT(panel_cells, 0);      // (tests: the multi-cell kernel on small graphs)
     if (np > 64) return pp;
     int C = (n + np - 1) / np;
+    if (want_u) C = (C + 1) & ~1;                      // (16-byte operand loads: every panel starts on an even column)
     np = (n + C - 1) / C;                              // panels that actually hold columns
     nb = std::max(1, std::min(nb, groups));
     int ntb = (groups + nb - 1) / nb;                            // tiles per row block
@@ -214,10 +239,17 @@ inline PanPlan plan_panel(const Options& opt, int n, long nnz, int maxlen, bool 
     if (mode < 0 && !shape_only && pp.cells > 1 && mean < 0.1 * OPT(panel_multi_min_mean10, 330)) return PanPlan();
     pp.on = true; pp.NP = np; pp.C = C; pp.NB = nb; pp.NTB = ntb; pp.TWW = (ntb + kPanWork - 1) / kPanWork;
     pp.RPT = (C + kPanWorkThreads - 1) / kPanWorkThreads;
+    if (want_u) {
+        pp.LPT = ((C + 1) / 2 + kPanWorkThreads - 1) / kPanWorkThreads;      // (16-byte loads per worker thread)
+        pp.TWT = pp.TWW <= 3 ? 3 : pp.TWW <= 5 ? 5 : 8;
+        pp.u = pp.cells == 1 && pp.LPT <= 9 && (pp.LPT < 9 || pp.TWT == 3) &&
+               C <= (pp.TWT == 3 ? pan_u_cols(pp.LPT, 3) : pp.TWT == 5 ? pan_u_cols(pp.LPT, 5) : pan_u_cols(pp.LPT, 8));
+        if (!pp.u) return plan_panel(opt, n, nnz, maxlen, allowed, nnz_cap, shape_only, false);      // the record form's shape rules
+    }
     // MACHIP_PANEL_FUSED=1: the one-launch form (k_pan_step; tickets for 256 row blocks, one partial-sum slot per slice).  Off by
     // default: 26.9 against 19.1 us per step at configs[3] -- the in-launch hand-off costs more than the launch it saves.
 #ifdef MACHIP_EXPERIMENTS
-    pp.fused = OPT(panel_fused, 0) != 0 && nb <= 256 && nb * np <= 256 && pp.cells == 1;
+    pp.fused = OPT(panel_fused, 0) != 0 && nb <= 256 && nb * np <= 256 && pp.cells == 1 && !pp.u;
 #endif
     pp.band = OPT(panel_band, 1) != 0 && (nnz_cap >= 0 ? nnz_cap : nnz) < (1l << 28);     // (CSR positions are packed with 3 count bits; the LOBPCG kernels finish rows without the band terms: solver.h passes band = false there)
     pp.block2 = OPT(panel_b2, 512);

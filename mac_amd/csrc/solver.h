@@ -189,6 +189,11 @@ struct Solver {
     bool pan_allowed = false;   // the CSR is one this library assembled (diagonal first, other columns ascending)
     PanPlan pan;
     PanView panv{};
+    bool pan_u = false;            // the running sequence's panel steps are those of the shifted recurrence (panel_u.h): 8-byte operand
+    bool pan_u_off = false;        // ... ruled out for the rest of this solve (the drift monitor tripped)
+    PanU pu{};
+    double* pu_sig = nullptr;
+    double last_amp = 0.0;         // largest accumulated drift factor of the last solve's shifted sequences (solve stats / tests)
     size_t pan_cap = 0, pan_nt_cap = 0, pan_y_cap = 0, pan_band_cap = 0;
     std::array<int, 5> pan_shape_key{0, 0, 0, 0, 0};     // shape the cells' static ranges (panv.cbase) were computed for
     PatternView pat{};          // union pattern of the handle (machip_create); none on a CSR-only handle
@@ -247,6 +252,8 @@ struct Solver {
         {
             void* pb[] = {panv.tptr, panv.thead, panv.bval, panv.bcol, panv.ypart, panv.coef, panv.cbase, panv.ps, panv.tick, panv.claim, panv.ovf, panv.bd, panv.bpk};
             for (void* q : pb) if (q) (void)hipFree(q);
+            void* pu_[] = {pu.U0, pu.U1, pu.W, pu_sig};
+            for (void* q : pu_) if (q) (void)hipFree(q);
             void* pk[] = {ppack.band, ppack.cc, ppack.crow, ppack.ccol, ppack.cval, ell_col, ell_val};
             for (void* q : pk) if (q) (void)hipFree(q);
         }
@@ -308,6 +315,7 @@ struct Solver {
     PipeViewT<T> pview(const SpmvPlan& pl) const {
         PipeViewT<T> L;     // T = float: records and basis live in the same buffers, read as fp32
         L.n = n; L.st = st; L.Z0 = reinterpret_cast<ZRec<T>*>(Z0); L.Z1 = reinterpret_cast<ZRec<T>*>(Z1); L.V = reinterpret_cast<T*>(V); L.tri = tri; L.htri = d_htri; L.hflag = d_hflag; L.part = part; L.P = pl.grid; L.chunk = 0; L.pub = 0; L.pubstep = 0;
+        L.sig = (pl.variant == kPanel && pan_u) ? pu_sig : nullptr;      // (shifted records: panel_u.h)
         return L;
     }
     LanView check_view(const SpmvPlan& pl) const {   // "column 0" machinery for the explicit check
@@ -391,7 +399,7 @@ struct Solver {
         *out = PanSpec();
         pan_rows_ready = false;
         if (!pan_allowed || !pat.prow) return MACHIP_OK;
-        const PanPlan sh = plan_panel(opt, n, 0, 1, true, (long)csr_cap, true);
+        const PanPlan sh = plan_panel(opt, n, 0, 1, true, (long)csr_cap, true, OPT(stream, 1) != 0);      // (the shape solve() will plan)
         if (!sh.on) return MACHIP_OK;
         ST_TRY(pan_row_buffers(sh, sh.band));
         HIP_TRY(hipMemsetAsync(panv.ovf, 0, sizeof(int), stream));
@@ -436,6 +444,9 @@ struct Solver {
         // band mode (Lanczos form, two launches): diagonal and chain neighbours stay out of the tiles -- k_pan_fin adds them
         panv.band = band ? 1 : 0;
         panv.spin_ticks = OPT(panel_spin_us, 20) * 100;
+#ifdef PAN_CLOCKS
+        if (!panv.clk) { ST_TRY(dev_alloc(&panv.clk, (size_t)16 * kMaxGrid)); HIP_TRY(hipMemsetAsync(panv.clk, 0, sizeof(long long) * 16 * kMaxGrid, stream)); }
+#endif
         panv.n = n; panv.NP = pn.NP; panv.C = pn.C; panv.NB = pn.NB; panv.NTB = pn.NTB; panv.TWW = pn.TWW; panv.CELLS = pn.cells;
         // static ranges of the cells in the value / column arrays: pattern slots of the cell + its rows (the diagonal, when the band
         // stays in the tiles) + 64 x 128 entries of zero padding (the tile heights telescope), whole 64-entry chunks; once per shape
@@ -492,7 +503,7 @@ struct Solver {
         (void)nnz;
         return MACHIP_OK;
     }
-    void launch_pan_step(const PipeView& L, int s) {
+    void launch_pan_step(const PipeView& L, int s, int jhost = -1) {
         const int g1 = pan.NB * pan.NP;
 #ifdef MACHIP_EXPERIMENTS
         if (pan.fused) {     // one launch per step (k_pan_step; measured slower: profiles/r4_c4_one_launch_step.md)
@@ -506,6 +517,27 @@ struct Solver {
             return;
         }
 #endif
+        if (pan_u) {             // shifted recurrence (panel_u.h): 8-byte operand, no prologue in the matrix kernel; the row kernel leads
+            switch (pan.LPT * 10 + pan.TWT) {
+#define MACHIP_PANU_CASE(LP, TW) case LP * 10 + TW: k_pan_mul8<LP, TW><<<g1, kPanThreads, 0, stream>>>(PAN_MUL8_ARGS(panv, pu, L, s)); break;
+#define MACHIP_PANU_ROW(LP) MACHIP_PANU_CASE(LP, 3) MACHIP_PANU_CASE(LP, 5) MACHIP_PANU_CASE(LP, 8)
+                MACHIP_PANU_ROW(1) MACHIP_PANU_ROW(2) MACHIP_PANU_ROW(3) MACHIP_PANU_ROW(4) MACHIP_PANU_ROW(5) MACHIP_PANU_ROW(6)
+                MACHIP_PANU_ROW(7) MACHIP_PANU_ROW(8) MACHIP_PANU_CASE(9, 3)
+#undef MACHIP_PANU_ROW
+#undef MACHIP_PANU_CASE
+                default: break;      // (plan_panel only hands out instantiated shapes)
+            }
+            const int npm = pan.NP <= 6 ? 6 : pan.NP <= 8 ? 8 : pan.NP <= 12 ? 12 : 16;
+            switch (pan.block2 * 100 + npm) {
+#define MACHIP_FINU_CASE(B, M) case B * 100 + M: k_pan_finu<B, M><<<pan.grid2, B, 0, stream>>>(PAN_FINU_ARGS(panv, pu, L, s), jhost); break;
+#define MACHIP_FINU_ROW(B) MACHIP_FINU_CASE(B, 6) MACHIP_FINU_CASE(B, 8) MACHIP_FINU_CASE(B, 12) MACHIP_FINU_CASE(B, 16)
+                MACHIP_FINU_ROW(256) MACHIP_FINU_ROW(512) MACHIP_FINU_ROW(1024)
+#undef MACHIP_FINU_ROW
+#undef MACHIP_FINU_CASE
+                default: break;
+            }
+            return;
+        }
         if (pan.cells > 1) {     // several row blocks per workgroup, the panel loaded once (k_pan_mul_multi)
             const int gm = pan.NP * ((pan.NB + pan.cells - 1) / pan.cells);
             switch (pan.RPT) {
@@ -660,11 +692,12 @@ struct Solver {
     // ---- one chunk = `steps` step kernels + the tail kernel ------------------------------------
     // tailless: no tail kernel -- the chunk's last step advances the counters and the NEXT chunk's first step (pub = this chunk's
     // step count there) hands the records to the host; a chunk that turns out to have no successor gets its tail from flush_tail.
-    void launch_chunk(const CsrView& A, const SpmvPlan& pl, int steps, bool f32 = false, bool tailless = false, int pub = 0) {
+    // j0 >= 0: the sequence's step index of the chunk's first step, known to the host (eager launches only: a captured chunk is replayed at any base)
+    void launch_chunk(const CsrView& A, const SpmvPlan& pl, int steps, bool f32 = false, bool tailless = false, int pub = 0, int j0 = -1) {
         if (pl.variant == kPanel) {
             PipeView L = pview(pl);
             L.chunk = tailless ? steps : 0; L.pub = std::max(pub, 0); L.pubstep = pub < 0;
-            for (int s = 0; s < steps; ++s) launch_pan_step(L, s);
+            for (int s = 0; s < steps; ++s) launch_pan_step(L, s, j0 >= 0 ? j0 + s : -1);
             if (!tailless) k_pipe_tail<<<1, 64, 0, stream>>>(L, steps);
             return;
         }
@@ -688,12 +721,12 @@ struct Solver {
         if (f32) k_pipe_tail<<<1, 64, 0, stream>>>(pview<float>(pl), steps);
         else k_pipe_tail<<<1, 64, 0, stream>>>(pview(pl), steps);
     }
-    int enqueue_chunk(const CsrView& A, const SpmvPlan& pl, int steps, bool f32 = false, bool tailless = false, int pub = 0) {
+    int enqueue_chunk(const CsrView& A, const SpmvPlan& pl, int steps, bool f32 = false, bool tailless = false, int pub = 0, int j0 = -1) {
         const bool sharded = shard && pl.variant == kVec && !f32;
         // row-partitioned chunks are launched eagerly: a captured chunk would be one graph of steps x ranks kernel nodes with
         // ranks - 1 cross-stream dependencies each (ROCm 7.2 crashes on it from 8 ranks on one device), and across devices
         // a single graph is not an option anyway
-        if (!use_graph(cur_launch_us) || sharded) { launch_chunk(A, pl, steps, f32, tailless, pub); HIP_TRY(hipGetLastError()); return MACHIP_OK; }
+        if (!use_graph(cur_launch_us) || sharded) { launch_chunk(A, pl, steps, f32, tailless, pub, j0); HIP_TRY(hipGetLastError()); return MACHIP_OK; }
         if (graph_csr_key != (const void*)A.val) {   // different matrix buffers: cached graphs are stale
             for (auto& kv : graphs) for (hipGraphExec_t ge : kv.second) if (ge) (void)hipGraphExecDestroy(ge);
             graphs.clear();
@@ -1052,7 +1085,7 @@ struct Solver {
         SpmvPlan pl = plan_spmv(opt, n, nnz, kAuto, jacobi && n > 32768 ? kMaxGrid : 0);
 #ifdef MACHIP_EXPERIMENTS
         if (jacobi) {
-            pan = plan_panel(opt, n, nnz, maxlen_hint, pan_allowed && precision == 0 && !shard && !ipc, (long)csr_cap);
+            pan = plan_panel(opt, n, nnz, maxlen_hint, pan_allowed && precision == 0 && !shard && !ipc, (long)csr_cap, false, false);
             lob_pan = false; lob_pan2 = false;
             if (pan.on && !pan.verify) {
                 ST_TRY(ensure_panel(A, nnz, pan));
@@ -1676,7 +1709,10 @@ struct Solver {
         // LDS-resident single-workgroup form when the matrix fits (classic recurrence: also fine after restarts)
         const bool pmode = pmode_early;
         // column-panel step (panel.h) where the gather operand is too large for the caches (fp64 sequences only)
-        pan = plan_panel(opt, n, nnz, maxlen_hint, pan_allowed && precision == 0 && !pmode && !classic && pp.variant == kVec && !shard && !ipc, (long)csr_cap);   // (the row-partitioned solve shards the gather step)
+        // (shifted recurrence, panel_u.h: only where the host follows the records step by step -- its drift monitor lives there)
+        pan = plan_panel(opt, n, nnz, maxlen_hint, pan_allowed && precision == 0 && !pmode && !classic && pp.variant == kVec && !shard && !ipc, (long)csr_cap,
+                         false, OPT(stream, 1) != 0);   // (the row-partitioned solve shards the gather step)
+        pan_u = false; last_amp = 0.0;
         // padded fixed-width form for short rows (pose graphs beyond the single-workgroup kernel): no row-pointer round trip
         if (!pan.on && !pmode && !classic && !shard && !ipc && precision == 0 && pp.variant == kVec && pp.width == 4 && pp.defer < 3 &&
             maxlen_hint >= 1 && maxlen_hint <= 16 && OPT(ell, 1) != 0) {
@@ -1699,7 +1735,15 @@ struct Solver {
         }
         if (pan.on) {
             pp.variant = kPanel; pp.grid = pan.fused ? pan.NB * pan.NP : pan.grid2; pp.block = pan.fused ? kBlock : pan.block2;   // (grid = partial sums per quantity)
-            pp.width = pan.NP * 100 + pan.RPT; pp.unroll = pan.TWW; pp.defer = pan.NB + (pan.fused ? 1000 : 0) + 10000 * pan.cells;
+            pp.width = pan.NP * 100 + pan.RPT; pp.unroll = pan.TWW; pp.defer = pan.NB + (pan.fused ? 1000 : 0) + 10000 * pan.cells + (pan.u ? 1000000 : 0);
+            if (pan.u) {
+                if (!pu.U0) {
+                    ST_TRY(dev_alloc(&pu.U0, (size_t)n + 2)); ST_TRY(dev_alloc(&pu.U1, (size_t)n + 2)); ST_TRY(dev_alloc(&pu.W, (size_t)n));
+                    ST_TRY(dev_alloc(&pu_sig, 2));
+                    pu.sig = pu_sig;
+                }
+                pan_u = true;
+            }
         }
         {   // eager launches or captured chunks for this solve's fused steps (use_graph)
             const int vk = std::max(0, std::min(7, (int)pp.variant));
@@ -1783,7 +1827,8 @@ struct Solver {
                 k_pipe_init<<<pp.grid, kBlock, 0, stream>>>(pview<float>(pp), u, (int)epoch);
             } else {
                 ++epoch;
-                k_pipe_init<<<pp.grid, kBlock, 0, stream>>>(L, u, (int)epoch);
+                if (pan_u) k_pipe_init_u<<<pp.grid, kBlock, 0, stream>>>(L, pu, u, (int)epoch);
+                else k_pipe_init<<<pp.grid, kBlock, 0, stream>>>(L, u, (int)epoch);
                 if (pan.on && pan.fused) {      // (experiments build) arrival tickets / slice claims of k_pan_step count from the sequence's step 0
                     HIP_TRY(hipMemsetAsync(panv.tick, 0, sizeof(unsigned int) * 256, stream));
                     HIP_TRY(hipMemsetAsync(panv.claim, 0, sizeof(unsigned int) * 4096, stream));
@@ -1853,6 +1898,9 @@ struct Solver {
                 int& next_a = F.next_a;      // the next analysis point
                 int& T = F.T;                // forecast: no step >= T is wanted (INT_MAX: no forecast yet)
                 int prog = -1;               // records up to beta_prog (alpha, l1 up to prog - 1) have landed
+                int amp_at = 0;              // shifted recurrence: drift factor accumulated over the steps < amp_at (a function of the records)
+                double amp = 1.0;
+                const double amp_max = (double)std::max(2, OPT(panel_u_amp, 100000));
                 int tail_at = -1;            // a tail kernel has been enqueued behind step tail_at - 1 (delivers beta_tail_at)
                 int last_chunk = 0;          // steps of the last enqueued chunk (what its tail kernel advances by)
                 unsigned long spins = 0;
@@ -1880,7 +1928,18 @@ struct Solver {
                         const bool broke = F.broke;
                         const double est = F.est;
                         est_latest = est; to_go = F.to_go;
-                        const bool at_cap = (J >= jcap) || (steps_total >= max_steps && J >= J_enq);
+                        bool amp_trip = false;
+                        if (pan_u && pp.variant == kPanel) {
+                            // w_{k+1} = (L u_k - (alpha_k - alpha_{k-1}) w_k) / beta_{k+1}: what step k multiplies the difference w_k - L v_k by
+                            for (; amp_at < J; ++amp_at) {
+                                const double ak = h_tri[3 * (size_t)amp_at], akm = amp_at ? h_tri[3 * (size_t)(amp_at - 1)] : 0.0, bk1 = h_tri[3 * (size_t)(amp_at + 1) + 1];
+                                amp = (bk1 > 0.0 ? std::fabs(ak - akm) / bk1 : 0.0) * amp + 1.0;
+                                last_amp = std::max(last_amp, amp);
+                            }
+                            amp_trip = !(last_amp <= amp_max);
+                            if (amp_trip && debug) fprintf(stderr, "[machip]    J=%d: drift factor of the shifted recurrence %.3g > %.3g -- this sequence ends here, the solve continues in the accurate form\n", J, last_amp, amp_max);
+                        }
+                        const bool at_cap = (J >= jcap) || (steps_total >= max_steps && J >= J_enq) || amp_trip;
                         const bool trig = F.triggered();
                         if (switch_est_us > 0.0 && restarts == 0 && !broke && !trig && !at_cap && J >= 128 && to_go < 1e17 &&
                             to_go * (4.2 + 2e-6 * (double)nnz) > 1.3 * switch_est_us) {
@@ -1937,7 +1996,7 @@ struct Solver {
                                 const double qnan = std::numeric_limits<double>::quiet_NaN();
                                 for (int j = J_enq ? J_enq + 1 : 0; j <= hi; ++j) h_tri[3 * (size_t)j + 1] = qnan;
                                 for (int j = J_enq; j < hi; ++j) { h_tri[3 * (size_t)j] = qnan; h_tri[3 * (size_t)j + 2] = qnan; }
-                                ST_TRY(enqueue_chunk(A, pp, chunk, false, false, 0));
+                                ST_TRY(enqueue_chunk(A, pp, chunk, false, false, 0, J_enq));
                                 if (debug) fprintf(stderr, "[machip] chunk enqueue J=%d chunk=%d T=%d next_a=%d\n", J_enq, chunk, T == INT_MAX ? -1 : T, next_a);
                                 J_enq = hi; last_chunk = chunk; tail_at = hi;
                                 steps_total += chunk; spmv_total += chunk;
@@ -1965,7 +2024,7 @@ struct Solver {
                                 const double qnan = std::numeric_limits<double>::quiet_NaN();
                                 for (int j = J_enq ? J_enq + 1 : 0; j <= hi; ++j) h_tri[3 * (size_t)j + 1] = qnan;
                                 for (int j = J_enq; j < hi; ++j) { h_tri[3 * (size_t)j] = qnan; h_tri[3 * (size_t)j + 2] = qnan; }
-                                ST_TRY(enqueue_chunk(A, pp, chunk, false, true, -1));
+                                ST_TRY(enqueue_chunk(A, pp, chunk, false, true, -1, J_enq));
                                 if (debug) fprintf(stderr, "[machip] stream enqueue J=%d chunk=%d prog=%d T=%d next_a=%d\n", J_enq, chunk, prog, T == INT_MAX ? -1 : T, next_a);
                                 J_enq = hi; last_chunk = chunk;
                                 steps_total += chunk; spmv_total += chunk;
@@ -2041,7 +2100,7 @@ struct Solver {
                     } else {
                         // far from the end (a successor will follow): no tail kernel, the successor's first step publishes
                         const bool tailless = tail_ok && depth >= 2 && chunk >= 2;
-                        ST_TRY(enqueue_chunk(A, pp, chunk, f32_seq, tailless, prev_tailless));
+                        ST_TRY(enqueue_chunk(A, pp, chunk, f32_seq, tailless, prev_tailless, J_enq));
                         if (debug) fprintf(stderr, "[machip] enqueue J=%d chunk=%d tailless=%d pub=%d depth=%d near=%d\n", J_enq, chunk, (int)tailless, prev_tailless, depth, (int)near);
                         prev_tailless = tailless ? chunk : 0;
                     }
@@ -2255,6 +2314,7 @@ struct Solver {
             stats->step_ms = step_ms_acc;
             stats->steps_timed = steps_timed_acc;
             stats->steps_lowp = steps_lowp;
+            stats->drift = last_amp;
         }
         if (status == MACHIP_OK && lam < 1e-12 * tiny_l)
             return fail(MACHIP_DISCONNECTED, "lambda_2 ~ 0: the graph is not connected");

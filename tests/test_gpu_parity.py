@@ -634,14 +634,15 @@ def test_teacher_forced_config2_all_twenty_reference_iterates(precision):
         assert sum(steps) <= 3750, sum(steps)
 
 
-@pytest.mark.parametrize("form", ["auto", "panel", "gather"])
+@pytest.mark.parametrize("form", ["auto", "panel", "panel_records", "gather"])
 def test_teacher_forced_config4_all_twenty_iterates(form):
     """BASELINE.json configs[3] (ER N = 100k, 2M candidates): lambda_2 on ALL 20 iterates of the reference's loop with
     ARPACK (tol 1e-13, residual <= 2e-13) standing in for the sparse LU that does not finish at this size
     (tests/golden/er100k_arpack.npz, generator `ER100K_ITERS=20 make_golden.py er100k_arpack`: the reference's
     MAC.laplacian / solve_subset_box_lp / update, SciPy eigsh).  These are the iterates the bench runs: nnz 0.7 M .. 4.0 M,
     the dense ones (6-19) are where the column-panel step spends its steps.  Forms: the automatic choice (gather step on
-    the sparse iterates, panel step on the dense ones), the panel step forced onto every iterate (k_pan_mul + k_pan_fin), the
+    the sparse iterates, panel step on the dense ones), the panel step forced onto every iterate -- round 6's shifted recurrence with
+    its 8-byte operand (panel_u.h: k_pan_mul8 + k_pan_finu, 6 x 42 cells) and round 3's record form (k_pan_mul + k_pan_fin, 12 x 21) --, the
     gather step forced onto every iterate.  (The one-launch panel step and the diagonally preconditioned LOBPCG forms of round 4
     -- measured slower, profiles/r4_c4_one_launch_step.md -- are compiled only with -DMACHIP_EXPERIMENTS and no longer tested here.)"""
     import bench
@@ -654,7 +655,7 @@ def test_teacher_forced_config4_all_twenty_iterates(form):
     P.set_start(reference_start_block(w["n"])[:, 0].copy())
     bits = gv["ref_s_bits"]
     vert = lambda i: np.unpackbits(bits[i])[:m].astype(np.float64)    # noqa: E731
-    P.set_options(**{"auto": {}, "panel": {"panel": 1}, "gather": {"panel": 0}}[form])
+    P.set_options(**{"auto": {}, "panel": {"panel": 1}, "panel_records": {"panel": 1, "panel_u": 0}, "gather": {"panel": 0}}[form])
     steps = []
     _teacher_forced(P, k, w["x0"], vert, gv["lam_traj"], steps_out=steps)
     P.close()
@@ -1148,7 +1149,12 @@ def test_full_size_config4_properties():
     {"stream": 0}, {"stream": 2}, {"stream": 0, "graph": 0, "chunk": 6, "chunk_near": 2}, {"stream": 1, "stream_look": 2, "stream_far": 34},
     {"vcap": 80}, {"asm_g": 8}, {"asm_g": 32, "g": 8, "unroll": 1},
     # column-panel step (panel.h) forced onto small graphs: several panels / row blocks, ragged last panel and tile
-    {"panel": 1, "panel_np": 3}, {"panel": 1, "panel_np": 1, "panel_nb": 2},
+    {"panel": 1}, {"panel": 1, "panel_np": 3}, {"panel": 1, "panel_np": 1, "panel_nb": 2},
+    # ... in record form (round 3: 16-byte records, k_pan_mul + k_pan_fin; the lines around this one run round 6's shifted recurrence, panel_u.h)
+    {"panel": 1, "panel_np": 3, "panel_u": 0}, {"panel": 1, "panel_np": 5, "panel_nb": 7, "panel_b2": 512, "panel_g2": 3, "panel_u": 0},
+    {"panel": 1, "panel_np": 7, "graph": 0, "chunk": 6, "panel_b2": 1024, "panel_u": 0}, {"panel": 1, "panel_u": 0, "stream": 0},
+    # ... the shifted recurrence where the host does not follow the records (no drift monitor there: the plan falls back to records), captured chunks
+    {"panel": 1, "stream": 0}, {"panel": 1, "panel_np": 3, "graph": 1, "chunk": 8},
     {"panel": 1, "panel_np": 5, "panel_nb": 7, "panel_b2": 512, "panel_g2": 3},
     {"panel": 1, "panel_np": 7, "graph": 0, "chunk": 6, "panel_b2": 1024},
     # ... several row blocks per workgroup, the panel loaded once (k_pan_mul_multi; round 4): even split, ragged split (cells that have no row block)
@@ -1292,7 +1298,7 @@ def test_panel_step_multi_round_windows_hub_rows_and_odd_sizes():
             lam, v, _ = P.fiedler(tol=1e-10)
             res[mode] = (lam, v, int(P.stats.lanczos_steps))
         assert abs(res["1"][0] - res["0"][0]) <= 1e-12 * res["0"][0], (n, deg, hub, res["0"][0], res["1"][0])
-        out8 = (C.c_int * 8)()
+        out8 = (C.c_int * 12)()
         nnz_l = n + 2 * (n - 1 + m)
         with _lib.default_options(panel=1):
             assert _lib.load().machip_panel_plan(n, nnz_l, hub + 3 if hub else 127, out8) == 0 and out8[0] == 1   # (the plan admits all four)
@@ -1330,7 +1336,7 @@ def test_automatic_mode_picks_the_multi_cell_panel_step_at_n_200000():
     P.set_start(reference_start_block(n)[:, 0].copy())
     P.set_x(np.ones(m))
     nnz = P.assemble()
-    out8 = (C.c_int * 8)()
+    out8 = (C.c_int * 12)()
     assert _lib.load().machip_panel_plan(n, nnz, 127, out8) == 0
     on, NP, Cc, NB = out8[0], out8[1], out8[2], out8[3]
     assert on == 1 and NB * NP > 256 and nnz / n >= 33.0, (list(out8), nnz / n)       # several cells per workgroup: k_pan_mul_multi
@@ -2220,6 +2226,42 @@ def test_column_panel_step_is_bit_reproducible_run_to_run():
         outs.append((lam, v.copy(), int(P.stats.lanczos_steps)))
     for o in outs[1:]:
         assert o[0] == outs[0][0] and o[2] == outs[0][2] and np.array_equal(o[1], outs[0][1])
+    P.close()
+
+
+def test_shifted_panel_recurrence_reports_its_drift_factor_and_survives_a_tripped_monitor():
+    """Round 6 (mac_amd/csrc/panel_u.h): the column-panel step multiplies the 8-byte vector u = t - sigma v and RECURS the product
+    L v_j = (L u_{j-1} - (alpha_{j-1} - alpha_{j-2}) w_{j-1}) / beta_j instead of gathering v_j.  A rounding error of w is carried forward
+    by |alpha_{j-1} - alpha_{j-2}| / beta_j per step; the host accumulates that factor from the tridiagonal records
+    (machip_solve_stats.drift) and ends the sequence if it passes option panel_u_amp.  On a dense configs[3] iterate: (a) the factor stays
+    tiny (alpha_j settles within a few steps) and lambda_2 / the step count equal the record form's (which gathers v_j itself: drift 0);
+    (b) with the limit forced down to 2 the monitor trips at the first analysis point, the solve goes on in the two-kernel form from the
+    Ritz vector it has (a restart) and still meets the reference's stop rule with the same lambda_2."""
+    import bench
+    w = bench.make_workload("c4")
+    P = _lib.Problem(w["n"], w["fi"], w["fj"], w["fw"], w["ci"], w["cj"], w["cw"])
+    P.set_start(reference_start_block(w["n"])[:, 0].copy())
+    P.set_x(w["x0"])
+    for it in range(7):
+        P.fw_step(w["k"], it); P.fw_commit()
+    P.set_option("panel", 1)
+    P.assemble()
+    lam_u, v_u, _ = P.fiedler()
+    st_u = P.stats.asdict()
+    assert P.solve_mode()[0] == 2 and 1.0 <= st_u["drift"] < 1e3 and st_u["restarts"] == 0, st_u
+    P.set_option("panel_u", 0)
+    P.assemble()
+    lam_r, v_r, _ = P.fiedler()
+    st_r = P.stats.asdict()
+    assert st_r["drift"] == 0.0 and abs(lam_u - lam_r) <= 1e-12 * lam_r and abs(st_u["lanczos_steps"] - st_r["lanczos_steps"]) <= 4, (lam_u, lam_r, st_u, st_r)
+    assert np.abs(sign_align(v_u, v_r) - v_r).max() <= 1e-7
+    P.set_option("panel_u", None)
+    P.set_option("panel_u_amp", 2)
+    P.assemble()
+    lam_t, v_t, _ = P.fiedler()
+    st_t = P.stats.asdict()
+    assert st_t["drift"] > 2.0 and st_t["restarts"] >= 1 and st_t["residual"] < 1e-8, st_t
+    assert abs(lam_t - lam_r) <= 1e-8 * lam_r and np.abs(sign_align(v_t, v_r) - v_r).max() <= 2e-6
     P.close()
 
 

@@ -183,13 +183,14 @@ def test_bench_refuses_to_launch_ranks_without_devices():
 def test_panel_plan_covers_every_row_and_column_within_the_kernel_limits():
     """Shape arithmetic of the column-panel Lanczos step (solver.h plan_panel, exported as machip_panel_plan; host only):
     the panels cover every column, the row blocks every row, a panel fits the LDS next to the row block's image
-    (RPT <= 13 records per worker thread), a worker wave owns at most 8 tiles, and the automatic rule turns the step on
+    (record form: RPT <= 13 records per worker thread; shifted recurrence, panel_u.h: an even panel width within what the chosen
+    k_pan_mul8<LPT, TWT> instantiation holds), a worker wave owns at most 8 tiles, and the automatic rule turns the step on
     only for large, dense-enough matrices with rows the build kernels can describe (a hub row of up to 64 x 127 entries is
     admitted subject to the build's per-panel check, test_gpu_parity's hub cases)."""
     import ctypes as C
     lib = _lib.load()
-    out = (C.c_int * 8)()
-    with _lib.default_options(panel=None, panel_np=None, panel_nb=None):
+    out = (C.c_int * 12)()
+    with _lib.default_options(panel=None, panel_np=None, panel_nb=None, panel_u=None):
         # automatic rule (BASELINE configs[3]: on for the dense iterates only)
         for n, nnz, maxlen, want in ((100000, 700344, 30, 0), (100000, 1747218, 40, 1), (100000, 4044528, 70, 1), (100000, 4044528, 200, 1), (100000, 4044528, 9000, 0),
                                      (10000, 956618, 120, 0), (1728, 5496, 9, 0), (65536, 65536 * 20, 60, 1), (500000, 500000 * 30, 60, 0)):
@@ -197,18 +198,30 @@ def test_panel_plan_covers_every_row_and_column_within_the_kernel_limits():
             assert out[0] == want, (n, nnz, maxlen, list(out))
         assert list(out)[:1] == [0]
         lib.machip_panel_plan(100000, 2700000, 60, out)
-        assert list(out)[:7] == [1, 12, 8334, 21, 75, 5, 9]               # the shape profiles/r3_c4_panel.md measures
+        assert list(out)[:6] == [1, 6, 16668, 42, 38, 3] and list(out)[8:12] == [1, 9, 3, 1]      # the shape profiles/r6_panel_u.md measures
+        with _lib.default_options(panel_u=0):
+            lib.machip_panel_plan(100000, 2700000, 60, out)
+            assert list(out)[:7] == [1, 12, 8334, 21, 75, 5, 9] and out[8] == 0       # the record form's (profiles/r3_c4_panel.md)
+        with _lib.default_options(stream=0):           # (no step-by-step records, no drift monitor: record form)
+            lib.machip_panel_plan(100000, 2700000, 60, out)
+            assert list(out)[:3] == [1, 12, 8334] and out[8] == 0
         rng = np.random.default_rng(3)
         for n in [128, 129, 300, 2000, 8448, 8449, 65536, 100000, 123457, 399999, 1000003] + [int(t) for t in rng.integers(130, 3000000, 40)]:
-            for extra in ({}, {"panel_np": int(rng.integers(1, 40))}, {"panel_nb": int(rng.integers(1, 400))}):
+            for extra in ({}, {"panel_np": int(rng.integers(1, 40))}, {"panel_nb": int(rng.integers(1, 400))}, {"panel_u": 0},
+                          {"panel_u": 0, "panel_np": int(rng.integers(1, 40))}):
                 with _lib.default_options(panel=1, **extra):          # (process defaults: what machip_panel_plan plans under)
                     assert lib.machip_panel_plan(n, 20 * n, 60, out) == _lib.OK
-                on, NP, Cc, NB, NTB, TWW, RPT, g2 = list(out)
+                on, NP, Cc, NB, NTB, TWW, RPT, g2, u, LPT, TWT, cells = list(out)
                 if not on:
                     continue
                 assert NP >= 1 and NP * Cc >= n and (NP - 1) * Cc < n          # every column in exactly one panel, none empty
                 assert NB * NTB * 64 >= n and (NB - 1) * NTB * 64 < n          # every row in exactly one block, none empty
-                assert 1 <= RPT <= 13 and RPT * 960 >= Cc                      # the panel fits LDS / registers
+                if u:       # k_pan_mul8<LPT, TWT>: operand panel + row-block image within 160 KB of LDS, 16-byte loads on even columns
+                    assert extra.get("panel_u") != 0 and cells == 1 and Cc % 2 == 0
+                    assert TWT in (3, 5, 8) and TWW <= TWT and 1 <= LPT <= (9 if TWT == 3 else 8)
+                    assert Cc <= min(1920 * LPT, ((163840 - 8 * 960 * TWT - 256) // 8) & ~1)
+                else:
+                    assert 1 <= RPT <= 13 and RPT * 960 >= Cc                  # the panel fits LDS / registers
                 assert 1 <= TWW <= 8 and TWW * 15 >= NTB and NTB <= 120        # a worker wave's tiles
                 assert 1 <= g2 <= 1024
         assert lib.machip_panel_plan(0, 0, 0, out) == _lib.BAD_ARG

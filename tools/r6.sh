@@ -1,0 +1,45 @@
+#!/bin/bash
+# Round-6 GPU sessions (one gpurun call each): tools/r6.sh <stage>; output under gpurun_out/r6_<stage>/
+set -u
+stage=${1:-a}
+out=gpurun_out/r6_$stage
+mkdir -p $out
+export TMPDIR=/tmp
+case $stage in
+a)  # shifted recurrence (panel_u.h): correctness on the forced-panel tests, then the shape sweep at configs[3]
+    timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "solver_variants_agree or panel_step_multi_round or panel_band_split or column_panel_step_is_bit" > $out/tests.txt 2>&1; tail -5 $out/tests.txt
+    timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "teacher_forced_config4" > $out/tests_c4.txt 2>&1; tail -5 $out/tests_c4.txt
+    timeout 1200 python tools/sweep_panel_u.py c4 20 > $out/sweep_c4.txt 2>&1; tail -16 $out/sweep_c4.txt
+    ;;
+b)  # after moving the prologue into k_pan_mul8's workgroup 0: sweep again, then per-kernel durations of four variants
+    timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "solver_variants_agree or teacher_forced_config4" > $out/tests.txt 2>&1; tail -3 $out/tests.txt
+    timeout 1200 python tools/sweep_panel_u.py c4 20 > $out/sweep_c4.txt 2>&1; tail -13 $out/sweep_c4.txt
+    tools/kstats.sh 24 python tools/sweep_panel_u.py c4 20 0,1,4,6 > $out/kstats.txt 2>&1; cat $out/kstats.txt
+    ;;
+c)  # serpentine tile dealing on / off; streaming bandwidth of this box by working-set size (is a 48 MB matrix served faster than HBM?)
+    timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "solver_variants_agree or teacher_forced_config4 or panel_step_multi_round or column_panel_step_is_bit" > $out/tests.txt 2>&1; tail -3 $out/tests.txt
+    timeout 1200 python tools/sweep_panel_u.py c4 20 0,11,6,12,4,13 > $out/sweep_c4.txt 2>&1; tail -9 $out/sweep_c4.txt
+    python - > $out/membench.txt 2>&1 <<'PY'
+import sys; sys.path.insert(0, ".")
+from mac_amd import _lib
+for mb in (16, 32, 48, 64, 96, 128, 192, 256, 512, 1024):
+    print(mb, "MiB:", _lib.membench(mb << 20, 20), flush=True)
+PY
+    cat $out/membench.txt
+    ;;
+d)  # phase clocks of the matrix kernel (developer build with -DPAN_CLOCKS) on the densest iterate
+    MACHIP_LIB=mac_amd/libmachip_clk.so timeout 900 python tools/pan_clocks.py c4 19 panel=1,panel_u=0 panel=1,panel_u=1 panel=1,panel_u=1,panel_np=8,panel_nb=32 panel=1,panel_u=1,panel_np=6,panel_nb=42 > $out/clocks.txt 2>&1; cat $out/clocks.txt
+    ;;
+e)  # k_pan_mul8 with countable loads (operand into LDS first, chunks multiplied as they land): tests, sweep, clocks
+    timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "solver_variants_agree or teacher_forced_config4 or panel_step_multi_round or column_panel_step_is_bit or panel_band_split" > $out/tests.txt 2>&1; tail -3 $out/tests.txt
+    timeout 1200 python tools/sweep_panel_u.py c4 20 0,1,4,5,6 > $out/sweep_c4.txt 2>&1; tail -8 $out/sweep_c4.txt
+    MACHIP_LIB=mac_amd/libmachip_clk.so timeout 900 python tools/pan_clocks.py c4 19 panel=1,panel_u=0 panel=1,panel_u=1 panel=1,panel_u=1,panel_np=6,panel_nb=42 > $out/clocks.txt 2>&1; cat $out/clocks.txt
+    ;;
+f)  # how many groups of chunk loads leave before the panel is in LDS (PAN_U_AHEAD builds)
+    for a in 1 2 3 5; do
+      echo "== AHEAD $a" >> $out/sweep.txt
+      MACHIP_LIB=mac_amd/libmachip_a$a.so timeout 600 python tools/sweep_panel_u.py c4 20 1,4,6 2>&1 | tail -4 >> $out/sweep.txt
+    done
+    cat $out/sweep.txt
+    ;;
+esac
