@@ -59,7 +59,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 KERNEL = ("one Lanczos step = k_pipe_vec (one kernel: CSR SpMV with gathered operand + all vector work) on sparse iterates, "
-          "k_pan_mul + k_pan_fin (column-panel form, operand in LDS; mac_amd/csrc/panel.h) from ~17 entries per row at N >= 65536")
+          "k_pan_mul8 + k_pan_finu (column-panel form, 8-byte operand of the shifted recurrence in LDS; mac_amd/csrc/panel_u.h) from ~11 entries per row at N >= 65536")
 STEP_KERNELS = ("k_pipe_vec", "k_pipe_stream", "k_pan_mul", "k_pan_fin")     # launches that make up Lanczos steps
 STEP_HEADS = ("k_pipe_vec", "k_pipe_stream", "k_pan_mul")                    # one of these per step
 # reference-equivalent CPU path at sizes where it does finish (measured in the build
@@ -336,7 +336,7 @@ def pmc_traffic(cfg, steps, precision=0, timeout_s=150):
 # ---------------------------------------------------------------------------------------------
 MODE_INFO = {
     1: ("fused Lanczos step, gather form: ONE launch of k_pipe_vec (CSR SpMV with gathered 16-byte records + all vector work of the step)", "step"),
-    2: ("fused Lanczos step, column-panel form: k_pan_mul + k_pan_fin (operand in LDS; mac_amd/csrc/panel.h)", "step"),
+    2: ("fused Lanczos step, column-panel form: k_pan_mul8 + k_pan_finu (8-byte operand in LDS; mac_amd/csrc/panel_u.h; record form k_pan_mul + k_pan_fin with option panel_u = 0)", "step"),
     3: ("fused Lanczos step on the padded fixed-width copy of L(x): ONE launch of k_pipe_vec<.., ELLW>", "step"),
     4: ("one Lanczos step INSIDE the single-workgroup kernel k_lan_persist (matrix in registers / LDS; 64 steps per launch; mac_amd/csrc/persist.h)", "step"),
     5: ("classic two-kernel Lanczos step: k_spmv_* <OpLanczos> + k_lan_update", "step"),
@@ -1169,9 +1169,9 @@ def main():
                 if eig_mode.startswith("row-partitioned"):
                     # measured on one MI355X (profiles/r4_ipc_one_gpu.txt): gather step 13 us + 4.1 us per million entries, device-ordered
                     # exchange +8 us per step (wait + publish launches, flag round trip), peer writes over xGMI ~3 us (unmeasured);
-                    # one GPU runs the column-panel step at 17.8 us
+                    # one GPU runs the column-panel step at 13.7 us (round 6)
                     nnz_m = float(np.mean([r[2] for r in rec])) / 1e6
-                    t1 = 17.8 if cfg == "c4" else 6.7
+                    t1 = 13.7 if cfg == "c4" else 6.7
                     tR = (13.0 if cfg == "c4" else 5.0) + 4.1 * nnz_m / world + 8.0 + 3.0
                     pred = t1 / tR
                     why = (f"row-partitioned eigen-solve: per step {tR:.1f} us predicted (fixed part of the gather step + 4.1 us x {nnz_m:.2f} M entries / {world} ranks "
@@ -1204,7 +1204,7 @@ def main():
             elif top[0] not in (1, 2, 3, 8):
                 tnote = "traffic: null -- the PMC passes count the fused step kernels only; this mode's unit spans several kernels of a chain (or a slice of one persistent launch)"
             if top[0] in (1, 2, 3):
-                note = ("unit = one Lanczos step (one launch of k_pipe_vec, or k_pan_mul + k_pan_fin where the column-panel form runs); "
+                note = ("unit = one Lanczos step (one launch of k_pipe_vec, or k_pan_mul8 + k_pan_finu where the column-panel form runs); "
                         "avg_launch_us = step_ms / steps_timed of machip_solve_stats: hipEvents on the handle's stream around the Krylov "
                         "chunks of every solve in the timed passes (step kernels + one 1-wave tail kernel per chunk, so slightly above "
                         "the pure kernel sums rocprofv3 reports); algorithmic bytes = 12 nnz + 4 (n+1) + 56 n per step whichever "

@@ -123,6 +123,7 @@ def load():
 
 
 OPTION_AUTO = -(1 << 63)      # MACHIP_OPTION_AUTO: "the measured default"
+CREATION_OPTIONS = frozenset({"asm_g", "asm_maxgrid", "vbudget_mb", "vcap"})      # read by machip_create only (options.h, last group)
 
 
 def option_names():
@@ -390,7 +391,11 @@ class Problem:
         return int(self._lib.machip_solve_mode(self._h, C.byref(c))), int(c.value)
 
     def set_option(self, name, value=None):
-        """Entry `name` of this handle's option table (mac_amd/csrc/options.h; value None = the measured default)."""
+        """Entry `name` of this handle's option table (mac_amd/csrc/options.h; value None = the measured default).  Options the library
+        reads when a handle is CREATED (CREATION_OPTIONS) are refused here -- on an existing handle they would silently do nothing: pass
+        them through `with default_options(...)` around the constructor (MAC(options=...) does)."""
+        if value is not None and name in CREATION_OPTIONS:
+            raise ValueError(f"option {name!r} is read when the handle is created: set it with mac_amd._lib.default_options({name}=...) around the constructor")
         check(self._lib.machip_set_option(self._h, name.encode(), OPTION_AUTO if value is None else int(value)))
 
     def set_options(self, **opts):

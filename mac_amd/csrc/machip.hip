@@ -892,6 +892,7 @@ int machip_fiedler_csr(int device, int64_t n, const int32_t* indptr, const int32
         Solver& S = p->sol;
         S.have_prev = false; S.warm_skip = 0; S.warm_fails = 0; S.have_start = false; S.hist_lan_steps = -1; S.hist_lob_iters = -1; S.hist_exact_iters = -1; S.last_steps = 0;
         S.last_steps_lowp = 0; S.J_last = 0; S.last_was_lob = false; S.last_seq_f32 = false; S.solver_mode = 0; S.precision = 0;
+        S.opt = default_options();       // (a cached handle too starts from the process defaults of THIS call: include/machip.h says so -- advisor finding on round 5)
         // same solver selection as a MAC handle gets (solver.h): chain-like matrices may run the
         // single-workgroup / preconditioned modes; "support" = off-chain edges
         p->sol.chain_like = chain_cnt >= (long)(0.98 * (double)(n - 1));
@@ -1450,7 +1451,9 @@ int machip_comm_drop_ipc(machip_problem* p) {
     HIP_TRY(hipStreamSynchronize(p->stream));
     p->sol.ipc = nullptr;
     p->ipcg.reset();
-    p->rank = 0; p->nranks = 1; p->m_pad = p->m;
+    // (an RCCL communicator attached before the IPC leg stays in charge of the gradient shards: rank, size and padding are ITS values --
+    // advisor finding on round 5: the reset below used to turn such a handle into a replicated one with a dangling communicator)
+    if (!p->comm) { p->rank = 0; p->nranks = 1; p->m_pad = p->m; }
     return MACHIP_OK;
 }
 

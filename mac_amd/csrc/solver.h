@@ -305,7 +305,8 @@ struct Solver {
         if (sweeps <= 0) return MACHIP_OK;
         const double pw = (double)std::max(1, OPT(start_pow, 128));
         const double* f = landscape_field(A, pl, sweeps);
-        k_land_weight<<<vgrid(), kBlock, 0, stream>>>(f, part_c, pl.grid, u, n, pw);
+        const double floor_w = 1e-6 * (double)std::max(0, OPT(start_floor_e6, 1000));      // (every entry keeps this share of its draw: kernels.h)
+        k_land_weight<<<vgrid(), kBlock, 0, stream>>>(f, part_c, pl.grid, u, n, pw, floor_w);
         HIP_TRY(hipGetLastError());
         return MACHIP_OK;
     }
@@ -420,11 +421,13 @@ struct Solver {
             ST_TRY(pan_regrow(&panv.ypart, (size_t)pn.NP * ((size_t)n + 2), &dropped));     // (k_pan_step: even plane stride, pairs of rows)
             ST_TRY(pan_regrow(&panv.ps, ((size_t)pn.NP + 1) * (size_t)n, &dropped));
             pan_y_cap = (size_t)pn.NP * (size_t)n;
+            pan_rows_ready = false;
         }
         if (!panv.ovf) ST_TRY(dev_alloc(&panv.ovf, 1));
         if (band && (size_t)n > pan_band_cap) {
             ST_TRY(pan_regrow(&panv.bd, 3 * (size_t)n, &dropped)); ST_TRY(pan_regrow(&panv.bpk, (size_t)n, &dropped));
             pan_band_cap = (size_t)n;
+            pan_rows_ready = false;
         }
         return MACHIP_OK;
     }
@@ -485,6 +488,9 @@ struct Solver {
         if (!rows_ready) {
             HIP_TRY(hipMemsetAsync(panv.ovf, 0, sizeof(int), stream));
             k_pan_rows<<<(n + kBlock - 1) / kBlock, kBlock, 0, stream>>>(A, panv);
+            // (the per-row tables now describe THIS shape: a later solve of the same matrix in the shape the assembly had written them for
+            // must not take the old flag for them -- advisor finding on round 5)
+            pan_rows_ready = true; pan_rows_NP = pn.NP; pan_rows_C = pn.C; pan_rows_band = band;
         }
         {
             const int g = pan_build_grid(pn.NB, pn.NP);

@@ -53,8 +53,12 @@ class MAC:
         self.fiedler_tol = fiedler_tol
         self.min_selection_weight_tol = min_selection_weight_tol
         self.max_lanczos_steps = max_lanczos_steps
-        self._dev = _lib.Problem(num_nodes, fi, fj, fw, ci, cj, cw,
-                                 min_selection_weight_tol=min_selection_weight_tol, device=device)
+        # (options read when the handle is MADE -- assembly group width, basis budget -- go in as process defaults around its creation)
+        options = dict(options or {})
+        at_creation = {k: options.pop(k) for k in list(options) if k in _lib.CREATION_OPTIONS}
+        with _lib.default_options(**at_creation):
+            self._dev = _lib.Problem(num_nodes, fi, fj, fw, ci, cj, cw,
+                                     min_selection_weight_tol=min_selection_weight_tol, device=device)
         # every cold eigen-solve starts from column 0 of the reference's block (fiedler.py:27-32)
         self._dev.set_start(_fiedler.reference_start_block(num_nodes)[:, 0].copy())
         self._dev.set_solver(_fiedler.solver_mode(fiedler_method))

@@ -1141,6 +1141,40 @@ def test_full_size_config4_properties():
     P.close()
 
 
+def test_landscape_start_keeps_a_floor_under_every_entry():
+    """Advisor finding on round 5 (kernels.h k_land_weight): (u / max u)^128 underflows to 0 almost everywhere, so the weighted start sits on
+    the lowest-degree vertices alone -- and where the Fiedler vector VANISHES there, Lanczos converges to lambda_3 first and the residual test
+    passes it (a true eigenpair).  The graph: two identical random clusters A, B joined through one middle vertex m (A_0 - m - B_0, weak
+    edges), and a pendant vertex p hung on m: by the mirror symmetry v_2 is antisymmetric and EXACTLY zero on m and p, while p (degree 0.5
+    against ~25) is the landscape's one peak; lambda_2 = 6.7e-5 (the bridge), lambda_3 = 2.0e-2 (the pendant's own mode).  With the floor
+    (default 1e-3 of every entry's draw) the solve returns lambda_2; without it (start_floor_e6 = 0) it returns a true eigenvalue, but the
+    wrong one whenever nothing else perturbs the start (NumPy emulation: lambda_3 for floors 0 and 1e-6, lambda_2 from 1e-4 on)."""
+    rng = np.random.default_rng(5)
+    nc = 300
+    A = np.triu(rng.random((nc, nc)) < 0.08, 1)
+    ai, aj = np.nonzero(A)
+    m_, p_ = 2 * nc, 2 * nc + 1
+    n = 2 * nc + 2
+    fi = np.concatenate([ai, ai + nc, [0, nc, m_]]).astype(np.int32)
+    fj = np.concatenate([aj, aj + nc, [m_, m_, p_]]).astype(np.int32)
+    fw = np.concatenate([np.ones(2 * len(ai)), [0.02, 0.02, 0.5]])
+    W = np.zeros((n, n)); W[fi, fj] = fw; W = W + W.T
+    L = np.diag(W.sum(1)) - W
+    ev, V = np.linalg.eigh(L)
+    assert ev[1] > 1e-6 and ev[2] > 100 * ev[1] and np.abs(V[[m_, p_], 1]).max() < 1e-9       # connected; v_2 vanishes on m and p
+    P = _lib.Problem(n, fi, fj, fw, np.array([1], dtype=np.int32), np.array([7], dtype=np.int32), np.array([1.0]))
+    P.set_start(reference_start_block(n)[:, 0].copy())
+    P.set_x(np.zeros(1))
+    lam, v, _ = P.fiedler(tol=1e-10)
+    assert P.solve_mode()[0] in (1, 3) and abs(lam - ev[1]) <= 1e-6 * ev[1] and P.stats.residual < 1e-10, (lam, ev[:4], P.solve_mode())
+    u = P.landscape(3)
+    assert int(np.argmax(u)) == p_                       # the pendant is the peak the weighting moves the start to
+    P.set_option("start_floor_e6", 0)
+    lam0, _, _ = P.fiedler(tol=1e-10)
+    assert min(abs(lam0 - ev[1]) / ev[1], abs(lam0 - ev[2]) / ev[2]) <= 1e-6, (lam0, ev[:4])      # (a true eigenvalue either way; lambda_3 on every run so far)
+    P.close()
+
+
 @pytest.mark.parametrize("opts", [
     {"spmv": 1, "tpr": 4}, {"spmv": 1, "tpr": 16},
     {"g": 4, "block": 256, "unroll": 2}, {"g": 16, "block": 1024},
@@ -2272,6 +2306,18 @@ def test_new_entry_points_reject_bad_arguments():
     m = len(g["cw"])
     with pytest.raises(AssertionError):
         P.set_precision(2)
+    # options read at creation are refused on an existing handle (they would silently do nothing: advisor finding on round 5) ...
+    for nm in sorted(_lib.CREATION_OPTIONS):
+        with pytest.raises(ValueError):
+            P.set_option(nm, 8)
+        P.set_option(nm, None)
+    # ... and MAC(options=...) hands them to the constructor
+    from mac_amd.solvers import MAC
+    from mac_amd.utils.graphs import Edge
+    fixed = [Edge(int(a), int(b), float(w_)) for a, b, w_ in zip(g["fi"], g["fj"], g["fw"])]
+    cand = [Edge(int(a), int(b), float(w_)) for a, b, w_ in zip(g["ci"], g["cj"], g["cw"])]
+    mac = MAC(fixed, cand, int(g["n"]), options={"vcap": 96, "asm_g": 8, "chunk": 6})
+    assert mac._dev.get_option("vcap") == 96 and mac._dev.get_option("asm_g") == 8 and mac._dev.get_option("chunk") == 6
     with pytest.raises(AssertionError):
         _lib.shard_plan(10, 0, 0)
     with pytest.raises(AssertionError):

@@ -42,4 +42,8 @@ f)  # how many groups of chunk loads leave before the panel is in LDS (PAN_U_AHE
     done
     cat $out/sweep.txt
     ;;
+g)  # full GPU test suite + default bench line
+    timeout 2400 python -m pytest tests -x -q -m gpu > $out/tests.txt 2>&1; tail -15 $out/tests.txt
+    timeout 900 python bench.py > $out/bench_c4.json 2> $out/bench_c4.err; cut -c1-1500 $out/bench_c4.json
+    ;;
 esac
