@@ -101,7 +101,16 @@ int machip_get_laplacian(machip_problem* p, int32_t* indptr, int32_t* indices, d
  * reuses the previous Fiedler vector resident on the device (the working form of
  * MAC.Cache, mac.py:17-20); NULL + warm_start==0 uses a fixed device-side
  * pseudo-random vector.  v_out (n) and X_out (n*q, column-major) may be NULL;
- * q in [1,4] Ritz vectors are produced when X_out != NULL. */
+ * q in [1,4] columns are produced when X_out != NULL.  ONLY COLUMN 0 OBEYS THE STOP RULE
+ * (it is v_out).  Columns 1..q-1 are what the reference's block X carries along (fiedler.py:44,
+ * nx:238) -- there q vectors converge together; here they are the next Ritz vectors of the LAST
+ * Krylov sequence of the solve, orthonormalised against column 0 and against 1: guaranteed
+ * orthonormal, orthogonal to the constant vector, with Rayleigh quotients >= lambda_2; how close
+ * they are to v_3, v_4, ... depends on that sequence alone -- after a few hundred steps they are
+ * accurate to 1e-3 .. 1e-7 (tests: er2000_x0), after a short sequence (a restart from an almost
+ * converged vector, 33 steps on er300_x0) or after the preconditioned / exact modes, which keep
+ * no Krylov basis, they are an arbitrary orthonormal completion.  A caller that needs more than
+ * the Fiedler pair must not take them for eigenvectors. */
 int machip_fiedler(machip_problem* p, double tol, int max_steps, const double* x0, int warm_start,
                    double* lambda2, double* v_out, double* X_out, int q,
                    machip_solve_stats* stats);

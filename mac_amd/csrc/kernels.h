@@ -1200,15 +1200,20 @@ __global__ __launch_bounds__(kBlock) void k_ritz_own_rows(const double* __restri
 __global__ __launch_bounds__(kBlock) void k_resid_l1(const double* __restrict__ w, const double* __restrict__ v,
                                                      int n, const double* __restrict__ part_a, int P_a,
                                                      double* __restrict__ part_out, double* __restrict__ rq_out,
-                                                     double* __restrict__ rq_host = nullptr) {
+                                                     double* __restrict__ rq_host = nullptr, double* __restrict__ q4_out = nullptr) {
     __shared__ double sm[4];
     const double rq = reduce_partials(part_a, P_a, sm);
-    double s = 0.0;
-    for (int r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock)
-        s += fabs(w[r] - rq * v[r]);
+    double s = 0.0, q4 = 0.0;
+    for (int r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
+        const double vr = v[r];
+        s += fabs(w[r] - rq * vr);
+        q4 += (vr * vr) * (vr * vr);       // sum v^4 of the unit vector: 1 / (its participation ratio) -- how localised the pair is (solver.h, landscape gate)
+    }
     s = block_sum(s, sm);
+    q4 = block_sum(q4, sm);
     if (threadIdx.x == 0) {
         part_out[blockIdx.x] = s;
+        if (q4_out) q4_out[blockIdx.x] = q4;
         if (blockIdx.x == 0) { *rq_out = rq; if (rq_host) *rq_host = rq; }
     }
 }

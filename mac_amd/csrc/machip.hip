@@ -890,7 +890,7 @@ int machip_fiedler_csr(int device, int64_t n, const int32_t* indptr, const int32
         p->nnz = nnz; p->lnorm = lnorm; p->maxlen = maxlen_csr; p->assembled = true; p->have_vec = false;
         // clean solver state: nothing learnt from, or left over by, an earlier matrix
         Solver& S = p->sol;
-        S.have_prev = false; S.warm_skip = 0; S.warm_fails = 0; S.have_start = false; S.hist_lan_steps = -1; S.hist_lob_iters = -1; S.hist_exact_iters = -1; S.last_steps = 0;
+        S.have_prev = false; S.warm_skip = 0; S.warm_fails = 0; S.last_pr = 0.0; S.have_start = false; S.hist_lan_steps = -1; S.hist_lob_iters = -1; S.hist_exact_iters = -1; S.last_steps = 0;
         S.last_steps_lowp = 0; S.J_last = 0; S.last_was_lob = false; S.last_seq_f32 = false; S.solver_mode = 0; S.precision = 0;
         S.opt = default_options();       // (a cached handle too starts from the process defaults of THIS call: include/machip.h says so -- advisor finding on round 5)
         // same solver selection as a MAC handle gets (solver.h): chain-like matrices may run the
@@ -1321,7 +1321,7 @@ int machip_eval_batch(machip_problem* p, int B, const double* X, double tol, int
                 st = assemble(q);
                 // clean solver state per entry (no step-count history from whatever this lane solved before: the automatic
                 // mode choice reads it): an entry's result does not depend on the lane that takes it or on its place in the batch
-                q->sol.have_prev = false; q->sol.warm_skip = 0; q->sol.warm_fails = 0; q->sol.hist_lan_steps = -1; q->sol.hist_lob_iters = -1; q->sol.hist_exact_iters = -1; q->sol.last_steps = 0; q->sol.last_steps_lowp = 0;
+                q->sol.have_prev = false; q->sol.warm_skip = 0; q->sol.warm_fails = 0; q->sol.last_pr = 0.0; q->sol.hist_lan_steps = -1; q->sol.hist_lob_iters = -1; q->sol.hist_exact_iters = -1; q->sol.last_steps = 0; q->sol.last_steps_lowp = 0;
                 if (st == MACHIP_OK) st = run_fiedler(q, tol, max_steps, nullptr, 0, &lam, nullptr);
             }
             lambda2[b] = lam;
@@ -1361,7 +1361,7 @@ int machip_fw_sweep(machip_problem* p, int B, const int64_t* ks, const double* X
             // every problem starts from a clean solver state: its result does not depend on which lane takes it or on
             // what that lane solved before (= a fresh handle running the reference's loop, frankwolfe.py:53-76)
             Solver& S = q->sol;
-            S.have_prev = false; S.warm_skip = 0; S.warm_fails = 0; S.hist_lan_steps = -1; S.hist_lob_iters = -1; S.hist_exact_iters = -1; S.last_steps = 0; S.last_steps_lowp = 0;
+            S.have_prev = false; S.warm_skip = 0; S.warm_fails = 0; S.last_pr = 0.0; S.hist_lan_steps = -1; S.hist_lob_iters = -1; S.hist_exact_iters = -1; S.last_steps = 0; S.last_steps_lowp = 0;
             int st = machip_set_x(q, X0 + (size_t)b * m);
             double u = std::numeric_limits<double>::infinity();
             int done = 0;

@@ -21,7 +21,7 @@ namespace machip {
 #define MACHIP_OPTION_LIST(X)                                                                                                      \
     /* eigen-solver driver */                                                                                                      \
     X(solver) X(graph) X(debug) X(chunk) X(chunk_near) X(sched) X(near_x10) X(trigger_pct) X(classic_n) X(persist) X(pchunk)      \
-    X(spec_epilogue) X(spec_slack_pct) X(f32_switch_e9) X(tailless) X(stream) X(stream_trigger_pct) X(stream_retry_pct) X(stream_look) X(stream_margin) X(stream_window) X(stream_far) X(start_land) X(start_pow) X(start_floor_e6)                                                                \
+    X(spec_epilogue) X(spec_slack_pct) X(f32_switch_e9) X(tailless) X(stream) X(stream_trigger_pct) X(stream_retry_pct) X(stream_look) X(stream_margin) X(stream_window) X(stream_far) X(start_land) X(start_pow) X(start_floor_e6) X(start_land_pr_permille) X(start_land_min_mean10)                                                                \
     /* launch shape of the fused step / stand-alone products */                                                                    \
     X(spmv) X(g) X(unroll) X(block) X(maxgrid) X(defer) X(tpr) X(ell)                                                              \
     /* column-panel step */                                                                                                        \

@@ -287,6 +287,7 @@ struct Solver {
     // a partitioned solve takes the same turn.
     static constexpr int kWarmSkip = 7;      // doubled by every further probe that fails in a row (at most 63): a trajectory whose vectors keep
     int warm_skip = 0, warm_fails = 0;       // moving pays for ever fewer probes
+    double last_pr = 0.0;                    // participation ratio 1 / sum v^4 of the last explicitly checked vector (0: none yet on this handle)
     // the landscape after `sweeps` Jacobi sweeps (in y_raw or w2; per-workgroup maxima of the last sweep in part_c[0 .. pl.grid))
     // (the sweeps' only per-workgroup output are the maxima in part_c, 3 x kMaxGrid doubles: their grid may exceed kMaxGrid)
     SpmvPlan landscape_plan(long nnz) const { return plan_spmv(opt, n, nnz, kAuto, 3 * kMaxGrid); }
@@ -782,7 +783,7 @@ struct Solver {
         // (the partials and the Rayleigh quotient go straight into mapped pinned memory: two copy kernels less per check)
         double* hp = h_pin + (vcap + 2);
         double* dhp = d_hpin + (vcap + 2);
-        k_resid_l1<<<g2, kBlock, 0, stream>>>(w2, yvec, n, part_a2, pl.grid, dhp, rq_dev, dhp + kMaxGrid);
+        k_resid_l1<<<g2, kBlock, 0, stream>>>(w2, yvec, n, part_a2, pl.grid, dhp, rq_dev, dhp + kMaxGrid, dhp + kMaxGrid + 8);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev1, stream));     // end of the solve's device time if this check passes (no second wait then)
         ++check_seq;
@@ -790,10 +791,11 @@ struct Solver {
         HIP_TRY(hipStreamSynchronize(stream));
         ST_TRY(ipc_check_err("explicit check"));
         ev1_at_check = true;
-        double s = 0.0;
-        for (int i = 0; i < g2; ++i) s += hp[i];
+        double s = 0.0, q4 = 0.0;
+        for (int i = 0; i < g2; ++i) { s += hp[i]; q4 += hp[kMaxGrid + 8 + i]; }
         *res_l1 = s;
         *rq = hp[kMaxGrid];
+        last_pr = q4 > 0.0 ? 1.0 / q4 : (double)n;      // participation ratio of the checked (unit) vector: ~ the number of vertices it lives on
         return MACHIP_OK;
     }
 
@@ -1680,7 +1682,17 @@ struct Solver {
         // (single-workgroup form: k_persist_begin of the first sequence copies it -- one launch less per solve)
         const bool pmode_early = OPT(persist, 1) != 0 && chain_like && persist_fits(n, nnz - n - 2 * chain_edges);
         const double* begin_src = nullptr;
-        const bool land_ok = !start_guess && !pmode_early && n > OPT(classic_n, 256) && OPT(start_land, 3) > 0;
+        // The landscape weighting moves the start to where low eigenvectors LOCALISE; it pays where they do (the Erdos-Renyi iterates:
+        // participation ratio 1-5 vertices, -15 % steps) and costs its sweeps where the Fiedler vector is global (city10000: thousands of
+        // vertices, 297 against 300 it/s in round 5).  Gate, round 6: what the LAST pair this handle checked looked like -- skipped when it lived on
+        // more than start_land_pr_permille of the vertices (default 2 %); a handle's first solve has nothing to go by and weights.
+        // A handle's FIRST solve is gated on the matrix alone: the weighting is for random-graph-like Laplacians (from ~6 entries per row), not for
+        // pose graphs (3-5 entries per row: chain + a few closures), where it never paid (+-1 %) and where a floored, half-localised start flattens
+        // the residual estimate's decay enough to fool the step forecast (city10000: a hand-over to the tridiagonally preconditioned mode, 26 ms
+        // per iteration instead of 3.3 -- tools/floor_probe.py).
+        const bool land_local = last_pr <= 0.0 || last_pr <= 0.001 * (double)std::max(1, OPT(start_land_pr_permille, 20)) * (double)n;
+        const bool land_dense = 10.0 * (double)nnz >= (double)std::max(0, OPT(start_land_min_mean10, 60)) * (double)n;
+        const bool land_ok = !start_guess && !pmode_early && n > OPT(classic_n, 256) && OPT(start_land, 3) > 0 && land_local && land_dense;
         bool warm = start_mode == 1 && have_prev;
         if (warm && land_ok && warm_skip > 0) { --warm_skip; warm = false; }      // (the last warm start was no better than a random vector)
         const bool warm_probe = warm && land_ok;      // this solve measures what its warm start was worth

@@ -50,9 +50,14 @@ def find_fiedler_pair(L, X=None, method="hip", tol=1e-8, seed=None):
     """Second-smallest eigenpair of the graph Laplacian ``L`` (any scipy sparse matrix).
 
     Returns ``(lambda_2, v_2, X)`` like the reference: X is n x q (q = min(4, n-1)), its
-    column 0 is v_2 (unit norm, orthogonal to 1) and the other columns are the next Ritz
-    vectors of the Krylov space (after the preconditioned mode, which keeps no Krylov basis: an
-    orthonormal completion orthogonal to 1 and v_2).  ``X`` (if given) supplies the start vector in column 0.
+    column 0 is v_2 (unit norm, orthogonal to 1) -- the ONLY column that obeys the stop rule.  The
+    other columns are the next Ritz vectors of the solve's last Krylov sequence (orthonormal,
+    orthogonal to 1 and to v_2, Rayleigh quotients >= lambda_2): close to v_3, v_4, ... after a
+    long sequence (1e-3 .. 1e-7 on er2000_x0), an arbitrary orthonormal completion after a short one
+    or after the preconditioned modes, which keep no Krylov basis (include/machip.h, machip_fiedler;
+    tests/test_gpu_parity.py::test_x_block_columns_are_what_the_header_says).  The reference's
+    TraceMIN block converges q vectors together (fiedler.py:44); nothing on the hot path reads more
+    than column 0 (mac.py:112-114).  ``X`` (if given) supplies the start vector in column 0.
     """
     check_method(method)
     L = csr_matrix(L, dtype=np.float64)

@@ -46,4 +46,10 @@ g)  # full GPU test suite + default bench line
     timeout 2400 python -m pytest tests -x -q -m gpu > $out/tests.txt 2>&1; tail -15 $out/tests.txt
     timeout 900 python bench.py > $out/bench_c4.json 2> $out/bench_c4.err; cut -c1-1500 $out/bench_c4.json
     ;;
+h)  # advisor fixes + landscape gate: full GPU suite, X-block probe, pose-graph benches, default bench
+    timeout 2400 python -m pytest tests -x -q -m gpu > $out/tests.txt 2>&1; tail -8 $out/tests.txt
+    timeout 300 python tools/xblock_probe.py > $out/xblock.txt 2>&1; cat $out/xblock.txt
+    for c in c5b c5a c3 c2; do timeout 600 python bench.py --config $c --no-cpu > $out/bench_$c.json 2> $out/bench_$c.err; python -c "import json,sys; d=json.loads(open('$out/bench_$c.json').read().strip().splitlines()[-1]); print('$c', d['value'], d.get('lanczos_steps_per_iter'), d['roofline']['frac'] if d.get('roofline') else None)"; done
+    timeout 900 python bench.py > $out/bench_c4.json 2> $out/bench_c4.err; python -c "import json,sys; d=json.loads(open('$out/bench_c4.json').read().strip().splitlines()[-1]); print('c4', d['value'], d.get('lanczos_steps_per_iter'), d['roofline']['frac'], d['roofline']['traffic'])"
+    ;;
 esac
