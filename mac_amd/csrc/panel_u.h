@@ -56,10 +56,12 @@ __host__ __device__ constexpr int pan_u_cols(int LPT, int TW) {
 // THIS launch -- wave 0 of workgroup 0 alone, beside 251 workgroups of loads -- and leaves (alpha', beta, mu, 1 / beta, j, sigma_j) in
 // A.coef for the row kernel: inside k_pan_finu the same chain (24 loads per lane, six wave totals, a dozen dependent fp64 operations)
 // sat in front of every row's arithmetic (first build of this file: 17.8 against 16.8 us per step at 12 x 21).
-template <int LPT, int TW>
+// TV: type the tile VALUES are read as -- double, or float for the mixed mode (machip_set_precision(1): `bv32` is the panel form's value
+// array rounded to fp32, 6 bytes per entry instead of 10; operand, products and sums stay fp64).
+template <int LPT, int TW, typename TV = double>
 __global__ __launch_bounds__(kPanThreads) void k_pan_mul8(const double* __restrict__ u_cur, const int* __restrict__ a_tptr,
                                                            const unsigned short* __restrict__ a_thead, int a_n, int a_C, int a_NP, int a_TWW,
-                                                           PanView A_, PipeView L, int jrel) {
+                                                           PanView A_, PipeView L, int jrel, const TV* __restrict__ bv32 = nullptr) {
     __shared__ double scoef[8];
     PanView A = A_;
     A.tptr = const_cast<int*>(a_tptr); A.thead = const_cast<unsigned short*>(a_thead); A.n = a_n; A.C = a_C; A.NP = a_NP; A.TWW = a_TWW;
@@ -115,9 +117,9 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul8(const double* __restri
     }
     const int nch = cend[TW - 1];
     const unsigned voff = (unsigned)(E0 + lane);
-    const double* __restrict__ bv = A.bval;
+    const TV* __restrict__ bv = sizeof(TV) == 8 ? reinterpret_cast<const TV*>(A.bval) : bv32;
     const unsigned short* __restrict__ bc = A.bcol;
-    double pv[kPanCH];
+    TV pv[kPanCH];
     int pk[kPanCH];
     constexpr int G = 4;        // chunks per group: their loads leave together, their gathers go out together once the loads are in
     constexpr int AHEAD = PAN_U_AHEAD;    // groups of loads in flight ahead of the group being multiplied; the first AHEAD groups leave BEFORE the panel goes into LDS
@@ -164,12 +166,12 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul8(const double* __restri
 #pragma unroll
             for (int i = 0; i < G; ++i) x[i] = sv[min(pk[g0 + i], Cp - 1)];
 #pragma unroll
-            for (int i = 0; i < G; ++i) pv[g0 + i] *= x[i];
+            for (int i = 0; i < G; ++i) x[i] *= (double)pv[g0 + i];
 #pragma unroll
             for (int i = 0; i < G; ++i) {
                 const int c = g0 + i;
                 if (c < nch) {
-                    acc += pv[c];
+                    acc += x[i];
                     if (endmask & (1u << c)) {       // its lanes' rows are complete
 #pragma unroll
                         for (int q = 0; q < TW; ++q)
@@ -185,8 +187,9 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul8(const double* __restri
 #pragma unroll
             for (int c = 0; c < kPanCH; ++c)
                 if (cb + c < nch) { pv[c] = bv[voff + (unsigned)((cb + c) * 64)]; pk[c] = bc[voff + (unsigned)((cb + c) * 64)]; }
+            double xr[kPanCH];
 #pragma unroll
-            for (int c = 0; c < kPanCH; ++c) pv[c] *= sv[min(pk[c], Cp - 1)];
+            for (int c = 0; c < kPanCH; ++c) xr[c] = (double)pv[c] * sv[min(pk[c], Cp - 1)];
             unsigned em = 0;
 #pragma unroll
             for (int q = 0; q < TW; ++q) {
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul8(const double* __restri
 #pragma unroll
             for (int c = 0; c < kPanCH; ++c) {
                 if (cb + c < nch) {
-                    acc += pv[c];
+                    acc += xr[c];
                     if (em & (1u << c)) {
 #pragma unroll
                         for (int q = 0; q < TW; ++q)

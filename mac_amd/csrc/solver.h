@@ -194,6 +194,11 @@ struct Solver {
     PanU pu{};
     double* pu_sig = nullptr;
     double last_amp = 0.0;         // largest accumulated drift factor of the last solve's shifted sequences (solve stats / tests)
+    // mixed mode of the panel step (machip_set_precision(1), round 6): the LATE steps of a sequence read the tile values rounded to fp32
+    bool pan32 = false;            // this solve may switch (shifted recurrence, eager launches, an instantiated shape)
+    int pan32_from = INT_MAX;      // ... from this step of the running sequence on (decided by the host from the records; INT_MAX: not yet)
+    float* pan_bv32 = nullptr;     // the panel form's value array rounded to fp32 (same layout as panv.bval)
+    size_t pan_bv32_cap = 0;
     size_t pan_cap = 0, pan_nt_cap = 0, pan_y_cap = 0, pan_band_cap = 0;
     std::array<int, 5> pan_shape_key{0, 0, 0, 0, 0};     // shape the cells' static ranges (panv.cbase) were computed for
     PatternView pat{};          // union pattern of the handle (machip_create); none on a CSR-only handle
@@ -252,7 +257,7 @@ struct Solver {
         {
             void* pb[] = {panv.tptr, panv.thead, panv.bval, panv.bcol, panv.ypart, panv.coef, panv.cbase, panv.ps, panv.tick, panv.claim, panv.ovf, panv.bd, panv.bpk};
             for (void* q : pb) if (q) (void)hipFree(q);
-            void* pu_[] = {pu.U0, pu.U1, pu.W, pu_sig};
+            void* pu_[] = {pu.U0, pu.U1, pu.W, pu_sig, pan_bv32};
             for (void* q : pu_) if (q) (void)hipFree(q);
             void* pk[] = {ppack.band, ppack.cc, ppack.crow, ppack.ccol, ppack.cval, ell_col, ell_val};
             for (void* q : pk) if (q) (void)hipFree(q);
@@ -525,6 +530,15 @@ struct Solver {
         }
 #endif
         if (pan_u) {             // shifted recurrence (panel_u.h): 8-byte operand, no prologue in the matrix kernel; the row kernel leads
+            if (pan32 && jhost >= 0 && jhost >= pan32_from) {      // mixed mode: this step reads fp32 tile values (TWT = 3 shapes only: solve() checks)
+                switch (pan.LPT) {
+#define MACHIP_PANU32_CASE(LP) case LP: k_pan_mul8<LP, 3, float><<<g1, kPanThreads, 0, stream>>>(PAN_MUL8_ARGS(panv, pu, L, s), pan_bv32); break;
+                    MACHIP_PANU32_CASE(1) MACHIP_PANU32_CASE(2) MACHIP_PANU32_CASE(3) MACHIP_PANU32_CASE(4) MACHIP_PANU32_CASE(5) MACHIP_PANU32_CASE(6)
+                    MACHIP_PANU32_CASE(7) MACHIP_PANU32_CASE(8) MACHIP_PANU32_CASE(9)
+#undef MACHIP_PANU32_CASE
+                    default: break;
+                }
+            } else
             switch (pan.LPT * 10 + pan.TWT) {
 #define MACHIP_PANU_CASE(LP, TW) case LP * 10 + TW: k_pan_mul8<LP, TW><<<g1, kPanThreads, 0, stream>>>(PAN_MUL8_ARGS(panv, pu, L, s)); break;
 #define MACHIP_PANU_ROW(LP) MACHIP_PANU_CASE(LP, 3) MACHIP_PANU_CASE(LP, 5) MACHIP_PANU_CASE(LP, 8)
@@ -1728,9 +1742,12 @@ struct Solver {
         const bool pmode = pmode_early;
         // column-panel step (panel.h) where the gather operand is too large for the caches (fp64 sequences only)
         // (shifted recurrence, panel_u.h: only where the host follows the records step by step -- its drift monitor lives there)
-        pan = plan_panel(opt, n, nnz, maxlen_hint, pan_allowed && precision == 0 && !pmode && !classic && pp.variant == kVec && !shard && !ipc, (long)csr_cap,
+        pan = plan_panel(opt, n, nnz, maxlen_hint, pan_allowed && !pmode && !classic && pp.variant == kVec && !shard && !ipc, (long)csr_cap,
                          false, OPT(stream, 1) != 0);   // (the row-partitioned solve shards the gather step)
-        pan_u = false; last_amp = 0.0;
+        pan_u = false; last_amp = 0.0; pan32 = false; pan32_from = INT_MAX;
+        // mixed mode: only the shifted recurrence in a shape whose fp32-tile kernel exists, launched eagerly (the step index decides which tiles
+        // a launch reads); anything else keeps round 2's fp32 gather sequences
+        if (precision == 1 && !(pan.on && pan.u && pan.TWT == 3 && OPT(pan32, 1) != 0)) pan.on = false;
         // padded fixed-width form for short rows (pose graphs beyond the single-workgroup kernel): no row-pointer round trip
         if (!pan.on && !pmode && !classic && !shard && !ipc && precision == 0 && pp.variant == kVec && pp.width == 4 && pp.defer < 3 &&
             maxlen_hint >= 1 && maxlen_hint <= 16 && OPT(ell, 1) != 0) {
@@ -1761,6 +1778,17 @@ struct Solver {
                     pu.sig = pu_sig;
                 }
                 pan_u = true;
+                if (precision == 1 && !use_graph(launch_us_hist[kPanel] > 0.0 ? launch_us_hist[kPanel] : 8.0)) {
+                    if (pan_bv32_cap < pan_cap) {
+                        HIP_TRY(hipStreamSynchronize(stream));
+                        if (pan_bv32) (void)hipFree(pan_bv32);
+                        pan_bv32 = nullptr; pan_bv32_cap = 0;
+                        ST_TRY(dev_alloc(&pan_bv32, pan_cap));
+                        pan_bv32_cap = pan_cap;
+                    }
+                    k_to_f32<<<(int)std::min<long>(kMaxGrid, ((long)pan_cap + kBlock - 1) / kBlock), kBlock, 0, stream>>>(panv.bval, pan_bv32, (long)pan_cap);
+                    pan32 = true;
+                }
             }
         }
         {   // eager launches or captured chunks for this solve's fused steps (use_graph)
@@ -1833,6 +1861,7 @@ struct Solver {
         while (!done && steps_total < max_steps) {
             // ---- (re)start a Krylov sequence from u ----
             seq_sharded = false; seq_ipc = false;
+            pan32_from = INT_MAX;
             if (pmode) {
                 ++epoch;
                 k_persist_begin<<<g2, kBlock, 0, stream>>>(persist_view(), (int)epoch, begin_src);
@@ -1946,6 +1975,19 @@ struct Solver {
                         const bool broke = F.broke;
                         const double est = F.est;
                         est_latest = est; to_go = F.to_go;
+                        // Mixed mode of the panel step: products may be INEXACT late in a Krylov sequence -- an error E_j in step j's product enters the
+                        // final residual weighted by the Ritz vector's coefficient of v_j, which is ~ the residual at that step (Simoncini 2005 /
+                        // Bouras & Fraysse: relaxed accuracy of matrix-vector products in projection methods) -- not early.  So the sequence starts on
+                        // the fp64 tiles and switches to the fp32 copy (6 bytes per entry instead of 10, relative error 6e-8) once the estimate is below
+                        // pan32_switch_e9 1e-9 ||L||.  Measured on the 20 configs[3] iterates (tools/pan32_probe.py, profiles/r6_pan32.md): 1e-3 passes the
+                        // explicit check on 19 -- residuals unchanged in the second digit -- and FAILS on the near-degenerate iterate 6 (353 steps:
+                        // the gap grows with 1 / (1 - convergence rate)), whose restart in the two-kernel form then costs 5 000 steps; 3e-4 (default)
+                        // passes on all twenty.  The switch step is a function of the records alone: 32 steps behind the analysis point that saw
+                        // the threshold -- as far as the feeder lets the queue run while undecided.
+                        if (pan32 && pan32_from == INT_MAX && est < 1e-9 * (double)std::max(1, OPT(pan32_switch_e9, 300000)) * tiny_l) {
+                            pan32_from = (J + 32 + 1) & ~1;       // (the feeder has held the queue at next_a + 32 = J + 32 until now)
+                            if (debug) fprintf(stderr, "[machip]    J=%d: estimate %.2e -- fp32 tile values from step %d on\n", J, est / tiny_l, pan32_from);
+                        }
                         bool amp_trip = false;
                         if (pan_u && pp.variant == kPanel) {
                             // w_{k+1} = (L u_k - (alpha_k - alpha_{k-1}) w_k) / beta_{k+1}: what step k multiplies the difference w_k - L v_k by
@@ -1989,10 +2031,11 @@ struct Solver {
                             if (debug) fprintf(stderr, "[machip]    check J=%d rq=%.15g res=%.3e (tol %.1e) ran=%d\n", Jeff, rq, res, tol, J_enq);
                             if (res < tol) {
                                 converged = true; status = MACHIP_OK; final_check_seq = check_seq; steps_used += Jeff;
+                                if (pan32 && pan32_from < Jeff) steps_lowp += Jeff - pan32_from;      // (steps that read fp32 tile values)
                                 if (restarts == 0 && !sm.s.empty()) start_overlap = std::fabs(sm.s[0]);     // <v_0, y>: what the start vector was worth
                                 break;
                             }
-                            if (broke || at_cap) { need_restart = true; steps_used += Jeff; break; }
+                            if (broke || at_cap) { need_restart = true; steps_used += Jeff; if (pan32 && pan32_from < Jeff) steps_lowp += Jeff - pan32_from; break; }
                             F.lower_target(retry_s * last_check_est);      // the estimate flattered the residual: further down before the next check
                             T = std::max(T, J_enq + 2);
                         }
@@ -2009,6 +2052,7 @@ struct Solver {
                                         : remaining >= 12 ? (int)std::min<long>(chunk0, ((long)(0.7 * (double)remaining) + 1) & ~1L) : (int)((remaining + 1) & ~1L);
                             chunk = std::min(std::max(chunk, 2), jcap - J_enq);
                             chunk = (int)std::min<long>(chunk, max_steps - steps_total) & ~1;
+                            if (pan32 && pan32_from == INT_MAX) chunk = std::min(chunk, std::max(0, next_a + 32 - J_enq)) & ~1;
                             if (chunk >= 2) {
                                 const int hi = J_enq + chunk;
                                 const double qnan = std::numeric_limits<double>::quiet_NaN();
@@ -2034,6 +2078,9 @@ struct Solver {
                             // shapes -- two steps at a time, every decision on the latest forecast
                             if (!eager) while (2 * chunk <= chunk0 && 5 * (long)(2 * chunk) <= 3 * remaining + 4) chunk *= 2;
                         }
+                        // (mixed panel mode, switch step not decided yet: nothing is enqueued beyond 32 steps behind the next analysis point, so that
+                        // the point that sees the threshold can still name a switch step nobody has launched -- a function of the records alone)
+                        if (pan32 && pan32_from == INT_MAX) chunk = std::min(chunk, std::max(0, next_a + 32 - J_enq));
                         if (chunk > 0) {
                             chunk = std::min(chunk, jcap - J_enq);
                             chunk = (int)std::min<long>(chunk, max_steps - steps_total) & ~1;

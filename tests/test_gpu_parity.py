@@ -571,7 +571,7 @@ def test_city10000_vertices_until_the_fork():
 # dv = 2e-6 (the Fiedler-vector tolerance of this file) gives |dg| <= 2 sqrt(w T) dv + w dv^2 (the golden stores the
 # reference's own relative gap at the K-th place: 1e-7 .. 1e-4, near-ties are the rule with equal weights).
 # --------------------------------------------------------------------------------------------
-def _teacher_forced(P, k, x0, ref_vertices, lam_ref, wmax=1.0, dv=2e-6, steps_out=None):
+def _teacher_forced(P, k, x0, ref_vertices, lam_ref, wmax=1.0, dv=2e-6, steps_out=None, stats_out=None):
     x = np.array(x0, dtype=np.float64)
     worst = 0.0
     for i, lam_gold in enumerate(lam_ref):
@@ -579,6 +579,8 @@ def _teacher_forced(P, k, x0, ref_vertices, lam_ref, wmax=1.0, dv=2e-6, steps_ou
         lam, _, _ = P.fiedler(tol=1e-8, want_vec=False)
         if steps_out is not None:
             steps_out.append(int(P.stats.lanczos_steps))
+        if stats_out is not None:
+            stats_out.append(P.stats.asdict())
         rel = abs(lam - lam_gold) / abs(lam_gold)
         worst = max(worst, rel)
         assert rel <= LAM_RTOL, (i, lam, lam_gold, rel)
@@ -634,7 +636,7 @@ def test_teacher_forced_config2_all_twenty_reference_iterates(precision):
         assert sum(steps) <= 3750, sum(steps)
 
 
-@pytest.mark.parametrize("form", ["auto", "panel", "panel_records", "gather"])
+@pytest.mark.parametrize("form", ["auto", "panel", "panel_records", "gather", "panel_mixed"])
 def test_teacher_forced_config4_all_twenty_iterates(form):
     """BASELINE.json configs[3] (ER N = 100k, 2M candidates): lambda_2 on ALL 20 iterates of the reference's loop with
     ARPACK (tol 1e-13, residual <= 2e-13) standing in for the sparse LU that does not finish at this size
@@ -643,7 +645,9 @@ def test_teacher_forced_config4_all_twenty_iterates(form):
     the dense ones (6-19) are where the column-panel step spends its steps.  Forms: the automatic choice (gather step on
     the sparse iterates, panel step on the dense ones), the panel step forced onto every iterate -- round 6's shifted recurrence with
     its 8-byte operand (panel_u.h: k_pan_mul8 + k_pan_finu, 6 x 42 cells) and round 3's record form (k_pan_mul + k_pan_fin, 12 x 21) --, the
-    gather step forced onto every iterate.  (The one-launch panel step and the diagonally preconditioned LOBPCG forms of round 4
+    gather step forced onto every iterate; and the panel step in the MIXED mode (machip_set_precision(1), BASELINE configs[4]'s technique at the one
+    config whose step is bound by bytes): fp64 tile values until the residual estimate is below 3e-4 ||L||, their fp32 copy (6 bytes per entry
+    instead of 10) from 32 steps behind that point on -- same stop rule on the fp64 matrix, lambda_2 to 1e-8 on every iterate.  (The one-launch panel step and the diagonally preconditioned LOBPCG forms of round 4
     -- measured slower, profiles/r4_c4_one_launch_step.md -- are compiled only with -DMACHIP_EXPERIMENTS and no longer tested here.)"""
     import bench
     w = bench.make_workload("c4")
@@ -655,10 +659,16 @@ def test_teacher_forced_config4_all_twenty_iterates(form):
     P.set_start(reference_start_block(w["n"])[:, 0].copy())
     bits = gv["ref_s_bits"]
     vert = lambda i: np.unpackbits(bits[i])[:m].astype(np.float64)    # noqa: E731
-    P.set_options(**{"auto": {}, "panel": {"panel": 1}, "panel_records": {"panel": 1, "panel_u": 0}, "gather": {"panel": 0}}[form])
-    steps = []
-    _teacher_forced(P, k, w["x0"], vert, gv["lam_traj"], steps_out=steps)
+    P.set_options(**{"auto": {}, "panel": {"panel": 1}, "panel_records": {"panel": 1, "panel_u": 0}, "gather": {"panel": 0}, "panel_mixed": {"panel": 1}}[form])
+    if form == "panel_mixed":
+        P.set_precision(1)
+    steps, stats = [], []
+    _teacher_forced(P, k, w["x0"], vert, gv["lam_traj"], steps_out=steps, stats_out=stats)
     P.close()
+    if form == "panel_mixed":       # the late steps really read fp32 tiles (a solve shorter than ~150 steps never gets there), and nothing restarted
+        # (measured: 838 of 4 226 steps on the bench trajectory -- Lanczos converges superlinearly, the estimate passes 3e-4 ||L|| late)
+        assert sum(1 for st in stats if st["steps_lowp"] > 0) >= 15 and sum(st["steps_lowp"] for st in stats) > 0.1 * sum(steps), [(st["lanczos_steps"], st["steps_lowp"]) for st in stats]
+        assert all(st["restarts"] == 0 for st in stats)
     assert sum(steps) <= 4250, sum(steps)       # landscape-weighted cold start: 3 913 steps on these 20 matrices, 4 632 from the start column as drawn
 
 

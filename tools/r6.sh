@@ -52,4 +52,9 @@ h)  # advisor fixes + landscape gate: full GPU suite, X-block probe, pose-graph 
     for c in c5b c5a c3 c2; do timeout 600 python bench.py --config $c --no-cpu > $out/bench_$c.json 2> $out/bench_$c.err; python -c "import json,sys; d=json.loads(open('$out/bench_$c.json').read().strip().splitlines()[-1]); print('$c', d['value'], d.get('lanczos_steps_per_iter'), d['roofline']['frac'] if d.get('roofline') else None)"; done
     timeout 900 python bench.py > $out/bench_c4.json 2> $out/bench_c4.err; python -c "import json,sys; d=json.loads(open('$out/bench_c4.json').read().strip().splitlines()[-1]); print('c4', d['value'], d.get('lanczos_steps_per_iter'), d['roofline']['frac'], d['roofline']['traffic'])"
     ;;
+j)  # mixed panel mode (late fp32 tiles) + everything since h
+    timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "teacher_forced_config4 or x_block or landscape or mixed or precision" > $out/tests_a.txt 2>&1; tail -6 $out/tests_a.txt
+    for p in 0 1; do timeout 600 python bench.py --config c4 --no-cpu --no-warm --no-pmc --no-same-node --precision $p > $out/bench_c4_p$p.json 2> $out/bench_c4_p$p.err; python -c "import json,sys; d=json.loads(open('$out/bench_c4_p$p.json').read().strip().splitlines()[-1]); print('c4 precision $p', d['value'], d.get('lanczos_steps_per_iter'), d['roofline']['frac'], d['roofline']['solver_modes'])"; done
+    timeout 2400 python -m pytest tests -x -q -m gpu > $out/tests.txt 2>&1; tail -6 $out/tests.txt
+    ;;
 esac
