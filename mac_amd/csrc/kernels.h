@@ -763,7 +763,11 @@ __device__ __forceinline__ PipeCoef pipe_prologue_wave0(const PV& L, int jrel, i
     const int lane = threadIdx.x;   // caller guarantees threadIdx.x < 64
     const int jA = *(jrel == 0 && adv_jA < 0 ? &L.st->jN : &L.st->jA);        // (requested first, consumed last: in flight together with the partial loads below)
     const double* __restrict__ pin = L.part + (size_t)(jrel & 1) * (kNP * kMaxGrid);
-    const double sg_prev = L.sig ? L.sig[jrel & 1] : 0.0;      // (shifted records: requested with the partials)
+    // (shifted records: sigma is requested with the partials.  The load is UNCONDITIONAL -- the record form reads a partial it ignores --
+    // because a branch here sat between the counter load and the 24 partial loads of every step of every form and cost the gather step
+    // 0.24 us: configs[1] 6.40 -> 6.64 us, the 4-lane sweep -5 %, same-box A/B of round 5's library against round 6's first)
+    const double sg_raw = *(L.sig ? L.sig + (jrel & 1) : pin);
+    const double sg_prev = L.sig ? sg_raw : 0.0;
     double a[kNP];
     {   // The first 256 partials per quantity: 24 UNCONDITIONAL loads per lane (always in bounds: the arrays hold kMaxGrid
         // entries), masked afterwards.  Round 2, tools/ubench5.hip + the ISA: written as `i < P ? pin[..] : 0` (or as a loop

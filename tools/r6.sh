@@ -57,4 +57,27 @@ j)  # mixed panel mode (late fp32 tiles) + everything since h
     for p in 0 1; do timeout 600 python bench.py --config c4 --no-cpu --no-warm --no-pmc --no-same-node --precision $p > $out/bench_c4_p$p.json 2> $out/bench_c4_p$p.err; python -c "import json,sys; d=json.loads(open('$out/bench_c4_p$p.json').read().strip().splitlines()[-1]); print('c4 precision $p', d['value'], d.get('lanczos_steps_per_iter'), d['roofline']['frac'], d['roofline']['solver_modes'])"; done
     timeout 2400 python -m pytest tests -x -q -m gpu > $out/tests.txt 2>&1; tail -6 $out/tests.txt
     ;;
+final)  # measurement round: bench lines of every config, rocprofv3 summaries (c4, c2, c3, c5b), the mixed leg, two ranks on one GPU
+    R=${2:-r6}
+    timeout 900 python bench.py > $out/${R}_bench_c4.json 2> $out/bench_c4.err
+    for c in c2 c3 c5a c5b; do timeout 600 python bench.py --config $c > $out/${R}_bench_$c.json 2> $out/bench_$c.err; done
+    timeout 300 python bench.py --config c5 > $out/${R}_bench_c5.json 2>> $out/bench_c5.err
+    timeout 300 python bench.py --config c5 --precision 1 > $out/${R}_bench_c5_mixed.json 2>> $out/bench_c5.err
+    timeout 600 python bench.py --config c4 --precision 1 --no-cpu --no-same-node > $out/${R}_bench_c4_mixed.json 2>> $out/bench_c4m.err
+    timeout 300 python bench.py --config c5s > $out/${R}_bench_c5s.json 2>> $out/bench_c5.err
+    timeout 600 python bench.py --config c4s > $out/${R}_bench_c4s.json 2>> $out/bench_c4s.err
+    timeout 600 python bench.py --config c2s > $out/${R}_bench_c2s.json 2>> $out/bench_c4s.err
+    MACHIP_SHARE_GPU=1 timeout 900 python bench.py --gpus 2 --steps 20 --warmup 2 > $out/${R}_bench_c4_2ranks_one_gpu.json 2> $out/bench_2r.err
+    for c in c4 c2 c3 c5b; do bash tools/profile_round.sh ${R}_$c --config $c --warmup 0 > $out/prof_$c.log 2>&1; done
+    for t in ${R}_c4 ${R}_c2 ${R}_c3 ${R}_c5b; do python tools/summarize_profile.py $t > $out/summarize_$t.log 2>&1; f=$(find gpurun_out/$t/trace -name "t_kernel_stats.csv" | head -1); cp "$f" $out/${t}_kernel_stats.csv; cp profiles/${t}_summary.md profiles/${t}_summary.json $out/; rm -rf gpurun_out/$t; done
+    for f in $out/${R}_bench_*.json; do python - $f <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(sys.argv[1].split("/")[-1], round(d["value"], 1), d.get("roofline", {}).get("frac"), d.get("roofline", {}).get("traffic"), d.get("warm_start", {}).get("value"), d.get("lanczos_steps_per_iter"))
+except Exception as e:
+    print(sys.argv[1], "ERR", e)
+PY
+    done
+    ;;
 esac

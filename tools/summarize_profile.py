@@ -48,7 +48,7 @@ for (n, calls, tot, avg, pct, mn, mx) in stats:
 heads = [r for r in rows if r["kernel"].startswith(("k_pipe_vec", "k_pipe_stream", "k_pan_mul"))]
 parts = [r for r in rows if r["kernel"].startswith(("k_pipe_vec", "k_pipe_stream", "k_pan_mul", "k_pan_fin"))]
 calls = sum(r["calls"] for r in heads)
-dom = dict(kernel="one Lanczos step: k_pipe_vec (gather form) or k_pan_mul + k_pan_fin (column-panel form)", calls=calls,
+dom = dict(kernel="one Lanczos step: k_pipe_vec (gather form) or k_pan_mul8 + k_pan_finu (column-panel form, 8-byte operand; k_pan_mul + k_pan_fin in record form)", calls=calls,
            avg_us=sum(r["avg_us"] * r["calls"] for r in parts) / max(1, calls),
            hbm_bytes_per_launch=sum(r["hbm_bytes_per_launch"] * r["calls"] for r in parts) / max(1, calls),
            gather_steps=sum(r["calls"] for r in heads if not r["kernel"].startswith("k_pan")),
@@ -81,7 +81,7 @@ with open(out_md, "w") as fh:
                  f"nothing to be cross-checked against: the working set lives in L2 / LDS and the solve is a latency chain (DESIGN section 5).\n\n")
     else:
         fh.write(f"Dominant work: **{dom['kernel']}**, {dom['calls']} steps ({dom['gather_steps']} gather-form at {dom['gather_avg_us']:.2f} us, "
-                 f"{dom['panel_steps']} panel-form at {dom['panel_avg_us']:.2f} us = k_pan_mul + k_pan_fin), kernel time per step {dom['avg_us']:.2f} us, "
+                 f"{dom['panel_steps']} panel-form at {dom['panel_avg_us']:.2f} us = k_pan_mul8 + k_pan_finu), kernel time per step {dom['avg_us']:.2f} us, "
                  f"HBM traffic per step (2*FETCH+WRITE) {dom['hbm_bytes_per_launch']/1e6:.2f} MB.\n\n")
     if bench_line and bench_line.get("roofline") and dom["calls"] > 0 and "inverse_launches" not in dom:
         r = bench_line["roofline"]
