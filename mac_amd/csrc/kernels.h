@@ -653,6 +653,18 @@ __global__ void k_ipc_abort(IpcView I) {   // best effort: release the peers' wa
             for (int ch = 0; ch < kIpcChannels; ++ch) __hip_atomic_store(I.peer_flags[q] + ch * kMaxPeers + I.rank, ~0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 struct PeerVecs { int n = 0; double* v[kMaxPeers] = {}; };     // one vector per rank (y_raw, g)
+// Deliveries into peer-visible copies (records, operand rows, partial sums, Ritz rows, gradient shards of a row-partitioned step) are
+// WRITE-THROUGH stores at system scope, and a delivering wave waits for their acknowledgements before it ends (round 6).  Plain stores
+// stay dirty in the L2 of the XCD the workgroup ran on; the flag that says "step j delivered" is published by the NEXT launch, whose
+// one thread's system fence writes back ITS XCD's L2 only -- so a partial sum stored by the last instructions of a step kernel could be
+// overtaken by the flag and a peer's prologue read the value of two steps before: 2 of 30 two-rank configs[3] runs ended with the ranks
+// disagreeing about where a solve ends (round 5's library and round 6's alike; 3 of 14 with the panel step, whose deliveries all sit at
+// the end of its row kernel; tools/archive/ipc_pan_debug.py).  MI355X_MICROARCH.md, row "publish-large": sc1 stores + vmcnt(0) + flag.
+__device__ __forceinline__ void peer_store(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void peer_store(float* p, float v) { __hip_atomic_store(reinterpret_cast<unsigned int*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void peer_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ---- wave64 sum on the VALU (DPP row shifts + row broadcasts), ~5x faster than the
 // ds_bpermute butterfly; the total lands in lane 63 and is broadcast through an SGPR. ----------
@@ -857,7 +869,7 @@ struct PipeRow {   // per-thread accumulation of the next step's partial sums
         const double v = o.v, t = o.t;              // the sums below are those of the vectors as stored
         vj[r] = o.v;
         if (PS && PS->n) {      // sharded step: the record goes into every rank's copy of the next operand
-            for (int q = 0; q < PS->n; ++q) reinterpret_cast<ZRec<T>*>(par ? PS->Z0[q] : PS->Z1[q])[r] = o;
+            for (int q = 0; q < PS->n; ++q) { ZRec<T>* zq = reinterpret_cast<ZRec<T>*>(par ? PS->Z0[q] : PS->Z1[q]) + r; peer_store(&zq->t, o.t); peer_store(&zq->v, o.v); }
         } else Zn[r] = o;
         acc[0] = __builtin_fma(t, t, acc[0]); acc[1] = __builtin_fma(t, v, acc[1]); acc[2] = __builtin_fma(v, v, acc[2]);
         acc[3] += t; acc[4] += v; acc[5] += fabs(v);
@@ -880,7 +892,7 @@ struct PipeRow {   // per-thread accumulation of the next step's partial sums
             s = wave_total(s);
             if (lane == 0) {
                 const size_t at = (size_t)((jrel + 1) & 1) * (kNP * kMaxGrid) + q * kMaxGrid;
-                if (PS && PS->n) { for (int k = 0; k < PS->n; ++k) PS->part[k][at + PS->first + blockIdx.x] = s; }
+                if (PS && PS->n) { for (int k = 0; k < PS->n; ++k) peer_store(PS->part[k] + at + PS->first + blockIdx.x, s); peer_drain(); }
                 else L.part[at + blockIdx.x] = s;
             }
         }
@@ -994,6 +1006,7 @@ __global__ __launch_bounds__(BLOCK) void k_pipe_vec(const int* __restrict__ a_ro
     }
     PIPE_CLK(wt == 0, 5);
     pr.template store<BLOCK>(L, jrel, smw, PSp);
+    if (SH) peer_drain();          // (every wave's deliveries -- its rows' records -- are acknowledged before the wave ends)
     PIPE_CLK(wt == 0, 6);
 }
 
@@ -1194,9 +1207,10 @@ __global__ __launch_bounds__(kBlock) void k_ritz_own_rows(const double* __restri
         if (!own.mine(r)) continue;
         double t = 0.0;
         for (int ks = 0; ks < KS; ++ks) t += ypart[(size_t)ks * n + r];
-        if (all.n) { for (int q = 0; q < all.n; ++q) all.v[q][r] = t; }      // (ranks in different processes: every rank's copy)
+        if (all.n) { for (int q = 0; q < all.n; ++q) peer_store(all.v[q] + r, t); }      // (ranks in different processes: every rank's copy)
         else y_leader[r] = t;
     }
+    if (all.n) peer_drain();
 }
 
 // ||w - rq * v||_1 partials, rq = sum of the alpha partials (the Rayleigh quotient v.Lv of the
@@ -1272,7 +1286,7 @@ __global__ __launch_bounds__(kBlock) void k_grad(const int* __restrict__ ci, con
         const double d = v[ci[k]] - v[cj[k]];
         const double t = cw[k] * d;
         const double gk = t * d;
-        if (all.n) { for (int q = 0; q < all.n; ++q) all.v[q][k] = gk; }   // (IPC communicator: the shard goes into every rank's gradient)
+        if (all.n) { for (int q = 0; q < all.n; ++q) peer_store(all.v[q] + k, gk); }   // (IPC communicator: the shard goes into every rank's gradient)
         else g[k] = gk;
         if (HIST) {
             const unsigned int bin = (unsigned int)(f64_key(gk) >> sel_shift(0));
@@ -1290,6 +1304,7 @@ __global__ __launch_bounds__(kBlock) void k_grad(const int* __restrict__ ci, con
         for (int i = threadIdx.x; i < kBins; i += kBlock)
             if (lh[i]) atomicAdd(&hr[i], lh[i]);
     }
+    if (all.n) peer_drain();
 }
 
 // The scan that closes a digit pass (one workgroup of BLOCK threads): walk the bins from the top until the cumulative count reaches

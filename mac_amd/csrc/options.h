@@ -31,7 +31,7 @@ namespace machip {
     X(woodbury) X(wb_max) X(wb_hard) X(wb_lane_max) X(exact_big) X(exact_switch) X(gj_look_min) X(lob_density_pct) X(lob_chunk)   \
     X(lob_patience) X(lob_small_s) X(lob_fuse)                                                                                     \
     /* select / assembly / lanes / communicators (the handle-creation ones are read when the handle, or its first lane, is made) */ \
-    X(sel_small) X(sel_fuse) X(asm_g) X(asm_maxgrid) X(vbudget_mb) X(vcap) X(lanes) X(lane_vbudget_mb) X(lane_queues) X(shard_eig) \
+    X(sel_small) X(sel_fuse) X(asm_g) X(asm_maxgrid) X(vbudget_mb) X(vcap) X(lanes) X(lane_vbudget_mb) X(lane_queues) X(shard_eig) X(ipc_panel) \
     X(rccl_timeout_s)                                                                                                              \
     /* experiments (compiled in with -DMACHIP_EXPERIMENTS only: tools/) */                                                         \
     X(cheb_deg) X(cheb_after) X(cheb_chunk) X(cheb_depth) X(panel_fused) X(panel_spin_us) X(lob_pan2)                              \

@@ -61,7 +61,7 @@ __host__ __device__ constexpr int pan_u_cols(int LPT, int TW) {
 template <int LPT, int TW, typename TV = double>
 __global__ __launch_bounds__(kPanThreads) void k_pan_mul8(const double* __restrict__ u_cur, const int* __restrict__ a_tptr,
                                                            const unsigned short* __restrict__ a_thead, int a_n, int a_C, int a_NP, int a_TWW,
-                                                           PanView A_, PipeView L, int jrel, const TV* __restrict__ bv32 = nullptr) {
+                                                           PanView A_, PipeView L, int jrel, const TV* __restrict__ bv32 = nullptr, int b_first = 0) {
     __shared__ double scoef[8];
     PanView A = A_;
     A.tptr = const_cast<int*>(a_tptr); A.thead = const_cast<unsigned short*>(a_thead); A.n = a_n; A.C = a_C; A.NP = a_NP; A.TWW = a_TWW;
@@ -70,7 +70,9 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul8(const double* __restri
     __shared__ double yblk[ROWS];
     static_assert((SVN + ROWS) * 8 <= 163840 - 128, "panel + row-block image exceed the LDS");
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x / A.NP, p = blockIdx.x - b * A.NP;
+    // (b_first: row-partitioned step between processes, solver.h launch_chunk_ipc_pan -- this rank launches the row blocks its rows of the
+    // row kernel need, all panels each; cells, sums and their order are those of the whole launch)
+    const int bl = blockIdx.x / A.NP, p = blockIdx.x - bl * A.NP, b = bl + b_first;
     const int c0 = p * A.C;
     const int Cp = min(A.C, A.n - c0);
     const int npair = (Cp + 1) >> 1;
@@ -230,8 +232,14 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul8(const double* __restri
 template <int BLOCK, int NPM>
 __global__ __launch_bounds__(BLOCK) void k_pan_finu(const double* __restrict__ u_cur, double* __restrict__ u_nxt, double* __restrict__ wvec,
                                                      const double* __restrict__ a_ypart, const double* __restrict__ a_coef, int a_n, int a_NP,
-                                                     PanView A_, PipeView L, int jrel, int jhost) {
+                                                     PanView A_, PipeView L, int jrel, int jhost, PeerSet PS = PeerSet()) {
+    // PS.n > 0: this rank's share [PS.first, PS.first + gridDim.x) of a PS.total-workgroup launch (row-partitioned step between processes):
+    // same rows per workgroup, same partial-sum slots; the next operand's rows and the six sums go into EVERY rank's copy (the operand
+    // buffers of such a sequence live in the record buffers Z0 / Z1, which the peers have mapped), v_j and w stay with the owner.
     __shared__ double smw[kNP * BLOCK];
+    const int bid = PS.n ? PS.first + (int)blockIdx.x : (int)blockIdx.x;
+    const int gtot = PS.n ? PS.total : (int)gridDim.x;
+    const int par = jrel & 1;
     PanView A = A_;
     A.ypart = const_cast<double*>(a_ypart); A.n = a_n; A.NP = a_NP;
     const int n = A.n, NP = A.NP;
@@ -242,7 +250,7 @@ __global__ __launch_bounds__(BLOCK) void k_pan_finu(const double* __restrict__ u
     const bool first = j == 0;
     PipeRow pr;
     pr.clear();
-    for (int r = blockIdx.x * BLOCK + threadIdx.x; r < n; r += gridDim.x * BLOCK) {
+    for (int r = bid * BLOCK + threadIdx.x; r < n; r += gtot * BLOCK) {
         double y[NPM];
 #pragma unroll
         for (int q = 0; q < NPM; ++q) y[q] = A.ypart[(size_t)min(q, NP - 1) * n + r];
@@ -269,12 +277,15 @@ __global__ __launch_bounds__(BLOCK) void k_pan_finu(const double* __restrict__ u
             const double v = pan_vj(alpha, mu, inv, up, vp);
             const double w = __builtin_fma(-alpha, wp, q) * inv;
             const double u = __builtin_fma(-sigma, v, __builtin_fma(-beta, vp, w));
-            vj[r] = v; wvec[r] = w; u_nxt[r] = u;
+            vj[r] = v; wvec[r] = w;
+            if (PS.n) { for (int q = 0; q < PS.n; ++q) peer_store(reinterpret_cast<double*>(par ? PS.Z0[q] : PS.Z1[q]) + r, u); }      // (write-through: kernels.h peer_store)
+            else u_nxt[r] = u;
             pr.acc[0] = __builtin_fma(u, u, pr.acc[0]); pr.acc[1] = __builtin_fma(u, v, pr.acc[1]); pr.acc[2] = __builtin_fma(v, v, pr.acc[2]);
             pr.acc[3] += u; pr.acc[4] += v; pr.acc[5] += fabs(v);
         }
     }
-    pr.template store<BLOCK>(L, jrel, smw);
+    pr.template store<BLOCK>(L, jrel, smw, PS.n ? &PS : nullptr);
+    if (PS.n) peer_drain();
 }
 
 // Start a sequence of the shifted recurrence from u0: U0 = u0, sigma = 0; partials such that step 0 normalises u0 (k_pipe_init's rule).

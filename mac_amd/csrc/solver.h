@@ -192,7 +192,7 @@ struct Solver {
     bool pan_u = false;            // the running sequence's panel steps are those of the shifted recurrence (panel_u.h): 8-byte operand
     bool pan_u_off = false;        // ... ruled out for the rest of this solve (the drift monitor tripped)
     PanU pu{};
-    double* pu_sig = nullptr;
+    double *pu_sig = nullptr, *pu_U0 = nullptr, *pu_U1 = nullptr;     // (pu.U0 / U1 point at these, or at the record buffers under an inter-process communicator)
     double last_amp = 0.0;         // largest accumulated drift factor of the last solve's shifted sequences (solve stats / tests)
     // mixed mode of the panel step (machip_set_precision(1), round 6): the LATE steps of a sequence read the tile values rounded to fp32
     bool pan32 = false;            // this solve may switch (shifted recurrence, eager launches, an instantiated shape)
@@ -257,7 +257,7 @@ struct Solver {
         {
             void* pb[] = {panv.tptr, panv.thead, panv.bval, panv.bcol, panv.ypart, panv.coef, panv.cbase, panv.ps, panv.tick, panv.claim, panv.ovf, panv.bd, panv.bpk};
             for (void* q : pb) if (q) (void)hipFree(q);
-            void* pu_[] = {pu.U0, pu.U1, pu.W, pu_sig, pan_bv32};
+            void* pu_[] = {pu_U0, pu_U1, pu.W, pu_sig, pan_bv32};
             for (void* q : pu_) if (q) (void)hipFree(q);
             void* pk[] = {ppack.band, ppack.cc, ppack.crow, ppack.ccol, ppack.cval, ell_col, ell_val};
             for (void* q : pk) if (q) (void)hipFree(q);
@@ -653,6 +653,43 @@ struct Solver {
         }
         k_pipe_tail<<<1, 64, 0, stream>>>(L, steps);
     }
+    // The same for the column-panel step of the shifted recurrence (round 6): rank r owns the row kernel's workgroups [g0, g1) -- rows
+    // [g0 B, g1 B) -- and launches the matrix kernel for the row blocks those rows lie in, all panels each (a block that straddles two ranks
+    // is multiplied by both: 1 of 42 at configs[3]); the row kernel writes its rows of the next operand and its six sums into every rank's
+    // copy.  Cells, row sums, partial sums and their order are those of the un-partitioned launch: bit-identical.
+    void launch_chunk_ipc_pan(const SpmvPlan& pl, int steps, int j0) {
+        ipc_split(pl);
+        const PipeView L = pview(pl);
+        const PeerSet PS = ipc_peers(pl);
+        const int Rb = 64 * pan.NTB;
+        const long r_lo = (long)ipc->g0 * pan.block2, r_hi = std::min<long>((long)ipc->g1 * pan.block2, (long)n);
+        const int b0 = (int)(r_lo / Rb), b1 = (int)((r_hi + Rb - 1) / Rb);
+        const int g1m = std::max(1, b1 - b0) * pan.NP, gf = ipc->g1 - ipc->g0;
+        const int npm = pan.NP <= 6 ? 6 : pan.NP <= 8 ? 8 : pan.NP <= 12 ? 12 : 16;
+        k_ipc_wait<<<1, 64, 0, stream>>>(ipc->view, 0);              // (whatever the previous chunk / the sequence start left pending)
+        for (int s = 0; s < steps; ++s) {
+            const int jhost = j0 >= 0 ? j0 + s : -1;
+            switch (pan.LPT * 10 + pan.TWT) {
+#define MACHIP_PANU_CASE(LP, TW) case LP * 10 + TW: k_pan_mul8<LP, TW, double><<<g1m, kPanThreads, 0, stream>>>(PAN_MUL8_ARGS(panv, pu, L, s), (const double*)nullptr, b0); break;
+#define MACHIP_PANU_ROW(LP) MACHIP_PANU_CASE(LP, 3) MACHIP_PANU_CASE(LP, 5) MACHIP_PANU_CASE(LP, 8)
+                MACHIP_PANU_ROW(1) MACHIP_PANU_ROW(2) MACHIP_PANU_ROW(3) MACHIP_PANU_ROW(4) MACHIP_PANU_ROW(5) MACHIP_PANU_ROW(6)
+                MACHIP_PANU_ROW(7) MACHIP_PANU_ROW(8) MACHIP_PANU_CASE(9, 3)
+#undef MACHIP_PANU_ROW
+#undef MACHIP_PANU_CASE
+                default: break;
+            }
+            switch (pan.block2 * 100 + npm) {
+#define MACHIP_FINU_CASE(B, M) case B * 100 + M: k_pan_finu<B, M><<<gf, B, 0, stream>>>(PAN_FINU_ARGS(panv, pu, L, s), jhost, PS); break;
+#define MACHIP_FINU_ROW(B) MACHIP_FINU_CASE(B, 6) MACHIP_FINU_CASE(B, 8) MACHIP_FINU_CASE(B, 12) MACHIP_FINU_CASE(B, 16)
+                MACHIP_FINU_ROW(256) MACHIP_FINU_ROW(512) MACHIP_FINU_ROW(1024)
+#undef MACHIP_FINU_ROW
+#undef MACHIP_FINU_CASE
+                default: break;
+            }
+            k_ipc_pubwait<<<1, 64, 0, stream>>>(ipc->view, 0);       // mine delivered; every peer has delivered its operand rows / partial sums of this step
+        }
+        k_pipe_tail<<<1, 64, 0, stream>>>(L, steps);
+    }
     // y_raw = V[:, :J] s: my rows of the basis -> my rows of EVERY rank's y_raw, then everybody holds the whole vector
     int ipc_ritz(const SpmvPlan& pl, int J, const double* s_host) {
         const int g2 = vgrid();
@@ -660,7 +697,7 @@ struct Solver {
         memcpy(h_pin, s_host, sizeof(double) * (size_t)J);
         HIP_TRY(hipMemcpyAsync(sdev, h_pin, sizeof(double) * (size_t)J, hipMemcpyHostToDevice, stream));
         ipc_split(pl);
-        RowOwner own; own.gpb = pipe_gpb(pl); own.gtot = pl.grid; own.g0 = ipc->g0; own.g1 = ipc->g1;
+        RowOwner own; own.gpb = pl.variant == kPanel ? pl.block : pipe_gpb(pl); own.gtot = pl.grid; own.g0 = ipc->g0; own.g1 = ipc->g1;      // (panel form: the row kernel's workgroups own the rows)
         PeerVecs all; all.n = ipc->nranks;
         for (int q = 0; q < all.n; ++q) all.v[q] = ipc->yraw[q];
         k_ritz_partial<<<dim3(g2, KS), kBlock, 0, stream>>>(V, n, J, sdev, ypart, own);
@@ -715,6 +752,7 @@ struct Solver {
     // step count there) hands the records to the host; a chunk that turns out to have no successor gets its tail from flush_tail.
     // j0 >= 0: the sequence's step index of the chunk's first step, known to the host (eager launches only: a captured chunk is replayed at any base)
     void launch_chunk(const CsrView& A, const SpmvPlan& pl, int steps, bool f32 = false, bool tailless = false, int pub = 0, int j0 = -1) {
+        if (pl.variant == kPanel && seq_ipc) { launch_chunk_ipc_pan(pl, steps, j0); return; }
         if (pl.variant == kPanel) {
             PipeView L = pview(pl);
             L.chunk = tailless ? steps : 0; L.pub = std::max(pub, 0); L.pubstep = pub < 0;
@@ -1742,9 +1780,12 @@ struct Solver {
         const bool pmode = pmode_early;
         // column-panel step (panel.h) where the gather operand is too large for the caches (fp64 sequences only)
         // (shifted recurrence, panel_u.h: only where the host follows the records step by step -- its drift monitor lives there)
-        pan = plan_panel(opt, n, nnz, maxlen_hint, pan_allowed && !pmode && !classic && pp.variant == kVec && !shard && !ipc, (long)csr_cap,
-                         false, OPT(stream, 1) != 0);   // (the row-partitioned solve shards the gather step)
+        pan = plan_panel(opt, n, nnz, maxlen_hint, pan_allowed && !pmode && !classic && pp.variant == kVec && !shard, (long)csr_cap,
+                         false, OPT(stream, 1) != 0);   // (the in-process row-partitioned solve shards the gather step)
         pan_u = false; last_amp = 0.0; pan32 = false; pan32_from = INT_MAX;
+        // between processes (round 6): the shifted recurrence partitions by the row kernel's workgroups (launch_chunk_ipc_pan) where one wave of
+        // them covers every row; the record form and the multi-cell shapes are not partitioned
+        if (ipc && !(pan.on && pan.u && precision == 0 && (long)pan.grid2 * pan.block2 >= (long)n && pan.grid2 >= ipc->nranks && OPT(ipc_panel, 1) != 0)) pan.on = false;
         // mixed mode: only the shifted recurrence in a shape whose fp32-tile kernel exists, launched eagerly (the step index decides which tiles
         // a launch reads); anything else keeps round 2's fp32 gather sequences
         if (precision == 1 && !(pan.on && pan.u && pan.TWT == 3 && OPT(pan32, 1) != 0)) pan.on = false;
@@ -1772,11 +1813,15 @@ struct Solver {
             pp.variant = kPanel; pp.grid = pan.fused ? pan.NB * pan.NP : pan.grid2; pp.block = pan.fused ? kBlock : pan.block2;   // (grid = partial sums per quantity)
             pp.width = pan.NP * 100 + pan.RPT; pp.unroll = pan.TWW; pp.defer = pan.NB + (pan.fused ? 1000 : 0) + 10000 * pan.cells + (pan.u ? 1000000 : 0);
             if (pan.u) {
-                if (!pu.U0) {
-                    ST_TRY(dev_alloc(&pu.U0, (size_t)n + 2)); ST_TRY(dev_alloc(&pu.U1, (size_t)n + 2)); ST_TRY(dev_alloc(&pu.W, (size_t)n));
+                if (!pu_U0) {
+                    ST_TRY(dev_alloc(&pu_U0, (size_t)n + 2)); ST_TRY(dev_alloc(&pu_U1, (size_t)n + 2)); ST_TRY(dev_alloc(&pu.W, (size_t)n));
                     ST_TRY(dev_alloc(&pu_sig, 2));
                     pu.sig = pu_sig;
                 }
+                // (inter-process communicator: the operand lives in the record buffers -- 16 n bytes each, idle in this form -- which the peers
+                // have mapped already: the row kernel writes its rows of the next operand into every rank's copy)
+                pu.U0 = ipc ? reinterpret_cast<double*>(Z0) : pu_U0;
+                pu.U1 = ipc ? reinterpret_cast<double*>(Z1) : pu_U1;
                 pan_u = true;
                 if (precision == 1 && !use_graph(launch_us_hist[kPanel] > 0.0 ? launch_us_hist[kPanel] : 8.0)) {
                     if (pan_bv32_cap < pan_cap) {
@@ -1883,7 +1928,7 @@ struct Solver {
                 if (shard && pp.variant == kVec) {       // row-partitioned sequence: every rank starts from the same records
                     seq_sharded = true; seq_plan = pp;
                     ST_TRY(shard_broadcast_init());
-                } else if (ipc && precision == 0 && pp.variant == kVec && pp.grid >= ipc->nranks) {
+                } else if (ipc && precision == 0 && ((pp.variant == kVec && pp.grid >= ipc->nranks) || (pp.variant == kPanel && pan_u))) {
                     // (precision 1: the fp32 sequences run replicated on the very record / partial-sum buffers the peers of a
                     // partitioned step write into, and nothing orders a rank that is still in its fp32 phase against a peer that has
                     // entered the fp64 one -- the mixed mode therefore never partitions; round-4 advisor finding)
@@ -1965,8 +2010,14 @@ struct Solver {
                     // (2) analysis, as soon as the records of the next point are there -- BEFORE the queue is fed: a host that cannot launch as
                     // fast as the GPU runs (eager launches under a profiler) would otherwise feed for ever and never look
                     const int a = std::min(next_a, std::min(J_enq, jcap));       // (J_enq < next_a only at the caps)
+                    // An analysis at a point SHORT of next_a is for the caps only (nothing more will be enqueued).  While the feeder still has
+                    // steps to enqueue it must come first: whether the records up to J_enq have landed before or after the loop passes here is
+                    // timing, and an analysis at J_enq would change every later point -- two ranks of a row-partitioned solve then disagreed
+                    // about where the sequence ends (2 of 30 two-rank configs[3] runs of round 5's library, 3 of 14 with the panel step:
+                    // tools/archive/ipc_pan_debug.py prints the first diverging trace line).
+                    const bool more_coming = J_enq < jcap && steps_total < max_steps && J_enq < std::max(T, next_a);
                     bool analysed = false;
-                    if (prog >= a && a > 0) {
+                    if (prog >= a && a > 0 && (a == next_a || !more_coming)) {
                         analysed = true;
                         ST_TRY(ipc_check_err("Lanczos steps"));
                         const int J = a;

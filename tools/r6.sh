@@ -80,4 +80,7 @@ except Exception as e:
 PY
     done
     ;;
+l)  # row-partitioned panel step between processes
+    timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -s -k "test_ipc_row_partitioned" > $out/tests.txt 2>&1; grep -E "panel step, us|passed|failed|Error" $out/tests.txt | tail -12
+    ;;
 esac
