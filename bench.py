@@ -1167,15 +1167,16 @@ def main():
                 why = ("candidate shard: only the supergradient (0.4 % of an iteration) is divided, the all-gather of the 16 MB gradient costs more "
                        "than it saves; the eigen-solve is replicated on every rank (MACHIP_IPC_EIG=1 row-partitions it between the processes)")
                 if eig_mode.startswith("row-partitioned"):
-                    # measured on one MI355X (profiles/r4_ipc_one_gpu.txt): gather step 13 us + 4.1 us per million entries, device-ordered
-                    # exchange +8 us per step (wait + publish launches, flag round trip), peer writes over xGMI ~3 us (unmeasured);
-                    # one GPU runs the column-panel step at 13.7 us (round 6)
+                    # DESIGN section 7, from measured components: configs[3] runs the column-panel step row-partitioned (round 6): tile-table
+                    # round trip 1.2 + tile stream 5.0 / R + tail 1.5 + boundary 1.8, row kernel 5.5 + boundary 1.8, publish / wait launch 2.5,
+                    # peer writes over xGMI + flag round trip >= 3 (unmeasured); one GPU alone: 13.5 us.  configs[1]: gather step 5 us fixed
+                    # + 4.1 us per million entries / R + 8 us of exchange measured on one GPU + 3.
                     nnz_m = float(np.mean([r[2] for r in rec])) / 1e6
-                    t1 = 13.7 if cfg == "c4" else 6.7
-                    tR = (13.0 if cfg == "c4" else 5.0) + 4.1 * nnz_m / world + 8.0 + 3.0
+                    t1 = 13.5 if cfg == "c4" else 6.7
+                    tR = (1.2 + 5.0 / world + 1.5 + 1.8 + 5.5 + 1.8 + 2.5 + 3.0) if cfg == "c4" else (5.0 + 4.1 * nnz_m / world + 8.0 + 3.0)
                     pred = t1 / tR
-                    why = (f"row-partitioned eigen-solve: per step {tR:.1f} us predicted (fixed part of the gather step + 4.1 us x {nnz_m:.2f} M entries / {world} ranks "
-                           f"+ 8 us device-ordered exchange measured on one GPU + ~3 us of peer writes over xGMI, unmeasured) against {t1} us on one GPU: a single "
+                    why = (f"row-partitioned eigen-solve: per step {tR:.1f} us predicted from measured components (DESIGN section 7: the step's fixed part -- two launch "
+                           f"floors, one cold round trip each, the exchange -- does not shrink with the rank count) against {t1} us on one GPU: a single "
                            "problem of this size does not get faster on more GPUs; replicas mode is what scales")
             out["predicted_vs_1gpu"] = {"factor": pred, "why": why}
     # ---- roofline of the dominant kernel: in-solve duration from the hipEvents that bracket the Krylov chunks

@@ -30,6 +30,9 @@
 #ifndef PAN_U_AHEAD
 #define PAN_U_AHEAD 2
 #endif
+#ifndef PAN_U_NT      // experiment bits: 1 = non-temporal tile loads, 2 = non-temporal partial-product stores, 4 = non-temporal stores of the row kernel
+#define PAN_U_NT 0
+#endif
 
 namespace machip {
 
@@ -131,7 +134,8 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul8(const double* __restri
         for (int i = 0; i < G; ++i) {
             const int c = g0 + i;
             const unsigned off = c < nch ? voff + (unsigned)(c * 64) : (unsigned)E0;      // (wave-uniform choice; no branch)
-            pv[c] = bv[off]; pk[c] = bc[off];
+            if (PAN_U_NT & 1) { pv[c] = __builtin_nontemporal_load(bv + off); pk[c] = __builtin_nontemporal_load(bc + off); }
+            else { pv[c] = bv[off]; pk[c] = bc[off]; }
         }
     };
 #pragma unroll
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul8(const double* __restri
     // the row block's sums, un-sorted by the LDS image: coalesced stores
     for (int rl = wt; rl < R; rl += kPanWorkThreads) {
         const int row = b * R + rl;
-        if (row < A.n) A.ypart[(size_t)p * A.n + row] = yblk[rl];
+        if (row < A.n) { if (PAN_U_NT & 2) __builtin_nontemporal_store(yblk[rl], A.ypart + (size_t)p * A.n + row); else A.ypart[(size_t)p * A.n + row] = yblk[rl]; }
     }
     PAN_CLK(tid == 64, 8); PAN_CLK(tid == 1023, 9);
 }
@@ -229,16 +233,19 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul8(const double* __restri
 // for the coefficient block.
 // NPM: panels whose partials are requested in one batch (>= NP wherever a shape is dispatched on it; clamped loads beyond NP would
 // only re-read the last plane).
-template <int BLOCK, int NPM>
+// SH (compile time): this launch is one rank's share of a row-partitioned step; its PeerSet sits in device memory (PSd).  (First builds of the
+// partitioned form: the set as a by-value argument whose address was taken at run time went to scratch memory, 13.5 -> 18.2 us per step; as a
+// by-value argument never touched it still cost the un-partitioned row kernel 0.46 us -- 208 more bytes of kernel arguments.)
+template <int BLOCK, int NPM, bool SH = false>
 __global__ __launch_bounds__(BLOCK) void k_pan_finu(const double* __restrict__ u_cur, double* __restrict__ u_nxt, double* __restrict__ wvec,
                                                      const double* __restrict__ a_ypart, const double* __restrict__ a_coef, int a_n, int a_NP,
-                                                     PanView A_, PipeView L, int jrel, int jhost, PeerSet PS = PeerSet()) {
-    // PS.n > 0: this rank's share [PS.first, PS.first + gridDim.x) of a PS.total-workgroup launch (row-partitioned step between processes):
+                                                     PanView A_, PipeView L, int jrel, int jhost, const PeerSet* __restrict__ PSd = nullptr) {
+    // SH: this rank's share [PSd->first, PSd->first + gridDim.x) of a PSd->total-workgroup launch (row-partitioned step between processes):
     // same rows per workgroup, same partial-sum slots; the next operand's rows and the six sums go into EVERY rank's copy (the operand
     // buffers of such a sequence live in the record buffers Z0 / Z1, which the peers have mapped), v_j and w stay with the owner.
     __shared__ double smw[kNP * BLOCK];
-    const int bid = PS.n ? PS.first + (int)blockIdx.x : (int)blockIdx.x;
-    const int gtot = PS.n ? PS.total : (int)gridDim.x;
+    const int bid = SH ? PSd->first + (int)blockIdx.x : (int)blockIdx.x;
+    const int gtot = SH ? PSd->total : (int)gridDim.x;
     const int par = jrel & 1;
     PanView A = A_;
     A.ypart = const_cast<double*>(a_ypart); A.n = a_n; A.NP = a_NP;
@@ -277,15 +284,16 @@ __global__ __launch_bounds__(BLOCK) void k_pan_finu(const double* __restrict__ u
             const double v = pan_vj(alpha, mu, inv, up, vp);
             const double w = __builtin_fma(-alpha, wp, q) * inv;
             const double u = __builtin_fma(-sigma, v, __builtin_fma(-beta, vp, w));
-            vj[r] = v; wvec[r] = w;
-            if (PS.n) { for (int q = 0; q < PS.n; ++q) peer_store(reinterpret_cast<double*>(par ? PS.Z0[q] : PS.Z1[q]) + r, u); }      // (write-through: kernels.h peer_store)
+            if (PAN_U_NT & 4) { __builtin_nontemporal_store(v, vj + r); __builtin_nontemporal_store(w, wvec + r); } else { vj[r] = v; wvec[r] = w; }
+            if (SH) { for (int q = 0; q < PSd->n; ++q) peer_store(reinterpret_cast<double*>(par ? PSd->Z0[q] : PSd->Z1[q]) + r, u); }      // (write-through: kernels.h peer_store)
+            else if (PAN_U_NT & 4) __builtin_nontemporal_store(u, u_nxt + r);
             else u_nxt[r] = u;
             pr.acc[0] = __builtin_fma(u, u, pr.acc[0]); pr.acc[1] = __builtin_fma(u, v, pr.acc[1]); pr.acc[2] = __builtin_fma(v, v, pr.acc[2]);
             pr.acc[3] += u; pr.acc[4] += v; pr.acc[5] += fabs(v);
         }
     }
-    pr.template store<BLOCK>(L, jrel, smw, PS.n ? &PS : nullptr);
-    if (PS.n) peer_drain();
+    pr.template store<BLOCK>(L, jrel, smw, SH ? PSd : nullptr);
+    if (SH) peer_drain();
 }
 
 // Start a sequence of the shifted recurrence from u0: U0 = u0, sigma = 0; partials such that step 0 normalises u0 (k_pipe_init's rule).

@@ -192,6 +192,7 @@ struct Solver {
     bool pan_u = false;            // the running sequence's panel steps are those of the shifted recurrence (panel_u.h): 8-byte operand
     bool pan_u_off = false;        // ... ruled out for the rest of this solve (the drift monitor tripped)
     PanU pu{};
+    PeerSet* d_ps = nullptr; PeerSet h_ps{};      // the row-partitioned panel step's peer set, in device memory
     double *pu_sig = nullptr, *pu_U0 = nullptr, *pu_U1 = nullptr;     // (pu.U0 / U1 point at these, or at the record buffers under an inter-process communicator)
     double last_amp = 0.0;         // largest accumulated drift factor of the last solve's shifted sequences (solve stats / tests)
     // mixed mode of the panel step (machip_set_precision(1), round 6): the LATE steps of a sequence read the tile values rounded to fp32
@@ -257,7 +258,7 @@ struct Solver {
         {
             void* pb[] = {panv.tptr, panv.thead, panv.bval, panv.bcol, panv.ypart, panv.coef, panv.cbase, panv.ps, panv.tick, panv.claim, panv.ovf, panv.bd, panv.bpk};
             for (void* q : pb) if (q) (void)hipFree(q);
-            void* pu_[] = {pu_U0, pu_U1, pu.W, pu_sig, pan_bv32};
+            void* pu_[] = {pu_U0, pu_U1, pu.W, pu_sig, pan_bv32, d_ps};
             for (void* q : pu_) if (q) (void)hipFree(q);
             void* pk[] = {ppack.band, ppack.cc, ppack.crow, ppack.ccol, ppack.cval, ell_col, ell_val};
             for (void* q : pk) if (q) (void)hipFree(q);
@@ -661,6 +662,11 @@ struct Solver {
         ipc_split(pl);
         const PipeView L = pview(pl);
         const PeerSet PS = ipc_peers(pl);
+        if (!d_ps) { if (dev_alloc(&d_ps, 1) != MACHIP_OK) return; }
+        if (memcmp(&PS, &h_ps, sizeof(PeerSet)) != 0) {       // (the row kernel reads its peer set from device memory: panel_u.h)
+            h_ps = PS;
+            (void)hipMemcpyAsync(d_ps, &h_ps, sizeof(PeerSet), hipMemcpyHostToDevice, stream);
+        }
         const int Rb = 64 * pan.NTB;
         const long r_lo = (long)ipc->g0 * pan.block2, r_hi = std::min<long>((long)ipc->g1 * pan.block2, (long)n);
         const int b0 = (int)(r_lo / Rb), b1 = (int)((r_hi + Rb - 1) / Rb);
@@ -679,7 +685,7 @@ struct Solver {
                 default: break;
             }
             switch (pan.block2 * 100 + npm) {
-#define MACHIP_FINU_CASE(B, M) case B * 100 + M: k_pan_finu<B, M><<<gf, B, 0, stream>>>(PAN_FINU_ARGS(panv, pu, L, s), jhost, PS); break;
+#define MACHIP_FINU_CASE(B, M) case B * 100 + M: k_pan_finu<B, M, true><<<gf, B, 0, stream>>>(PAN_FINU_ARGS(panv, pu, L, s), jhost, d_ps); break;
 #define MACHIP_FINU_ROW(B) MACHIP_FINU_CASE(B, 6) MACHIP_FINU_CASE(B, 8) MACHIP_FINU_CASE(B, 12) MACHIP_FINU_CASE(B, 16)
                 MACHIP_FINU_ROW(256) MACHIP_FINU_ROW(512) MACHIP_FINU_ROW(1024)
 #undef MACHIP_FINU_ROW
