@@ -30,9 +30,6 @@
 #ifndef PAN_U_AHEAD
 #define PAN_U_AHEAD 2
 #endif
-#ifndef PAN_U_NT      // experiment bits: 1 = non-temporal tile loads, 2 = non-temporal partial-product stores, 4 = non-temporal stores of the row kernel
-#define PAN_U_NT 0
-#endif
 
 namespace machip {
 
@@ -134,8 +131,7 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul8(const double* __restri
         for (int i = 0; i < G; ++i) {
             const int c = g0 + i;
             const unsigned off = c < nch ? voff + (unsigned)(c * 64) : (unsigned)E0;      // (wave-uniform choice; no branch)
-            if (PAN_U_NT & 1) { pv[c] = __builtin_nontemporal_load(bv + off); pk[c] = __builtin_nontemporal_load(bc + off); }
-            else { pv[c] = bv[off]; pk[c] = bc[off]; }
+            pv[c] = bv[off]; pk[c] = bc[off];      // (non-temporal loads here: +10 % per step; non-temporal stores of the partials +6 %, of the row kernel +8 %: profiles/r6_panel_u.md)
         }
     };
 #pragma unroll
@@ -221,7 +217,7 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul8(const double* __restri
     // the row block's sums, un-sorted by the LDS image: coalesced stores
     for (int rl = wt; rl < R; rl += kPanWorkThreads) {
         const int row = b * R + rl;
-        if (row < A.n) { if (PAN_U_NT & 2) __builtin_nontemporal_store(yblk[rl], A.ypart + (size_t)p * A.n + row); else A.ypart[(size_t)p * A.n + row] = yblk[rl]; }
+        if (row < A.n) A.ypart[(size_t)p * A.n + row] = yblk[rl];
     }
     PAN_CLK(tid == 64, 8); PAN_CLK(tid == 1023, 9);
 }
@@ -284,9 +280,8 @@ __global__ __launch_bounds__(BLOCK) void k_pan_finu(const double* __restrict__ u
             const double v = pan_vj(alpha, mu, inv, up, vp);
             const double w = __builtin_fma(-alpha, wp, q) * inv;
             const double u = __builtin_fma(-sigma, v, __builtin_fma(-beta, vp, w));
-            if (PAN_U_NT & 4) { __builtin_nontemporal_store(v, vj + r); __builtin_nontemporal_store(w, wvec + r); } else { vj[r] = v; wvec[r] = w; }
+            vj[r] = v; wvec[r] = w;
             if (SH) { for (int q = 0; q < PSd->n; ++q) peer_store(reinterpret_cast<double*>(par ? PSd->Z0[q] : PSd->Z1[q]) + r, u); }      // (write-through: kernels.h peer_store)
-            else if (PAN_U_NT & 4) __builtin_nontemporal_store(u, u_nxt + r);
             else u_nxt[r] = u;
             pr.acc[0] = __builtin_fma(u, u, pr.acc[0]); pr.acc[1] = __builtin_fma(u, v, pr.acc[1]); pr.acc[2] = __builtin_fma(v, v, pr.acc[2]);
             pr.acc[3] += u; pr.acc[4] += v; pr.acc[5] += fabs(v);
