@@ -81,7 +81,7 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul8(const double* __restri
     if (wv == 0) {
         // Wave 0 owns no tiles.  In workgroup 0 it is the step's lead (counters, tridiagonal records, the host's copy, the row kernel's
         // coefficients) -- a role of its own, so that the prologue's 48 partial loads and the workers' chunks never share a register file.
-        if (blockIdx.x == 0) {
+        if (blockIdx.x == 0 && jrel >= 0) {      // (jrel < 0: a plain product y_p = L[., p] x outside the recurrence -- k_pan_rowop finishes it)
             int jd;
             const PipeCoef c = pipe_prologue_wave0(L, jrel, -1, scoef, &jd);
             if (lane == 0) { A.coef[0] = c.alpha; A.coef[1] = c.beta; A.coef[2] = c.mu; A.coef[3] = c.inv; A.coef[4] = (double)jd; A.coef[5] = c.atrue; }
@@ -289,6 +289,34 @@ __global__ __launch_bounds__(BLOCK) void k_pan_finu(const double* __restrict__ u
     }
     pr.template store<BLOCK>(L, jrel, smw, SH ? PSd : nullptr);
     if (SH) peer_drain();
+}
+
+// Row kernel of a PLAIN product in panel form (round 6): (L x)[r] = sum_p y_p[r] + band . x, handed to the same `Op` objects the CSR
+// products take (kernels.h: begin / row / end) -- the landscape sweeps of the cold start (OpLand) and the product of the explicit residual
+// check (OpLanczos) run on the panel form while a solve has it (k_pan_mul8 with jrel < 0 + this kernel: 9.4 + ~4 us against 27.5 / 35 us for
+// the gathering CSR kernels at configs[3]).  Row sums are added in panel order, not CSR order: equal to rounding.
+template <class Op>
+__global__ __launch_bounds__(kBlock) void k_pan_rowop(PanView A, const double* __restrict__ x, Op op) {
+    __shared__ double sm[4];
+    op.begin(sm);
+    const int n = A.n, NP = A.NP;
+    for (int r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) {
+        double q = 0.0;
+        for (int p0 = 0; p0 < NP; p0 += 8) {
+            double y[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) y[k] = A.ypart[(size_t)min(p0 + k, NP - 1) * n + r];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) q += (p0 + k < NP) ? y[k] : 0.0;
+        }
+        if (A.band) {
+            q = __builtin_fma(A.bd[r], x[r], q);
+            q = __builtin_fma(A.bd[(size_t)n + r], x[max(r - 1, 0)], q);
+            q = __builtin_fma(A.bd[2 * (size_t)n + r], x[min(r + 1, n - 1)], q);
+        }
+        op.row(r, q);
+    }
+    op.end(sm);
 }
 
 // Start a sequence of the shifted recurrence from u0: U0 = u0, sigma = 0; partials such that step 0 normalises u0 (k_pipe_init's rule).

@@ -189,6 +189,7 @@ struct Solver {
     bool pan_allowed = false;   // the CSR is one this library assembled (diagonal first, other columns ascending)
     PanPlan pan;
     PanView panv{};
+    bool pan_live = false;         // the panel form (shifted-recurrence shape) of the matrix being solved is built: plain products may use it (panel_spmv)
     bool pan_u = false;            // the running sequence's panel steps are those of the shifted recurrence (panel_u.h): 8-byte operand
     bool pan_u_off = false;        // ... ruled out for the rest of this solve (the drift monitor tripped)
     PanU pu{};
@@ -229,7 +230,7 @@ struct Solver {
         ST_TRY(dev_alloc(&Z0, n)); ST_TRY(dev_alloc(&Z1, n));
         ST_TRY(dev_alloc(&st, 1)); ST_TRY(dev_alloc(&st2, 1));
         HIP_TRY(hipMemsetAsync(st2, 0, sizeof(LanState), stream));      // (the explicit check's "column 0" counters stay {0, 0}: nothing advances them)
-        ST_TRY(dev_alloc(&y_raw, n)); ST_TRY(dev_alloc(&w2, n)); ST_TRY(dev_alloc(&yvec, n));
+        ST_TRY(dev_alloc(&y_raw, (size_t)n + 2)); ST_TRY(dev_alloc(&w2, (size_t)n + 2)); ST_TRY(dev_alloc(&yvec, n));      // (+2: a panel's 16-byte operand loads may touch one double past n)
         ST_TRY(dev_alloc(&ypart, (size_t)n * ks_max)); ST_TRY(dev_alloc(&sdev, vcap + 2));
         ST_TRY(dev_alloc(&part_c, 3 * kMaxGrid)); ST_TRY(dev_alloc(&part_a2, kMaxGrid));
         ST_TRY(dev_alloc(&part_r, kMaxGrid)); ST_TRY(dev_alloc(&scratch3, 8)); ST_TRY(dev_alloc(&rq_dev, 1));
@@ -297,23 +298,44 @@ struct Solver {
     // the landscape after `sweeps` Jacobi sweeps (in y_raw or w2; per-workgroup maxima of the last sweep in part_c[0 .. pl.grid))
     // (the sweeps' only per-workgroup output are the maxima in part_c, 3 x kMaxGrid doubles: their grid may exceed kMaxGrid)
     SpmvPlan landscape_plan(long nnz) const { return plan_spmv(opt, n, nnz, kAuto, 3 * kMaxGrid); }
-    const double* landscape_field(const CsrView& A, const SpmvPlan& pl, int sweeps) {
+    // (*grid_out: how many workgroups left a maximum in part_c -- the CSR product's launch shape, or the panel row kernel's)
+    const double* landscape_field(const CsrView& A, const SpmvPlan& pl, int sweeps, int* grid_out = nullptr) {
         k_land_init<<<vgrid(), kBlock, 0, stream>>>(A, wc, y_raw);
         double *src = y_raw, *dst = w2;
+        const bool via_panel = pan_live && OPT(panel_ops, 1) != 0;
         for (int s = 0; s < sweeps; ++s) {
             OpLand op{src, dst, wc, part_c, 0.0};
-            launch_spmv(pl, stream, A, src, op);
+            if (via_panel) panel_spmv(src, op, vgrid());
+            else launch_spmv(pl, stream, A, src, op);
             std::swap(src, dst);
         }
+        if (grid_out) *grid_out = via_panel ? vgrid() : pl.grid;
         return src;
+    }
+    // y = L x for a plain vector on the panel form of the running solve (k_pan_mul8 without the recurrence's prologue + k_pan_rowop<Op>)
+    template <class Op>
+    void panel_spmv(const double* x, const Op& op, int grid) {
+        const int g1 = pan.NB * pan.NP;
+        const PipeView L = pview(SpmvPlan());
+        switch (pan.LPT * 10 + pan.TWT) {
+#define MACHIP_PANU_CASE(LP, TW) case LP * 10 + TW: k_pan_mul8<LP, TW, double><<<g1, kPanThreads, 0, stream>>>(x, panv.tptr, panv.thead, panv.n, panv.C, panv.NP, panv.TWW, panv, L, -1, (const double*)nullptr, 0); break;
+#define MACHIP_PANU_ROW(LP) MACHIP_PANU_CASE(LP, 3) MACHIP_PANU_CASE(LP, 5) MACHIP_PANU_CASE(LP, 8)
+            MACHIP_PANU_ROW(1) MACHIP_PANU_ROW(2) MACHIP_PANU_ROW(3) MACHIP_PANU_ROW(4) MACHIP_PANU_ROW(5) MACHIP_PANU_ROW(6)
+            MACHIP_PANU_ROW(7) MACHIP_PANU_ROW(8) MACHIP_PANU_CASE(9, 3)
+#undef MACHIP_PANU_ROW
+#undef MACHIP_PANU_CASE
+            default: break;
+        }
+        k_pan_rowop<Op><<<grid, kBlock, 0, stream>>>(panv, x, op);
     }
     int landscape_start(const CsrView& A, const SpmvPlan& pl) {
         const int sweeps = std::min(16, OPT(start_land, 3));
         if (sweeps <= 0) return MACHIP_OK;
         const double pw = (double)std::max(1, OPT(start_pow, 128));
-        const double* f = landscape_field(A, pl, sweeps);
+        int gmax = pl.grid;
+        const double* f = landscape_field(A, pl, sweeps, &gmax);
         const double floor_w = 1e-6 * (double)std::max(0, OPT(start_floor_e6, 1000));      // (every entry keeps this share of its draw: kernels.h)
-        k_land_weight<<<vgrid(), kBlock, 0, stream>>>(f, part_c, pl.grid, u, n, pw, floor_w);
+        k_land_weight<<<vgrid(), kBlock, 0, stream>>>(f, part_c, gmax, u, n, pw, floor_w);
         HIP_TRY(hipGetLastError());
         return MACHIP_OK;
     }
@@ -837,11 +859,14 @@ struct Solver {
         const int g2 = vgrid();
         OpLanczos op;
         op.L = check_view(pl);
-        launch_spmv(pl, stream, A, y_raw, op);
+        const bool via_panel = pan_live && OPT(panel_ops, 1) != 0;
+        const int pa = via_panel ? vgrid() : pl.grid;            // alpha partials: one per workgroup of the kernel that finishes the rows
+        if (via_panel) { op.L.P_a = pa; panel_spmv(y_raw, op, pa); }
+        else launch_spmv(pl, stream, A, y_raw, op);
         // (the partials and the Rayleigh quotient go straight into mapped pinned memory: two copy kernels less per check)
         double* hp = h_pin + (vcap + 2);
         double* dhp = d_hpin + (vcap + 2);
-        k_resid_l1<<<g2, kBlock, 0, stream>>>(w2, yvec, n, part_a2, pl.grid, dhp, rq_dev, dhp + kMaxGrid, dhp + kMaxGrid + 8);
+        k_resid_l1<<<g2, kBlock, 0, stream>>>(w2, yvec, n, part_a2, pa, dhp, rq_dev, dhp + kMaxGrid, dhp + kMaxGrid + 8);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev1, stream));     // end of the solve's device time if this check passes (no second wait then)
         ++check_seq;
@@ -1767,7 +1792,7 @@ struct Solver {
 
         // ---- landscape weighting of a cold start (kernels.h, k_land_*): the multi-workgroup recurrence only (a single-workgroup solve
         // costs less than the sweeps would), never a caller's own guess or a warm start ----
-        if (!warm && land_ok) ST_TRY(landscape_start(A, landscape_plan(nnz)));
+        pan_live = false;       // (the landscape sweeps run further down, once the panel form -- if this solve takes it -- is built: they can use it)
 
         const int chunk0 = std::min(kMaxChunk, std::max(2, OPT(chunk, 32) & ~1));   // even: Z parity = jrel & 1
         const int chunk_near = std::min(chunk0, std::max(2, OPT(chunk_near, 8) & ~1));   // once the residual estimate is within 1e3 of the target
@@ -1842,6 +1867,8 @@ struct Solver {
                 }
             }
         }
+        pan_live = pan.on && pan_u;
+        if (!warm && land_ok) ST_TRY(landscape_start(A, landscape_plan(nnz)));
         {   // eager launches or captured chunks for this solve's fused steps (use_graph)
             const int vk = std::max(0, std::min(7, (int)pp.variant));
             // (model before the first measurement: the gather step's; a panel launch never runs under ~8 us -- n >= 65 536.  A first solve must not
