@@ -24,9 +24,9 @@ variants = [
     ("u 8x32 fin256", dict(panel=1, panel_u=1, panel_np=8, panel_nb=32, panel_b2=256)),
     ("u 6x42 fin256", dict(panel=1, panel_u=1, panel_np=6, panel_nb=42, panel_b2=256)),
     ("gather", dict(panel=0)),
-    ("record 12x21 deal0", dict(panel=1, panel_u=0, panel_deal=0)),
-    ("u 6x42 deal0", dict(panel=1, panel_u=1, panel_np=6, panel_nb=42, panel_deal=0)),
-    ("u 8x32 deal0", dict(panel=1, panel_u=1, panel_np=8, panel_nb=32, panel_deal=0)),
+    ("u 6x42 fin1024", dict(panel=1, panel_u=1, panel_np=6, panel_nb=42, panel_b2=1024)),
+    ("u 6x42 fin512 g2=128", dict(panel=1, panel_u=1, panel_np=6, panel_nb=42, panel_g2=128)),
+    ("u 6x42 fin256 g2=256", dict(panel=1, panel_u=1, panel_np=6, panel_nb=42, panel_b2=256, panel_g2=256)),
 ]
 if len(sys.argv) > 3:
     variants = [variants[int(t)] for t in sys.argv[3].split(",")]
