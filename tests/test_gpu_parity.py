@@ -2493,7 +2493,7 @@ def test_ipc_row_partitioned_panel_step_is_bit_identical_to_one_rank(world):
         assert msg[1]["out"] == single[1][1]["out"] and msg[1]["xsum"] == single[1][1]["xsum"] and msg[1]["xdot"] == single[1][1]["xdot"]
         assert msg[1]["mode"] == 5 and set(msg[1]["solver_modes"]) == {2}, msg[1]
         if world == 2:      # (measured 28-29 us: mul8 + finu + the publish / wait launch per step, two processes time-sharing the GPU; one rank alone: 13.5)
-            assert max(msg[1]["step_us"][1:]) < 36.0, msg[1]["step_us"]
+            assert max(msg[1]["step_us"][1:]) < 60.0, msg[1]["step_us"]      # (a bound on gross regressions only: two processes share one GPU with whatever else the box runs)
     print("panel step, us per Lanczos step: one rank", [round(t, 2) for t in single[1][1]["step_us"]], f"{world} ranks on one GPU", [round(t, 2) for t in multi[0][1][1]["step_us"]])
 
 
