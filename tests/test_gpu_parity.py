@@ -2497,6 +2497,23 @@ def test_ipc_row_partitioned_panel_step_is_bit_identical_to_one_rank(world):
     print("panel step, us per Lanczos step: one rank", [round(t, 2) for t in single[1][1]["step_us"]], f"{world} ranks on one GPU", [round(t, 2) for t in multi[0][1][1]["step_us"]])
 
 
+def test_ipc_ranks_agree_on_where_every_solve_ends_run_after_run():
+    """Round 6 regression (solver.h, `more_coming`): the chunk feeder of a row-partitioned solve analysed the tridiagonal at the END OF THE
+    QUEUE whenever the records up to there had landed before the loop came by -- short of the next analysis point, and only on the rank whose
+    timing happened to be so; from there the ranks' analysis points differed, one went to the explicit check while the other waited for more
+    steps, and both sat out the time limit: 2 of 30 two-rank configs[3] runs of round 5's library, 3 of 14 with the panel step.  Eight
+    two-process runs of five iterations each (panel step forced) must all finish, with identical results."""
+    first = None
+    for rep in range(8):
+        res = _run_ipc_job(2, "c4", 5, opts={"panel": 1}, env_extra={"IPC_TIMEOUT": "5"})
+        for rc, msg, se in res:
+            assert rc == 0 and msg and msg[0] == "RESULT", (rep, rc, msg, se)
+        out = (res[0][1][1]["out"], res[0][1][1]["xsum"])
+        assert (res[1][1][1]["out"], res[1][1][1]["xsum"]) == out
+        first = first or out
+        assert out == first, rep
+
+
 @pytest.mark.parametrize("wl,opts", [("golden:er2000_solve", {"vcap": 80}), ("golden:g2o_kitti_05", {}), ("golden:g2o_city10000", {}),
                                      ("golden:er2000_solve", {"graph": 0, "chunk": 6})])
 def test_ipc_communicator_with_restarts_and_unpartitioned_solver_modes(wl, opts):
