@@ -1385,6 +1385,47 @@ def test_panel_step_multi_round_windows_hub_rows_and_odd_sizes():
         P.close()
 
 
+def test_shifted_panel_step_across_the_instantiations_the_planner_reaches():
+    """The shifted panel step is a table of template instantiations (`k_pan_mul8<LPT, TWT>`: operand columns per lane pair x tiles per
+    worker wave; `k_pan_finu<block, panels>`), and the bench sits on ONE of them (9, 3 | 6 panels).  The planner reaches others with the
+    size alone -- here seven sizes from 3 500 to 135 500 rows, chosen so that `machip_panel_plan` names seven different (LPT, TWT) pairs, among
+    them the 5- and 8-tile forms that only exist beyond n = 1e5: the forced panel solve must run the shifted form (a drift factor is reported),
+    agree with the gather step to 1e-12 in lambda_2 and pass the reference's stop rule evaluated with SciPy's SpMV."""
+    rng = np.random.default_rng(23)
+    pairs = set()
+    for n, deg in ((3500, 12), (8000, 12), (12500, 16), (32000, 16), (61001, 14), (104000, 14), (135500, 12)):
+        m0 = n * deg // 2
+        a = rng.integers(0, n, m0); b = rng.integers(0, n, m0)
+        keep = np.abs(a - b) > 1
+        key = np.unique(np.minimum(a, b)[keep].astype(np.int64) * n + np.maximum(a, b)[keep])
+        ci, cj = (key // n).astype(np.int32), (key % n).astype(np.int32)
+        m = len(ci)
+        fi = np.arange(n - 1, dtype=np.int32)
+        P = _lib.Problem(n, fi, fi + 1, np.ones(n - 1), ci, cj, 0.5 + rng.random(m))
+        P.set_start(reference_start_block(n)[:, 0].copy())
+        P.set_x(np.ones(m))
+        nnz = P.assemble()
+        out12 = (C.c_int * 12)()
+        with _lib.default_options(panel=1):
+            assert _lib.load().machip_panel_plan(n, nnz, 127, out12) == 0
+        assert out12[0] == 1 and out12[8] == 1 and out12[11] == 1, (n, list(out12))       # shifted form, one cell per workgroup
+        pairs.add((out12[9], out12[10]))
+        res = {}
+        for mode in (0, 1):
+            P.set_option("panel", mode)
+            lam, v, _ = P.fiedler(tol=1e-10)
+            res[mode] = (lam, v, P.stats.drift, P.solve_mode()[0])
+        assert res[1][3] == 2 and res[1][2] > 0.0 and res[0][2] == 0.0, (n, res[0][2:], res[1][2:])
+        assert abs(res[1][0] - res[0][0]) <= 1e-12 * res[0][0], (n, list(out12), res[0][0], res[1][0])
+        ip, ix, da = P.laplacian_csr()
+        L = sp.csr_matrix((da, ix, ip), shape=(n, n))
+        v1 = res[1][1]
+        assert np.abs(L @ v1 - res[1][0] * v1).sum() / abs(L).sum(axis=1).max() < 1e-8, (n, list(out12))
+        assert np.abs(sign_align(v1, res[0][1]) - res[0][1]).max() <= 1e-6
+        P.close()
+    assert len(pairs) == 7 and {(8, 5), (7, 8), (9, 3)} <= pairs, pairs
+
+
 def test_automatic_mode_picks_the_multi_cell_panel_step_at_n_200000():
     """k_pan_mul_multi (several row blocks per workgroup, the panel kept in LDS) is what the AUTOMATIC mode
     takes from ~33 entries per row at n = 150 000 .. 400 000 (plan.h), but rounds 1-4 only ever ran it forced onto er2000 through an
