@@ -48,7 +48,8 @@ __host__ __device__ constexpr int pan_u_cols(int LPT, int TW) {
     return ((2 * kPanWorkThreads * LPT) < ((163840 - 8 * pan_u_rows(TW) - 256) / 8) ? (2 * kPanWorkThreads * LPT) : ((163840 - 8 * pan_u_rows(TW) - 256) / 8)) & ~1;
 }
 
-#define PAN_MUL8_ARGS(P, U, L, jrel) (((jrel) & 1) ? (U).U1 : (U).U0), (P).tptr, (P).thead, (P).n, (P).C, (P).NP, (P).TWW, (P), (L), (jrel)
+#define PAN_MUL8_ARGS(P, U, L, jrel) (((jrel) & 1) ? (U).U1 : (U).U0), (P).tptr, (P).thead, (P).bval, (P).bcol, (P).n, (P).C, ((P).NP | ((P).TWW << 16)), ((P).NTB << 16), (P), (L), (jrel)
+#define PAN_MUL8_ARGS_AT(P, U, L, jrel, b_first) (((jrel) & 1) ? (U).U1 : (U).U0), (P).tptr, (P).thead, (P).bval, (P).bcol, (P).n, (P).C, ((P).NP | ((P).TWW << 16)), ((b_first) | ((P).NTB << 16)), (P), (L), (jrel)
 
 // y_p = L[block b, panel p] u  for a plain operand vector: every thread of the workgroup loads its share of the panel with 16-byte
 // loads (LPT per thread; C even, so every panel starts on a 16-byte boundary), the 15 worker waves their tiles exactly as k_pan_mul.
@@ -60,11 +61,15 @@ __host__ __device__ constexpr int pan_u_cols(int LPT, int TW) {
 // array rounded to fp32, 6 bytes per entry instead of 10; operand, products and sums stay fp64).
 template <int LPT, int TW, typename TV = double>
 __global__ __launch_bounds__(kPanThreads) void k_pan_mul8(const double* __restrict__ u_cur, const int* __restrict__ a_tptr,
-                                                           const unsigned short* __restrict__ a_thead, int a_n, int a_C, int a_NP, int a_TWW,
-                                                           PanView A_, PipeView L, int jrel, const TV* __restrict__ bv32 = nullptr, int b_first = 0) {
+                                                           const unsigned short* __restrict__ a_thead, const double* __restrict__ a_bval,
+                                                           const unsigned short* __restrict__ a_bcol, int a_n, int a_C, int a_npt, int a_bf,
+                                                           PanView A_, PipeView L, int jrel, const TV* __restrict__ bv32 = nullptr) {
+    // (the first 14 dwords of the arguments arrive in SGPRs with the wave: everything the operand, tile-table and chunk loads need -- a field of
+    // the by-value views costs a scalar load of the argument block and a wait in front of the first vector load)
     __shared__ double scoef[8];
     PanView A = A_;
-    A.tptr = const_cast<int*>(a_tptr); A.thead = const_cast<unsigned short*>(a_thead); A.n = a_n; A.C = a_C; A.NP = a_NP; A.TWW = a_TWW;
+    A.tptr = const_cast<int*>(a_tptr); A.thead = const_cast<unsigned short*>(a_thead); A.n = a_n; A.C = a_C; A.NP = a_npt & 0xffff; A.TWW = a_npt >> 16; A.NTB = a_bf >> 16;
+    const int b_first = a_bf & 0xffff;
     constexpr int SVN = pan_u_cols(LPT, TW), ROWS = pan_u_rows(TW);
     __shared__ __attribute__((aligned(16))) double sv[SVN];
     __shared__ double yblk[ROWS];
@@ -119,8 +124,8 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul8(const double* __restri
     }
     const int nch = cend[TW - 1];
     const unsigned voff = (unsigned)(E0 + lane);
-    const TV* __restrict__ bv = sizeof(TV) == 8 ? reinterpret_cast<const TV*>(A.bval) : bv32;
-    const unsigned short* __restrict__ bc = A.bcol;
+    const TV* __restrict__ bv = sizeof(TV) == 8 ? reinterpret_cast<const TV*>(a_bval) : bv32;
+    const unsigned short* __restrict__ bc = a_bcol;
     TV pv[kPanCH];
     int pk[kPanCH];
     constexpr int G = 4;        // chunks per group: their loads leave together, their gathers go out together once the loads are in
@@ -222,57 +227,72 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul8(const double* __restri
     PAN_CLK(tid == 64, 8); PAN_CLK(tid == 1023, 9);
 }
 
-#define PAN_FINU_ARGS(P, U, L, jrel) (((jrel) & 1) ? (U).U1 : (U).U0), (((jrel) & 1) ? (U).U0 : (U).U1), (U).W, (P).ypart, (P).coef, (P).n, (P).NP, (P), (L), (jrel)
+#define PAN_FINU_ARGS(P, U, L, jrel) (((jrel) & 1) ? (U).U1 : (U).U0), (P).ypart, (U).W, (L).V, ((P).band ? (P).bd : nullptr), (P).n, (P).NP, (jrel)
+#define PAN_FINU_TAIL(P, U, L, jrel) (P).coef, (((jrel) & 1) ? (U).U0 : (U).U1), (L)
 
-// Row kernel of the shifted recurrence: the coefficients come from k_pan_mul8's workgroup 0 through A.coef (as k_pan_fin gets them).
+// Row kernel of the shifted recurrence: the coefficients come from k_pan_mul8's workgroup 0 through the coefficient block (as k_pan_fin gets them).
+// Argument order (round 6, late): everything the ROW LOADS need -- operand, partial products, w, the basis, the band, n, NP, both step indices --
+// sits in the first 16 dwords, which arrive in SGPRs with the wave (build.sh: kernarg preload), and the six coefficients are requested
+// BEHIND the row loads as one more (uniform) vector load each.  Before, the kernel waited for the rest of its argument block, then for the
+// coefficient block (scalar loads: one counter, so the wait for an address also waited for them), and only then asked for its rows: three
+// round trips in a row where one is needed (ISA of round 6's first build; profiles/r6_panel_u.md section 6).
 // jhost >= 0: the step index, known to the host on eager launches -- the address of the basis column of v_{j-1} then does not wait
 // for the coefficient block.
 // NPM: panels whose partials are requested in one batch (>= NP wherever a shape is dispatched on it; clamped loads beyond NP would
 // only re-read the last plane).
-// SH (compile time): this launch is one rank's share of a row-partitioned step; its PeerSet sits in device memory (PSd).  (First builds of the
-// partitioned form: the set as a by-value argument whose address was taken at run time went to scratch memory, 13.5 -> 18.2 us per step; as a
-// by-value argument never touched it still cost the un-partitioned row kernel 0.46 us -- 208 more bytes of kernel arguments.)
+// SH (compile time): this launch is one rank's share of a row-partitioned step; its PeerSet sits in device memory (PSd), its first workgroup and
+// the launch's total are plain arguments.  (First builds of the partitioned form: the set as a by-value argument whose address was taken at run
+// time went to scratch memory, 13.5 -> 18.2 us per step; as a by-value argument never touched it still cost the un-partitioned row kernel 0.46 us.)
 template <int BLOCK, int NPM, bool SH = false>
-__global__ __launch_bounds__(BLOCK) void k_pan_finu(const double* __restrict__ u_cur, double* __restrict__ u_nxt, double* __restrict__ wvec,
-                                                     const double* __restrict__ a_ypart, const double* __restrict__ a_coef, int a_n, int a_NP,
-                                                     PanView A_, PipeView L, int jrel, int jhost, const PeerSet* __restrict__ PSd = nullptr) {
-    // SH: this rank's share [PSd->first, PSd->first + gridDim.x) of a PSd->total-workgroup launch (row-partitioned step between processes):
+__global__ __launch_bounds__(BLOCK) void k_pan_finu(const double* __restrict__ u_cur, const double* __restrict__ a_ypart, double* __restrict__ wvec,
+                                                     double* __restrict__ a_V, const double* __restrict__ a_bd, int n, int NP, int jrel, int jhost,
+                                                     const double* a_coef, double* __restrict__ u_nxt, PipeView L,
+                                                     const PeerSet* __restrict__ PSd = nullptr, int sh_first = 0, int sh_total = 0) {
+    // SH: this rank's share [sh_first, sh_first + gridDim.x) of a sh_total-workgroup launch (row-partitioned step between processes):
     // same rows per workgroup, same partial-sum slots; the next operand's rows and the six sums go into EVERY rank's copy (the operand
     // buffers of such a sequence live in the record buffers Z0 / Z1, which the peers have mapped), v_j and w stay with the owner.
     __shared__ double smw[kNP * BLOCK];
-    const int bid = SH ? PSd->first + (int)blockIdx.x : (int)blockIdx.x;
-    const int gtot = SH ? PSd->total : (int)gridDim.x;
+    const int bid = SH ? sh_first + (int)blockIdx.x : (int)blockIdx.x;
+    const int gtot = SH ? sh_total : (int)gridDim.x;
     const int par = jrel & 1;
-    PanView A = A_;
-    A.ypart = const_cast<double*>(a_ypart); A.n = a_n; A.NP = a_NP;
-    const int n = A.n, NP = A.NP;
-    const double alpha = a_coef[0], beta = a_coef[1], mu = a_coef[2], inv = a_coef[3], sigma = a_coef[5];
     const int j = jhost >= 0 ? jhost : (int)a_coef[4];
-    const double* __restrict__ vprev = L.V + (size_t)max(j - 1, 0) * (size_t)n;
-    double* __restrict__ vj = L.V + (size_t)j * (size_t)n;
+    const double* __restrict__ vprev = a_V + (size_t)max(j - 1, 0) * (size_t)n;
+    double* __restrict__ vj = a_V + (size_t)j * (size_t)n;
     const bool first = j == 0;
     PipeRow pr;
     pr.clear();
-    for (int r = bid * BLOCK + threadIdx.x; r < n; r += gtot * BLOCK) {
-        double y[NPM];
+    int r = bid * BLOCK + threadIdx.x;
+    // the first batch of row loads leaves before anything else is asked for
+    double y[NPM], up = 0.0, ul = 0.0, uu = 0.0, vp = 0.0, wp = 0.0, b0 = 0.0, bl = 0.0, bu = 0.0;
+    auto request = [&](int rr) {
 #pragma unroll
-        for (int q = 0; q < NPM; ++q) y[q] = A.ypart[(size_t)min(q, NP - 1) * n + r];
-        const double up = u_cur[r], ul = u_cur[max(r - 1, 0)], uu = u_cur[min(r + 1, n - 1)];
-        const double vp = first ? 0.0 : vprev[r], wp = first ? 0.0 : wvec[r];
-        double b0 = 0.0, bl = 0.0, bu = 0.0;
-        if (A.band) { b0 = A.bd[r]; bl = A.bd[(size_t)n + r]; bu = A.bd[2 * (size_t)n + r]; }
+        for (int q = 0; q < NPM; ++q) y[q] = a_ypart[(size_t)min(q, NP - 1) * n + rr];
+        up = u_cur[rr]; ul = u_cur[max(rr - 1, 0)]; uu = u_cur[min(rr + 1, n - 1)];
+        vp = vprev[rr]; wp = wvec[rr];
+        if (a_bd) { b0 = a_bd[rr]; bl = a_bd[(size_t)n + rr]; bu = a_bd[2 * (size_t)n + rr]; }
+    };
+    if (r < n) request(r);
+    __builtin_amdgcn_sched_barrier(0);
+    // the coefficients: uniform vector loads BEHIND the rows' (a scalar load would share its counter with the argument block's)
+    int zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zero));        // (0 in a vector register the compiler knows nothing about: keeps these loads on the vector-memory path)
+    const pan_f2* __restrict__ cf = reinterpret_cast<const pan_f2*>(a_coef) + zero;
+    const pan_f2 c01 = cf[0], c23 = cf[1], c45 = cf[2];
+    const double alpha = c01.x, beta = c01.y, mu = c23.x, inv = c23.y, sigma = c45.y;
+    for (; r < n; ) {
+        if (first) { vp = 0.0; wp = 0.0; }
         double q = 0.0;
 #pragma unroll
         for (int k = 0; k < NPM; ++k) q += (k < NP) ? y[k] : 0.0;
         for (int p0 = NPM; p0 < NP; p0 += NPM) {     // (more panels than one batch: tests)
 #pragma unroll
-            for (int k = 0; k < NPM; ++k) y[k] = A.ypart[(size_t)min(p0 + k, NP - 1) * n + r];
+            for (int k = 0; k < NPM; ++k) y[k] = a_ypart[(size_t)min(p0 + k, NP - 1) * n + r];
 #pragma unroll
             for (int k = 0; k < NPM; ++k) q += (p0 + k < NP) ? y[k] : 0.0;
         }
         {
 #pragma clang fp contract(off)
-            if (A.band) {       // the tridiagonal band, kept out of the panel form
+            if (a_bd) {       // the tridiagonal band, kept out of the panel form
                 q = __builtin_fma(b0, up, q);
                 q = __builtin_fma(bl, ul, q);
                 q = __builtin_fma(bu, uu, q);
@@ -281,11 +301,13 @@ __global__ __launch_bounds__(BLOCK) void k_pan_finu(const double* __restrict__ u
             const double w = __builtin_fma(-alpha, wp, q) * inv;
             const double u = __builtin_fma(-sigma, v, __builtin_fma(-beta, vp, w));
             vj[r] = v; wvec[r] = w;
-            if (SH) { for (int q = 0; q < PSd->n; ++q) peer_store(reinterpret_cast<double*>(par ? PSd->Z0[q] : PSd->Z1[q]) + r, u); }      // (write-through: kernels.h peer_store)
+            if (SH) { for (int q2 = 0; q2 < PSd->n; ++q2) peer_store(reinterpret_cast<double*>(par ? PSd->Z0[q2] : PSd->Z1[q2]) + r, u); }      // (write-through: kernels.h peer_store)
             else u_nxt[r] = u;
             pr.acc[0] = __builtin_fma(u, u, pr.acc[0]); pr.acc[1] = __builtin_fma(u, v, pr.acc[1]); pr.acc[2] = __builtin_fma(v, v, pr.acc[2]);
             pr.acc[3] += u; pr.acc[4] += v; pr.acc[5] += fabs(v);
         }
+        r += gtot * BLOCK;
+        if (r < n) request(r);
     }
     pr.template store<BLOCK>(L, jrel, smw, SH ? PSd : nullptr);
     if (SH) peer_drain();

@@ -318,7 +318,7 @@ struct Solver {
         const int g1 = pan.NB * pan.NP;
         const PipeView L = pview(SpmvPlan());
         switch (pan.LPT * 10 + pan.TWT) {
-#define MACHIP_PANU_CASE(LP, TW) case LP * 10 + TW: k_pan_mul8<LP, TW, double><<<g1, kPanThreads, 0, stream>>>(x, panv.tptr, panv.thead, panv.n, panv.C, panv.NP, panv.TWW, panv, L, -1, (const double*)nullptr, 0); break;
+#define MACHIP_PANU_CASE(LP, TW) case LP * 10 + TW: k_pan_mul8<LP, TW, double><<<g1, kPanThreads, 0, stream>>>(x, panv.tptr, panv.thead, panv.bval, panv.bcol, panv.n, panv.C, panv.NP | (panv.TWW << 16), panv.NTB << 16, panv, L, -1); break;
 #define MACHIP_PANU_ROW(LP) MACHIP_PANU_CASE(LP, 3) MACHIP_PANU_CASE(LP, 5) MACHIP_PANU_CASE(LP, 8)
             MACHIP_PANU_ROW(1) MACHIP_PANU_ROW(2) MACHIP_PANU_ROW(3) MACHIP_PANU_ROW(4) MACHIP_PANU_ROW(5) MACHIP_PANU_ROW(6)
             MACHIP_PANU_ROW(7) MACHIP_PANU_ROW(8) MACHIP_PANU_CASE(9, 3)
@@ -573,7 +573,7 @@ struct Solver {
             }
             const int npm = pan.NP <= 6 ? 6 : pan.NP <= 8 ? 8 : pan.NP <= 12 ? 12 : 16;
             switch (pan.block2 * 100 + npm) {
-#define MACHIP_FINU_CASE(B, M) case B * 100 + M: k_pan_finu<B, M><<<pan.grid2, B, 0, stream>>>(PAN_FINU_ARGS(panv, pu, L, s), jhost); break;
+#define MACHIP_FINU_CASE(B, M) case B * 100 + M: k_pan_finu<B, M><<<pan.grid2, B, 0, stream>>>(PAN_FINU_ARGS(panv, pu, L, s), jhost, PAN_FINU_TAIL(panv, pu, L, s)); break;
 #define MACHIP_FINU_ROW(B) MACHIP_FINU_CASE(B, 6) MACHIP_FINU_CASE(B, 8) MACHIP_FINU_CASE(B, 12) MACHIP_FINU_CASE(B, 16)
                 MACHIP_FINU_ROW(256) MACHIP_FINU_ROW(512) MACHIP_FINU_ROW(1024)
 #undef MACHIP_FINU_ROW
@@ -698,7 +698,7 @@ struct Solver {
         for (int s = 0; s < steps; ++s) {
             const int jhost = j0 >= 0 ? j0 + s : -1;
             switch (pan.LPT * 10 + pan.TWT) {
-#define MACHIP_PANU_CASE(LP, TW) case LP * 10 + TW: k_pan_mul8<LP, TW, double><<<g1m, kPanThreads, 0, stream>>>(PAN_MUL8_ARGS(panv, pu, L, s), (const double*)nullptr, b0); break;
+#define MACHIP_PANU_CASE(LP, TW) case LP * 10 + TW: k_pan_mul8<LP, TW, double><<<g1m, kPanThreads, 0, stream>>>(PAN_MUL8_ARGS_AT(panv, pu, L, s, b0)); break;
 #define MACHIP_PANU_ROW(LP) MACHIP_PANU_CASE(LP, 3) MACHIP_PANU_CASE(LP, 5) MACHIP_PANU_CASE(LP, 8)
                 MACHIP_PANU_ROW(1) MACHIP_PANU_ROW(2) MACHIP_PANU_ROW(3) MACHIP_PANU_ROW(4) MACHIP_PANU_ROW(5) MACHIP_PANU_ROW(6)
                 MACHIP_PANU_ROW(7) MACHIP_PANU_ROW(8) MACHIP_PANU_CASE(9, 3)
@@ -707,7 +707,7 @@ struct Solver {
                 default: break;
             }
             switch (pan.block2 * 100 + npm) {
-#define MACHIP_FINU_CASE(B, M) case B * 100 + M: k_pan_finu<B, M, true><<<gf, B, 0, stream>>>(PAN_FINU_ARGS(panv, pu, L, s), jhost, d_ps); break;
+#define MACHIP_FINU_CASE(B, M) case B * 100 + M: k_pan_finu<B, M, true><<<gf, B, 0, stream>>>(PAN_FINU_ARGS(panv, pu, L, s), jhost, PAN_FINU_TAIL(panv, pu, L, s), d_ps, PS.first, PS.total); break;
 #define MACHIP_FINU_ROW(B) MACHIP_FINU_CASE(B, 6) MACHIP_FINU_CASE(B, 8) MACHIP_FINU_CASE(B, 12) MACHIP_FINU_CASE(B, 16)
                 MACHIP_FINU_ROW(256) MACHIP_FINU_ROW(512) MACHIP_FINU_ROW(1024)
 #undef MACHIP_FINU_ROW
