@@ -26,7 +26,7 @@ namespace machip {
     X(spmv) X(g) X(unroll) X(block) X(maxgrid) X(defer) X(tpr) X(ell)                                                              \
     /* column-panel step */                                                                                                        \
     X(panel) X(panel_min_n) X(panel_min_mean10) X(panel_multi_min_mean10) X(panel_np) X(panel_nb) X(panel_b2) X(panel_g2)         \
-    X(panel_cells) X(panel_maxcells) X(panel_band) X(panel_u) X(panel_u_amp) X(pan32) X(pan32_switch_e9) X(panel_ops)                                                                               \
+    X(panel_cells) X(panel_maxcells) X(panel_band) X(panel_u) X(panel_u_amp) X(pan32) X(pan32_switch_e9) X(panel_ops) X(panel_rev)                                                                               \
     /* preconditioned / exact modes */                                                                                             \
     X(woodbury) X(wb_max) X(wb_hard) X(wb_lane_max) X(exact_big) X(exact_switch) X(gj_look_min) X(lob_density_pct) X(lob_chunk)   \
     X(lob_patience) X(lob_small_s) X(lob_fuse)                                                                                     \

@@ -67,6 +67,7 @@ struct PanView {
     unsigned int* claim;    // [NB * NP] ... and which step's share (row block b, rows of slice p) has been taken
     int spin_ticks;         // ... how long (100 MHz ticks) a workgroup waits for its row block before leaving its share to the last arriver
     int* ovf;               // set by k_pan_rows when a row has more than kPanMaxLen entries inside ONE panel (the build would clamp it)
+    int rev;                // 1: k_pan_mul8 walks its chunks backwards on odd steps (option panel_rev; panel_u.h)
     int band;               // 1: the tridiagonal band (diagonal, columns r - 1 and r + 1) is kept OUT of the panel form -- bd holds it, k_pan_fin adds it
     double* bd;             // [3][n] band values: diagonal, column r - 1, column r + 1 (0 where absent)
     int* bpk;               // [n] (CSR index of the row's first off-diagonal band entry) << 3 | how many there are (0..7): the hole the build skips

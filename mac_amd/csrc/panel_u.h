@@ -48,8 +48,8 @@ __host__ __device__ constexpr int pan_u_cols(int LPT, int TW) {
     return ((2 * kPanWorkThreads * LPT) < ((163840 - 8 * pan_u_rows(TW) - 256) / 8) ? (2 * kPanWorkThreads * LPT) : ((163840 - 8 * pan_u_rows(TW) - 256) / 8)) & ~1;
 }
 
-#define PAN_MUL8_ARGS(P, U, L, jrel) (((jrel) & 1) ? (U).U1 : (U).U0), (P).tptr, (P).thead, (P).bval, (P).bcol, (P).n, (P).C, ((P).NP | ((P).TWW << 16)), ((P).NTB << 16), (P), (L), (jrel)
-#define PAN_MUL8_ARGS_AT(P, U, L, jrel, b_first) (((jrel) & 1) ? (U).U1 : (U).U0), (P).tptr, (P).thead, (P).bval, (P).bcol, (P).n, (P).C, ((P).NP | ((P).TWW << 16)), ((b_first) | ((P).NTB << 16)), (P), (L), (jrel)
+#define PAN_MUL8_ARGS(P, U, L, jrel) (((jrel) & 1) ? (U).U1 : (U).U0), (P).tptr, (P).thead, (P).bval, (P).bcol, (P).n, (P).C, ((P).NP | ((P).TWW << 16)), (((P).NTB << 16) | ((P).rev << 15)), (P), (L), (jrel)
+#define PAN_MUL8_ARGS_AT(P, U, L, jrel, b_first) (((jrel) & 1) ? (U).U1 : (U).U0), (P).tptr, (P).thead, (P).bval, (P).bcol, (P).n, (P).C, ((P).NP | ((P).TWW << 16)), ((b_first) | ((P).NTB << 16) | ((P).rev << 15)), (P), (L), (jrel)
 
 // y_p = L[block b, panel p] u  for a plain operand vector: every thread of the workgroup loads its share of the panel with 16-byte
 // loads (LPT per thread; C even, so every panel starts on a 16-byte boundary), the 15 worker waves their tiles exactly as k_pan_mul.
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul8(const double* __restri
     __shared__ double scoef[8];
     PanView A = A_;
     A.tptr = const_cast<int*>(a_tptr); A.thead = const_cast<unsigned short*>(a_thead); A.n = a_n; A.C = a_C; A.NP = a_npt & 0xffff; A.TWW = a_npt >> 16; A.NTB = a_bf >> 16;
-    const int b_first = a_bf & 0xffff;
+    const int b_first = a_bf & 0x7fff;
     constexpr int SVN = pan_u_cols(LPT, TW), ROWS = pan_u_rows(TW);
     __shared__ __attribute__((aligned(16))) double sv[SVN];
     __shared__ double yblk[ROWS];
@@ -123,6 +123,18 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul8(const double* __restri
         for (int q = 0; q < TW; ++q) cend[q] = (tp[q + 1] - E0) >> 6;      // (tiles q >= TWW: same as the last real one)
     }
     const int nch = cend[TW - 1];
+    // Odd steps walk the wave's chunks BACKWARDS (option panel_rev): what a step requested last is what the XCD's L2 still holds when the next
+    // step starts, and a stream of 5 MB per XCD through a 4 MB L2 in the same order every time never hits -- in alternating order the most
+    // recent part does.  cendP / roP: tile ends and slot rows in PROCESSING order; position k of the walk is chunk nch - 1 - k.  (A row's
+    // sum then adds its entries in the opposite order on odd steps: equal to rounding, and the same in every run and on every rank.)
+    const bool rev = ((a_bf >> 15) & 1) != 0 && jrel >= 0 && (jrel & 1) != 0;
+    int cendP[TW], roP[TW];
+#pragma unroll
+    for (int i = 0; i < TW; ++i) {
+        const int q = TW - 1 - i;
+        cendP[i] = rev ? nch - (q ? cend[q - 1] : 0) : cend[i];
+        roP[i] = rev ? ro[q] : ro[i];
+    }
     const unsigned voff = (unsigned)(E0 + lane);
     const TV* __restrict__ bv = sizeof(TV) == 8 ? reinterpret_cast<const TV*>(a_bval) : bv32;
     const unsigned short* __restrict__ bc = a_bcol;
@@ -135,7 +147,7 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul8(const double* __restri
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const int c = g0 + i;
-            const unsigned off = c < nch ? voff + (unsigned)(c * 64) : (unsigned)E0;      // (wave-uniform choice; no branch)
+            const unsigned off = c < nch ? voff + (unsigned)((rev ? nch - 1 - c : c) * 64) : (unsigned)E0;      // (wave-uniform choice; no branch)
             pv[c] = bv[off]; pk[c] = bc[off];      // (non-temporal loads here: +10 % per step; non-temporal stores of the partials +6 %, of the row kernel +8 %: profiles/r6_panel_u.md)
         }
     };
@@ -163,8 +175,8 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul8(const double* __restri
         unsigned endmask = 0;      // chunks of the first round that close a (non-empty) tile
 #pragma unroll
         for (int q = 0; q < TW; ++q) {
-            const int prev = q ? cend[q - 1] : 0, last = cend[q] - 1;
-            if (q < A.TWW && cend[q] > prev && last >= 0 && last < kPanCH) endmask |= 1u << last;
+            const int prev = q ? cendP[q - 1] : 0, last = cendP[q] - 1;
+            if (cendP[q] > prev && last >= 0 && last < kPanCH) endmask |= 1u << last;      // (tiles beyond TWW are empty: they end where their predecessor does)
         }
 #pragma unroll
         for (int g0 = 0; g0 < kPanCH; g0 += G) {
@@ -182,7 +194,7 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul8(const double* __restri
                     if (endmask & (1u << c)) {       // its lanes' rows are complete
 #pragma unroll
                         for (int q = 0; q < TW; ++q)
-                            if (c + 1 == cend[q] && (q == 0 ? cend[0] > 0 : cend[q] > cend[q - 1])) yblk[ro[q]] = acc;
+                            if (c + 1 == cendP[q] && (q == 0 ? cendP[0] > 0 : cendP[q] > cendP[q - 1])) yblk[roP[q]] = acc;
                         acc = 0.0;
                     }
                 }
@@ -193,15 +205,15 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul8(const double* __restri
         for (int cb = kPanCH; cb < nch; cb += kPanCH) {     // more chunks than the registers hold: further rounds (dense rows; one more round trip each)
 #pragma unroll
             for (int c = 0; c < kPanCH; ++c)
-                if (cb + c < nch) { pv[c] = bv[voff + (unsigned)((cb + c) * 64)]; pk[c] = bc[voff + (unsigned)((cb + c) * 64)]; }
+                if (cb + c < nch) { const unsigned o2 = voff + (unsigned)((rev ? nch - 1 - (cb + c) : cb + c) * 64); pv[c] = bv[o2]; pk[c] = bc[o2]; }
             double xr[kPanCH];
 #pragma unroll
             for (int c = 0; c < kPanCH; ++c) xr[c] = (double)pv[c] * sv[min(pk[c], Cp - 1)];
             unsigned em = 0;
 #pragma unroll
             for (int q = 0; q < TW; ++q) {
-                const int prev = q ? cend[q - 1] : 0, last = cend[q] - 1 - cb;
-                if (q < A.TWW && cend[q] > prev && last >= 0 && last < kPanCH) em |= 1u << last;
+                const int prev = q ? cendP[q - 1] : 0, last = cendP[q] - 1 - cb;
+                if (cendP[q] > prev && last >= 0 && last < kPanCH) em |= 1u << last;
             }
 #pragma unroll
             for (int c = 0; c < kPanCH; ++c) {
@@ -210,7 +222,7 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul8(const double* __restri
                     if (em & (1u << c)) {
 #pragma unroll
                         for (int q = 0; q < TW; ++q)
-                            if (cb + c + 1 == cend[q] && (q == 0 ? cend[0] > 0 : cend[q] > cend[q - 1])) yblk[ro[q]] = acc;
+                            if (cb + c + 1 == cendP[q] && (q == 0 ? cendP[0] > 0 : cendP[q] > cendP[q - 1])) yblk[roP[q]] = acc;
                         acc = 0.0;
                     }
                 }
@@ -266,7 +278,7 @@ __global__ __launch_bounds__(BLOCK) void k_pan_finu(const double* __restrict__ u
     double y[NPM], up = 0.0, ul = 0.0, uu = 0.0, vp = 0.0, wp = 0.0, b0 = 0.0, bl = 0.0, bu = 0.0;
     auto request = [&](int rr) {
 #pragma unroll
-        for (int q = 0; q < NPM; ++q) y[q] = a_ypart[(size_t)min(q, NP - 1) * n + rr];
+        for (int q = 0; q < NPM; ++q) y[q] = __builtin_nontemporal_load(a_ypart + (size_t)min(q, NP - 1) * n + rr);      // (read once: must not displace the tiles the next step finds in L2)
         up = u_cur[rr]; ul = u_cur[max(rr - 1, 0)]; uu = u_cur[min(rr + 1, n - 1)];
         vp = vprev[rr]; wp = wvec[rr];
         if (a_bd) { b0 = a_bd[rr]; bl = a_bd[(size_t)n + rr]; bu = a_bd[2 * (size_t)n + rr]; }
@@ -300,7 +312,7 @@ __global__ __launch_bounds__(BLOCK) void k_pan_finu(const double* __restrict__ u
             const double v = pan_vj(alpha, mu, inv, up, vp);
             const double w = __builtin_fma(-alpha, wp, q) * inv;
             const double u = __builtin_fma(-sigma, v, __builtin_fma(-beta, vp, w));
-            vj[r] = v; wvec[r] = w;
+            vj[r] = v; wvec[r] = w;      // (a non-temporal store of the basis column: +1 % per step; of the partial products in k_pan_mul8: a tie)
             if (SH) { for (int q2 = 0; q2 < PSd->n; ++q2) peer_store(reinterpret_cast<double*>(par ? PSd->Z0[q2] : PSd->Z1[q2]) + r, u); }      // (write-through: kernels.h peer_store)
             else u_nxt[r] = u;
             pr.acc[0] = __builtin_fma(u, u, pr.acc[0]); pr.acc[1] = __builtin_fma(u, v, pr.acc[1]); pr.acc[2] = __builtin_fma(v, v, pr.acc[2]);
