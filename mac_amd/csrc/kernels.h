@@ -899,7 +899,7 @@ struct PipeRow {   // per-thread accumulation of the next step's partial sums
     }
 };
 
-#define PIPE_ARGS(A, L, jrel) (A).rowptr, (A).col, (A).val, (((jrel) & 1) ? (L).Z1 : (L).Z0), (L).part, (L).st, (A).n, (A), (L), (jrel)
+#define PIPE_ARGS(A, L, jrel) (A).rowptr, (A).col, (A).val, (((jrel) & 1) ? (L).Z1 : (L).Z0), (L).part, (L).st, (A).n, (jrel), (A), (L)
 
 // ---- sub-wave vector form: G lanes per row, BLOCK threads per workgroup -------------------------
 // Raw sums (L t)[r], (L v)[r] of one row by its G-lane group, and the row's own record (lane 0).
@@ -945,14 +945,16 @@ __device__ __forceinline__ void pipe_row_sums(const CsrViewT<T>& A, const ZRec<T
 // barrier comes after them; finish() then runs in the same row order as before (bit-identical partial sums).
 template <int BLOCK, int G, int UNR = 1, bool DED = false, typename T = double, int DEFER = 3, bool SH = false, int ELLW = 0>
 __global__ __launch_bounds__(BLOCK) void k_pipe_vec(const int* __restrict__ a_rowptr, const int* __restrict__ a_col, const T* __restrict__ a_val,
-                                                    const ZRec<T>* __restrict__ z_cur, double* l_part, LanState* l_st, int a_n,
-                                                    CsrViewT<T> A_, PipeViewT<T> L_, int jrel, PeerSet PS = PeerSet()) {
+                                                    const ZRec<T>* __restrict__ z_cur, double* l_part, LanState* l_st, int a_n, int jrel,
+                                                    CsrViewT<T> A_, PipeViewT<T> L_, PeerSet PS = PeerSet()) {
     using Z2 = ZRec<T>;
     // The pointers every wave needs for its FIRST loads come as leading scalar arguments (PIPE_ARGS): with
     // -amdgpu-kernarg-preload-count they are in SGPRs when the wave starts, instead of behind a scalar load of the argument
     // block (itself a cold round trip at the head of every step).  A_ / L_ carry the rest.
     // (Not for the padded fixed-width form: there every wave's value / column loads leave at kernel entry anyway, and having
-    // them out even before wave 0's partial-sum loads measured 1.7 % slower on city10000.)
+    // them out even before wave 0's partial-sum loads measured 1.7 % slower on city10000; round 6 again: a tie.)
+    // jrel is one of them (round 6): wave 0's partial-sum loads need its parity, and as a trailing argument it sat behind a scalar load
+    // and a wait in front of them -- configs[1] 6.57 -> 6.33 us per step.
     const CsrViewT<T> A = ELLW ? A_ : CsrViewT<T>{a_n, a_rowptr, a_col, a_val};
     PipeViewT<T> L = L_;
     L.part = l_part; L.st = l_st;      // (the prologue's pointers are preloaded in either form: its chain is the longest)
