@@ -239,12 +239,12 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul8(const double* __restri
     PAN_CLK(tid == 64, 8); PAN_CLK(tid == 1023, 9);
 }
 
-#define PAN_FINU_ARGS(P, U, L, jrel) (((jrel) & 1) ? (U).U1 : (U).U0), (P).ypart, (U).W, (L).V, ((P).band ? (P).bd : nullptr), (P).n, (P).NP, (jrel)
-#define PAN_FINU_TAIL(P, U, L, jrel) (P).coef, (((jrel) & 1) ? (U).U0 : (U).U1), (L)
+#define PAN_FINU_ARGS(P, U, L, jrel, jhost) (((jrel) & 1) ? (U).U1 : (U).U0), (P).ypart, (U).W, (L).V, ((P).band ? (P).bd : nullptr), (P).coef, (P).n, \
+    ((P).NP | (((jrel) & 0xff) << 7) | (((jhost) + 1) << 15)), (((jrel) & 1) ? (U).U0 : (U).U1), (L)
 
 // Row kernel of the shifted recurrence: the coefficients come from k_pan_mul8's workgroup 0 through the coefficient block (as k_pan_fin gets them).
 // Argument order (round 6, late): everything the ROW LOADS need -- operand, partial products, w, the basis, the band, n, NP, both step indices --
-// sits in the first 16 dwords, which arrive in SGPRs with the wave (build.sh: kernarg preload), and the six coefficients are requested
+// sits in the first 14 dwords, which arrive in SGPRs with the wave (build.sh: kernarg preload), and the six coefficients are requested
 // BEHIND the row loads as one more (uniform) vector load each.  Before, the kernel waited for the rest of its argument block, then for the
 // coefficient block (scalar loads: one counter, so the wait for an address also waited for them), and only then asked for its rows: three
 // round trips in a row where one is needed (ISA of round 6's first build; profiles/r6_panel_u.md section 6).
@@ -257,13 +257,14 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul8(const double* __restri
 // time went to scratch memory, 13.5 -> 18.2 us per step; as a by-value argument never touched it still cost the un-partitioned row kernel 0.46 us.)
 template <int BLOCK, int NPM, bool SH = false>
 __global__ __launch_bounds__(BLOCK) void k_pan_finu(const double* __restrict__ u_cur, const double* __restrict__ a_ypart, double* __restrict__ wvec,
-                                                     double* __restrict__ a_V, const double* __restrict__ a_bd, int n, int NP, int jrel, int jhost,
-                                                     const double* a_coef, double* __restrict__ u_nxt, PipeView L,
+                                                     double* __restrict__ a_V, const double* __restrict__ a_bd, const double* a_coef, int n, int a_pk,
+                                                     double* __restrict__ u_nxt, PipeView L,
                                                      const PeerSet* __restrict__ PSd = nullptr, int sh_first = 0, int sh_total = 0) {
     // SH: this rank's share [sh_first, sh_first + gridDim.x) of a sh_total-workgroup launch (row-partitioned step between processes):
     // same rows per workgroup, same partial-sum slots; the next operand's rows and the six sums go into EVERY rank's copy (the operand
     // buffers of such a sequence live in the record buffers Z0 / Z1, which the peers have mapped), v_j and w stay with the owner.
     __shared__ double smw[kNP * BLOCK];
+    const int NP = a_pk & 0x7f, jrel = (a_pk >> 7) & 0xff, jhost = (a_pk >> 15) - 1;      // (one dword: the 14 preloaded ones are all taken)
     const int bid = SH ? sh_first + (int)blockIdx.x : (int)blockIdx.x;
     const int gtot = SH ? sh_total : (int)gridDim.x;
     const int par = jrel & 1;

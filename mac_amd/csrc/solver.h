@@ -574,7 +574,7 @@ struct Solver {
             }
             const int npm = pan.NP <= 6 ? 6 : pan.NP <= 8 ? 8 : pan.NP <= 12 ? 12 : 16;
             switch (pan.block2 * 100 + npm) {
-#define MACHIP_FINU_CASE(B, M) case B * 100 + M: k_pan_finu<B, M><<<pan.grid2, B, 0, stream>>>(PAN_FINU_ARGS(panv, pu, L, s), jhost, PAN_FINU_TAIL(panv, pu, L, s)); break;
+#define MACHIP_FINU_CASE(B, M) case B * 100 + M: k_pan_finu<B, M><<<pan.grid2, B, 0, stream>>>(PAN_FINU_ARGS(panv, pu, L, s, jhost)); break;
 #define MACHIP_FINU_ROW(B) MACHIP_FINU_CASE(B, 6) MACHIP_FINU_CASE(B, 8) MACHIP_FINU_CASE(B, 12) MACHIP_FINU_CASE(B, 16)
                 MACHIP_FINU_ROW(256) MACHIP_FINU_ROW(512) MACHIP_FINU_ROW(1024)
 #undef MACHIP_FINU_ROW
@@ -708,7 +708,7 @@ struct Solver {
                 default: break;
             }
             switch (pan.block2 * 100 + npm) {
-#define MACHIP_FINU_CASE(B, M) case B * 100 + M: k_pan_finu<B, M, true><<<gf, B, 0, stream>>>(PAN_FINU_ARGS(panv, pu, L, s), jhost, PAN_FINU_TAIL(panv, pu, L, s), d_ps, PS.first, PS.total); break;
+#define MACHIP_FINU_CASE(B, M) case B * 100 + M: k_pan_finu<B, M, true><<<gf, B, 0, stream>>>(PAN_FINU_ARGS(panv, pu, L, s, jhost), d_ps, PS.first, PS.total); break;
 #define MACHIP_FINU_ROW(B) MACHIP_FINU_CASE(B, 6) MACHIP_FINU_CASE(B, 8) MACHIP_FINU_CASE(B, 12) MACHIP_FINU_CASE(B, 16)
                 MACHIP_FINU_ROW(256) MACHIP_FINU_ROW(512) MACHIP_FINU_ROW(1024)
 #undef MACHIP_FINU_ROW
