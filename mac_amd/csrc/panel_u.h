@@ -240,7 +240,7 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul8(const double* __restri
 }
 
 #define PAN_FINU_ARGS(P, U, L, jrel, jhost) (((jrel) & 1) ? (U).U1 : (U).U0), (P).ypart, (U).W, (L).V, ((P).band ? (P).bd : nullptr), (P).coef, (P).n, \
-    ((P).NP | (((jrel) & 0xff) << 7) | (((jhost) + 1) << 15)), (((jrel) & 1) ? (U).U0 : (U).U1), (L)
+    ((P).NP | (((jrel) & 0xff) << 7) | (((jhost) + 1) << 15)), (((jrel) & 1) ? (U).U0 : (U).U1), (L).part
 
 // Row kernel of the shifted recurrence: the coefficients come from k_pan_mul8's workgroup 0 through the coefficient block (as k_pan_fin gets them).
 // Argument order (round 6, late): everything the ROW LOADS need -- operand, partial products, w, the basis, the band, n, NP, both step indices --
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul8(const double* __restri
 template <int BLOCK, int NPM, bool SH = false>
 __global__ __launch_bounds__(BLOCK) void k_pan_finu(const double* __restrict__ u_cur, const double* __restrict__ a_ypart, double* __restrict__ wvec,
                                                      double* __restrict__ a_V, const double* __restrict__ a_bd, const double* a_coef, int n, int a_pk,
-                                                     double* __restrict__ u_nxt, PipeView L,
+                                                     double* __restrict__ u_nxt, double* l_part,
                                                      const PeerSet* __restrict__ PSd = nullptr, int sh_first = 0, int sh_total = 0) {
     // SH: this rank's share [sh_first, sh_first + gridDim.x) of a sh_total-workgroup launch (row-partitioned step between processes):
     // same rows per workgroup, same partial-sum slots; the next operand's rows and the six sums go into EVERY rank's copy (the operand
@@ -322,7 +322,8 @@ __global__ __launch_bounds__(BLOCK) void k_pan_finu(const double* __restrict__ u
         r += gtot * BLOCK;
         if (r < n) request(r);
     }
-    pr.template store<BLOCK>(L, jrel, smw, SH ? PSd : nullptr);
+    struct { double* part; } Lp{l_part};          // (the six sums' slots are all the row kernel needs of the recurrence's view: 200 bytes of arguments less)
+    pr.template store<BLOCK>(Lp, jrel, smw, SH ? PSd : nullptr);
     if (SH) peer_drain();
 }
 
