@@ -1169,11 +1169,12 @@ def main():
                 if eig_mode.startswith("row-partitioned"):
                     # DESIGN section 7, from measured components: configs[3] runs the column-panel step row-partitioned (round 6): tile-table
                     # round trip 1.2 + tile stream 5.0 / R + tail 1.5 + boundary 1.8, row kernel 5.5 + boundary 1.8, publish / wait launch 2.5,
-                    # peer writes over xGMI + flag round trip >= 3 (unmeasured); one GPU alone: 13.5 us.  configs[1]: gather step 5 us fixed
+                    # peer writes over xGMI + flag round trip >= 3 (unmeasured); one GPU alone: 12.5 us at the end of round 6 (the late work on the step took ~1 us
+                    # out of both kernels' fronts: 1.2 -> 0.7 and 5.5 -> 4.5 below).  configs[1]: gather step 5 us fixed
                     # + 4.1 us per million entries / R + 8 us of exchange measured on one GPU + 3.
                     nnz_m = float(np.mean([r[2] for r in rec])) / 1e6
-                    t1 = 13.5 if cfg == "c4" else 6.7
-                    tR = (1.2 + 5.0 / world + 1.5 + 1.8 + 5.5 + 1.8 + 2.5 + 3.0) if cfg == "c4" else (5.0 + 4.1 * nnz_m / world + 8.0 + 3.0)
+                    t1 = 12.5 if cfg == "c4" else 6.4
+                    tR = (0.7 + 5.0 / world + 1.5 + 1.8 + 4.5 + 1.8 + 2.5 + 3.0) if cfg == "c4" else (5.0 + 4.1 * nnz_m / world + 8.0 + 3.0)
                     pred = t1 / tR
                     why = (f"row-partitioned eigen-solve: per step {tR:.1f} us predicted from measured components (DESIGN section 7: the step's fixed part -- two launch "
                            f"floors, one cold round trip each, the exchange -- does not shrink with the rank count) against {t1} us on one GPU: a single "
