@@ -475,7 +475,7 @@ struct Solver {
         if (!panv.tick) { ST_TRY(dev_alloc(&panv.tick, 256)); ST_TRY(dev_alloc(&panv.claim, 4096)); }     // (NB <= 256, NB NP <= 4096: plan_panel)
         // band mode (Lanczos form, two launches): diagonal and chain neighbours stay out of the tiles -- k_pan_fin adds them
         panv.band = band ? 1 : 0;
-        panv.rev = OPT(panel_rev, 1) != 0 ? 1 : 0;
+        panv.rev = OPT(panel_rev, 1) != 0 ? 1 : 0;     // odd steps of the shifted form walk each wave's chunks backwards (panel_u.h: what the XCD's L2 still holds comes first); 0: forwards always
         panv.spin_ticks = OPT(panel_spin_us, 20) * 100;
 #ifdef PAN_CLOCKS
         if (!panv.clk) { ST_TRY(dev_alloc(&panv.clk, (size_t)16 * kMaxGrid)); HIP_TRY(hipMemsetAsync(panv.clk, 0, sizeof(long long) * 16 * kMaxGrid, stream)); }

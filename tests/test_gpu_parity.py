@@ -1227,6 +1227,8 @@ def test_landscape_start_keeps_a_floor_under_every_entry():
     {"panel": 1, "stream": 0}, {"panel": 1, "panel_np": 3, "graph": 1, "chunk": 8},
     {"panel": 1, "panel_np": 5, "panel_nb": 7, "panel_b2": 512, "panel_g2": 3},
     {"panel": 1, "panel_np": 7, "graph": 0, "chunk": 6, "panel_b2": 1024},
+    # ... every step walking the tiles forwards (default: odd steps backwards, for the L2's sake)
+    {"panel": 1, "panel_rev": 0}, {"panel": 1, "panel_np": 3, "panel_rev": 0, "graph": 1, "chunk": 8},
     # ... several row blocks per workgroup, the panel loaded once (k_pan_mul_multi; round 4): even split, ragged split (cells that have no row block)
     {"panel": 1, "panel_np": 3, "panel_nb": 6, "panel_cells": 2},
     {"panel": 1, "panel_np": 5, "panel_nb": 7, "panel_cells": 3, "graph": 0, "chunk": 6},
