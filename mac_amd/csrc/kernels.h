@@ -766,7 +766,10 @@ __device__ __forceinline__ void pipe_publish(const PV& L, const PipeCoef& c, int
 // `lead`: this launch is the one of its step that advances the counters (the panel form runs the prologue in both of its launches);
 // `pub_wg`: the workgroup that hands a tail-less predecessor chunk's records to the host (any workgroup can: all compute the same
 // coefficients) -- the caller names one with slack.
-template <class PV>
+// SIG = false: a kernel that never runs the shifted recurrence (the gather step, the record-form panel step) -- no sigma load at all: as a
+// run-time test of L.sig, a field of the by-value view, it was a scalar load of the argument block, a wait and THEN the load, ~0.5 us
+// behind the partial loads on the chain every row wave waits for at its first barrier (round 6).
+template <bool SIG = true, class PV>
 __device__ __forceinline__ PipeCoef pipe_prologue_wave0(const PV& L, int jrel, int adv_jA, double* scoef, int* j_out, int bid = -1,
                                                         bool lead = true, int pub_wg = 0) {
     // (sharded step: the tridiagonal records go to the launching rank's own arrays -- its first workgroup writes them; ranks of
@@ -778,8 +781,8 @@ __device__ __forceinline__ PipeCoef pipe_prologue_wave0(const PV& L, int jrel, i
     // (shifted records: sigma is requested with the partials.  The load is UNCONDITIONAL -- the record form reads a partial it ignores --
     // because a branch here sat between the counter load and the 24 partial loads of every step of every form and cost the gather step
     // 0.24 us: configs[1] 6.40 -> 6.64 us, the 4-lane sweep -5 %, same-box A/B of round 5's library against round 6's first)
-    const double sg_raw = *(L.sig ? L.sig + (jrel & 1) : pin);
-    const double sg_prev = L.sig ? sg_raw : 0.0;
+    double sg_prev = 0.0;
+    if (SIG) { const double sg_raw = *(L.sig ? L.sig + (jrel & 1) : pin); sg_prev = L.sig ? sg_raw : 0.0; }
     double a[kNP];
     {   // The first 256 partials per quantity: 24 UNCONDITIONAL loads per lane (always in bounds: the arrays hold kMaxGrid
         // entries), masked afterwards.  Round 2, tools/ubench5.hip + the ISA: written as `i < P ? pin[..] : 0` (or as a loop
@@ -825,7 +828,7 @@ __device__ __forceinline__ PipeCoef pipe_prologue_wave0(const PV& L, int jrel, i
     if (lane == 0) {
         scoef[0] = c.alpha; scoef[1] = c.beta; scoef[2] = c.mu; scoef[3] = c.inv; scoef[4] = (double)j; scoef[5] = c.atrue;
         if (bid == 0) {
-            if (L.sig && lead && adv_jA < 0) L.sig[(jrel + 1) & 1] = c.atrue;      // sigma_j = alpha_{j-1}
+            if (SIG && L.sig && lead && adv_jA < 0) L.sig[(jrel + 1) & 1] = c.atrue;      // sigma_j = alpha_{j-1}
             if (j > 0) { L.tri[3 * (j - 1)] = c.atrue; L.tri[3 * (j - 1) + 2] = c.l1prev; }
             L.tri[3 * j + 1] = c.beta;
             if (adv_jA >= 0) { L.st->jA = j; L.st->jN = j; }   // tail kernel: new chunk base
@@ -974,7 +977,7 @@ __global__ __launch_bounds__(BLOCK) void k_pipe_vec(const int* __restrict__ a_ro
     const int lane = wt >= 0 ? wt % G : 0, g = wt >= 0 ? wt / G : 0;
     PIPE_CLK(threadIdx.x == 0, 0);
     PIPE_CLK(wt == 0, 2);
-    if (threadIdx.x < 64) { int jdummy; (void)pipe_prologue_wave0(L, jrel, -1, scoef, &jdummy, bid, true, (int)gridDim.x - 1); }
+    if (threadIdx.x < 64) { int jdummy; (void)pipe_prologue_wave0<false>(L, jrel, -1, scoef, &jdummy, bid, true, (int)gridDim.x - 1); }
     PIPE_CLK(threadIdx.x == 0, 1);
     const Z2* __restrict__ Zc = ELLW ? ((jrel & 1) ? L.Z1 : L.Z0) : z_cur;
     Z2* __restrict__ Zn = (jrel & 1) ? L.Z0 : L.Z1;
