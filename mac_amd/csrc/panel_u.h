@@ -243,8 +243,8 @@ __global__ __launch_bounds__(kPanThreads) void k_pan_mul8(const double* __restri
     ((P).NP | (((jrel) & 0xff) << 7) | (((jhost) + 1) << 15)), (((jrel) & 1) ? (U).U0 : (U).U1), (L).part
 
 // Row kernel of the shifted recurrence: the coefficients come from k_pan_mul8's workgroup 0 through the coefficient block (as k_pan_fin gets them).
-// Argument order (round 6, late): everything the ROW LOADS need -- operand, partial products, w, the basis, the band, n, NP, both step indices --
-// sits in the first 14 dwords, which arrive in SGPRs with the wave (build.sh: kernarg preload), and the six coefficients are requested
+// Argument order (round 6, late): everything the ROW LOADS need -- operand, partial products, w, the basis, the band, n, NP and both step indices (one packed dword) -- and the
+// coefficient block's address sit in the first 14 dwords, which arrive in SGPRs with the wave (build.sh: kernarg preload), and the six coefficients are requested
 // BEHIND the row loads as one more (uniform) vector load each.  Before, the kernel waited for the rest of its argument block, then for the
 // coefficient block (scalar loads: one counter, so the wait for an address also waited for them), and only then asked for its rows: three
 // round trips in a row where one is needed (ISA of round 6's first build; profiles/r6_panel_u.md section 6).
