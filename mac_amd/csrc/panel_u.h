@@ -259,7 +259,17 @@ template <int BLOCK, int NPM, bool SH = false>
 __global__ __launch_bounds__(BLOCK) void k_pan_finu(const double* __restrict__ u_cur, const double* __restrict__ a_ypart, double* __restrict__ wvec,
                                                      double* __restrict__ a_V, const double* __restrict__ a_bd, const double* a_coef, int n, int a_pk,
                                                      double* __restrict__ u_nxt, double* l_part,
-                                                     const PeerSet* __restrict__ PSd = nullptr, int sh_first = 0, int sh_total = 0) {
+                                                     const PeerSet* __restrict__ PSd = nullptr, int sh_first = 0, int sh_total = 0
+#ifdef PAN_CLOCKS
+                                                     , long long* clk = nullptr
+#endif
+                                                     ) {
+#ifdef PAN_CLOCKS
+#define FINU_CLK(i) do { if (clk && threadIdx.x == 0) clk[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define FINU_CLK(i) do { } while (0)
+#endif
+    FINU_CLK(10);
     // SH: this rank's share [sh_first, sh_first + gridDim.x) of a sh_total-workgroup launch (row-partitioned step between processes):
     // same rows per workgroup, same partial-sum slots; the next operand's rows and the six sums go into EVERY rank's copy (the operand
     // buffers of such a sequence live in the record buffers Z0 / Z1, which the peers have mapped), v_j and w stay with the owner.
@@ -292,6 +302,10 @@ __global__ __launch_bounds__(BLOCK) void k_pan_finu(const double* __restrict__ u
     const pan_f2* __restrict__ cf = reinterpret_cast<const pan_f2*>(a_coef) + zero;
     const pan_f2 c01 = cf[0], c23 = cf[1], c45 = cf[2];
     const double alpha = c01.x, beta = c01.y, mu = c23.x, inv = c23.y, sigma = c45.y;
+#ifdef PAN_CLOCKS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FINU_CLK(11);
+#endif
     for (; r < n; ) {
         if (first) { vp = 0.0; wp = 0.0; }
         double q = 0.0;
@@ -322,9 +336,15 @@ __global__ __launch_bounds__(BLOCK) void k_pan_finu(const double* __restrict__ u
         r += gtot * BLOCK;
         if (r < n) request(r);
     }
+    FINU_CLK(12);
     struct { double* part; } Lp{l_part};          // (the six sums' slots are all the row kernel needs of the recurrence's view: 200 bytes of arguments less)
     pr.template store<BLOCK>(Lp, jrel, smw, SH ? PSd : nullptr);
     if (SH) peer_drain();
+#ifdef PAN_CLOCKS
+    FINU_CLK(13);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FINU_CLK(14);
+#endif
 }
 
 // Row kernel of a PLAIN product in panel form (round 6): (L x)[r] = sum_p y_p[r] + band . x, handed to the same `Op` objects the CSR

@@ -539,6 +539,11 @@ struct Solver {
         (void)nnz;
         return MACHIP_OK;
     }
+#ifdef PAN_CLOCKS
+#define MACHIP_FINU_CLK , (const PeerSet*)nullptr, 0, 0, panv.clk
+#else
+#define MACHIP_FINU_CLK
+#endif
     void launch_pan_step(const PipeView& L, int s, int jhost = -1) {
         const int g1 = pan.NB * pan.NP;
 #ifdef MACHIP_EXPERIMENTS
@@ -574,7 +579,7 @@ struct Solver {
             }
             const int npm = pan.NP <= 6 ? 6 : pan.NP <= 8 ? 8 : pan.NP <= 12 ? 12 : 16;
             switch (pan.block2 * 100 + npm) {
-#define MACHIP_FINU_CASE(B, M) case B * 100 + M: k_pan_finu<B, M><<<pan.grid2, B, 0, stream>>>(PAN_FINU_ARGS(panv, pu, L, s, jhost)); break;
+#define MACHIP_FINU_CASE(B, M) case B * 100 + M: k_pan_finu<B, M><<<pan.grid2, B, 0, stream>>>(PAN_FINU_ARGS(panv, pu, L, s, jhost) MACHIP_FINU_CLK); break;
 #define MACHIP_FINU_ROW(B) MACHIP_FINU_CASE(B, 6) MACHIP_FINU_CASE(B, 8) MACHIP_FINU_CASE(B, 12) MACHIP_FINU_CASE(B, 16)
                 MACHIP_FINU_ROW(256) MACHIP_FINU_ROW(512) MACHIP_FINU_ROW(1024)
 #undef MACHIP_FINU_ROW

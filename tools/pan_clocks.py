@@ -22,7 +22,9 @@ lib.machip_debug_pan_clocks.restype = C.c_int
 lib.machip_debug_pan_clocks.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.c_int]
 names = {0: "workgroup entry (wave 0)", 1: "wave 1 entry", 2: "record form: all of wave 1's loads arrived / u form: operand in LDS, tile table known", 3: "prologue done (record form: wave 0)",
          4: "barrier 1 passed (record form)", 5: "operand in LDS, barrier passed", 6: "first chunks multiplied (wave 1)", 7: "tiles accumulated (wave 1)",
-         8: "wave 1 done (stores issued)", 9: "wave 15 done"}
+         8: "wave 1 done (stores issued)", 9: "wave 15 done",
+         10: "ROW KERNEL (last launch; its own time base): workgroup entry", 11: "row kernel: row loads + coefficients arrived", 12: "row kernel: rows done, stores issued",
+         13: "row kernel: six sums reduced and stored", 14: "row kernel: every store acknowledged"}
 for o in sets:
     keys = list(o)
     for k_, v in o.items(): P.set_option(k_, v)
@@ -41,8 +43,11 @@ for o in sets:
     c = c[live]
     t0 = c[:, 0].min()
     print(f"== {o}: nnz {int(st.nnz)} steps {int(st.lanczos_steps)} in-solve {1e3 * st.step_ms / max(1, st.steps_timed):.2f} us per step, {len(c)} workgroups")
-    for i in range(10):
-        v = (c[:, i] - t0) * 0.01
+    live2 = c[:, 10] > 0
+    t1 = c[live2, 10].min() if live2.any() else 0
+    if live2.any(): print(f"      (row kernel's first workgroup enters {(t1 - t0) * 0.01:.2f} us after the matrix kernel's first)")
+    for i in range(15):
+        v = (c[:, i] - (t0 if i < 10 else t1)) * 0.01
         if (c[:, i] > 0).any():
             v = v[c[:, i] > 0]
             print(f"      {names[i]:96s} min {v.min():6.2f}  mean {v.mean():6.2f}  max {v.max():6.2f} us")
